@@ -1,0 +1,84 @@
+/*
+ * lvk_hip.h -- C-ABI of the MI355X-native LiveVisionKit stabilization hot path (liblvk_hip.so).
+ *
+ * This is the drop-in boundary: plain C, opaque handles, plain pointers and sizes, `int` status
+ * (0 = ok, negative = error; lvk_hip_last_error() gives the text).  Nothing here throws and there are
+ * no torch / OpenCV types.  Each entry point names the reference interface it replaces
+ * (paths relative to the LiveVisionKit source tree).  The C++ facade in include/lvk/ (the
+ * lvk::StabilizationFilter / lvk::VideoFilter API the OBS plugin compiles against) is a header-level
+ * wrapper over these calls; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - "d_" pointers are device (HBM) pointers valid on the context's device; all others are host pointers.
+ *   - Frames are packed 8UC3 (the reference's cv::UMat CV_8UC3 layout, Data/VideoFrame.hpp:25) with a
+ *     row pitch `step` in bytes, or planar 8UC1 where stated.
+ *   - All work is enqueued on the context's HIP stream and is asynchronous, exactly like the
+ *     reference's `run_(..., false)` kernel launches (Functions/Image.cpp:76); results are complete
+ *     after lvk_hip_sync() (reference: Stopwatch::sync_gpu -> cv::ocl::finish, Timing/Stopwatch.cpp:127-131).
+ *   - One context is driven by one host thread at a time; different contexts are independent
+ *     (reference threading contract: SURVEY.md section 8b).
+ */
+#ifndef LVK_HIP_H
+#define LVK_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVK_HIP_OK              0
+#define LVK_HIP_ERR_ARG        -1   /* violated pre-condition (the reference would LVK_ASSERT) */
+#define LVK_HIP_ERR_RUNTIME    -2   /* HIP runtime error */
+#define LVK_HIP_ERR_NO_DEVICE  -3   /* no usable gfx950 device / extension cannot run */
+
+typedef struct lvk_hip_ctx lvk_hip_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------
+ * Replaces the implicit OpenCL context/queue of cv::ocl (Functions/OpenCL/Kernels.cpp:27-45).
+ * `stream` may be an existing hipStream_t (e.g. the caller's) or NULL to let the context create its own. */
+int  lvk_hip_ctx_create(int device, void* stream, lvk_hip_ctx** out);
+void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx);
+int  lvk_hip_sync(lvk_hip_ctx* ctx);                 /* Stopwatch::sync_gpu, Timing/Stopwatch.cpp:127-131 */
+void* lvk_hip_stream(lvk_hip_ctx* ctx);              /* the hipStream_t work is enqueued on */
+const char* lvk_hip_last_error(lvk_hip_ctx* ctx);    /* NULL ctx: last error of a failed ctx_create */
+const char* lvk_hip_version(void);
+
+/* ---- device memory helpers (for hosts without their own allocator) ------------------------------
+ * Replace cv::UMat(USAGE_ALLOCATE_DEVICE_MEMORY) allocation / upload / download (Data/VideoFrame.cpp:27-29). */
+int lvk_hip_malloc(lvk_hip_ctx* ctx, size_t bytes, void** d_ptr);
+int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr);
+int lvk_hip_upload(lvk_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* async on the stream */
+int lvk_hip_download(lvk_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* async on the stream */
+
+/* ---- a15/a16: dense remap ------------------------------------------------------------------------
+ * lvk::remap(src, dst, homography, background, inverted=true)  (Functions/Image.cpp:85-151) running
+ * easu_remap_homography (Functions/OpenCL/Sources/FSR.cl:407-452).  H = dst->src 3x3, row major, already
+ * cast to float as Image.cpp:137-139 does.  (off_x, off_y) = ROI offset of dst (Image.cpp:121-123).
+ * yuv != 0 <=> src.format == VideoFrame::YUV (selects the "-D YUV_INPUT" program, Image.cpp:36-41). */
+int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
+                             const void* d_src, int src_step, int src_rows, int src_cols,
+                             void* d_dst, int dst_step, int dst_rows, int dst_cols,
+                             int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv);
+
+/* lvk::remap(src, dst, offset_map, background) (Functions/Image.cpp:28-81, easu_remap FSR.cl:362-403) with the
+ * offset map of WarpMesh::apply (Math/WarpMesh.cpp:190-191) evaluated inside the kernel from the mesh
+ * vertices instead of being materialised (saves 4 full-resolution float2 passes).  `mesh` is a HOST pointer
+ * to mesh_rows x mesh_cols x 2 floats of normalised backward offsets; dst has the size of src. */
+int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
+                       const void* d_src, int src_step, int src_rows, int src_cols,
+                       void* d_dst, int dst_step,
+                       const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
+
+/* WarpMesh::apply(src, dst, background) (Math/WarpMesh.cpp:183-223): a 2x2 mesh goes through
+ * cv::getPerspectiveTransform + the homography kernel, anything larger through the mesh kernel. */
+int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
+                           const void* d_src, int src_step, int rows, int cols,
+                           void* d_dst, int dst_step,
+                           const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVK_HIP_H */

@@ -1,0 +1,58 @@
+"""ctypes loader for liblvk_hip.so (the HIP kernels + C-ABI declared in include/lvk_hip.h).
+
+There is deliberately NO fallback: if the extension is missing or cannot run, importing callers fail
+loudly.  torch is imported first so that liblvk_hip.so binds to the HIP runtime torch already loaded
+(both export the soname libamdhip64.so.7) -- two HIP runtimes in one process cannot share pointers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblvk_hip.so")
+
+# every symbol include/lvk_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+_SIG = {
+    "lvk_hip_ctx_create": (_c.c_int, [_c.c_int, _P, _c.POINTER(_P)]),
+    "lvk_hip_ctx_destroy": (None, [_P]),
+    "lvk_hip_sync": (_c.c_int, [_P]),
+    "lvk_hip_stream": (_P, [_P]),
+    "lvk_hip_last_error": (_c.c_char_p, [_P]),
+    "lvk_hip_version": (_c.c_char_p, []),
+    "lvk_hip_malloc": (_c.c_int, [_P, _c.c_size_t, _c.POINTER(_P)]),
+    "lvk_hip_free": (_c.c_int, [_P, _P]),
+    "lvk_hip_upload": (_c.c_int, [_P, _P, _P, _c.c_size_t]),
+    "lvk_hip_download": (_c.c_int, [_P, _P, _P, _c.c_size_t]),
+    "lvk_hip_remap_homography": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int,
+                                            _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _c.POINTER(_c.c_uint8), _c.c_int]),
+    "lvk_hip_remap_mesh": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
+                                      _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
+    "lvk_hip_warpmesh_apply": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
+                                          _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
+}
+
+_lib = None
+
+
+def symbols():
+    return sorted(_SIG.keys())
+
+
+def load():
+    """Load liblvk_hip.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C livevisionkit_amd/csrc`). There is no CPU fallback.")
+    import torch  # noqa: F401  (loads the process-wide HIP runtime first)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in _SIG.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

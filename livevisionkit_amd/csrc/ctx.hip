@@ -1,0 +1,172 @@
+// Context, stream, staging and memory helpers of liblvk_hip.so.
+// Replaces the implicit cv::ocl context/queue the reference relies on
+// (reference: LiveVisionKit/Functions/OpenCL/Kernels.cpp:27-45, Timing/Stopwatch.cpp:127-131).
+#include "lvk_hip_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <tuple>
+#include <algorithm>
+
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+const char* lvk_hip_version(void) { return "lvk-hip 0.1 (gfx950)"; }
+
+int lvk_hip_ctx_create(int device, void* stream, lvk_hip_ctx** out)
+{
+    if (!out) { g_create_error = "out == NULL"; return LVK_HIP_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+    {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return LVK_HIP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { g_create_error = "device index out of range"; return LVK_HIP_ERR_ARG; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return LVK_HIP_ERR_RUNTIME; }
+
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return LVK_HIP_ERR_RUNTIME; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return LVK_HIP_ERR_NO_DEVICE;
+    }
+
+    auto* ctx = new lvk_hip_ctx();
+    ctx->device = device;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
+    else
+    {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        { g_create_error = hipGetErrorString(e); delete ctx; return LVK_HIP_ERR_RUNTIME; }
+        ctx->owns_stream = true;
+    }
+    const size_t total = lvk_hip_ctx::kStageSlots * lvk_hip_ctx::kStageBytes;
+    if ((e = hipHostMalloc((void**)&ctx->stage_host, total, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->stage_dev, total)) != hipSuccess)
+    { g_create_error = hipGetErrorString(e); lvk_hip_ctx_destroy(ctx); return LVK_HIP_ERR_RUNTIME; }
+    for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++)
+        if ((e = hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming)) != hipSuccess)
+        { g_create_error = hipGetErrorString(e); lvk_hip_ctx_destroy(ctx); return LVK_HIP_ERR_RUNTIME; }
+    *out = ctx;
+    return LVK_HIP_OK;
+}
+
+void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->lintabs) (void)hipFree(kv.second);
+    for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+    if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+    if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int lvk_hip_sync(lvk_hip_ctx* ctx)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVK_HIP_OK;
+}
+
+void* lvk_hip_stream(lvk_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+const char* lvk_hip_last_error(lvk_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int lvk_hip_malloc(lvk_hip_ctx* ctx, size_t bytes, void** d_ptr)
+{
+    if (!ctx || !d_ptr) return LVK_HIP_ERR_ARG;
+    LVK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LVK_HIP_CHECK(ctx, hipMalloc(d_ptr, bytes));
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_CHECK(ctx, hipFree(d_ptr));
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_upload(lvk_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_download(lvk_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return LVK_HIP_OK;
+}
+
+} // extern "C"
+
+int lvk_stage_params(lvk_hip_ctx* ctx, const void* host, size_t bytes, void** d_out)
+{
+    LVK_HIP_REQUIRE(ctx, bytes <= lvk_hip_ctx::kStageBytes);
+    const int slot = ctx->stage_next;
+    ctx->stage_next = (slot + 1) % lvk_hip_ctx::kStageSlots;
+    // The slot's previous copy must have been consumed by the device before the host bytes are rewritten.
+    LVK_HIP_CHECK(ctx, hipEventSynchronize(ctx->stage_done[slot]));
+    uint8_t* h = ctx->stage_host + (size_t)slot * lvk_hip_ctx::kStageBytes;
+    uint8_t* d = ctx->stage_dev + (size_t)slot * lvk_hip_ctx::kStageBytes;
+    std::memcpy(h, host, bytes);
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LVK_HIP_CHECK(ctx, hipEventRecord(ctx->stage_done[slot], ctx->stream));
+    *d_out = d;
+    return LVK_HIP_OK;
+}
+
+// cv::resize(..., INTER_LINEAR) source index / weight table for float data (OpenCV 4.8 resize.cpp; the call is
+// Math/WarpMesh.cpp:190).  Columns clamp (sx, fx) at the edges and use a single tap beyond xmax; rows keep
+// (1-fy, fy) and clip the two row indices.  Depends only on the two extents, so it is built once and cached.
+int lvk_get_lintab(lvk_hip_ctx* ctx, int msize, int fsize, bool vertical, const LinTabEntry** d_out)
+{
+    const auto key = std::make_tuple(msize, fsize, vertical ? 1 : 0);
+    auto it = ctx->lintabs.find(key);
+    if (it != ctx->lintabs.end()) { *d_out = it->second; return LVK_HIP_OK; }
+
+    std::vector<LinTabEntry> tab((size_t)fsize);
+    const double scale = 1.0 / ((double)fsize / (double)msize);
+    for (int d = 0; d < fsize; d++)
+    {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        LinTabEntry e;
+        if (vertical)
+        {
+            e.s0 = std::min(std::max(s, 0), msize - 1);
+            e.s1 = std::min(std::max(s + 1, 0), msize - 1);
+            e.a0 = 1.0f - f;
+            e.a1 = f;
+        }
+        else
+        {
+            if (s < 0) { f = 0.0f; s = 0; }
+            bool single = false;
+            if (s + 1 >= msize) { single = true; if (s >= msize - 1) { f = 0.0f; s = msize - 1; } }
+            e.s0 = s;
+            e.s1 = single ? s : s + 1;
+            e.a0 = single ? 1.0f : 1.0f - f;
+            e.a1 = single ? 0.0f : f;
+        }
+        tab[(size_t)d] = e;
+    }
+    LinTabEntry* d_tab = nullptr;
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_tab, tab.size() * sizeof(LinTabEntry)));
+    LVK_HIP_CHECK(ctx, hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(LinTabEntry), hipMemcpyHostToDevice));
+    ctx->lintabs[key] = d_tab;
+    *d_out = d_tab;
+    return LVK_HIP_OK;
+}

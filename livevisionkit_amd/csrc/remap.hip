@@ -1,0 +1,430 @@
+// Dense frame remap for gfx950: the EASU (edge adaptive, 12-tap) resampler driven either by a 3x3
+// homography or by a warp mesh that is interpolated inside the kernel.
+//
+// Replaces lvk::remap x2 (reference: LiveVisionKit/Functions/Image.cpp:28-151) and the OpenCL kernels
+// easu_remap / easu_remap_homography (LiveVisionKit/Functions/OpenCL/Sources/FSR.cl:362-452) including
+// WarpMesh::apply's map construction (LiveVisionKit/Math/WarpMesh.cpp:183-223).
+//
+// Arithmetic contract (must stay in lock-step with the specification the tests check against):
+// binary32 IEEE ops, no implicit contraction (the file is compiled with -ffp-contract=off), fused
+// multiply-adds exactly where written as fma(), correctly rounded division.
+//
+// Work decomposition: a thread produces PXT horizontally adjacent output pixels so that the packed
+// 3-byte pixels leave as aligned dwords; a 256-thread block covers a (64*PXT) x 4 output tile.
+#include "lvk_hip_internal.hpp"
+
+#include <cstring>
+#include <cmath>
+
+namespace {
+
+constexpr int PXT = 4;          // output pixels per thread (4 px * 3 B = 3 aligned dwords)
+constexpr int BLOCK_X = 64;     // threads along x  -> tile width  = 256 px
+constexpr int BLOCK_Y = 4;      // threads along y  -> tile height = 4 rows
+
+struct HomographyArgs { float h[9]; };
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ float rcp_lo(float a) { return __uint_as_float(0x7ef07ebbu - __float_as_uint(a)); }   // FSR.cl:65
+__device__ __forceinline__ float rsq_lo(float a) { return __uint_as_float(0x5f347d74u - (__float_as_uint(a) >> 1)); } // FSR.cl:60
+__device__ __forceinline__ float sat_(float x) { return max_(0.0f, min_(1.0f, x)); }                             // FSR.cl:79
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 unpack3(uint32_t lo_bytes)   // bytes 0,1,2 of the dword
+{
+    const float norm_factor = 0.00392156862f;               // FSR.cl:205
+    F3 r;
+    r.x = (float)(lo_bytes & 0xffu) * norm_factor;
+    r.y = (float)((lo_bytes >> 8) & 0xffu) * norm_factor;
+    r.z = (float)((lo_bytes >> 16) & 0xffu) * norm_factor;
+    return r;
+}
+
+template <bool YUV>
+__device__ __forceinline__ float luma(const F3& p)
+{
+    // FSR.cl:229-241 (the YUV program is the one that uses the 3-channel pseudo luma)
+    return YUV ? fma_(p.z, 0.5f, fma_(p.x, 0.5f, p.y)) : p.x;
+}
+
+__device__ __forceinline__ void accumulate(float& dirx, float& diry, float& len, float w,
+                                           float lA, float lB, float lC, float lD, float lE)
+{
+    // FSR.cl:131-176
+    const float dc = lD - lC, cb = lC - lB;
+    float lenX = rcp_lo(max_(abs_(dc), abs_(cb)));
+    const float dirX = lD - lB;
+    dirx = fma_(dirX, w, dirx);
+    lenX = sat_(abs_(dirX) * lenX);
+    lenX *= lenX;
+    len = fma_(lenX, w, len);
+    const float ec = lE - lC, ca = lC - lA;
+    float lenY = rcp_lo(max_(abs_(ec), abs_(ca)));
+    const float dirY = lE - lA;
+    diry = fma_(dirY, w, diry);
+    lenY = sat_(abs_(dirY) * lenY);
+    lenY *= lenY;
+    len = fma_(lenY, w, len);
+}
+
+__device__ __forceinline__ void tap(F3& aC, float& aW, float offx, float offy, float dirx, float diry,
+                                    float lenx, float leny, float lob, float clp, const F3& c)
+{
+    // FSR.cl:98-126
+    float vx = fma_(offx, dirx, offy * diry);
+    float vy = fma_(offx, -diry, offy * dirx);
+    vx *= lenx;
+    vy *= leny;
+    const float d2 = min_(fma_(vx, vx, vy * vy), clp);
+    float wA = fma_(lob, d2, -1.0f);
+    float wB = fma_(2.0f / 5.0f, d2, -1.0f);
+    wA *= wA;
+    wB = fma_(25.0f / 16.0f, wB * wB, -(25.0f / 16.0f - 1.0f));
+    const float w = wB * wA;
+    aC.x = fma_(c.x, w, aC.x);
+    aC.y = fma_(c.y, w, aC.y);
+    aC.z = fma_(c.z, w, aC.z);
+    aW += w;
+}
+
+// Unaligned little-endian loads straight from global memory (gfx950 runs in unaligned access mode;
+// these lower to single global_load_dwordx{2,4}).
+struct __attribute__((packed, aligned(1))) U16B { uint32_t w[4]; };
+struct __attribute__((packed, aligned(1))) U8B { uint32_t w[2]; };
+
+__device__ __forceinline__ uint32_t byte_window(uint32_t lo, uint32_t hi, int shift_bytes)
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * shift_bytes));
+}
+
+// FSR.cl:181-318.  Returns the output pixel as 0x00ZZYYXX.
+template <bool YUV>
+__device__ __forceinline__ uint32_t easu(const uint8_t* __restrict__ src, int step, int sx, int sy, float ppx, float ppy)
+{
+    const uint8_t* r0p = src + (long)(sy - 1) * step + 3 * sx;      // b, c        (8 bytes read, 6 used)
+    const uint8_t* r1p = r0p + step - 3;                            // e, f, g, h  (16 bytes read, 12 used)
+    const uint8_t* r2p = r1p + step;                                // i, j, k, l
+    const uint8_t* r3p = r0p + 3 * (long)step;                      // n, o
+    const U8B r0 = *reinterpret_cast<const U8B*>(r0p);
+    const U16B r1 = *reinterpret_cast<const U16B*>(r1p);
+    const U16B r2 = *reinterpret_cast<const U16B*>(r2p);
+    const U8B r3 = *reinterpret_cast<const U8B*>(r3p);
+
+    const F3 b = unpack3(r0.w[0]), c = unpack3(byte_window(r0.w[0], r0.w[1], 3));
+    const F3 e = unpack3(r1.w[0]), f = unpack3(byte_window(r1.w[0], r1.w[1], 3));
+    const F3 g = unpack3(byte_window(r1.w[1], r1.w[2], 2)), h = unpack3(byte_window(r1.w[2], 0u, 1));
+    const F3 i = unpack3(r2.w[0]), j = unpack3(byte_window(r2.w[0], r2.w[1], 3));
+    const F3 k = unpack3(byte_window(r2.w[1], r2.w[2], 2)), l = unpack3(byte_window(r2.w[2], 0u, 1));
+    const F3 n = unpack3(r3.w[0]), o = unpack3(byte_window(r3.w[0], r3.w[1], 3));
+
+    const float bL = luma<YUV>(b), cL = luma<YUV>(c), eL = luma<YUV>(e), fL = luma<YUV>(f), gL = luma<YUV>(g), hL = luma<YUV>(h);
+    const float iL = luma<YUV>(i), jL = luma<YUV>(j), kL = luma<YUV>(k), lL = luma<YUV>(l), nL = luma<YUV>(n), oL = luma<YUV>(o);
+
+    // FSR.cl:244-249
+    float len = 0.0f, dirx = 0.0f, diry = 0.0f;
+    const float omx = 1.0f - ppx, omy = 1.0f - ppy;
+    accumulate(dirx, diry, len, omx * omy, bL, eL, fL, gL, jL);
+    accumulate(dirx, diry, len, ppx * omy, cL, fL, gL, hL, kL);
+    accumulate(dirx, diry, len, omx * ppy, fL, iL, jL, kL, nL);
+    accumulate(dirx, diry, len, ppx * ppy, gL, jL, kL, lL, oL);
+
+    // FSR.cl:252-258
+    float dirR = fma_(dirx, dirx, diry * diry);
+    const bool zro = dirR < (1.0f / 32768.0f);
+    dirR = rsq_lo(dirR);
+    dirR = zro ? 1.0f : dirR;
+    dirx = zro ? 1.0f : dirx;
+    dirx *= dirR;
+    diry *= dirR;
+
+    // FSR.cl:261-277
+    len = len * 0.5f;
+    len *= len;
+    const float stretch = fma_(dirx, dirx, diry * diry) * rcp_lo(max_(abs_(dirx), abs_(diry)));
+    const float len2x = fma_(stretch - 1.0f, len, 1.0f);
+    const float len2y = fma_(-0.5f, len, 1.0f);
+    const float lob = fma_((1.0f / 4.0f - 0.04f) - 0.5f, len, 0.5f);
+    const float clp = rcp_lo(lob);
+
+    // FSR.cl:284-296
+    const F3 mi4{ min_(f.x, min_(g.x, min_(j.x, k.x))), min_(f.y, min_(g.y, min_(j.y, k.y))), min_(f.z, min_(g.z, min_(j.z, k.z))) };
+    const F3 ma4{ max_(f.x, max_(g.x, max_(j.x, k.x))), max_(f.y, max_(g.y, max_(j.y, k.y))), max_(f.z, max_(g.z, max_(j.z, k.z))) };
+
+    // FSR.cl:299-313
+    F3 aC{0.0f, 0.0f, 0.0f};
+    float aW = 0.0f;
+    tap(aC, aW,  0.0f - ppx, -1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, b);
+    tap(aC, aW,  1.0f - ppx, -1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, c);
+    tap(aC, aW, -1.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, i);
+    tap(aC, aW,  0.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, j);
+    tap(aC, aW,  0.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, f);
+    tap(aC, aW, -1.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, e);
+    tap(aC, aW,  1.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, k);
+    tap(aC, aW,  2.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, l);
+    tap(aC, aW,  2.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, h);
+    tap(aC, aW,  1.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, g);
+    tap(aC, aW,  0.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, n);
+    tap(aC, aW,  1.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, o);
+
+    // FSR.cl:316-317
+    const float rW = 1.0f / aW;
+    const float px = min_(ma4.x, max_(mi4.x, aC.x * rW));
+    const float py = min_(ma4.y, max_(mi4.y, aC.y * rW));
+    const float pz = min_(ma4.z, max_(mi4.z, aC.z * rW));
+    const uint32_t ux = (uint32_t)(int)(px * 255.0f) & 0xffu;
+    const uint32_t uy = (uint32_t)(int)(py * 255.0f) & 0xffu;
+    const uint32_t uz = (uint32_t)(int)(pz * 255.0f) & 0xffu;
+    return ux | (uy << 8) | (uz << 16);
+}
+
+// Shared tail of FSR.cl:380-402 / 429-451.  Returns the pixel as 0x00ZZYYXX.
+template <bool YUV>
+__device__ __forceinline__ uint32_t remap_pixel(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                                                float subx, float suby, uint32_t bg)
+{
+    const int sx = (int)subx;                 // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+    const int sy = (int)suby;
+    const float ppx = subx - __builtin_floorf(subx);
+    const float ppy = suby - __builtin_floorf(suby);
+    if (sx < 1 || sy < 1 || sx >= src_cols - 4 || sy >= src_rows - 4)
+    {
+        if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)
+        {
+            const uint8_t* s = src + (long)sy * src_step + 3 * sx;
+            return (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+        }
+        return bg;
+    }
+    return easu<YUV>(src, src_step, sx, sy, ppx, ppy);
+}
+
+__device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
+{
+    if (npx == PXT && aligned)
+    {
+        // 4 packed pixels = 12 bytes = 3 dwords
+        uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);
+        d[0] = px[0] | (px[1] << 24);
+        d[1] = (px[1] >> 8) | (px[2] << 16);
+        d[2] = (px[2] >> 16) | (px[3] << 8);
+    }
+    else
+    {
+        for (int p = 0; p < npx; p++)
+        {
+            uint8_t* d = drow + 3 * (x0 + p);
+            d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16);
+        }
+    }
+}
+
+template <bool YUV>
+__global__ __launch_bounds__(BLOCK_X * BLOCK_Y)
+void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                        uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
+                        int off_x, int off_y, HomographyArgs H, uint32_t bg)
+{
+    const int x0 = (blockIdx.x * BLOCK_X + threadIdx.x) * PXT;
+    const int y = blockIdx.y * BLOCK_Y + threadIdx.y;
+    if (x0 >= dst_cols || y >= dst_rows) return;
+    const int npx = min(PXT, dst_cols - x0);
+    const float fy = (float)y;
+    uint32_t px[PXT];
+#pragma unroll
+    for (int p = 0; p < PXT; p++)
+    {
+        px[p] = 0;
+        if (p < npx)
+        {
+            // FSR.cl:422-430
+            const float fx = (float)(x0 + p);
+            const float dz = 1.0f / fma_(H.h[6], fx, fma_(H.h[7], fy, H.h[8]));
+            const float ox = fma_(H.h[0], fx, fma_(H.h[1], fy, H.h[2])) * dz - fx;
+            const float oy = fma_(H.h[3], fx, fma_(H.h[4], fy, H.h[5])) * dz - fy;
+            const float subx = (float)(x0 + p + off_x) + ox;
+            const float suby = (float)(y + off_y) + oy;
+            px[p] = remap_pixel<YUV>(src, src_step, src_rows, src_cols, subx, suby, bg);
+        }
+    }
+    uint8_t* drow = dst + (long)y * dst_step;
+    store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
+}
+
+template <bool YUV>
+__global__ __launch_bounds__(BLOCK_X * BLOCK_Y)
+void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                  uint8_t* __restrict__ dst, int dst_step,
+                  const float* __restrict__ mesh, int mesh_cols,
+                  const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
+{
+    const int x0 = (blockIdx.x * BLOCK_X + threadIdx.x) * PXT;
+    const int y = blockIdx.y * BLOCK_Y + threadIdx.y;
+    if (x0 >= src_cols || y >= src_rows) return;
+    const int npx = min(PXT, src_cols - x0);
+    const LinTabEntry ty = ytab[y];
+    const float* __restrict__ m0 = mesh + (long)ty.s0 * mesh_cols * 2;
+    const float* __restrict__ m1 = mesh + (long)ty.s1 * mesh_cols * 2;
+    const float sw = (float)src_cols, sh = (float)src_rows;
+    uint32_t px[PXT];
+#pragma unroll
+    for (int p = 0; p < PXT; p++)
+    {
+        px[p] = 0;
+        if (p < npx)
+        {
+            // WarpMesh.cpp:190-191 evaluated per pixel: HResizeLinear then VResizeLinear on the float2 mesh, then * (cols, rows)
+            const LinTabEntry tx = xtab[x0 + p];
+            float off[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+            {
+                const float h0 = (tx.s1 == tx.s0) ? m0[2 * tx.s0 + ch] * 1.0f : m0[2 * tx.s0 + ch] * tx.a0 + m0[2 * tx.s1 + ch] * tx.a1;
+                const float h1 = (tx.s1 == tx.s0) ? m1[2 * tx.s0 + ch] * 1.0f : m1[2 * tx.s0 + ch] * tx.a0 + m1[2 * tx.s1 + ch] * tx.a1;
+                off[ch] = (h0 * ty.a0 + h1 * ty.a1) * (ch == 0 ? sw : sh);
+            }
+            const float subx = (float)(x0 + p) + off[0];      // FSR.cl:381
+            const float suby = (float)y + off[1];
+            px[p] = remap_pixel<YUV>(src, src_step, src_rows, src_cols, subx, suby, bg);
+        }
+    }
+    uint8_t* drow = dst + (long)y * dst_step;
+    store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
+}
+
+inline uint32_t pack_bg(const uint8_t bg[3]) { return (uint32_t)bg[0] | ((uint32_t)bg[1] << 8) | ((uint32_t)bg[2] << 16); }
+
+// cv::getPerspectiveTransform (OpenCV 4.8 imgproc; call site Math/WarpMesh.cpp:214): 8x8 double system,
+// LU with partial pivoting.  Maps src[i] -> dst[i].
+bool perspective_transform(const float src[8], const float dst[8], double M[9])
+{
+    double A[8][8], B[8];
+    for (int i = 0; i < 4; i++)
+    {
+        const double x = src[2 * i], y = src[2 * i + 1], u = dst[2 * i], v = dst[2 * i + 1];
+        A[i][0] = A[i + 4][3] = x;  A[i][1] = A[i + 4][4] = y;  A[i][2] = A[i + 4][5] = 1.0;
+        A[i][3] = A[i][4] = A[i][5] = A[i + 4][0] = A[i + 4][1] = A[i + 4][2] = 0.0;
+        A[i][6] = -x * u;  A[i][7] = -y * u;  A[i + 4][6] = -x * v;  A[i + 4][7] = -y * v;
+        B[i] = u;  B[i + 4] = v;
+    }
+    for (int i = 0; i < 8; i++)
+    {
+        int piv = i;
+        for (int j = i + 1; j < 8; j++) if (std::fabs(A[j][i]) > std::fabs(A[piv][i])) piv = j;
+        if (std::fabs(A[piv][i]) < 2.220446049250313e-16 * 100) return false;
+        if (piv != i) { for (int j = i; j < 8; j++) std::swap(A[i][j], A[piv][j]); std::swap(B[i], B[piv]); }
+        const double d = -1.0 / A[i][i];
+        for (int j = i + 1; j < 8; j++)
+        {
+            const double alpha = A[j][i] * d;
+            for (int q = i + 1; q < 8; q++) A[j][q] += alpha * A[i][q];
+            B[j] += alpha * B[i];
+        }
+    }
+    for (int i = 7; i >= 0; i--)
+    {
+        double s = B[i];
+        for (int q = i + 1; q < 8; q++) s -= A[i][q] * B[q];
+        B[i] = s / A[i][i];
+    }
+    for (int q = 0; q < 8; q++) M[q] = B[q];
+    M[8] = 1.0;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
+                             const void* d_src, int src_step, int src_rows, int src_cols,
+                             void* d_dst, int dst_step, int dst_rows, int dst_cols,
+                             int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    // Image.cpp:93-98
+    LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && H != nullptr && bg != nullptr);
+    LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0 && dst_cols > 0 && dst_rows > 0);
+    LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * dst_cols);
+    HomographyArgs args;
+    std::memcpy(args.h, H, sizeof(args.h));
+    const dim3 block(BLOCK_X, BLOCK_Y);
+    const dim3 grid((dst_cols + BLOCK_X * PXT - 1) / (BLOCK_X * PXT), (dst_rows + BLOCK_Y - 1) / BLOCK_Y);
+    if (yuv)
+        hipLaunchKernelGGL(k_remap_homography<true>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                           (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, pack_bg(bg));
+    else
+        hipLaunchKernelGGL(k_remap_homography<false>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                           (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, pack_bg(bg));
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
+                       const void* d_src, int src_step, int src_rows, int src_cols,
+                       void* d_dst, int dst_step,
+                       const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    // Image.cpp:30-34
+    LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && mesh != nullptr && bg != nullptr);
+    LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0);
+    LVK_HIP_REQUIRE(ctx, mesh_rows >= 2 && mesh_cols >= 2);           // WarpMesh::MinimumSize
+    LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * src_cols);
+    const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
+    LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
+
+    void* d_mesh = nullptr;
+    int rc = lvk_stage_params(ctx, mesh, mesh_bytes, &d_mesh);
+    if (rc != LVK_HIP_OK) return rc;
+    const LinTabEntry *xtab = nullptr, *ytab = nullptr;
+    if ((rc = lvk_get_lintab(ctx, mesh_cols, src_cols, false, &xtab)) != LVK_HIP_OK) return rc;
+    if ((rc = lvk_get_lintab(ctx, mesh_rows, src_rows, true, &ytab)) != LVK_HIP_OK) return rc;
+
+    const dim3 block(BLOCK_X, BLOCK_Y);
+    const dim3 grid((src_cols + BLOCK_X * PXT - 1) / (BLOCK_X * PXT), (src_rows + BLOCK_Y - 1) / BLOCK_Y);
+    if (yuv)
+        hipLaunchKernelGGL(k_remap_mesh<true>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                           (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
+    else
+        hipLaunchKernelGGL(k_remap_mesh<false>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                           (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
+                           const void* d_src, int src_step, int rows, int cols,
+                           void* d_dst, int dst_step,
+                           const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, mesh != nullptr && mesh_rows >= 2 && mesh_cols >= 2);
+    if (mesh_rows == 2 && mesh_cols == 2)
+    {
+        // WarpMesh.cpp:194-217: corners + offsets * (cols, rows) -> getPerspectiveTransform(destination, source)
+        const float w = (float)cols, h = (float)rows;
+        const float dstp[8] = { 0, 0, w, 0, 0, h, w, h };
+        float srcp[8];
+        for (int i = 0; i < 4; i++)
+        {
+            // Point2f * Scalar: float * double, rounded back to float (Functions/Extensions.cpp operator*(Point2f, Scalar))
+            const float mx = (float)((double)mesh[2 * i] * (double)cols);
+            const float my = (float)((double)mesh[2 * i + 1] * (double)rows);
+            srcp[2 * i] = dstp[2 * i] + mx;
+            srcp[2 * i + 1] = dstp[2 * i + 1] + my;
+        }
+        double M[9];
+        if (!perspective_transform(dstp, srcp, M))
+            for (int q = 0; q < 9; q++) M[q] = (q % 4 == 0) ? 1.0 : 0.0;
+        float H[9];
+        for (int q = 0; q < 9; q++) H[q] = (float)M[q];              // Image.cpp:137-139
+        return lvk_hip_remap_homography(ctx, d_src, src_step, rows, cols, d_dst, dst_step, rows, cols, 0, 0, H, bg, yuv);
+    }
+    return lvk_hip_remap_mesh(ctx, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
+}
+
+} // extern "C"

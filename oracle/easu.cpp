@@ -1,0 +1,415 @@
+// ORACLE (test infrastructure only -- see lvk_oracle.h).
+// CPU restatement of the reference's dense remap: Functions/OpenCL/Sources/FSR.cl:55-452 (kernels
+// easu_remap / easu_remap_homography and helpers), launched by Functions/Image.cpp:28-151 from
+// Math/WarpMesh.cpp:183-223.  Scalar, one output pixel at a time, in the reference's own order.
+//
+// Arithmetic definition (the reference is OpenCL C, where a*b+c may or may not be contracted and
+// native_recip is implementation defined, so the oracle fixes both):
+//   * every multiply-add that FSR.cl writes as `x * y + z` / `z + x * y` / `acc += x * y` is ONE fused
+//     fmaf (what an OpenCL compiler with FP_CONTRACT ON emits for a GPU); a sum of two products
+//     `a*b + c*d` is fmaf(a, b, c*d).  Everything else is a separately rounded binary32 op.
+//   * native_recip(x) and `1.0f / x` are the correctly rounded 1.0f / x.
+//   * convert_int2_rtz saturates (NaN -> 0); convert_uchar3 truncates (values are within [0,255]).
+//   * min/max are fminf/fmaxf.
+#include "lvk_oracle.h"
+
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+inline float as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// FSR.cl:60,65
+inline float APrxLoRsqF1(float a) { return as_float(0x5f347d74u - (as_uint(a) >> 1)); }
+inline float APrxLoRcpF1(float a) { return as_float(0x7ef07ebbu - as_uint(a)); }
+// FSR.cl:79
+inline float saturate(float x) { return fmaxf(0.0f, fminf(1.0f, x)); }
+
+struct F3 { float x, y, z; };
+
+// FSR.cl:98-126
+inline void easu_tap(F3& aC, float& aW, float offx, float offy, float dirx, float diry,
+                     float lenx, float leny, float lob, float clp, const F3& c)
+{
+    float vx = fmaf(offx, dirx, offy * diry);
+    float vy = fmaf(offx, -diry, offy * dirx);
+    vx *= lenx;
+    vy *= leny;
+    float d2 = fminf(fmaf(vx, vx, vy * vy), clp);
+    float wA = fmaf(lob, d2, -1.0f);
+    float wB = fmaf(2.0f / 5.0f, d2, -1.0f);
+    wA *= wA;
+    wB = fmaf(25.0f / 16.0f, wB * wB, -(25.0f / 16.0f - 1.0f));
+    float w = wB * wA;
+    aC.x = fmaf(c.x, w, aC.x);
+    aC.y = fmaf(c.y, w, aC.y);
+    aC.z = fmaf(c.z, w, aC.z);
+    aW += w;
+}
+
+// FSR.cl:131-176 (w is the bilinear weight selected by the biS/biT/biU/biV predicates)
+inline void easu_accumulate(float& dirx, float& diry, float& len, float w,
+                            float lA, float lB, float lC, float lD, float lE)
+{
+    float dc = lD - lC;
+    float cb = lC - lB;
+    float lenX = APrxLoRcpF1(fmaxf(fabsf(dc), fabsf(cb)));
+    float dirX = lD - lB;
+    dirx = fmaf(dirX, w, dirx);
+    lenX = saturate(fabsf(dirX) * lenX);
+    lenX *= lenX;
+    len = fmaf(lenX, w, len);
+
+    float ec = lE - lC;
+    float ca = lC - lA;
+    float lenY = APrxLoRcpF1(fmaxf(fabsf(ec), fabsf(ca)));
+    float dirY = lE - lA;
+    diry = fmaf(dirY, w, diry);
+    lenY = saturate(fabsf(dirY) * lenY);
+    lenY *= lenY;
+    len = fmaf(lenY, w, len);
+}
+
+inline F3 load_px(const uint8_t* p)
+{
+    const float norm_factor = 0.00392156862f;                         // FSR.cl:205
+    return F3{ (float)p[0] * norm_factor, (float)p[1] * norm_factor, (float)p[2] * norm_factor };
+}
+
+// FSR.cl:181-318.  (sx, sy) = src_coord, (ppx, ppy) = sub_pixel.
+inline void easu(const uint8_t* src, int step, int sx, int sy, float ppx, float ppy, bool yuv, uint8_t out[3])
+{
+    //      b c
+    //    e f g h
+    //    i j k l
+    //      n o
+    const uint8_t* r0 = src + (size_t)(sy - 1) * step + 3 * sx;        // b at (sx, sy-1)
+    const uint8_t* r1 = r0 + step - 3;                                // e at (sx-1, sy)
+    const uint8_t* r2 = r1 + step;                                    // i at (sx-1, sy+1)
+    const uint8_t* r3 = r0 + 3 * (size_t)step;                        // n at (sx, sy+2)
+
+    const F3 b = load_px(r0), c = load_px(r0 + 3);
+    const F3 e = load_px(r1), f = load_px(r1 + 3), g = load_px(r1 + 6), h = load_px(r1 + 9);
+    const F3 i = load_px(r2), j = load_px(r2 + 3), k = load_px(r2 + 6), l = load_px(r2 + 9);
+    const F3 n = load_px(r3), o = load_px(r3 + 3);
+
+    // FSR.cl:229-241 -- note the reference's inverted macro: the YUV program uses the 3-channel luma.
+    auto luma = [yuv](const F3& p) -> float {
+        return yuv ? fmaf(p.z, 0.5f, fmaf(p.x, 0.5f, p.y)) : p.x;
+    };
+    const float bL = luma(b), cL = luma(c), eL = luma(e), fL = luma(f), gL = luma(g), hL = luma(h);
+    const float iL = luma(i), jL = luma(j), kL = luma(k), lL = luma(l), nL = luma(n), oL = luma(o);
+
+    // FSR.cl:244-249
+    float len = 0.0f, dirx = 0.0f, diry = 0.0f;
+    const float omx = 1.0f - ppx, omy = 1.0f - ppy;
+    easu_accumulate(dirx, diry, len, omx * omy, bL, eL, fL, gL, jL);   // s
+    easu_accumulate(dirx, diry, len, ppx * omy, cL, fL, gL, hL, kL);   // t
+    easu_accumulate(dirx, diry, len, omx * ppy, fL, iL, jL, kL, nL);   // u
+    easu_accumulate(dirx, diry, len, ppx * ppy, gL, jL, kL, lL, oL);   // v
+
+    // FSR.cl:252-258
+    float dirR = fmaf(dirx, dirx, diry * diry);
+    const bool zro = dirR < (1.0f / 32768.0f);
+    dirR = APrxLoRsqF1(dirR);
+    dirR = zro ? 1.0f : dirR;
+    dirx = zro ? 1.0f : dirx;
+    dirx *= dirR;
+    diry *= dirR;
+
+    // FSR.cl:261-277
+    len = len * 0.5f;
+    len *= len;
+    const float stretch = fmaf(dirx, dirx, diry * diry) * APrxLoRcpF1(fmaxf(fabsf(dirx), fabsf(diry)));
+    const float len2x = fmaf(stretch - 1.0f, len, 1.0f);
+    const float len2y = fmaf(-0.5f, len, 1.0f);
+    const float lob = fmaf((1.0f / 4.0f - 0.04f) - 0.5f, len, 0.5f);
+    const float clp = APrxLoRcpF1(lob);
+
+    // FSR.cl:284-296  min/max of the 2x2 centre (f, g, j, k)
+    F3 mi4{ fminf(f.x, fminf(g.x, fminf(j.x, k.x))), fminf(f.y, fminf(g.y, fminf(j.y, k.y))), fminf(f.z, fminf(g.z, fminf(j.z, k.z))) };
+    F3 ma4{ fmaxf(f.x, fmaxf(g.x, fmaxf(j.x, k.x))), fmaxf(f.y, fmaxf(g.y, fmaxf(j.y, k.y))), fmaxf(f.z, fmaxf(g.z, fmaxf(j.z, k.z))) };
+
+    // FSR.cl:299-313 (tap order preserved)
+    F3 aC{0.0f, 0.0f, 0.0f};
+    float aW = 0.0f;
+    easu_tap(aC, aW,  0.0f - ppx, -1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, b);
+    easu_tap(aC, aW,  1.0f - ppx, -1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, c);
+    easu_tap(aC, aW, -1.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, i);
+    easu_tap(aC, aW,  0.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, j);
+    easu_tap(aC, aW,  0.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, f);
+    easu_tap(aC, aW, -1.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, e);
+    easu_tap(aC, aW,  1.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, k);
+    easu_tap(aC, aW,  2.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, l);
+    easu_tap(aC, aW,  2.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, h);
+    easu_tap(aC, aW,  1.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, g);
+    easu_tap(aC, aW,  0.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, n);
+    easu_tap(aC, aW,  1.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, o);
+
+    // FSR.cl:316-317
+    const float rW = 1.0f / aW;
+    const float px = fminf(ma4.x, fmaxf(mi4.x, aC.x * rW));
+    const float py = fminf(ma4.y, fmaxf(mi4.y, aC.y * rW));
+    const float pz = fminf(ma4.z, fmaxf(mi4.z, aC.z * rW));
+    out[0] = (uint8_t)(int)(px * 255.0f);
+    out[1] = (uint8_t)(int)(py * 255.0f);
+    out[2] = (uint8_t)(int)(pz * 255.0f);
+}
+
+inline int cvt_int_rtz_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int)(-2147483647 - 1);
+    return (int)v;   // C conversion truncates toward zero
+}
+
+// Shared tail of FSR.cl:380-402 / 429-451: given the source coordinate of one output pixel.
+inline void remap_pixel(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                        uint8_t* dpx, float subx, float suby, const uint8_t bg[3], bool yuv)
+{
+    const int sx = cvt_int_rtz_sat(subx);
+    const int sy = cvt_int_rtz_sat(suby);
+    const float ppx = subx - floorf(subx);
+    const float ppy = suby - floorf(suby);
+
+    if (sx < 1 || sy < 1 || sx >= src_cols - 4 || sy >= src_rows - 4)
+    {
+        if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)
+        {
+            const uint8_t* s = src + (size_t)sy * src_step + 3 * sx;
+            dpx[0] = s[0]; dpx[1] = s[1]; dpx[2] = s[2];
+        }
+        else { dpx[0] = bg[0]; dpx[1] = bg[1]; dpx[2] = bg[2]; }
+        return;
+    }
+    easu(src, src_step, sx, sy, ppx, ppy, yuv, dpx);
+}
+
+template <class Fn>
+void parallel_rows(int rows, int nthreads, Fn fn)
+{
+    if (nthreads <= 1 || rows < 2 * nthreads) { fn(0, rows); return; }
+    std::vector<std::thread> pool;
+    const int chunk = (rows + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; t++)
+    {
+        const int r0 = t * chunk, r1 = std::min(rows, r0 + chunk);
+        if (r0 >= r1) break;
+        pool.emplace_back([=] { fn(r0, r1); });
+    }
+    for (auto& th : pool) th.join();
+}
+
+// cv::resize(INTER_LINEAR) coordinate table on float data (OpenCV 4.8 imgproc resize.cpp):
+// fx = (float)((d + 0.5) * scale - 0.5); s = floor(fx); fx -= s; columns clamp (sx, fx) at the edges and use a
+// single tap beyond xmax; rows keep (1-fy, fy) and clip the two row indices instead.
+struct LinTab { std::vector<int> s0, s1; std::vector<float> a0, a1; };
+
+LinTab make_lintab(int ssize, int dsize, bool vertical)
+{
+    LinTab t; t.s0.resize(dsize); t.s1.resize(dsize); t.a0.resize(dsize); t.a1.resize(dsize);
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    for (int d = 0; d < dsize; d++)
+    {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(fx);
+        fx -= (float)s;
+        if (vertical)
+        {
+            // resizeGeneric_Invoker: beta = (1-fy, fy) unclamped; the two source rows are clipped
+            // individually: clip(sy, 0, h), clip(sy+1, 0, h).
+            t.s0[d] = std::min(std::max(s, 0), ssize - 1);
+            t.s1[d] = std::min(std::max(s + 1, 0), ssize - 1);
+            t.a0[d] = 1.0f - fx;
+            t.a1[d] = fx;
+            continue;
+        }
+        if (s < 0) { fx = 0.0f; s = 0; }
+        bool single = false;
+        if (s + 1 >= ssize)                      // sx + ksize2 >= ssize.width (ksize2 = 1): dx >= xmax
+        {
+            single = true;                       // HResizeLinear tail: D = S[sx] * 1
+            if (s >= ssize - 1) { fx = 0.0f; s = ssize - 1; }
+        }
+        t.s0[d] = s;
+        t.s1[d] = single ? s : s + 1;
+        t.a0[d] = single ? 1.0f : 1.0f - fx;
+        t.a1[d] = single ? 0.0f : fx;
+    }
+    return t;
+}
+
+} // namespace
+
+extern "C" {
+
+int lvko_remap_homography(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                          uint8_t* dst, int dst_step, int dst_rows, int dst_cols,
+                          int off_x, int off_y, const float H[9], const uint8_t bg[3],
+                          int yuv, int nthreads)
+{
+    if (!src || !dst || src_rows <= 0 || src_cols <= 0) return -1;
+    parallel_rows(dst_rows, nthreads, [=](int r0, int r1) {
+        for (int y = r0; y < r1; y++)
+        {
+            uint8_t* drow = dst + (size_t)y * dst_step;
+            for (int x = 0; x < dst_cols; x++)
+            {
+                // FSR.cl:422-427
+                const float fx = (float)x, fy = (float)y;
+                const float dz = 1.0f / fmaf(H[6], fx, fmaf(H[7], fy, H[8]));
+                const float ox = fmaf(H[0], fx, fmaf(H[1], fy, H[2])) * dz - fx;
+                const float oy = fmaf(H[3], fx, fmaf(H[4], fy, H[5])) * dz - fy;
+                // FSR.cl:430
+                const float subx = (float)(x + off_x) + ox;
+                const float suby = (float)(y + off_y) + oy;
+                remap_pixel(src, src_step, src_rows, src_cols, drow + 3 * x, subx, suby, bg, yuv != 0);
+            }
+        }
+    });
+    return 0;
+}
+
+void lvko_mesh_to_map(const float* mesh, int mesh_rows, int mesh_cols, int rows, int cols, float* map)
+{
+    // WarpMesh.cpp:190-191: resize(offsets, src.size, INTER_LINEAR_EXACT) then multiply by (cols, rows).
+    const LinTab tx = make_lintab(mesh_cols, cols, false), ty = make_lintab(mesh_rows, rows, true);
+    const float sw = (float)cols, sh = (float)rows;
+    for (int y = 0; y < rows; y++)
+    {
+        const float* m0 = mesh + (size_t)ty.s0[y] * mesh_cols * 2;
+        const float* m1 = mesh + (size_t)ty.s1[y] * mesh_cols * 2;
+        const float b0 = ty.a0[y], b1 = ty.a1[y];
+        for (int x = 0; x < cols; x++)
+        {
+            const int x0 = tx.s0[x], x1 = tx.s1[x];
+            const float a0 = tx.a0[x], a1 = tx.a1[x];
+            for (int ch = 0; ch < 2; ch++)
+            {
+                // HResizeLinear: D = S[sx]*alpha0 + S[sx+cn]*alpha1 (tail: S[sx]*1); VResizeLinear: S0*b0 + S1*b1
+                const float h0 = (x1 == x0) ? m0[2 * x0 + ch] * 1.0f : m0[2 * x0 + ch] * a0 + m0[2 * x1 + ch] * a1;
+                const float h1 = (x1 == x0) ? m1[2 * x0 + ch] * 1.0f : m1[2 * x0 + ch] * a0 + m1[2 * x1 + ch] * a1;
+                const float v = h0 * b0 + h1 * b1;
+                map[((size_t)y * cols + x) * 2 + ch] = v * (ch == 0 ? sw : sh);
+            }
+        }
+    }
+}
+
+int lvko_remap_mesh(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                    uint8_t* dst, int dst_step,
+                    const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                    int yuv, int nthreads)
+{
+    if (!src || !dst || !mesh || mesh_rows < 2 || mesh_cols < 2) return -1;
+    const LinTab tx = make_lintab(mesh_cols, src_cols, false), ty = make_lintab(mesh_rows, src_rows, true);
+    const float sw = (float)src_cols, sh = (float)src_rows;
+    parallel_rows(src_rows, nthreads, [&, sw, sh](int r0, int r1) {
+        for (int y = r0; y < r1; y++)
+        {
+            const float* m0 = mesh + (size_t)ty.s0[y] * mesh_cols * 2;
+            const float* m1 = mesh + (size_t)ty.s1[y] * mesh_cols * 2;
+            const float b0 = ty.a0[y], b1 = ty.a1[y];
+            uint8_t* drow = dst + (size_t)y * dst_step;
+            for (int x = 0; x < src_cols; x++)
+            {
+                const int x0 = tx.s0[x], x1 = tx.s1[x];
+                const float a0 = tx.a0[x], a1 = tx.a1[x];
+                float off[2];
+                for (int ch = 0; ch < 2; ch++)
+                {
+                    const float h0 = (x1 == x0) ? m0[2 * x0 + ch] * 1.0f : m0[2 * x0 + ch] * a0 + m0[2 * x1 + ch] * a1;
+                    const float h1 = (x1 == x0) ? m1[2 * x0 + ch] * 1.0f : m1[2 * x0 + ch] * a0 + m1[2 * x1 + ch] * a1;
+                    off[ch] = (h0 * b0 + h1 * b1) * (ch == 0 ? sw : sh);
+                }
+                // FSR.cl:381 (dst_bounds.xy == 0: the map is never an ROI on this path)
+                const float subx = (float)x + off[0];
+                const float suby = (float)y + off[1];
+                remap_pixel(src, src_step, src_rows, src_cols, drow + 3 * x, subx, suby, bg, yuv != 0);
+            }
+        }
+    });
+    return 0;
+}
+
+int lvko_get_perspective_transform(const float src[8], const float dst[8], double M[9])
+{
+    // OpenCV imgproc getPerspectiveTransform: rows i<4 [x y 1 0 0 0 -x*u -y*u | u], rows i+4 [0 0 0 x y 1 -x*v -y*v | v]
+    double A[8][8], B[8];
+    for (int i = 0; i < 4; i++)
+    {
+        const double x = src[2 * i], y = src[2 * i + 1], u = dst[2 * i], v = dst[2 * i + 1];
+        A[i][0] = A[i + 4][3] = x;
+        A[i][1] = A[i + 4][4] = y;
+        A[i][2] = A[i + 4][5] = 1.0;
+        A[i][3] = A[i][4] = A[i][5] = A[i + 4][0] = A[i + 4][1] = A[i + 4][2] = 0.0;
+        A[i][6] = -x * u; A[i][7] = -y * u;
+        A[i + 4][6] = -x * v; A[i + 4][7] = -y * v;
+        B[i] = u; B[i + 4] = v;
+    }
+    // LU with partial pivoting (cv::solve DECOMP_LU), double.
+    for (int i = 0; i < 8; i++)
+    {
+        int k = i;
+        for (int j = i + 1; j < 8; j++) if (std::fabs(A[j][i]) > std::fabs(A[k][i])) k = j;
+        if (std::fabs(A[k][i]) < 2.220446049250313e-16 * 100) { for (int q = 0; q < 9; q++) M[q] = (q % 4 == 0) ? 1.0 : 0.0; return -1; }
+        if (k != i) { for (int j = i; j < 8; j++) std::swap(A[i][j], A[k][j]); std::swap(B[i], B[k]); }
+        const double d = -1.0 / A[i][i];
+        for (int j = i + 1; j < 8; j++)
+        {
+            const double alpha = A[j][i] * d;
+            for (int q = i + 1; q < 8; q++) A[j][q] += alpha * A[i][q];
+            B[j] += alpha * B[i];
+        }
+    }
+    for (int i = 7; i >= 0; i--)
+    {
+        double s = B[i];
+        for (int q = i + 1; q < 8; q++) s -= A[i][q] * B[q];
+        B[i] = s / A[i][i];
+    }
+    for (int q = 0; q < 8; q++) M[q] = B[q];
+    M[8] = 1.0;
+    return 0;
+}
+
+int lvko_mesh2x2_to_homography(const float mesh[8], int rows, int cols, float H[9])
+{
+    // WarpMesh.cpp:185,197-214: destination corners, source = destination + offset * (cols, rows)
+    // (Point2f * Scalar: float * double -> rounded back to float, Extensions.cpp operator*(Point2f, Scalar)).
+    const float w = (float)cols, h = (float)rows;
+    const float dstp[8] = { 0, 0, w, 0, 0, h, w, h };
+    float srcp[8];
+    for (int i = 0; i < 4; i++)
+    {
+        const float mx = (float)((double)mesh[2 * i] * (double)cols);
+        const float my = (float)((double)mesh[2 * i + 1] * (double)rows);
+        srcp[2 * i] = dstp[2 * i] + mx;
+        srcp[2 * i + 1] = dstp[2 * i + 1] + my;
+    }
+    double M[9];
+    const int rc = lvko_get_perspective_transform(dstp, srcp, M);   // maps destination -> source
+    for (int q = 0; q < 9; q++) H[q] = (float)M[q];                 // Image.cpp:137-139
+    return rc;
+}
+
+int lvko_warpmesh_apply(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step,
+                        const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                        int yuv, int nthreads)
+{
+    if (mesh_rows == 2 && mesh_cols == 2)
+    {
+        float H[9];
+        lvko_mesh2x2_to_homography(mesh, rows, cols, H);
+        return lvko_remap_homography(src, src_step, rows, cols, dst, dst_step, rows, cols, 0, 0, H, bg, yuv, nthreads);
+    }
+    return lvko_remap_mesh(src, src_step, rows, cols, dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, nthreads);
+}
+
+} // extern "C"

@@ -1,0 +1,75 @@
+/*
+ * lvk_oracle.h -- CPU ORACLE for the LiveVisionKit stabilization hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library.  The product (livevisionkit_amd/, include/)
+ * never includes, links or calls anything in oracle/.
+ *
+ * What it is: a dependency-free CPU restatement of the reference algorithm for every stage on the
+ * path `lvk::StabilizationFilter::filter` (reference: LiveVisionKit/Filters/StabilizationFilter.cpp:69-135).
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ *
+ * PARITY STATUS: "parity unpinned".  The reference ships no tests, golden vectors or fixtures
+ * (SURVEY.md section 4), cannot be compiled here (needs OpenCV 4.8.0 + OpenCL + Eigen 3.4, none present)
+ * and most of the arithmetic lives in those absent third-party libraries.  The oracle is therefore
+ * pinned only against (a) hand-computable known-answer tests and (b) synthetic ground truth
+ * (tests/test_oracle_*.py).  Where the third-party library is not bit-defined (OpenCL fp contraction,
+ * USAC randomisation, SIMD summation order) the oracle DEFINES the arithmetic; the definitions are
+ * spelled out next to each function.
+ *
+ * Floating-point convention: all float math is IEEE-754 binary32 with round-to-nearest-even, compiled
+ * with -ffp-contract=off; every fused multiply-add in the specification is written explicitly as
+ * fmaf()/fma().  Division and sqrt are correctly rounded.
+ */
+#ifndef LVK_ORACLE_H
+#define LVK_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage a14-a16: dense frame remap (EASU).  Reference: Functions/OpenCL/Sources/FSR.cl:55-452,
+ * Functions/Image.cpp:28-151, Math/WarpMesh.cpp:183-223.
+ * Frames are packed 8UC3 (3 bytes / pixel), `step` = row pitch in bytes.
+ * `yuv` != 0 selects the program built with -D YUV_INPUT (Image.cpp:36-41), which -- reference quirk,
+ * FSR.cl:229-241 -- uses the 3-channel pseudo luma; `yuv` == 0 uses channel 0 as luma.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* FSR.cl:407-452 easu_remap_homography.  H = dst->src 3x3 (row major, already float: Image.cpp:137-139).
+ * (off_x, off_y) = dst_bounds.xy (ROI offset, Image.cpp:121-123); dst is dst_cols x dst_rows. */
+int lvko_remap_homography(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                          uint8_t* dst, int dst_step, int dst_rows, int dst_cols,
+                          int off_x, int off_y, const float H[9], const uint8_t bg[3],
+                          int yuv, int nthreads);
+
+/* FSR.cl:362-403 easu_remap with the per-pixel offset map of WarpMesh.cpp:190-191 evaluated on the
+ * fly: map = resize(mesh, dst size, INTER_LINEAR(_EXACT on f32 == INTER_LINEAR)) * (src_cols, src_rows).
+ * mesh = mesh_rows x mesh_cols x 2 floats (normalised backward offsets).  dst size == src size. */
+int lvko_remap_mesh(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                    uint8_t* dst, int dst_step,
+                    const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                    int yuv, int nthreads);
+
+/* Materialise the W x H x 2 offset map exactly as WarpMesh.cpp:190-191 would (for tests). */
+void lvko_mesh_to_map(const float* mesh, int mesh_rows, int mesh_cols, int rows, int cols, float* map);
+
+/* cv::getPerspectiveTransform (OpenCV 4.8 imgproc): 8x8 double system, LU with partial
+ * pivoting.  src/dst = 4 points (x0,y0,...).  M (row major 3x3, M[8] = 1) maps src -> dst. */
+int lvko_get_perspective_transform(const float src[8], const float dst[8], double M[9]);
+
+/* WarpMesh::apply (WarpMesh.cpp:183-223): 2x2 mesh -> homography branch, otherwise map branch. */
+int lvko_warpmesh_apply(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step,
+                        const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                        int yuv, int nthreads);
+
+/* 2x2 branch only: the float 3x3 the kernel receives (WarpMesh.cpp:197-214 + Image.cpp:137-139). */
+int lvko_mesh2x2_to_homography(const float mesh[8], int rows, int cols, float H[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,48 @@
+"""Deterministic synthetic frames for the tests and the bench (no external media)."""
+import numpy as np
+
+
+def textured_frame(rows, cols, seed=0x4C564B31, channels=3):
+    """Gratings + rectangles + noise: has FAST corners, edges for EASU and smooth chroma."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    img = np.zeros((rows, cols), np.float32)
+    for _ in range(12):
+        th = rng.uniform(0, np.pi)
+        f = rng.uniform(0.01, 0.15)
+        ph = rng.uniform(0, 2 * np.pi)
+        img += rng.uniform(4, 14) * np.sin((np.cos(th) * xx + np.sin(th) * yy) * f * 2 * np.pi + ph)
+    img += 128
+    nrect = max(20, rows * cols // 2500)
+    for _ in range(nrect):
+        h = int(rng.integers(4, max(5, rows // 6)))
+        w = int(rng.integers(4, max(5, cols // 6)))
+        y = int(rng.integers(0, rows - h))
+        x = int(rng.integers(0, cols - w))
+        img[y:y + h, x:x + w] = rng.uniform(10, 245)
+    img += rng.normal(0, 1.5, img.shape)
+    y8 = np.clip(img, 0, 255).astype(np.uint8)
+    if channels == 1:
+        return y8
+    out = np.empty((rows, cols, 3), np.uint8)
+    out[..., 0] = y8
+    out[..., 1] = np.clip(128 + 60 * np.sin(xx / cols * 5.0 + 0.3) + 20 * np.cos(yy / rows * 7.0), 0, 255).astype(np.uint8)
+    out[..., 2] = np.clip(128 + 50 * np.cos(xx / cols * 3.0 - yy / rows * 4.0), 0, 255).astype(np.uint8)
+    return out
+
+
+def random_homography(rows, cols, rng, strength=1.0):
+    """dst->src homography: small rotation/scale/shift/perspective about the frame centre."""
+    th = rng.uniform(-0.03, 0.03) * strength
+    s = 1.0 + rng.uniform(-0.04, 0.04) * strength
+    tx, ty = rng.uniform(-0.03, 0.03, 2) * strength * np.array([cols, rows])
+    cx, cy = cols / 2.0, rows / 2.0
+    c, si = np.cos(th) * s, np.sin(th) * s
+    A = np.array([[c, -si, cx - c * cx + si * cy + tx], [si, c, cy - si * cx - c * cy + ty], [0, 0, 1]], np.float64)
+    A[2, 0] = rng.uniform(-2e-5, 2e-5) * strength
+    A[2, 1] = rng.uniform(-2e-5, 2e-5) * strength
+    return A.astype(np.float32)
+
+
+def random_mesh(mrows, mcols, rng, amp=0.02):
+    return rng.uniform(-amp, amp, (mrows, mcols, 2)).astype(np.float32)
