@@ -37,8 +37,10 @@ typedef struct lvk_hip_ctx lvk_hip_ctx;
 
 /* ---- context ------------------------------------------------------------------------------------
  * Replaces the implicit OpenCL context/queue of cv::ocl (Functions/OpenCL/Kernels.cpp:27-45).
- * `stream` may be an existing hipStream_t (e.g. the caller's) or NULL to let the context create its own. */
-int  lvk_hip_ctx_create(int device, void* stream, lvk_hip_ctx** out);
+ * lvk_hip_ctx_create makes its own non-blocking stream; lvk_hip_ctx_create_on_stream enqueues on the caller's
+ * hipStream_t (NULL = the device's default stream) so the work is ordered with the caller's own GPU work. */
+int  lvk_hip_ctx_create(int device, lvk_hip_ctx** out);
+int  lvk_hip_ctx_create_on_stream(int device, void* hip_stream, lvk_hip_ctx** out);
 void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx);
 int  lvk_hip_sync(lvk_hip_ctx* ctx);                 /* Stopwatch::sync_gpu, Timing/Stopwatch.cpp:127-131 */
 void* lvk_hip_stream(lvk_hip_ctx* ctx);              /* the hipStream_t work is enqueued on */

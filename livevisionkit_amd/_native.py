@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "liblvk_hip.so")
 _c = ctypes
 _P = _c.c_void_p
 _SIG = {
-    "lvk_hip_ctx_create": (_c.c_int, [_c.c_int, _P, _c.POINTER(_P)]),
+    "lvk_hip_ctx_create": (_c.c_int, [_c.c_int, _c.POINTER(_P)]),
+    "lvk_hip_ctx_create_on_stream": (_c.c_int, [_c.c_int, _P, _c.POINTER(_P)]),
     "lvk_hip_ctx_destroy": (None, [_P]),
     "lvk_hip_sync": (_c.c_int, [_P]),
     "lvk_hip_stream": (_P, [_P]),

@@ -32,7 +32,8 @@ class Context:
         torch.cuda.set_device(device)
         self._torch_stream = stream if stream is not None else torch.cuda.current_stream(device)
         handle = ctypes.c_void_p()
-        rc = self.lib.lvk_hip_ctx_create(device, ctypes.c_void_p(self._torch_stream.cuda_stream), ctypes.byref(handle))
+        # enqueue on torch's stream so kernels are ordered with the tensors' producers/consumers
+        rc = self.lib.lvk_hip_ctx_create_on_stream(device, ctypes.c_void_p(self._torch_stream.cuda_stream), ctypes.byref(handle))
         if rc != 0:
             raise LvkHipError(f"lvk_hip_ctx_create failed ({rc}): {self.lib.lvk_hip_last_error(None).decode()}")
         self.handle = handle

@@ -14,7 +14,7 @@ extern "C" {
 
 const char* lvk_hip_version(void) { return "lvk-hip 0.1 (gfx950)"; }
 
-int lvk_hip_ctx_create(int device, void* stream, lvk_hip_ctx** out)
+static int ctx_create_impl(int device, bool own_stream, void* stream, lvk_hip_ctx** out)
 {
     if (!out) { g_create_error = "out == NULL"; return LVK_HIP_ERR_ARG; }
     *out = nullptr;
@@ -38,7 +38,7 @@ int lvk_hip_ctx_create(int device, void* stream, lvk_hip_ctx** out)
 
     auto* ctx = new lvk_hip_ctx();
     ctx->device = device;
-    if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
+    if (!own_stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
     else
     {
         if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
@@ -56,11 +56,15 @@ int lvk_hip_ctx_create(int device, void* stream, lvk_hip_ctx** out)
     return LVK_HIP_OK;
 }
 
+int lvk_hip_ctx_create(int device, lvk_hip_ctx** out) { return ctx_create_impl(device, true, nullptr, out); }
+
+int lvk_hip_ctx_create_on_stream(int device, void* hip_stream, lvk_hip_ctx** out) { return ctx_create_impl(device, false, hip_stream, out); }
+
 void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->lintabs) (void)hipFree(kv.second);
     for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);

@@ -1,0 +1,232 @@
+// ORACLE (test infrastructure only -- see lvk_oracle.h).
+// CPU restatement of the OpenCV 4.8.0 image operations the tracker calls (sources are NOT in /root/reference;
+// OpenCV is pinned by Scripts/setup_deb.sh:42).  Call sites:
+//   cv::extractChannel(YUV, 0)                    Data/VideoFrame.cpp:260
+//   cv::resize(..., INTER_AREA)                   Vision/FrameTracker.cpp:117
+//   pyrDown / Scharr derivatives                  inside cv::SparsePyrLKOpticalFlow::calc, Vision/FrameTracker.cpp:140-146
+//   cv::FastFeatureDetector(TYPE_9_16, nms=true)  Vision/FeatureDetector.cpp:38-41,130-134
+// Everything here is integer arithmetic except the non-integer INTER_AREA path (binary32, no contraction).
+#include "lvk_oracle.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+inline uint8_t sat_u8_round(float v)          // cv::saturate_cast<uchar>(float): cvRound (half to even) then clamp
+{
+    long r = lrintf(v);
+    return (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+inline int reflect101(int p, int len)        // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len)
+    {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+struct AreaTab { int di, si; float alpha; };
+
+// imgproc/resize.cpp computeResizeAreaTab
+std::vector<AreaTab> area_tab(int ssize, int dsize, double scale)
+{
+    std::vector<AreaTab> tab;
+    for (int dx = 0; dx < dsize; dx++)
+    {
+        const double fsx1 = dx * scale;
+        const double fsx2 = fsx1 + scale;
+        const double cellWidth = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3)
+            tab.push_back({dx, sx1 - 1, (float)((sx1 - fsx1) / cellWidth)});
+        for (int sx = sx1; sx < sx2; sx++)
+            tab.push_back({dx, sx, (float)(1.0 / cellWidth)});
+        if (fsx2 - sx2 > 1e-3)
+            tab.push_back({dx, sx2, (float)(std::min(std::min(fsx2 - sx2, 1.0), cellWidth) / cellWidth)});
+    }
+    return tab;
+}
+
+} // namespace
+
+extern "C" {
+
+// a3 + a4: gray = channel `channel` of a packed frame with `pix_stride` bytes per pixel (3 for 8UC3, 1 for planar),
+// then cv::resize(gray, dst, (dcols, drows), INTER_AREA).
+int lvko_luma_area_resize(const uint8_t* src, int src_step, int pix_stride, int channel, int srows, int scols,
+                          uint8_t* dst, int dst_step, int drows, int dcols)
+{
+    if (!src || !dst || srows <= 0 || scols <= 0 || drows <= 0 || dcols <= 0) return -1;
+    auto S = [&](int y, int x) -> int { return src[(size_t)y * src_step + (size_t)x * pix_stride + channel]; };
+    if (drows == srows && dcols == scols)
+    {
+        for (int y = 0; y < drows; y++) for (int x = 0; x < dcols; x++) dst[(size_t)y * dst_step + x] = (uint8_t)S(y, x);
+        return 0;
+    }
+    if (dcols > scols || drows > srows) return -2;           // the tracker only ever downscales (INTER_AREA upscale == linear; not on the path)
+    const double scale_x = (double)scols / dcols, scale_y = (double)srows / drows;
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    const bool fast = std::fabs(scale_x - iscale_x) < 2.220446049250313e-16 && std::fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (fast)
+    {
+        // resizeAreaFast_: integer box sum * (1.f / area), saturate_cast (round half to even);
+        // the 2x2 case uses the dedicated (a + b + c + d + 2) >> 2 vector kernel.
+        const int area = iscale_x * iscale_y;
+        const float scale = 1.f / (float)area;
+        for (int y = 0; y < drows; y++)
+            for (int x = 0; x < dcols; x++)
+            {
+                int sum = 0;
+                for (int ky = 0; ky < iscale_y; ky++)
+                    for (int kx = 0; kx < iscale_x; kx++)
+                        sum += S(y * iscale_y + ky, x * iscale_x + kx);
+                dst[(size_t)y * dst_step + x] = (iscale_x == 2 && iscale_y == 2) ? (uint8_t)((sum + 2) >> 2) : sat_u8_round((float)sum * scale);
+            }
+        return 0;
+    }
+    // resizeArea_: separable "decimate alpha" tables, float accumulation in table order.
+    const std::vector<AreaTab> xtab = area_tab(scols, dcols, scale_x), ytab = area_tab(srows, drows, scale_y);
+    std::vector<float> buf(dcols), sum(dcols, 0.0f);
+    int prev_dy = ytab.empty() ? 0 : ytab[0].di;
+    for (size_t j = 0; j < ytab.size(); j++)
+    {
+        const float beta = ytab[j].alpha;
+        const int dy = ytab[j].di, sy = ytab[j].si;
+        std::fill(buf.begin(), buf.end(), 0.0f);
+        for (const AreaTab& t : xtab) buf[t.di] = buf[t.di] + (float)S(sy, t.si) * t.alpha;
+        if (dy != prev_dy)
+        {
+            for (int dx = 0; dx < dcols; dx++) { dst[(size_t)prev_dy * dst_step + dx] = sat_u8_round(sum[dx]); sum[dx] = beta * buf[dx]; }
+            prev_dy = dy;
+        }
+        else
+            for (int dx = 0; dx < dcols; dx++) sum[dx] = sum[dx] + beta * buf[dx];
+    }
+    for (int dx = 0; dx < dcols; dx++) dst[(size_t)prev_dy * dst_step + dx] = sat_u8_round(sum[dx]);
+    return 0;
+}
+
+// cv::pyrDown (8UC1, BORDER_REFLECT_101): 5x5 [1 4 6 4 1] separable, (sum + 128) >> 8, dst = ((w+1)/2, (h+1)/2).
+int lvko_pyr_down(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step)
+{
+    const int drows = (rows + 1) / 2, dcols = (cols + 1) / 2;
+    for (int y = 0; y < drows; y++)
+        for (int x = 0; x < dcols; x++)
+        {
+            static const int w[5] = {1, 4, 6, 4, 1};
+            int acc = 0;
+            for (int ky = 0; ky < 5; ky++)
+            {
+                const uint8_t* row = src + (size_t)reflect101(2 * y - 2 + ky, rows) * src_step;
+                int h = 0;
+                for (int kx = 0; kx < 5; kx++) h += w[kx] * row[reflect101(2 * x - 2 + kx, cols)];
+                acc += w[ky] * h;
+            }
+            dst[(size_t)y * dst_step + x] = (uint8_t)((acc + 128) >> 8);
+        }
+    return 0;
+}
+
+// video/lkpyramid.cpp calcScharrDeriv: int16 (Ix, Iy) interleaved, REFLECT_101 at the image edge.
+int lvko_scharr_deriv(const uint8_t* src, int src_step, int rows, int cols, int16_t* dst /* rows*cols*2 */)
+{
+    std::vector<int> t0(cols + 2), t1(cols + 2);
+    for (int y = 0; y < rows; y++)
+    {
+        const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : rows > 1 ? 1 : 0) * src_step;
+        const uint8_t* r1 = src + (size_t)y * src_step;
+        const uint8_t* r2 = src + (size_t)(y < rows - 1 ? y + 1 : rows > 1 ? rows - 2 : 0) * src_step;
+        for (int x = 0; x < cols; x++)
+        {
+            t0[x + 1] = (int16_t)((r0[x] + r2[x]) * 3 + r1[x] * 10);
+            t1[x + 1] = (int16_t)(r2[x] - r0[x]);
+        }
+        const int x0 = cols > 1 ? 1 : 0, x1 = cols > 1 ? cols - 2 : 0;
+        t0[0] = t0[x0 + 1]; t0[cols + 1] = t0[x1 + 1];
+        t1[0] = t1[x0 + 1]; t1[cols + 1] = t1[x1 + 1];
+        for (int x = 0; x < cols; x++)
+        {
+            dst[((size_t)y * cols + x) * 2 + 0] = (int16_t)(t0[x + 2] - t0[x]);
+            dst[((size_t)y * cols + x) * 2 + 1] = (int16_t)((t1[x + 2] + t1[x]) * 3 + t1[x + 1] * 10);
+        }
+    }
+    return 0;
+}
+
+// features2d/fast.cpp FAST_t<16> + cornerScore<16> on an ROI of `img` (the ROI edge is the image edge).
+// Emits (x, y, score) in ROI-local coordinates, row-major (the CPU path's order).  Returns the count
+// (all of them are counted even when `cap` is smaller).
+int lvko_fast9_16(const uint8_t* img, int step, int roi_x, int roi_y, int roi_w, int roi_h, int threshold,
+                  int* out_xys /* 3 ints each */, int cap)
+{
+    static const int off[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+    threshold = std::min(std::max(threshold, 0), 255);
+    const uint8_t* base = img + (size_t)roi_y * step + roi_x;
+    std::vector<uint8_t> score((size_t)roi_w * roi_h, 0);
+    for (int i = 3; i < roi_h - 3; i++)
+        for (int j = 3; j < roi_w - 3; j++)
+        {
+            const uint8_t* p = base + (size_t)i * step + j;
+            const int v = p[0];
+            int d[25];
+            for (int k = 0; k < 25; k++) d[k] = v - p[off[k % 16][0] + off[k % 16][1] * step];
+            // corner test: > 8 contiguous ring pixels darker than v - t or brighter than v + t (strict)
+            bool corner = false;
+            int count = 0;
+            for (int k = 0; k < 25 && !corner; k++) { if (d[k] > threshold) { if (++count > 8) corner = true; } else count = 0; }
+            count = 0;
+            for (int k = 0; k < 25 && !corner; k++) { if (d[k] < -threshold) { if (++count > 8) corner = true; } else count = 0; }
+            if (!corner) continue;
+            // cornerScore<16>
+            int a0 = threshold;
+            for (int k = 0; k < 16; k += 2)
+            {
+                int a = std::min(d[k + 1], d[k + 2]);
+                a = std::min(a, d[k + 3]);
+                if (a <= a0) continue;
+                a = std::min(a, d[k + 4]); a = std::min(a, d[k + 5]); a = std::min(a, d[k + 6]); a = std::min(a, d[k + 7]); a = std::min(a, d[k + 8]);
+                a0 = std::max(a0, std::min(a, d[k]));
+                a0 = std::max(a0, std::min(a, d[k + 9]));
+            }
+            int b0 = -a0;
+            for (int k = 0; k < 16; k += 2)
+            {
+                int b = std::max(d[k + 1], d[k + 2]);
+                b = std::max(b, d[k + 3]); b = std::max(b, d[k + 4]); b = std::max(b, d[k + 5]);
+                if (b >= b0) continue;
+                b = std::max(b, d[k + 6]); b = std::max(b, d[k + 7]); b = std::max(b, d[k + 8]);
+                b0 = std::min(b0, std::max(b, d[k]));
+                b0 = std::min(b0, std::max(b, d[k + 9]));
+            }
+            score[(size_t)i * roi_w + j] = (uint8_t)(-b0 - 1);
+        }
+    // 3x3 non-max suppression: strictly greater than all 8 neighbours (non-corners score 0)
+    int n = 0;
+    for (int i = 3; i < roi_h - 3; i++)
+        for (int j = 3; j < roi_w - 3; j++)
+        {
+            const int s = score[(size_t)i * roi_w + j];
+            if (s == 0) continue;
+            const uint8_t* pp = &score[(size_t)(i - 1) * roi_w + j];
+            const uint8_t* pc = &score[(size_t)i * roi_w + j];
+            const uint8_t* pn = &score[(size_t)(i + 1) * roi_w + j];
+            if (s > pc[-1] && s > pc[1] && s > pp[-1] && s > pp[0] && s > pp[1] && s > pn[-1] && s > pn[0] && s > pn[1])
+            {
+                if (n < cap) { out_xys[3 * n] = j; out_xys[3 * n + 1] = i; out_xys[3 * n + 2] = s; }
+                n++;
+            }
+        }
+    return n;
+}
+
+} // extern "C"

@@ -69,6 +69,34 @@ int lvko_warpmesh_apply(const uint8_t* src, int src_step, int rows, int cols, ui
 /* 2x2 branch only: the float 3x3 the kernel receives (WarpMesh.cpp:197-214 + Image.cpp:137-139). */
 int lvko_mesh2x2_to_homography(const float mesh[8], int rows, int cols, float H[9]);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Stages a3-a7: tracker image operations (OpenCV 4.8.0 semantics; see oracle/imgproc.cpp, oracle/pyrlk.cpp).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* a3+a4: VideoFrame::viewAsFormat(GRAY) for YUV (= channel 0, Data/VideoFrame.cpp:260) fused with
+ * cv::resize(gray, T, INTER_AREA) (Vision/FrameTracker.cpp:117).  pix_stride = bytes per source pixel. */
+int lvko_luma_area_resize(const uint8_t* src, int src_step, int pix_stride, int channel, int srows, int scols,
+                          uint8_t* dst, int dst_step, int drows, int dcols);
+
+/* cv::pyrDown 8UC1, BORDER_REFLECT_101; dst is ((cols+1)/2) x ((rows+1)/2). */
+int lvko_pyr_down(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step);
+
+/* lkpyramid.cpp calcScharrDeriv: dst = rows x cols x (Ix, Iy) int16. */
+int lvko_scharr_deriv(const uint8_t* src, int src_step, int rows, int cols, int16_t* dst);
+
+/* a5 (inner): cv::FastFeatureDetector(threshold, nonmax=true, TYPE_9_16)->detect(img(roi)) (Vision/FeatureDetector.cpp:130-134).
+ * Output triplets (x, y, score) in ROI-local coordinates, row-major.  Returns the total count. */
+int lvko_fast9_16(const uint8_t* img, int step, int roi_x, int roi_y, int roi_w, int roi_h, int threshold,
+                  int* out_xys, int cap);
+
+/* a7: cv::SparsePyrLKOpticalFlow::calc (Vision/FrameTracker.cpp:140-146).  Returns the effective maxLevel. */
+int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next_step, int rows, int cols,
+               const float* prev_pts, int n, float* next_pts, uint8_t* status,
+               int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
+
+int lvko_pyramid_levels(int rows, int cols, int max_level, int win_w, int win_h, int* out_rows, int* out_cols);
+
 #ifdef __cplusplus
 }
 #endif

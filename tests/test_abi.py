@@ -35,7 +35,7 @@ def test_no_device_fails_loudly_not_silently():
     import livevisionkit_amd as lvk
     lib = _native.load()
     handle = ctypes.c_void_p()
-    rc = lib.lvk_hip_ctx_create(0, None, ctypes.byref(handle))
+    rc = lib.lvk_hip_ctx_create(0, ctypes.byref(handle))
     assert rc != 0 and handle.value is None
     assert b"device" in lib.lvk_hip_last_error(None).lower()
     with pytest.raises(Exception):

@@ -1,0 +1,162 @@
+"""CPU tests pinning the oracle's tracker image operations (INTER_AREA, pyrDown, Scharr, FAST-9/16, PyrLK) against
+known answers and independent numpy restatements of the OpenCV 4.8 semantics."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+
+def _round_half_even(x):
+    return np.rint(x)
+
+
+def test_area_resize_integer_scales_exact(oracle):
+    rng = np.random.default_rng(0)
+    for scale in (3, 4, 8):
+        src = rng.integers(0, 256, (scale * 9, scale * 13), dtype=np.uint8)
+        got = oracle.luma_area_resize(src, 9, 13)
+        s = src.reshape(9, scale, 13, scale).astype(np.int64).sum(axis=(1, 3))
+        want = _round_half_even((s.astype(np.float32) * np.float32(1.0 / (scale * scale))).astype(np.float32))
+        assert np.array_equal(got, want.astype(np.uint8))
+
+
+def test_area_resize_2x2_rounds_half_up(oracle):
+    src = np.array([[1, 2], [0, 0]], np.uint8).repeat(1, 0)          # sum 3 -> (3+2)>>2 = 1 ; 0.75 rounds to 1
+    assert oracle.luma_area_resize(src, 1, 1)[0, 0] == 1
+    src = np.array([[1, 1], [0, 0]], np.uint8)                         # sum 2 -> 0.5: (2+2)>>2 = 1 (half-even would give 0)
+    assert oracle.luma_area_resize(src, 1, 1)[0, 0] == 1
+
+
+def test_area_resize_packed_channel0_and_planar_agree(oracle):
+    frame = synth.textured_frame(64 * 4, 96 * 4, seed=3)
+    a = oracle.luma_area_resize(frame, 64, 96)
+    b = oracle.luma_area_resize(np.ascontiguousarray(frame[..., 0]), 64, 96)
+    assert np.array_equal(a, b)
+
+
+def test_area_resize_non_integer_matches_area_average(oracle):
+    """720p -> 480x270 (scale 2.667): decimate-alpha tables == exact box-area average up to float rounding."""
+    src = synth.textured_frame(720, 1280, seed=5, channels=1)
+    got = oracle.luma_area_resize(src, 270, 480).astype(np.float64)
+    # exact area average via integral image in float64
+    ii = np.zeros((721, 1281)); ii[1:, 1:] = src.astype(np.float64).cumsum(0).cumsum(1)
+    def integral_at(y, x):   # bilinear-free: exact for the piecewise constant image using fractional coverage
+        y0 = np.floor(y).astype(int); x0 = np.floor(x).astype(int)
+        fy = y - y0; fx = x - x0
+        y1 = np.minimum(y0 + 1, 720); x1 = np.minimum(x0 + 1, 1280)
+        return (ii[y0][:, x0] * np.outer(1 - fy, 1 - fx) + ii[y0][:, x1] * np.outer(1 - fy, fx)
+                + ii[y1][:, x0] * np.outer(fy, 1 - fx) + ii[y1][:, x1] * np.outer(fy, fx))
+    sy = np.arange(271) * (720 / 270); sx = np.arange(481) * (1280 / 480)
+    I = integral_at(sy, sx)
+    want = (I[1:, 1:] - I[:-1, 1:] - I[1:, :-1] + I[:-1, :-1]) / ((720 / 270) * (1280 / 480))
+    assert np.abs(got - want).max() <= 0.51
+
+
+def _np_pyr_down(img):
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    p = np.pad(img.astype(np.int64), 2, mode="reflect")
+    rows, cols = img.shape
+    dr, dc = (rows + 1) // 2, (cols + 1) // 2
+    h = sum(k[i] * p[:, i:i + 2 * dc:2][:, :dc] for i in range(5))
+    v = sum(k[i] * h[i:i + 2 * dr:2][:dr] for i in range(5))
+    return ((v + 128) >> 8).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(270, 480), (135, 240), (68, 120), (33, 47)])
+def test_pyr_down_matches_numpy(oracle, shape):
+    img = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(oracle.pyr_down(img), _np_pyr_down(img))
+
+
+def test_pyramid_level_sizes(oracle):
+    assert oracle.pyramid_levels(270, 480) == [(270, 480), (135, 240), (68, 120), (34, 60)]
+    assert oracle.pyramid_levels(256, 256) == [(256, 256), (128, 128), (64, 64), (32, 32)]
+    assert oracle.pyramid_levels(40, 40) == [(40, 40), (20, 20)]          # next level (10x10) <= window -> stop
+
+
+def test_scharr_matches_numpy(oracle):
+    img = np.random.default_rng(1).integers(0, 256, (37, 53), dtype=np.uint8)
+    p = np.pad(img.astype(np.int64), 1, mode="reflect")
+    t0 = 3 * (p[:-2] + p[2:]) + 10 * p[1:-1]            # vertical smooth   (rows x cols+2)
+    t1 = p[2:] - p[:-2]                                  # vertical diff
+    ix = t0[:, 2:] - t0[:, :-2]
+    iy = 3 * (t1[:, 2:] + t1[:, :-2]) + 10 * t1[:, 1:-1]
+    d = oracle.scharr_deriv(img)
+    assert np.array_equal(d[..., 0], ix.astype(np.int16)) and np.array_equal(d[..., 1], iy.astype(np.int16))
+
+
+def _brute_fast(img, t):
+    off = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    rows, cols = img.shape
+    score = np.zeros((rows, cols), np.int32)
+    im = img.astype(np.int32)
+    for y in range(3, rows - 3):
+        for x in range(3, cols - 3):
+            d = [im[y, x] - im[y + dy, x + dx] for dx, dy in off]
+            best = 0
+            for s in range(16):
+                arc = [d[(s + k) % 16] for k in range(9)]
+                best = max(best, min(arc), min(-a for a in arc))
+            if best > t:
+                score[y, x] = best - 1
+    out = []
+    for y in range(3, rows - 3):
+        for x in range(3, cols - 3):
+            s = score[y, x]
+            if s > 0:
+                nb = score[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = -1
+                if (s > nb).all():
+                    out.append((x, y, s))
+    return np.array(out, np.int32).reshape(-1, 3)
+
+
+def test_fast_matches_bruteforce_definition(oracle):
+    img = synth.textured_frame(48, 64, seed=9, channels=1)
+    for t in (10, 25, 60):
+        got = oracle.fast(img, t)
+        want = _brute_fast(img, t)
+        assert np.array_equal(got, want), (t, len(got), len(want))
+    assert len(oracle.fast(img, 10)) > 5
+
+
+def test_fast_roi_edge_is_image_edge(oracle):
+    img = synth.textured_frame(60, 80, seed=10, channels=1)
+    roi = (40, 0, 40, 60)
+    got = oracle.fast(img, 10, roi=roi)
+    want = _brute_fast(np.ascontiguousarray(img[:, 40:80]), 10)
+    assert np.array_equal(got, want)
+    assert got[:, 0].min() >= 3 and got[:, 0].max() <= 36
+
+
+def _smooth_scene(rows, cols, dx, dy):
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    xx = xx + dx; yy = yy + dy
+    v = (128 + 50 * np.sin(xx * 0.11 + 0.3) * np.cos(yy * 0.13) + 40 * np.sin((xx + 2 * yy) * 0.07)
+         + 30 * np.cos((xx - yy) * 0.05 + 1.0) + 15 * np.sin(xx * 0.31) * np.sin(yy * 0.29))
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shift", [(0.0, 0.0), (1.3, -0.7), (-3.6, 2.2), (6.5, 4.25)])
+def test_pyrlk_recovers_known_translation(oracle, shift):
+    rows, cols = 270, 480
+    prev = _smooth_scene(rows, cols, 0, 0)
+    nxt = _smooth_scene(rows, cols, -shift[0], -shift[1])          # content moves by +shift
+    rng = np.random.default_rng(2)
+    pts = np.c_[rng.uniform(30, cols - 30, 200), rng.uniform(30, rows - 30, 200)].astype(np.float32)
+    out, st = oracle.pyrlk(prev, nxt, pts)
+    ok = st == 1
+    assert ok.mean() > 0.95
+    err = np.abs(out[ok] - (pts[ok] + np.array(shift, np.float32)))
+    assert np.median(err) < 0.05 and np.percentile(err, 95) < 0.3
+
+
+def test_pyrlk_status_rules(oracle):
+    rows, cols = 135, 240
+    img = _smooth_scene(rows, cols, 0, 0)
+    flat = np.full((rows, cols), 77, np.uint8)
+    pts = np.array([[50, 50], [-20.0, 40.0], [239.9, 134.9], [500.0, 500.0]], np.float32)
+    out, st = oracle.pyrlk(img, img, pts)
+    assert st[0] == 1 and np.abs(out[0] - pts[0]).max() < 1e-3
+    assert st[1] == 0 and st[3] == 0                                # window origin left of -winSize / beyond the image
+    out, st = oracle.pyrlk(flat, flat, pts[:1])
+    assert st[0] == 0                                               # minEig below threshold on a flat patch
