@@ -80,6 +80,34 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
                            void* d_dst, int dst_step,
                            const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 
+/* ---- a3/a4: luma + INTER_AREA downscale ---------------------------------------------------------------
+ * VideoFrame::viewAsFormat(GRAY) for YUV frames (= channel 0, Data/VideoFrame.cpp:260) fused with
+ * cv::resize(gray, detection_resolution, INTER_AREA) (Vision/FrameTracker.cpp:117).
+ * pix_stride = bytes per source pixel (3 packed 8UC3, 1 planar); d_dst is 8UC1 drows x dcols. */
+int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
+                             int srows, int scols, void* d_dst, int dst_step, int drows, int dcols);
+
+/* ---- a7 (pyramid): cv::pyrDown and the Scharr derivative image that cv::SparsePyrLKOpticalFlow::calc builds
+ * internally (Vision/FrameTracker.cpp:140-146).  d_dst of pyr_down is ((cols+1)/2) x ((rows+1)/2) 8UC1;
+ * d_dst of scharr is rows x cols x (Ix, Iy) int16, tightly packed. */
+int lvk_hip_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
+int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
+
+/* ---- a5 (inner): FAST-9/16 + non-max suppression per detection region -----------------------------------
+ * cv::FastFeatureDetector(threshold, true, TYPE_9_16)->detect(frame(region)) (Vision/FeatureDetector.cpp:130-134).
+ * regions = nregions x {x, y, w, h, threshold, active} ints; out = nregions x cap keypoints packed as
+ * x | y << 12 | score << 24 (region-local, row-major like the CPU detector); counts = nregions totals.
+ * Synchronous (returns after the results are on the host). */
+int lvk_hip_fast_detect(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
+                        const int* regions, int nregions, uint32_t* out, int cap, int* counts);
+
+/* ---- a7: cv::SparsePyrLKOpticalFlow::calc(prev, next, prevPts, nextPts, status) -----------------------------
+ * (Vision/FrameTracker.cpp:42-48,140-146).  Device images of the tracking resolution, host point arrays
+ * (n x 2 floats), status n bytes.  Synchronous. */
+int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const void* d_next, int next_step, int rows, int cols,
+                  const float* prev_pts, int n, float* next_pts, uint8_t* status,
+                  int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
+
 #ifdef __cplusplus
 }
 #endif

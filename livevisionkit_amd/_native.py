@@ -31,6 +31,14 @@ _SIG = {
                                       _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
     "lvk_hip_warpmesh_apply": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                           _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
+    "lvk_hip_luma_area_resize": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int]),
+    "lvk_hip_pyr_down": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int]),
+    "lvk_hip_scharr": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "lvk_hip_fast_detect": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int,
+                                       _c.POINTER(_c.c_uint32), _c.c_int, _c.POINTER(_c.c_int)]),
+    "lvk_hip_pyrlk": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _c.c_int,
+                                 _c.POINTER(_c.c_float), _c.POINTER(_c.c_uint8), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                 _c.c_double, _c.c_double]),
 }
 
 _lib = None

@@ -98,3 +98,56 @@ class Context:
             self.handle, src.data_ptr(), src.stride(0), rows, cols, out.data_ptr(), out.stride(0),
             mp, m.shape[0], m.shape[1], bgp, 1 if yuv else 0))
         return out
+
+    # ---- a3/a4/a7 image ops --------------------------------------------------------------------------
+    def luma_area_resize(self, frame, drows, dcols, channel=0):
+        """frame: torch uint8 [rows, cols, 3] (packed) or [rows, cols] (planar) -> [drows, dcols] uint8."""
+        import torch
+        pix = frame.shape[2] if frame.dim() == 3 else 1
+        out = torch.empty((drows, dcols), dtype=torch.uint8, device=frame.device)
+        self._check(self.lib.lvk_hip_luma_area_resize(self.handle, frame.data_ptr(), frame.stride(0), pix, channel,
+                                                      frame.shape[0], frame.shape[1], out.data_ptr(), out.stride(0), drows, dcols))
+        return out
+
+    def pyr_down(self, img):
+        import torch
+        out = torch.empty(((img.shape[0] + 1) // 2, (img.shape[1] + 1) // 2), dtype=torch.uint8, device=img.device)
+        self._check(self.lib.lvk_hip_pyr_down(self.handle, img.data_ptr(), img.stride(0), img.shape[0], img.shape[1],
+                                              out.data_ptr(), out.stride(0)))
+        return out
+
+    def scharr(self, img):
+        import torch
+        out = torch.empty((img.shape[0], img.shape[1], 2), dtype=torch.int16, device=img.device)
+        self._check(self.lib.lvk_hip_scharr(self.handle, img.data_ptr(), img.stride(0), img.shape[0], img.shape[1], out.data_ptr()))
+        return out
+
+    # ---- a5 / a7 ----------------------------------------------------------------------------------------
+    def fast_detect(self, img, regions, cap=None):
+        """regions: list of (x, y, w, h, threshold, active). Returns a list of [n, 3] int32 (x, y, score) arrays, region-local."""
+        rg = np.ascontiguousarray(regions, dtype=np.int32).reshape(-1, 6)
+        n = rg.shape[0]
+        cap = cap or int(max(1, (rg[:, 2] * rg[:, 3]).max()))
+        out = np.zeros((n, cap), np.uint32)
+        counts = np.zeros(n, np.int32)
+        self._check(self.lib.lvk_hip_fast_detect(self.handle, img.data_ptr(), img.stride(0), img.shape[0], img.shape[1],
+                                                 rg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n,
+                                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cap,
+                                                 counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        res = []
+        for i in range(n):
+            e = out[i, :min(cap, counts[i])]
+            res.append(np.stack([e & 0xFFF, (e >> 12) & 0xFFF, e >> 24], axis=1).astype(np.int32))
+        return res, counts
+
+    def pyrlk(self, prev, nxt, pts, win=(11, 11), max_level=3, max_count=5, epsilon=0.01, min_eig=1e-4):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(pts)
+        st = np.zeros(len(pts), np.uint8)
+        self._check(self.lib.lvk_hip_pyrlk(self.handle, prev.data_ptr(), prev.stride(0), nxt.data_ptr(), nxt.stride(0),
+                                           prev.shape[0], prev.shape[1],
+                                           pts.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(pts),
+                                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                           st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                           win[0], win[1], max_level, max_count, float(epsilon), float(min_eig)))
+        return out, st

@@ -1,0 +1,215 @@
+// FAST-9/16 corner detection with 3x3 non-max suppression for gfx950, run per detection region.
+//
+// Replaces cv::FastFeatureDetector(threshold, nonmax=true, TYPE_9_16)->detect(frame(region.bounds)) as called by
+// FeatureDetector::detect (reference: LiveVisionKit/Vision/FeatureDetector.cpp:38-41,130-134; arithmetic: OpenCV 4.8.0
+// features2d/fast.cpp FAST_t<16> + cornerScore<16>).  Integer only -> bit-exact.
+//
+// Structure: k_fast_detect stages a (64+8) x (8+8) image tile (3-px ring apron + 1-px suppression apron) in LDS,
+// scores the tile plus its 1-px halo, suppresses non-maxima and emits one wave ballot per 64-pixel row segment.
+// k_fast_compact turns the ballots into the row-major keypoint list the CPU path would produce (the order is
+// load-bearing: it fixes feature indices downstream).
+#include "lvk_hip_internal.hpp"
+
+namespace {
+
+constexpr int TW = 64, TH = 8;              // output tile
+constexpr int AP = 4;                       // apron: 3 (ring radius) + 1 (NMS neighbourhood)
+constexpr int IW = TW + 2 * AP, IH = TH + 2 * AP;
+constexpr int SW = TW + 2, SH = TH + 2;     // score tile incl. 1-px halo
+
+__device__ __forceinline__ int fast_score(const uint8_t* c, int stride, int threshold)
+{
+    // ring offsets (dx, dy), radius 3, starting at (0, 3) -- fast.cpp makeOffsets
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * stride];          d[1] = v - c[1 + 3 * stride];   d[2] = v - c[2 + 2 * stride];   d[3] = v - c[3 + stride];
+    d[4] = v - c[3];                   d[5] = v - c[3 - stride];       d[6] = v - c[2 - 2 * stride];   d[7] = v - c[1 - 3 * stride];
+    d[8] = v - c[-3 * stride];         d[9] = v - c[-1 - 3 * stride];  d[10] = v - c[-2 - 2 * stride]; d[11] = v - c[-3 - stride];
+    d[12] = v - c[-3];                 d[13] = v - c[-3 + stride];     d[14] = v - c[-2 + 2 * stride]; d[15] = v - c[-1 + 3 * stride];
+    // best 9-arc: max over arcs of min(d) (darker ring) and of min(-d) (brighter ring), by doubling
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int dark = -256, bright_neg = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        dark = max(dark, lo9);
+        bright_neg = min(bright_neg, hi9);
+    }
+    const int m = max(dark, -bright_neg);
+    return m > threshold ? m - 1 : 0;       // cornerScore: (largest threshold at which it is still a corner)
+}
+
+__global__ __launch_bounds__(TW * TH)
+void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols,
+                   const FastRegion* __restrict__ regions, int segs_x,
+                   unsigned long long* __restrict__ masks, uint8_t* __restrict__ scores, int max_rh, int max_rw)
+{
+    const FastRegion rg = regions[blockIdx.z];
+    if (!rg.active) return;
+    const int lx0 = blockIdx.x * TW, ly0 = blockIdx.y * TH;
+    if (lx0 >= rg.w || ly0 >= rg.h) return;
+
+    __shared__ uint8_t s_img[IH][IW];
+    __shared__ uint8_t s_score[SH][SW];
+    const int tid = threadIdx.y * TW + threadIdx.x;
+
+    // stage the image tile (addresses clamped to the frame; out-of-region pixels are never used for a valid score)
+    for (int i = tid; i < IW * IH; i += TW * TH)
+    {
+        const int ty = i / IW, tx = i - ty * IW;
+        const int gx = min(max(rg.x + lx0 - AP + tx, 0), cols - 1);
+        const int gy = min(max(rg.y + ly0 - AP + ty, 0), rows - 1);
+        s_img[ty][tx] = img[(long)gy * step + gx];
+    }
+    __syncthreads();
+
+    // score the tile and its 1-px halo; positions whose ring leaves the region score 0 (the ROI edge is the image edge)
+    for (int i = tid; i < SW * SH; i += TW * TH)
+    {
+        const int ty = i / SW, tx = i - ty * SW;
+        const int lx = lx0 - 1 + tx, ly = ly0 - 1 + ty;
+        int s = 0;
+        if (lx >= 3 && lx < rg.w - 3 && ly >= 3 && ly < rg.h - 3)
+            s = fast_score(&s_img[ty + AP - 1][tx + AP - 1], IW, rg.threshold);
+        s_score[ty][tx] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    const int lx = lx0 + threadIdx.x, ly = ly0 + threadIdx.y;
+    const int sx = threadIdx.x + 1, sy = threadIdx.y + 1;
+    const int s = s_score[sy][sx];
+    const bool keep = s > 0 &&
+        s > s_score[sy][sx - 1] && s > s_score[sy][sx + 1] &&
+        s > s_score[sy - 1][sx - 1] && s > s_score[sy - 1][sx] && s > s_score[sy - 1][sx + 1] &&
+        s > s_score[sy + 1][sx - 1] && s > s_score[sy + 1][sx] && s > s_score[sy + 1][sx + 1];
+    const unsigned long long mask = __ballot(keep);
+    if (ly < rg.h)
+    {
+        if (threadIdx.x == 0) masks[((long)blockIdx.z * max_rh + ly) * segs_x + blockIdx.x] = mask;
+        if (keep) scores[((long)blockIdx.z * max_rh + ly) * max_rw + lx] = (uint8_t)s;
+    }
+}
+
+// One block per region: exclusive scan of the per-segment popcounts in row-major order, then ordered scatter.
+__global__ __launch_bounds__(1024)
+void k_fast_compact(const FastRegion* __restrict__ regions, int segs_x,
+                    const unsigned long long* __restrict__ masks, const uint8_t* __restrict__ scores, int max_rh, int max_rw,
+                    uint32_t* __restrict__ out, int cap, int* __restrict__ counts)
+{
+    const int r = blockIdx.x;
+    const FastRegion rg = regions[r];
+    if (!rg.active) { if (threadIdx.x == 0) counts[r] = 0; return; }
+    const int rsegs = (rg.w + TW - 1) / TW;
+    const int nseg = rg.h * rsegs;
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int chunk = 0; chunk < nseg; chunk += 1024)
+    {
+        const int seg = chunk + threadIdx.x;
+        int ly = 0, sg = 0;
+        unsigned long long m = 0;
+        if (seg < nseg)
+        {
+            ly = seg / rsegs; sg = seg - ly * rsegs;
+            m = masks[((long)r * max_rh + ly) * segs_x + sg];
+        }
+        const int cnt = __popcll(m);
+        // inclusive scan inside the wave
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+        int pos = s_base + wave_off + incl - cnt;
+        while (m)
+        {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int lx = sg * TW + bit;
+            if (pos < cap)
+                out[(long)r * cap + pos] = (uint32_t)lx | ((uint32_t)ly << 12) | ((uint32_t)scores[((long)r * max_rh + ly) * max_rw + lx] << 24);
+            pos++;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = s_base + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[r] = s_base;
+}
+
+} // namespace
+
+int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks_bytes, size_t* scores_bytes)
+{
+    const int segs_x = (max_rw + TW - 1) / TW;
+    *masks_bytes = (size_t)nregions * max_rh * segs_x * sizeof(unsigned long long);
+    *scores_bytes = (size_t)nregions * max_rh * max_rw;
+    return segs_x;
+}
+
+// Enqueues detection for `nregions` regions (device array d_regions).  d_out: nregions x cap packed keypoints
+// (x | y << 12 | score << 24, region-local), d_counts: nregions totals (may exceed cap; entries beyond cap are dropped).
+int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
+                    const FastRegion* d_regions, int nregions, int max_rw, int max_rh,
+                    void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts)
+{
+    LVK_HIP_REQUIRE(ctx, d_img && d_regions && nregions > 0 && max_rw > 0 && max_rh > 0 && max_rw < 4096 && max_rh < 4096);
+    const int segs_x = (max_rw + TW - 1) / TW;
+    const dim3 block(TW, TH), grid(segs_x, (max_rh + TH - 1) / TH, nregions);
+    hipLaunchKernelGGL(k_fast_detect, grid, block, 0, ctx->stream, (const uint8_t*)d_img, step, rows, cols, d_regions, segs_x,
+                       (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw);
+    hipLaunchKernelGGL(k_fast_compact, dim3(nregions), dim3(1024), 0, ctx->stream, d_regions, segs_x,
+                       (const unsigned long long*)d_masks, (const uint8_t*)d_scores, max_rh, max_rw, d_out, cap, d_counts);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+extern "C" {
+
+// Synchronous test entry point: regions = nregions x {x, y, w, h, threshold, active} ints (host); out = nregions x cap
+// packed keypoints (host), counts = nregions ints (host).
+int lvk_hip_fast_detect(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
+                        const int* regions, int nregions, uint32_t* out, int cap, int* counts)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, regions && out && counts && nregions > 0 && cap > 0);
+    std::vector<FastRegion> rg((size_t)nregions);
+    int max_rw = 1, max_rh = 1;
+    for (int i = 0; i < nregions; i++)
+    {
+        rg[i] = FastRegion{regions[6 * i], regions[6 * i + 1], regions[6 * i + 2], regions[6 * i + 3], regions[6 * i + 4], regions[6 * i + 5]};
+        LVK_HIP_REQUIRE(ctx, rg[i].x >= 0 && rg[i].y >= 0 && rg[i].w > 0 && rg[i].h > 0 && rg[i].x + rg[i].w <= cols && rg[i].y + rg[i].h <= rows);
+        max_rw = std::max(max_rw, rg[i].w); max_rh = std::max(max_rh, rg[i].h);
+    }
+    size_t mb, sb;
+    lvk_fast_workspace_bytes(nregions, max_rw, max_rh, &mb, &sb);
+    void *d_masks = nullptr, *d_scores = nullptr, *d_regions = nullptr; uint32_t* d_out = nullptr; int* d_counts = nullptr;
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_masks, mb));
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_scores, sb));
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_regions, rg.size() * sizeof(FastRegion)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_out, (size_t)nregions * cap * sizeof(uint32_t)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_counts, nregions * sizeof(int)));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_regions, rg.data(), rg.size() * sizeof(FastRegion), hipMemcpyHostToDevice, ctx->stream));
+    int rc = lvk_launch_fast(ctx, d_img, step, rows, cols, (const FastRegion*)d_regions, nregions, max_rw, max_rh, d_masks, d_scores, d_out, cap, d_counts);
+    if (rc == LVK_HIP_OK)
+    {
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)nregions * cap * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(counts, d_counts, nregions * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(d_masks); (void)hipFree(d_scores); (void)hipFree(d_regions); (void)hipFree(d_out); (void)hipFree(d_counts);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,223 @@
+// Tracker image operations for gfx950: luma extraction fused with the INTER_AREA downscale to the tracking
+// resolution, the pyrDown pyramid and the Scharr derivative images used by the sparse optical flow.
+//
+// Replaces (reference call sites; the arithmetic is OpenCV 4.8.0's):
+//   VideoFrame::viewAsFormat(GRAY) for YUV frames            LiveVisionKit/Data/VideoFrame.cpp:260
+//   cv::resize(gray, detection_resolution, INTER_AREA)        LiveVisionKit/Vision/FrameTracker.cpp:117
+//   buildOpticalFlowPyramid / calcScharrDeriv inside calc()   LiveVisionKit/Vision/FrameTracker.cpp:140-146
+// All integer except the non-integer-scale INTER_AREA path (binary32, no contraction, table order).
+#include "lvk_hip_internal.hpp"
+
+#include <cmath>
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { p = (p < 0) ? -p : 2 * (len - 1) - p; }
+    return p;
+}
+
+__device__ __forceinline__ uint8_t sat_u8_rint(float v)
+{
+    const float r = __builtin_rintf(v);                      // v_rndne_f32: half to even, like cvRound
+    return (uint8_t)(int)__builtin_fminf(__builtin_fmaxf(r, 0.0f), 255.0f);
+}
+
+// ---- INTER_AREA, integer scale (resizeAreaFast_): box sum * (1.f/area), round half to even; 2x2 -> (s+2)>>2 ----
+__global__ __launch_bounds__(256)
+void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
+                 uint8_t* __restrict__ dst, int dst_step, int drows, int dcols, int sx, int sy)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dcols || y >= drows) return;
+    const uint8_t* p = src + (long)(y * sy) * src_step + (long)(x * sx) * pix_stride + channel;
+    int sum = 0;
+    for (int ky = 0; ky < sy; ky++, p += src_step)
+        for (int kx = 0; kx < sx; kx++)
+            sum += p[kx * pix_stride];
+    uint8_t out;
+    if (sx == 2 && sy == 2) out = (uint8_t)((sum + 2) >> 2);
+    else out = sat_u8_rint((float)sum * (1.f / (float)(sx * sy)));
+    dst[(long)y * dst_step + x] = out;
+}
+
+// ---- INTER_AREA, general scale (resizeArea_ + computeResizeAreaTab) ----
+__global__ __launch_bounds__(256)
+void k_area_general(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
+                    uint8_t* __restrict__ dst, int dst_step, int drows, int dcols,
+                    const int2* __restrict__ xrange, const AreaTabEntry* __restrict__ xtab,
+                    const int2* __restrict__ yrange, const AreaTabEntry* __restrict__ ytab)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dcols || y >= drows) return;
+    const int2 xr = xrange[x], yr = yrange[y];
+    float sum = 0.0f;
+    for (int j = yr.x; j < yr.x + yr.y; j++)
+    {
+        const uint8_t* row = src + (long)ytab[j].si * src_step + channel;
+        float buf = 0.0f;
+        for (int k = xr.x; k < xr.x + xr.y; k++)
+            buf = buf + (float)row[(long)xtab[k].si * pix_stride] * xtab[k].alpha;
+        sum = sum + ytab[j].alpha * buf;
+    }
+    dst[(long)y * dst_step + x] = sat_u8_rint(sum);
+}
+
+// ---- cv::pyrDown 8UC1 BORDER_REFLECT_101 ----
+__global__ __launch_bounds__(256)
+void k_pyr_down(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
+                uint8_t* __restrict__ dst, int dst_step, int drows, int dcols)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dcols || y >= drows) return;
+    int xi[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xi[k] = reflect101(2 * x - 2 + k, cols);
+    int acc = 0;
+#pragma unroll
+    for (int ky = 0; ky < 5; ky++)
+    {
+        const uint8_t* row = src + (long)reflect101(2 * y - 2 + ky, rows) * src_step;
+        const int h = row[xi[0]] + row[xi[4]] + 4 * (row[xi[1]] + row[xi[3]]) + 6 * row[xi[2]];
+        const int w = (ky == 0 || ky == 4) ? 1 : (ky == 2 ? 6 : 4);
+        acc += w * h;
+    }
+    dst[(long)y * dst_step + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+// ---- calcScharrDeriv: (Ix, Iy) int16 interleaved, reflect-101 at the image edge ----
+__global__ __launch_bounds__(256)
+void k_scharr(const uint8_t* __restrict__ src, int src_step, int rows, int cols, short2* __restrict__ dst)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const uint8_t* r0 = src + (long)(y > 0 ? y - 1 : (rows > 1 ? 1 : 0)) * src_step;
+    const uint8_t* r1 = src + (long)y * src_step;
+    const uint8_t* r2 = src + (long)(y < rows - 1 ? y + 1 : (rows > 1 ? rows - 2 : 0)) * src_step;
+    const int xm = x > 0 ? x - 1 : (cols > 1 ? 1 : 0);
+    const int xp = x < cols - 1 ? x + 1 : (cols > 1 ? cols - 2 : 0);
+    // vertical pass at columns xm, x, xp
+    const int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10, t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
+    const int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
+    short2 o;
+    o.x = (short)(t0p - t0m);
+    o.y = (short)((t1p + t1m) * 3 + t1c * 10);
+    dst[(long)y * cols + x] = o;
+}
+
+// imgproc/resize.cpp computeResizeAreaTab, grouped per destination index.
+void build_area_tab(int ssize, int dsize, std::vector<int2>& range, std::vector<AreaTabEntry>& tab)
+{
+    const double scale = (double)ssize / dsize;
+    range.resize(dsize);
+    tab.clear();
+    for (int dx = 0; dx < dsize; dx++)
+    {
+        const int start = (int)tab.size();
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) tab.push_back({sx1 - 1, (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; sx++) tab.push_back({sx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3) tab.push_back({sx2, (float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell)});
+        range[dx] = make_int2(start, (int)tab.size() - start);
+    }
+}
+
+} // namespace
+
+int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab)
+{
+    const auto key = std::make_pair(ssize, dsize);
+    auto it = ctx->areatabs.find(key);
+    if (it == ctx->areatabs.end())
+    {
+        std::vector<int2> range; std::vector<AreaTabEntry> tab;
+        build_area_tab(ssize, dsize, range, tab);
+        lvk_hip_ctx::AreaTabDev dev;
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&dev.range, range.size() * sizeof(int2)));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&dev.tab, tab.size() * sizeof(AreaTabEntry)));
+        LVK_HIP_CHECK(ctx, hipMemcpy(dev.range, range.data(), range.size() * sizeof(int2), hipMemcpyHostToDevice));
+        LVK_HIP_CHECK(ctx, hipMemcpy(dev.tab, tab.data(), tab.size() * sizeof(AreaTabEntry), hipMemcpyHostToDevice));
+        it = ctx->areatabs.emplace(key, dev).first;
+    }
+    *d_range = it->second.range;
+    *d_tab = it->second.tab;
+    return LVK_HIP_OK;
+}
+
+int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
+                                int srows, int scols, void* d_dst, int dst_step, int drows, int dcols)
+{
+    LVK_HIP_REQUIRE(ctx, d_src && d_dst && srows > 0 && scols > 0 && drows > 0 && dcols > 0);
+    LVK_HIP_REQUIRE(ctx, pix_stride >= 1 && channel >= 0 && channel < pix_stride);
+    LVK_HIP_REQUIRE(ctx, drows <= srows && dcols <= scols);          // the tracker only downscales (FrameTracker.cpp:117)
+    const dim3 block(64, 4), grid((dcols + 63) / 64, (drows + 3) / 4);
+    if (scols % dcols == 0 && srows % drows == 0)
+    {
+        hipLaunchKernelGGL(k_area_fast, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, pix_stride, channel,
+                           (uint8_t*)d_dst, dst_step, drows, dcols, scols / dcols, srows / drows);
+    }
+    else
+    {
+        const int2 *xr, *yr; const AreaTabEntry *xt, *yt;
+        int rc;
+        if ((rc = lvk_get_areatab(ctx, scols, dcols, &xr, &xt)) != LVK_HIP_OK) return rc;
+        if ((rc = lvk_get_areatab(ctx, srows, drows, &yr, &yt)) != LVK_HIP_OK) return rc;
+        hipLaunchKernelGGL(k_area_general, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, pix_stride, channel,
+                           (uint8_t*)d_dst, dst_step, drows, dcols, xr, xt, yr, yt);
+    }
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_launch_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step)
+{
+    LVK_HIP_REQUIRE(ctx, d_src && d_dst && rows > 0 && cols > 0);
+    const int drows = (rows + 1) / 2, dcols = (cols + 1) / 2;
+    const dim3 block(64, 4), grid((dcols + 63) / 64, (drows + 3) / 4);
+    hipLaunchKernelGGL(k_pyr_down, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, drows, dcols);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_launch_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst)
+{
+    LVK_HIP_REQUIRE(ctx, d_src && d_dst && rows > 0 && cols > 0);
+    const dim3 block(64, 4), grid((cols + 63) / 64, (rows + 3) / 4);
+    hipLaunchKernelGGL(k_scharr, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, rows, cols, (short2*)d_dst);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+extern "C" {
+
+int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
+                             int srows, int scols, void* d_dst, int dst_step, int drows, int dcols)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_luma_area_resize(ctx, d_src, src_step, pix_stride, channel, srows, scols, d_dst, dst_step, drows, dcols);
+}
+
+int lvk_hip_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_pyr_down(ctx, d_src, src_step, rows, cols, d_dst, dst_step);
+}
+
+int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_scharr(ctx, d_src, src_step, rows, cols, d_dst);
+}
+
+} // extern "C"

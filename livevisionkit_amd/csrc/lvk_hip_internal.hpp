@@ -12,6 +12,12 @@
 #include "lvk_hip.h"
 
 struct LinTabEntry { int s0, s1; float a0, a1; };   // one column/row of the INTER_LINEAR mesh->frame table
+struct AreaTabEntry { int si; float alpha; };        // one source tap of the INTER_AREA "decimate alpha" table
+struct FastRegion { int x, y, w, h, threshold, active; };   // one FAST detection region (integer ROI of the tracking frame)
+
+constexpr int LVK_MAX_PYR_LEVELS = 8;
+struct PyrLevel { const uint8_t* img; const short2* deriv; int rows, cols, step; };
+struct PyrArgs { PyrLevel lv[LVK_MAX_PYR_LEVELS]; int nlevels; };
 
 struct lvk_hip_ctx
 {
@@ -30,6 +36,10 @@ struct lvk_hip_ctx
 
     // Cached INTER_LINEAR tables: key = (mesh extent, frame extent, vertical?)
     std::map<std::tuple<int, int, int>, LinTabEntry*> lintabs;
+
+    // Cached INTER_AREA tables: key = (source extent, destination extent)
+    struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; };
+    std::map<std::pair<int, int>, AreaTabDev> areatabs;
 
     int fail(int code, const std::string& msg) { last_error = msg; return code; }
 };
@@ -50,3 +60,34 @@ int lvk_stage_params(lvk_hip_ctx* ctx, const void* host, size_t bytes, void** d_
 
 // Device-resident INTER_LINEAR table for resizing a mesh axis of `msize` vertices to `fsize` pixels.
 int lvk_get_lintab(lvk_hip_ctx* ctx, int msize, int fsize, bool vertical, const LinTabEntry** d_out);
+
+// Device-resident INTER_AREA table (per destination index: [start, count) into the tap list).
+int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab);
+
+// Asynchronous launches on ctx->stream (device pointers).
+int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
+                                int srows, int scols, void* d_dst, int dst_step, int drows, int dcols);
+int lvk_launch_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
+int lvk_launch_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
+
+// FAST-9/16 + NMS per region (fast.hip)
+int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks_bytes, size_t* scores_bytes);
+int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
+                    const FastRegion* d_regions, int nregions, int max_rw, int max_rh,
+                    void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts);
+
+// Pyramidal LK (pyrlk.hip)
+int lvk_pyramid_geometry(int rows, int cols, int max_level, int win_w, int win_h, int* lrows, int* lcols);
+int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
+                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig);
+
+// Image pyramid + Scharr derivative images of one tracking frame, resident in HBM.
+struct DevicePyramid
+{
+    uint8_t* img_base = nullptr;
+    uint8_t* deriv_base = nullptr;
+    PyrArgs args{};
+    int allocate(lvk_hip_ctx* ctx, int rows, int cols, int max_level, int win_w, int win_h);
+    int build(lvk_hip_ctx* ctx);      // level 0 image must be filled; enqueues pyrDown + Scharr
+    void release();
+};

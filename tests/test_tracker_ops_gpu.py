@@ -1,0 +1,118 @@
+"""GPU parity of the tracker image operations against the CPU oracle, through
+the C-ABI.  Bar: bit-exact (integer arithmetic; the float steps use the same binary32 op sequence)."""
+import numpy as np
+import pytest
+
+from tests import synth
+from tests.test_oracle_imgproc import _smooth_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("src_size,dst_size", [((1080, 1920), (270, 480)), ((2160, 3840), (270, 480)), ((720, 1280), (270, 480)),
+                                               ((540, 960), (270, 480)), ((270, 480), (270, 480)), ((300, 500), (256, 256)),
+                                               ((777, 1033), (100, 333))])
+def test_luma_area_resize_packed(ctx, oracle, src_size, dst_size):
+    rng = np.random.default_rng(src_size[0])
+    frame = rng.integers(0, 256, src_size + (3,), dtype=np.uint8)
+    want = oracle.luma_area_resize(frame, *dst_size)
+    got = ctx.luma_area_resize(_gpu(frame), *dst_size)
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_luma_area_resize_planar(ctx, oracle):
+    plane = synth.textured_frame(1080, 1920, seed=2, channels=1)
+    want = oracle.luma_area_resize(plane, 270, 480)
+    got = ctx.luma_area_resize(_gpu(plane), 270, 480)
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("shape", [(270, 480), (135, 240), (68, 120), (33, 47), (256, 256)])
+def test_pyr_down_and_scharr(ctx, oracle, shape):
+    img = np.random.default_rng(shape[1]).integers(0, 256, shape, dtype=np.uint8)
+    d = _gpu(img)
+    got_p = ctx.pyr_down(d)
+    got_s = ctx.scharr(d)
+    ctx.sync()
+    assert np.array_equal(got_p.cpu().numpy(), oracle.pyr_down(img))
+    assert np.array_equal(got_s.cpu().numpy(), oracle.scharr_deriv(img))
+
+
+@pytest.mark.parametrize("layout", ["2x1", "2x2", "1x1", "odd"])
+def test_fast_detect_regions(ctx, oracle, layout):
+    rows, cols = 270, 480
+    img = synth.textured_frame(rows, cols, seed=17, channels=1)
+    if layout == "2x1":
+        regions = [(0, 0, 240, 270, 10, 1), (240, 0, 240, 270, 35, 1)]
+    elif layout == "2x2":
+        regions = [(0, 0, 240, 135, 10, 1), (240, 0, 240, 135, 20, 0), (0, 135, 240, 135, 60, 1), (240, 135, 240, 135, 15, 1)]
+    elif layout == "1x1":
+        regions = [(0, 0, 480, 270, 12, 1)]
+    else:
+        regions = [(5, 7, 131, 77, 10, 1), (200, 100, 65, 9, 10, 1), (300, 3, 6, 200, 10, 1), (100, 150, 201, 119, 250, 1)]
+    got, counts = ctx.fast_detect(_gpu(img), regions)
+    total = 0
+    for i, (x, y, w, h, t, active) in enumerate(regions):
+        want = oracle.fast(img, t, roi=(x, y, w, h)) if active else np.zeros((0, 3), np.int32)
+        assert counts[i] == len(want), (layout, i, counts[i], len(want))
+        assert np.array_equal(got[i], want), (layout, i)
+        total += len(want)
+    assert total > 50 or layout == "odd"
+
+
+def test_fast_detect_capacity_truncates_but_counts_all(ctx, oracle):
+    img = synth.textured_frame(270, 480, seed=3, channels=1)
+    want = oracle.fast(img, 10)
+    got, counts = ctx.fast_detect(_gpu(img), [(0, 0, 480, 270, 10, 1)], cap=40)
+    assert counts[0] == len(want) and len(want) > 40
+    assert np.array_equal(got[0], want[:40])
+
+
+@pytest.mark.parametrize("shift", [(0.0, 0.0), (1.3, -0.7), (-3.6, 2.2), (6.5, 4.25)])
+def test_pyrlk_bit_exact_smooth_scene(ctx, oracle, shift):
+    rows, cols = 270, 480
+    prev = _smooth_scene(rows, cols, 0, 0)
+    nxt = _smooth_scene(rows, cols, -shift[0], -shift[1])
+    rng = np.random.default_rng(4)
+    pts = np.c_[rng.uniform(-5, cols + 5, 600), rng.uniform(-5, rows + 5, 600)].astype(np.float32)
+    want_p, want_s = oracle.pyrlk(prev, nxt, pts)
+    got_p, got_s = ctx.pyrlk(_gpu(prev), _gpu(nxt), pts)
+    assert np.array_equal(got_s, want_s)
+    assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)), np.abs(got_p - want_p).max()
+
+
+def test_pyrlk_bit_exact_textured_and_corners(ctx, oracle):
+    """Real feature positions (FAST corners) on a noisy textured frame warped by a homography-like shift."""
+    rows, cols = 270, 480
+    big = synth.textured_frame(rows + 20, cols + 20, seed=23, channels=1)
+    prev = np.ascontiguousarray(big[10:-10, 10:-10])
+    nxt = np.ascontiguousarray(big[8:-12, 13:-7])                    # content moves by (-3, +2)
+    kp = oracle.fast(prev, 20)
+    pts = kp[:, :2].astype(np.float32)
+    assert len(pts) > 200
+    want_p, want_s = oracle.pyrlk(prev, nxt, pts)
+    got_p, got_s = ctx.pyrlk(_gpu(prev), _gpu(nxt), pts)
+    assert np.array_equal(got_s, want_s)
+    assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32))
+    ok = want_s == 1
+    assert np.median(np.abs(want_p[ok] - (pts[ok] + np.array([-3, 2], np.float32)))) < 0.1
+
+
+def test_pyrlk_other_geometry(ctx, oracle):
+    """Library-default 256x256 tracking frame, small frames with fewer pyramid levels, other windows."""
+    for (rows, cols, win, lv) in [(256, 256, (11, 11), 3), (40, 40, (11, 11), 3), (90, 120, (7, 9), 2), (135, 240, (15, 15), 3)]:
+        prev = _smooth_scene(rows, cols, 0, 0)
+        nxt = _smooth_scene(rows, cols, 0.8, -1.1)
+        rng = np.random.default_rng(rows)
+        pts = np.c_[rng.uniform(0, cols, 150), rng.uniform(0, rows, 150)].astype(np.float32)
+        want_p, want_s = oracle.pyrlk(prev, nxt, pts, win=win, max_level=lv)
+        got_p, got_s = ctx.pyrlk(_gpu(prev), _gpu(nxt), pts, win=win, max_level=lv)
+        assert np.array_equal(got_s, want_s), (rows, cols, win)
+        assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)), (rows, cols, win)
