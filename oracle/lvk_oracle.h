@@ -97,6 +97,61 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
 
 int lvko_pyramid_levels(int rows, int cols, int max_level, int win_w, int win_h, int* out_rows, int* out_cols);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage a9: robust global motion (oracle/ransac.cpp -- OUR deterministic specification).
+ * ---------------------------------------------------------------------------------------------- */
+int lvko_find_homography(const float* pts1, const float* pts2, int n, double threshold, double region_w, double region_h,
+                         double H[9], uint8_t* mask);
+int lvko_estimate_affine_partial(const float* pts1, const float* pts2, int n, double threshold, double region_w, double region_h,
+                                 double H[9], uint8_t* mask);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rows a1/a2/a5/a6/a8/a11/a12/a13: the stateful filter (oracle/stabilizer.cpp).
+ * lvko_stab_settings flattens lvk::StabilizationFilterSettings (Filters/StabilizationFilter.hpp:28-39 and its
+ * bases Vision/FrameTracker.hpp:31-44, Vision/FeatureDetector.hpp:28-37, Vision/PathSmoother.hpp:29-39).
+ * The product's lvk_stab_settings (include/lvk_hip.h) has the same field order on purpose.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lvko_stab_settings
+{
+    int detection_width, detection_height;          /* FeatureDetectorSettings::detection_resolution */
+    int detection_regions_x, detection_regions_y;   /* ::detection_regions */
+    int force_detection;
+    float max_feature_density, min_feature_density, accumulation_rate;
+    int track_local_motions;                        /* FrameTrackerSettings */
+    float temporal_smoothing, local_smoothing;
+    int min_motion_samples;
+    float acceptance_threshold, uniformity_threshold;
+    int predictive_samples;                         /* PathSmootherSettings */
+    float corrective_limit_x, corrective_limit_y;
+    float smoothing_steps, response_rate;
+    int motion_width, motion_height;                /* StabilizationFilterSettings::motion_resolution */
+    float background[3];
+    int crop_to_stable_region, stabilize_output;
+    float min_scene_quality, min_tracking_quality;
+} lvko_stab_settings;
+
+typedef struct lvko_stab_stats
+{
+    float tracking_stability, scene_quality, trust, distribution;
+    int n_detected, n_matched, n_tracked, frame_delay;
+    double smoothing_factor;
+    double homography[9];
+} lvko_stab_stats;
+
+typedef struct lvko_stab lvko_stab;
+
+void lvko_stab_default_settings(lvko_stab_settings* s);
+lvko_stab* lvko_stab_create(const lvko_stab_settings* settings);
+void lvko_stab_destroy(lvko_stab* st);
+void lvko_stab_configure(lvko_stab* st, const lvko_stab_settings* settings);
+void lvko_stab_restart(lvko_stab* st);
+int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts,
+                   uint8_t* out, int out_step, uint64_t* out_ts, int nthreads);
+void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* out);
+int lvko_stab_get_meshes(const lvko_stab* st, float* motion, float* correction, int cap_floats);
+int lvko_stab_get_features(const lvko_stab* st, float* xy_resp_age, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,15 @@ class Oracle:
         assert lv >= 0
         return out, st
 
+    def find_homography(self, p1, p2, threshold, region=(480, 270), partial=False):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8)
+        fn = self.lib.lvko_estimate_affine_partial if partial else self.lib.lvko_find_homography
+        fn.restype = _c.c_int
+        fn.argtypes = [_f32p, _f32p, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _f64p, _u8p]
+        rc = fn(_p(p1, _f32p), _p(p2, _f32p), len(p1), float(threshold), float(region[0]), float(region[1]), _p(H, _f64p), _p(mask, _u8p))
+        return rc, H.reshape(3, 3), mask
+
     def mesh_to_map(self, mesh, rows, cols):
         mesh = np.ascontiguousarray(mesh, np.float32)
         out = np.zeros((rows, cols, 2), np.float32)
@@ -158,6 +167,121 @@ class Oracle:
         H = np.zeros(9, np.float32)
         self.lib.lvko_mesh2x2_to_homography(_p(mesh, _f32p), rows, cols, _p(H, _f32p))
         return H.reshape(3, 3)
+
+
+class StabSettings(_c.Structure):
+    """Field-for-field mirror of lvko_stab_settings / lvk_stab_settings (flattened lvk::StabilizationFilterSettings)."""
+    _fields_ = [("detection_width", _c.c_int), ("detection_height", _c.c_int),
+                ("detection_regions_x", _c.c_int), ("detection_regions_y", _c.c_int), ("force_detection", _c.c_int),
+                ("max_feature_density", _c.c_float), ("min_feature_density", _c.c_float), ("accumulation_rate", _c.c_float),
+                ("track_local_motions", _c.c_int), ("temporal_smoothing", _c.c_float), ("local_smoothing", _c.c_float),
+                ("min_motion_samples", _c.c_int), ("acceptance_threshold", _c.c_float), ("uniformity_threshold", _c.c_float),
+                ("predictive_samples", _c.c_int), ("corrective_limit_x", _c.c_float), ("corrective_limit_y", _c.c_float),
+                ("smoothing_steps", _c.c_float), ("response_rate", _c.c_float),
+                ("motion_width", _c.c_int), ("motion_height", _c.c_int), ("background", _c.c_float * 3),
+                ("crop_to_stable_region", _c.c_int), ("stabilize_output", _c.c_int),
+                ("min_scene_quality", _c.c_float), ("min_tracking_quality", _c.c_float)]
+
+
+class StabStats(_c.Structure):
+    _fields_ = [("tracking_stability", _c.c_float), ("scene_quality", _c.c_float), ("trust", _c.c_float), ("distribution", _c.c_float),
+                ("n_detected", _c.c_int), ("n_matched", _c.c_int), ("n_tracked", _c.c_int), ("frame_delay", _c.c_int),
+                ("smoothing_factor", _c.c_double), ("homography", _c.c_double * 9)]
+
+
+def preset(name="homography", **over):
+    """The two OBS presets (Modules/OBS-Plugin/Sources/Stabilisation/VSFilter.cpp:255-293) on top of the library defaults."""
+    s = StabSettings()
+    s.detection_width, s.detection_height = 256, 256
+    s.detection_regions_x, s.detection_regions_y, s.force_detection = 2, 2, 0
+    s.max_feature_density, s.min_feature_density, s.accumulation_rate = 0.20, 0.05, 2.0
+    s.track_local_motions, s.temporal_smoothing, s.local_smoothing = 1, 1.0, 20.0
+    s.min_motion_samples, s.acceptance_threshold, s.uniformity_threshold = 75, 8.0, 0.20
+    s.predictive_samples, s.corrective_limit_x, s.corrective_limit_y, s.smoothing_steps, s.response_rate = 10, 0.1, 0.1, 20.0, 0.04
+    s.motion_width, s.motion_height = 2, 2
+    s.background[0], s.background[1], s.background[2] = 255, 0, 255
+    s.crop_to_stable_region, s.stabilize_output, s.min_scene_quality, s.min_tracking_quality = 0, 1, 0.8, 0.3
+    if name == "homography":
+        s.detection_width, s.detection_height = 480, 270
+        s.acceptance_threshold, s.track_local_motions = 3.0, 0
+        s.motion_width, s.motion_height = 2, 2
+        s.detection_regions_x, s.detection_regions_y = 2, 1
+        s.max_feature_density, s.min_feature_density, s.accumulation_rate = 0.12, 0.04, 3.0
+    elif name == "field":
+        s.detection_width, s.detection_height = 480, 270
+        s.acceptance_threshold, s.track_local_motions = 10.0, 1
+        s.motion_width, s.motion_height = 16, 16
+        s.detection_regions_x, s.detection_regions_y = 2, 2
+        s.max_feature_density, s.min_feature_density, s.accumulation_rate = 0.12, 0.06, 3.0
+    elif name != "default":
+        raise ValueError(name)
+    if name in ("homography", "field"):
+        s.min_scene_quality, s.min_tracking_quality = 0.95, 0.35           # "strict" QA
+        s.corrective_limit_x = s.corrective_limit_y = 0.05                  # UI crop default 5 %
+        s.crop_to_stable_region = 1
+        s.background[0], s.background[1], s.background[2] = 105, 212, 235   # rgb2yuv of the default magenta (approx.)
+    for k, v in over.items():
+        setattr(s, k, v)
+    return s
+
+
+class OracleStabilizer:
+    def __init__(self, oracle, settings):
+        self.L = oracle.lib
+        L = self.L
+        L.lvko_stab_create.restype = _c.c_void_p
+        L.lvko_stab_create.argtypes = [_c.POINTER(StabSettings)]
+        L.lvko_stab_destroy.argtypes = [_c.c_void_p]
+        L.lvko_stab_configure.argtypes = [_c.c_void_p, _c.POINTER(StabSettings)]
+        L.lvko_stab_restart.argtypes = [_c.c_void_p]
+        L.lvko_stab_push.restype = _c.c_int
+        L.lvko_stab_push.argtypes = [_c.c_void_p, _u8p, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _u8p, _c.c_int,
+                                     _c.POINTER(_c.c_uint64), _c.c_int]
+        L.lvko_stab_get_stats.argtypes = [_c.c_void_p, _c.POINTER(StabStats)]
+        L.lvko_stab_get_meshes.restype = _c.c_int
+        L.lvko_stab_get_meshes.argtypes = [_c.c_void_p, _f32p, _f32p, _c.c_int]
+        L.lvko_stab_get_features.restype = _c.c_int
+        L.lvko_stab_get_features.argtypes = [_c.c_void_p, _f32p, _c.c_int]
+        self.settings = settings
+        self.h = L.lvko_stab_create(_c.byref(settings))
+
+    def close(self):
+        if self.h:
+            self.L.lvko_stab_destroy(self.h)
+            self.h = None
+
+    def configure(self, settings):
+        self.settings = settings
+        self.L.lvko_stab_configure(self.h, _c.byref(settings))
+
+    def restart(self):
+        self.L.lvko_stab_restart(self.h)
+
+    def push(self, frame, ts=0, nthreads=8):
+        frame = np.ascontiguousarray(frame, np.uint8)
+        out = np.zeros_like(frame)
+        ots = _c.c_uint64(0)
+        rc = self.L.lvko_stab_push(self.h, _p(frame, _u8p), frame.strides[0], frame.shape[0], frame.shape[1], ts,
+                                   _p(out, _u8p), out.strides[0], _c.byref(ots), nthreads)
+        assert rc >= 0
+        return (out, ots.value) if rc == 1 else (None, None)
+
+    def stats(self):
+        st = StabStats()
+        self.L.lvko_stab_get_stats(self.h, _c.byref(st))
+        return st
+
+    def meshes(self):
+        n = self.settings.motion_width * self.settings.motion_height * 2
+        a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+        self.L.lvko_stab_get_meshes(self.h, _p(a, _f32p), _p(b, _f32p), n)
+        shp = (self.settings.motion_height, self.settings.motion_width, 2)
+        return a.reshape(shp), b.reshape(shp)
+
+    def features(self, cap=4096):
+        a = np.zeros((cap, 4), np.float32)
+        n = self.L.lvko_stab_get_features(self.h, _p(a, _f32p), cap)
+        return a[:n].copy()
 
 
 _inst = None

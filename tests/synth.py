@@ -46,3 +46,38 @@ def random_homography(rows, cols, rng, strength=1.0):
 
 def random_mesh(mrows, mcols, rng, amp=0.02):
     return rng.uniform(-amp, amp, (mrows, mcols, 2)).astype(np.float32)
+
+
+def camera_path(nframes, cols, rng, jitter=1.0, pan=0.0015):
+    """Smooth pan + AR(1) jitter: per-frame (tx, ty, theta, zoom) of the camera in pixels / radians."""
+    t = np.zeros((nframes, 4))
+    ar = np.zeros(4)
+    sig = np.array([0.004 * cols, 0.004 * cols, np.deg2rad(0.15), 0.002]) * jitter
+    for i in range(nframes):
+        ar = 0.6 * ar + np.sqrt(1 - 0.36) * rng.normal(0, 1, 4) * sig
+        t[i] = ar
+        t[i, 0] += pan * cols * i
+        t[i, 1] += 0.3 * pan * cols * i
+    return t
+
+
+def make_clip(rows, cols, nframes, seed=0x4C564B31, jitter=1.0):
+    """Synthetic shaky clip: packed YUV444 frames sampled (bilinear) from one textured canvas.
+    Returns (frames [n, rows, cols, 3] uint8, path [n, 4]); path[i] = (tx, ty, theta, zoom-1) of frame i in the canvas."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    m = int(0.10 * cols) + 8
+    canvas = textured_frame(rows + 2 * m, cols + 2 * m, seed=seed).astype(np.float32)
+    path = camera_path(nframes, cols, rng, jitter=jitter)
+    frames = np.empty((nframes, rows, cols, 3), np.uint8)
+    cy, cx = (rows - 1) / 2.0, (cols - 1) / 2.0
+    for i in range(nframes):
+        tx, ty, th, z = path[i]
+        s = 1.0 + z
+        c, si = np.cos(th) * s, np.sin(th) * s
+        # output (y, x) -> canvas (y, x): rotate/zoom about the frame centre, then translate
+        A = np.array([[c, si], [-si, c]])
+        off = np.array([cy + m + ty, cx + m + tx]) - A @ np.array([cy, cx])
+        for ch in range(3):
+            frames[i, ..., ch] = np.clip(np.rint(ndimage.affine_transform(canvas[..., ch], A, offset=off, output_shape=(rows, cols), order=1, mode="nearest")), 0, 255)
+    return frames, path

@@ -1,0 +1,127 @@
+"""CPU tests pinning the oracle's motion estimate and the stateful filter against synthetic ground truth
+(the reference has no fixtures for this path: SURVEY.md section 4 / 8c)."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib, synth
+
+
+def _apply(H, p):
+    q = np.c_[p, np.ones(len(p))] @ H.T
+    return q[:, :2] / q[:, 2:]
+
+
+def test_find_homography_recovers_ground_truth_with_outliers(oracle):
+    rng = np.random.default_rng(0)
+    H = np.array([[1.01, 0.012, 3.1], [-0.011, 0.995, -2.2], [2e-5, -1e-5, 1.0]])
+    p1 = np.c_[rng.uniform(0, 480, 800), rng.uniform(0, 270, 800)].astype(np.float32)
+    p2 = _apply(H, p1) + rng.normal(0, 0.15, p1.shape)
+    out = rng.random(800) < 0.3
+    p2[out] += rng.uniform(-40, 40, (out.sum(), 2))
+    rc, He, mask = oracle.find_homography(p1, p2.astype(np.float32), 3.0)
+    assert rc > 500
+    corners = np.array([[0, 0], [480, 0], [0, 270], [480, 270]], np.float64)
+    assert np.abs(_apply(He, corners) - _apply(H, corners)).max() < 0.25
+    assert mask[~out].mean() > 0.98 and mask[out].mean() < 0.08
+    assert abs(He[2, 2] - 1.0) < 1e-12
+
+
+def test_find_homography_is_deterministic_and_exact_on_clean_data(oracle):
+    rng = np.random.default_rng(1)
+    p1 = np.c_[rng.uniform(0, 480, 300), rng.uniform(0, 270, 300)].astype(np.float32)
+    H = np.array([[1, 0, 2.5], [0, 1, -1.25], [0, 0, 1.0]])
+    p2 = _apply(H, p1).astype(np.float32)
+    rc1, H1, m1 = oracle.find_homography(p1, p2, 3.0)
+    rc2, H2, m2 = oracle.find_homography(p1, p2, 3.0)
+    assert rc1 == 300 and np.array_equal(H1, H2) and np.array_equal(m1, m2)
+    assert np.abs(H1 - H).max() < 1e-4
+
+
+def test_affine_partial_recovers_similarity(oracle):
+    rng = np.random.default_rng(2)
+    th, s = 0.02, 1.03
+    H = np.array([[s * np.cos(th), -s * np.sin(th), 4.0], [s * np.sin(th), s * np.cos(th), -3.0], [0, 0, 1]])
+    p1 = np.c_[rng.uniform(0, 480, 400), rng.uniform(0, 270, 400)].astype(np.float32)
+    p2 = _apply(H, p1) + rng.normal(0, 0.1, p1.shape)
+    p2[:60] += 30
+    rc, He, mask = oracle.find_homography(p1, p2.astype(np.float32), 3.0, partial=True)
+    assert np.abs(He - H).max() < 0.05 and He[2, 0] == 0 and He[2, 1] == 0
+    assert mask[60:].mean() > 0.98 and mask[:60].sum() == 0
+
+
+def test_too_few_points_gives_identity_and_empty_mask(oracle):
+    p = np.array([[1, 2], [3, 4], [5, 6]], np.float32)
+    rc, H, mask = oracle.find_homography(p, p, 3.0)
+    assert rc < 0 and np.array_equal(H, np.eye(3)) and mask.sum() == 0
+
+
+@pytest.fixture(scope="module")
+def clip():
+    return synth.make_clip(360, 640, 36, seed=7, jitter=1.0)
+
+
+def test_stabilizer_delay_timestamps_and_tracking(oracle, clip):
+    frames, path = clip
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("homography", predictive_samples=5))
+    outs = []
+    for i, f in enumerate(frames):
+        out, ts = st.push(f, ts=1000 + i)
+        s = st.stats()
+        if i == 0:
+            assert s.n_detected == 0 and s.tracking_stability == 0       # first frame: nullopt
+        if i >= 2:
+            assert s.n_detected >= 75 and s.tracking_stability > 0.8, (i, s.n_detected, s.tracking_stability)
+            # ground truth inter-frame translation at tracking resolution (content moves opposite to the camera)
+            d = (path[i, :2] - path[i - 1, :2]) * (480 / 640)
+            H = np.array(s.homography).reshape(3, 3)
+            c = _apply(H, np.array([[240.0, 135.0]]))[0] - np.array([240.0, 135.0])
+            assert np.abs(c + d).max() < 0.35, (i, c, d)
+        if i < 5:
+            assert out is None
+        else:
+            assert out is not None and ts == 1000 + i - 5               # frame_delay == predictive_samples
+            outs.append(out)
+    assert st.stats().frame_delay == 5
+    st.close()
+
+
+def test_stabilizer_reduces_jitter(oracle, clip):
+    """Measure the residual shake through pixels: median LK flow between consecutive frames, in vs out."""
+    frames, path = clip
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("homography", predictive_samples=5, min_scene_quality=0.4,
+                                                                 min_tracking_quality=0.2))
+    outs = []
+    for i, f in enumerate(frames):
+        out, _ = st.push(f, ts=i)
+        if out is not None:
+            outs.append(out)
+    st.close()
+
+    def shake(seq):
+        grid = np.stack(np.meshgrid(np.arange(80, 400, 40), np.arange(60, 220, 40)), -1).reshape(-1, 2).astype(np.float32)
+        flows = []
+        for a, b in zip(seq[:-1], seq[1:]):
+            ga = oracle.luma_area_resize(a[20:-20, 20:-20], 240, 450) if False else np.ascontiguousarray(a[..., 0])
+            gb = np.ascontiguousarray(b[..., 0])
+            p, s = oracle.pyrlk(ga, gb, grid * (640 / 480))
+            ok = s == 1
+            flows.append(np.median(p[ok] - (grid * (640 / 480))[ok], axis=0))
+        flows = np.array(flows)
+        return np.abs(np.diff(flows, axis=0)).mean()                    # frame-to-frame change of the motion = shake
+
+    n = len(outs)
+    shake_in = shake(list(frames[12:12 + n - 8]))
+    shake_out = shake(outs[8:])                                         # skip the trust ramp-up
+    assert shake_out < 0.5 * shake_in, (shake_in, shake_out)
+
+
+def test_passthrough_mode_keeps_the_delay(oracle, clip):
+    frames, _ = clip
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("homography", predictive_samples=3, stabilize_output=0, crop_to_stable_region=0))
+    for i, f in enumerate(frames[:8]):
+        out, ts = st.push(f, ts=i)
+        if i < 3:
+            assert out is None
+        else:
+            assert ts == i - 3 and np.array_equal(out, frames[i - 3])
+    st.close()
