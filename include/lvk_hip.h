@@ -108,6 +108,86 @@ int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const voi
                   const float* prev_pts, int n, float* next_pts, uint8_t* status,
                   int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
 
+/* ---- a9: robust global motion --------------------------------------------------------------------------
+ * cv::findHomography(tracked, matched, mask, UsacParams{threshold}) (full_homography != 0) or
+ * cv::estimateAffinePartial2D(..., RANSAC, threshold, 50) + Homography::FromAffineMatrix (full_homography == 0)
+ * as used by FrameTracker::estimate_global_motion (Vision/FrameTracker.cpp:325-375).  Host point arrays (n x 2
+ * floats); H = 3x3 row-major double normalised by H22; mask = n bytes.  (region_w, region_h) = tracking resolution.
+ * Returns the inlier count, or a negative value when no model exists (H = identity, mask = 0).  Synchronous.
+ * The estimator is the deterministic RANSAC of DESIGN.md (OpenCV's USAC is randomised and not restated). */
+int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const float* pts2, int n, double threshold,
+                                   double region_w, double region_h, int full_homography, double H[9], uint8_t* mask);
+
+/* ---- a1/a2: the stabilization filter ----------------------------------------------------------------------
+ * lvk_stab_settings flattens lvk::StabilizationFilterSettings (Filters/StabilizationFilter.hpp:28-39) and its bases
+ * FrameTrackerSettings (Vision/FrameTracker.hpp:31-44) : FeatureDetectorSettings (Vision/FeatureDetector.hpp:28-37) and
+ * PathSmootherSettings (Vision/PathSmoother.hpp:29-39); same names, same defaults (lvk_stab_default_settings). */
+typedef struct lvk_stab_settings
+{
+    int detection_width, detection_height;          /* detection_resolution {256, 256} */
+    int detection_regions_x, detection_regions_y;   /* detection_regions {2, 2} */
+    int force_detection;                            /* false */
+    float max_feature_density, min_feature_density, accumulation_rate;    /* 0.20, 0.05, 2.0 */
+    int track_local_motions;                        /* true */
+    float temporal_smoothing, local_smoothing;      /* 1.0, 20.0 */
+    int min_motion_samples;                         /* 75 */
+    float acceptance_threshold, uniformity_threshold;                     /* 8.0, 0.20 */
+    int predictive_samples;                         /* 10 */
+    float corrective_limit_x, corrective_limit_y;   /* corrective_limits {0.1, 0.1} */
+    float smoothing_steps, response_rate;           /* 20.0, 0.04 */
+    int motion_width, motion_height;                /* StabilizationFilterSettings::motion_resolution {2, 2} */
+    float background[3];                            /* background_colour {255, 0, 255} */
+    int crop_to_stable_region, stabilize_output;    /* false, true */
+    float min_scene_quality, min_tracking_quality;  /* 0.8, 0.3 */
+} lvk_stab_settings;
+
+typedef struct lvk_stab_stats
+{
+    float tracking_stability;      /* FrameTracker::tracking_stability() */
+    float scene_quality, trust;    /* m_SceneQuality, m_TrustFactor */
+    float distribution;            /* FeatureDetector::detect() return value of the last frame */
+    int n_detected, n_matched, n_tracked, frame_delay;
+    double smoothing_factor;       /* PathSmoother m_SmoothingFactor */
+    double homography[9];          /* last global motion estimate (tracking-resolution pixels) */
+} lvk_stab_stats;
+
+/* lvk::VideoFrame::Format (Data/VideoFrame.hpp:27) */
+#define LVK_FORMAT_BGR 0
+#define LVK_FORMAT_BGRA 1
+#define LVK_FORMAT_RGB 2
+#define LVK_FORMAT_RGBA 3
+#define LVK_FORMAT_YUV 4
+#define LVK_FORMAT_GRAY 5
+
+typedef struct lvk_hip_stab lvk_hip_stab;
+
+void lvk_stab_default_settings(lvk_stab_settings* s);
+/* StabilizationFilter(settings) / configure(settings) (Filters/StabilizationFilter.cpp:34-65) */
+int  lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lvk_hip_stab** out);
+void lvk_hip_stab_destroy(lvk_hip_stab* stab);
+int  lvk_hip_stab_configure(lvk_hip_stab* stab, const lvk_stab_settings* settings);
+int  lvk_hip_stab_restart(lvk_hip_stab* stab);            /* :139-144 */
+int  lvk_hip_stab_reset_context(lvk_hip_stab* stab);      /* :155-159 */
+int  lvk_hip_stab_ready(const lvk_hip_stab* stab);        /* :148-151 */
+int  lvk_hip_stab_frame_delay(const lvk_hip_stab* stab);  /* :192-195 */
+int  lvk_hip_stab_stable_region(const lvk_hip_stab* stab, int rows, int cols, int rect_xywh[4]);   /* :199-205 */
+
+/* VideoFilter::apply(std::move(input), output) -> StabilizationFilter::filter (Filters/VideoFilter.cpp:46-51,
+ * Filters/StabilizationFilter.cpp:69-135).  d_frame: packed 8UC3 device frame; like the reference's moved-in
+ * input it is BORROWED (not copied) until it has been emitted `frame_delay` pushes later -- `*released` then
+ * returns its pointer (or NULL); the caller may reuse that buffer once the stream has passed this call.
+ * d_out receives the stabilized delayed frame when *produced == 1 (and carries *out_timestamp = that frame's
+ * timestamp, Math/WarpMesh.cpp:221-222); *produced == 0 while the delay builds ("output.release()").
+ * The output remap is only enqueued: call lvk_hip_sync() before reading d_out on the host. */
+int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
+                       void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released);
+
+int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
+/* last frame motion (after the trust factor) and last applied correction; each motion_height x motion_width x 2 floats */
+int  lvk_hip_stab_get_meshes(const lvk_hip_stab* stab, float* motion, float* correction, int cap_floats);
+/* FrameTracker::features(): (x, y, response, age) per tracked feature; returns the total count */
+int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@ the C++ facade in include/lvk/.  This Python package is the thin host-side mirro
 bench driver: it calls the C-ABI through ctypes and uses torch only for device memory and streams.
 """
 from . import _native
-from .context import Context
+from .context import Context, LvkHipError
+from .stabilization import StabilizationFilter, StabilizationFilterSettings
 
-__all__ = ["Context", "_native"]
+__all__ = ["Context", "LvkHipError", "StabilizationFilter", "StabilizationFilterSettings", "_native"]

@@ -39,6 +39,22 @@ _SIG = {
     "lvk_hip_pyrlk": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _c.c_int,
                                  _c.POINTER(_c.c_float), _c.POINTER(_c.c_uint8), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                  _c.c_double, _c.c_double]),
+    "lvk_hip_estimate_global_motion": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int, _c.c_double,
+                                                  _c.c_double, _c.c_double, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint8)]),
+    "lvk_stab_default_settings": (None, [_P]),
+    "lvk_hip_stab_create": (_c.c_int, [_P, _P, _c.POINTER(_P)]),
+    "lvk_hip_stab_destroy": (None, [_P]),
+    "lvk_hip_stab_configure": (_c.c_int, [_P, _P]),
+    "lvk_hip_stab_restart": (_c.c_int, [_P]),
+    "lvk_hip_stab_reset_context": (_c.c_int, [_P]),
+    "lvk_hip_stab_ready": (_c.c_int, [_P]),
+    "lvk_hip_stab_frame_delay": (_c.c_int, [_P]),
+    "lvk_hip_stab_stable_region": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
+    "lvk_hip_stab_push": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _P, _c.c_int,
+                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_P)]),
+    "lvk_hip_stab_get_stats": (_c.c_int, [_P, _P]),
+    "lvk_hip_stab_get_meshes": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int]),
+    "lvk_hip_stab_get_features": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.c_int]),
 }
 
 _lib = None

@@ -151,3 +151,16 @@ class Context:
                                            st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
                                            win[0], win[1], max_level, max_count, float(epsilon), float(min_eig)))
         return out, st
+
+    def estimate_global_motion(self, p1, p2, threshold, region=(480, 270), full_homography=True):
+        """cv::findHomography(UsacParams) / cv::estimateAffinePartial2D stand-in; returns (n_inliers, H 3x3 float64, mask)."""
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8)
+        rc = self.lib.lvk_hip_estimate_global_motion(self.handle, p1.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                     p2.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(p1), float(threshold),
+                                                     float(region[0]), float(region[1]), 1 if full_homography else 0,
+                                                     H.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                     mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+        if rc in (-1, -2, -3):
+            self._check(rc)
+        return rc, H.reshape(3, 3), mask

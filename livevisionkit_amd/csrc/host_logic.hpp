@@ -1,0 +1,298 @@
+// Host-side state machines of the stabilization path (no device code): warp-mesh arithmetic, the path
+// smoother, and the feature detector's suppression grid / region bookkeeping.  These are tiny (<= a few
+// thousand elements per frame) and inherently sequential, so they stay on the host exactly as in the reference.
+//
+// Reference (paths relative to LiveVisionKit/):
+//   Math/WarpMesh.cpp:318-551, Math/Homography.cpp:125-130         -> WarpMeshF
+//   Vision/PathSmoother.cpp:36-145, Functions/Logic.tpp:53-65       -> PathSmootherH
+//   Vision/FeatureDetector.cpp:48-214, Data/SpatialMap.tpp:589-625  -> FeatureGridH
+// Elementwise float ops follow OpenCV's scalar definitions: one rounding per op, no contraction.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+#include <deque>
+#include <algorithm>
+
+#include "lvk_hip.h"
+
+namespace lvkh {
+
+inline int cv_round(float v) { return (int)lrintf(v); }     // cv::saturate_cast<int>(float)
+
+struct Feature { float x, y, response; int age; };          // cv::KeyPoint {pt, response, class_id}; class_id carries the age
+
+// ------------------------------------------------------------------------------------------------ WarpMesh
+class WarpMeshF
+{
+public:
+    int rows = 2, cols = 2;
+    std::vector<float> off;                                 // rows x cols x (dx, dy), normalised, "warp specified backwards"
+
+    WarpMeshF() : off(8, 0.0f) {}
+    WarpMeshF(int r, int c) : rows(r), cols(c), off((size_t)r * c * 2, 0.0f) {}
+
+    void set_identity() { std::fill(off.begin(), off.end(), 0.0f); }
+    void scale(float s) { for (float& v : off) v = v * s; }                                                  // operator*=(float)
+    void operator+=(const WarpMeshF& o) { for (size_t i = 0; i < off.size(); i++) off[i] = off[i] + o.off[i]; }
+    void operator-=(const WarpMeshF& o) { for (size_t i = 0; i < off.size(); i++) off[i] = off[i] - o.off[i]; }
+    void scale_add(const WarpMeshF& o, float a) { for (size_t i = 0; i < off.size(); i++) off[i] = o.off[i] * a + off[i]; }   // combine(): cv::scaleAdd
+
+    void clamp(float mx, float my)
+    {
+        for (size_t i = 0; i + 1 < off.size(); i += 2)
+        {
+            off[i] = std::min(std::max(off[i], -mx), mx);
+            off[i + 1] = std::min(std::max(off[i + 1], -my), my);
+        }
+    }
+
+    void crop_in(float x, float y, float w, float h)                                                         // WarpMesh.cpp:379-390
+    {
+        const float kx = (w - 1.0f) / (float)(cols - 1), ky = (h - 1.0f) / (float)(rows - 1);
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++)
+            {
+                float* p = &off[((size_t)r * cols + c) * 2];
+                p[0] += (float)c * kx + x;
+                p[1] += (float)r * ky + y;
+            }
+    }
+
+    // WarpMesh::set_to(Homography, motion_scale) with Homography::transform -> cv::perspectiveTransform (double math)
+    void from_homography(const double H[9], float sw, float sh)
+    {
+        const float gx = sw / (float)(cols - 1), gy = sh / (float)(rows - 1);
+        const float nx = 1.0f / sw, ny = 1.0f / sh;
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++)
+            {
+                const float px = (float)c * gx, py = (float)r * gy;
+                double w = px * H[6] + py * H[7] + H[8];
+                float qx = 0.0f, qy = 0.0f;
+                if (std::fabs(w) > 1.1920928955078125e-07)
+                {
+                    w = 1. / w;
+                    qx = (float)((px * H[0] + py * H[1] + H[2]) * w);
+                    qy = (float)((px * H[3] + py * H[4] + H[5]) * w);
+                }
+                float* p = &off[((size_t)r * cols + c) * 2];
+                p[0] = (px - qx) * nx;
+                p[1] = (py - qy) * ny;
+            }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ PathSmoother
+class PathSmootherH
+{
+public:
+    void configure(const lvk_stab_settings& s)
+    {
+        const int mr = s.motion_height, mc = s.motion_width;
+        if (!m_configured || m_position.rows != mr || m_position.cols != mc)
+        {
+            const size_t keep = m_configured ? m_path.size() : 1;
+            m_path.assign(keep, WarpMeshF(mr, mc));
+            m_trace = WarpMeshF(mr, mc);
+            m_position = WarpMeshF(mr, mc);
+        }
+        const size_t window = 2 * (size_t)s.predictive_samples + 1;
+        if (m_path.size() != window)
+        {
+            while (m_path.size() > window) m_path.pop_front();                       // keep the newest samples
+            while (m_path.size() < window) m_path.push_front(WarpMeshF(mr, mc));     // pad the front with identity
+            m_position = m_path.front();
+            for (size_t i = 1; i <= centre(); i++) m_position += m_path[i];
+            m_base = (double)window / 12.0;
+        }
+        m_margin_x = (1.0f * s.corrective_limit_x) / 2;
+        m_margin_y = (1.0f * s.corrective_limit_y) / 2;
+        m_margin_w = 1.0f - 1.0f * s.corrective_limit_x;
+        m_margin_h = 1.0f - 1.0f * s.corrective_limit_y;
+        m_crop = WarpMeshF(mr, mc);
+        m_crop.crop_in(m_margin_x, m_margin_y, m_margin_w, m_margin_h);
+        m_steps = s.smoothing_steps;
+        m_rate = s.response_rate;
+        m_configured = true;
+    }
+
+    WarpMeshF next(const WarpMeshF& motion)
+    {
+        m_position -= m_path.front();
+        m_path.pop_front();
+        m_path.push_back(motion);
+        m_position += m_path[centre()];
+
+        // cv::getGaussianKernel(n, sigma, CV_32F): exp(-x^2 / (2 sigma^2)) in double, normalised, cast to float
+        const size_t n = m_path.size();
+        const double sigma = m_base + m_factor;
+        const double s2 = -0.5 / (sigma * sigma);
+        m_kd.resize(n);
+        double total = 0;
+        for (size_t i = 0; i < n; i++) { const double x = (double)i - (double)(n - 1) * 0.5; m_kd[i] = std::exp(s2 * x * x); total += m_kd[i]; }
+        total = 1. / total;
+
+        float weight = 1.0f;
+        m_trace = m_path.front();
+        for (size_t i = 1; i < n; i++)
+        {
+            weight -= (float)(m_kd[i - 1] * total);
+            m_trace.scale_add(m_path[i], weight);
+        }
+        WarpMeshF corr = m_trace;
+        corr -= m_position;
+
+        float drift = 0.0f;
+        for (size_t i = 0; i + 1 < corr.off.size(); i += 2)
+        {
+            drift = std::max(drift, std::fabs(corr.off[i]) / m_margin_x);
+            drift = std::max(drift, std::fabs(corr.off[i + 1]) / m_margin_y);
+        }
+        if (drift > 1.0f) { corr.clamp(m_margin_x, m_margin_y); drift = 1.0f; }
+
+        const double d = (double)drift;
+        const double target = d >= 0.7 ? 0.0 : (d <= 0.3 ? (double)m_steps : d);      // hysteresis<double>
+        m_factor = m_factor + m_rate * (target - m_factor);                            // exp_moving_average
+        return corr;
+    }
+
+    void restart()
+    {
+        for (WarpMeshF& m : m_path) m.set_identity();
+        m_position.set_identity();
+        m_trace.set_identity();
+    }
+
+    const WarpMeshF& scene_crop() const { return m_crop; }
+    double smoothing_factor() const { return m_factor; }
+    void margins(float out[4]) const { out[0] = m_margin_x; out[1] = m_margin_y; out[2] = m_margin_w; out[3] = m_margin_h; }
+
+private:
+    size_t centre() const { return (m_path.size() - 1) / 2; }
+    bool m_configured = false;
+    std::deque<WarpMeshF> m_path;            // sliding window of 2N+1 frame motions, always full; front() = oldest
+    WarpMeshF m_trace, m_position, m_crop;
+    double m_factor = 0.0, m_base = 0.0;
+    float m_margin_x = 0, m_margin_y = 0, m_margin_w = 1, m_margin_h = 1, m_steps = 20.0f, m_rate = 0.04f;
+    std::vector<double> m_kd;
+};
+
+// ------------------------------------------------------------------------------------------------ FeatureDetector bookkeeping
+class FeatureGridH
+{
+public:
+    struct Zone { float x, y, w, h; int threshold; size_t load; bool ran; };
+
+    void configure(const lvk_stab_settings& s)
+    {
+        m_w = s.detection_width; m_h = s.detection_height;
+        const int gc = cv_round((float)m_w * s.max_feature_density), gr = cv_round((float)m_h * s.max_feature_density);
+        if (gc != m_gc || gr != m_gr || m_cells.empty()) { m_gc = gc; m_gr = gr; m_cells.assign((size_t)gc * gr, -1); m_used = 0; }
+        m_cw = (float)m_w / (float)m_gc; m_ch = (float)m_h / (float)m_gr;
+        m_zc = s.detection_regions_x; m_zr = s.detection_regions_y;
+        m_zw = (float)m_w / (float)m_zc; m_zh = (float)m_h / (float)m_zr;
+        zones.clear();
+        for (int r = 0; r < m_zr; r++)
+            for (int c = 0; c < m_zc; c++)
+                zones.push_back(Zone{(float)c * m_zw, (float)r * m_zh, m_zw, m_zh, 10 /* FAST_MIN_THRESHOLD */, 0, false});
+        const float per_zone = (float)((size_t)m_gc * m_gr) / (float)(m_zc * m_zr);
+        m_min_load = (size_t)(per_zone * (s.min_feature_density / s.max_feature_density));
+        m_target = (size_t)(s.accumulation_rate * per_zone);
+        m_force = s.force_detection != 0;
+    }
+
+    size_t capacity() const { return (size_t)m_gc * m_gr; }
+
+    // Which zones run FAST this frame (load <= minimum, or forced), with their integer ROI and threshold.
+    void plan(std::vector<FastRegion>& out)
+    {
+        out.resize(zones.size());
+        for (size_t i = 0; i < zones.size(); i++)
+        {
+            Zone& z = zones[i];
+            z.ran = m_force || z.load <= m_min_load;
+            out[i] = FastRegion{cv_round(z.x), cv_round(z.y), cv_round(z.w), cv_round(z.h), z.threshold, z.ran ? 1 : 0};
+        }
+    }
+
+    // Feed one zone's raw FAST output (row-major packed x | y<<12 | score<<24, zone-local) through the suppression grid.
+    void absorb(size_t zone, const uint32_t* kp, int count)
+    {
+        Zone& z = zones[zone];
+        for (int i = 0; i < count; i++)
+        {
+            Feature f{(float)(kp[i] & 0xFFFu) + z.x, (float)((kp[i] >> 12) & 0xFFFu) + z.y, (float)(kp[i] >> 24), 0};
+            long& cell = m_cells[cell_of(f.x, f.y)];
+            if (cell < 0) { cell = (long)held.size(); m_used++; held.push_back(f); }
+            else if (f.response > held[(size_t)cell].response && held[(size_t)cell].age <= 0) held[(size_t)cell] = f;
+        }
+        const size_t n = (size_t)count;
+        if (n > m_target + 150) z.threshold = std::min(z.threshold + 5, 250);
+        else if (n < m_target - 150) z.threshold = z.threshold > 10 ? std::max(z.threshold - 5, 10) : std::min(z.threshold + 5, 10);
+    }
+
+    // End of detect(): hand the surviving features over, compute the distribution quality, clear the grid.
+    float finish(std::vector<Feature>& out)
+    {
+        for (Zone& z : zones) z.load = 0;
+        out.swap(held);
+        held.clear();
+        const float q = quality();
+        std::fill(m_cells.begin(), m_cells.end(), -1); m_used = 0;
+        return q;
+    }
+
+    void propagate(const std::vector<Feature>& feats)
+    {
+        for (const Feature& f : feats)
+        {
+            if (!(f.x >= 0.0f && f.x < (float)m_w && f.y >= 0.0f && f.y < (float)m_h)) continue;
+            long& cell = m_cells[cell_of(f.x, f.y)];
+            if (cell < 0)
+            {
+                cell = (long)held.size(); m_used++;
+                zones[(size_t)(f.y / m_zh) * (size_t)m_zc + (size_t)(f.x / m_zw)].load++;
+                held.push_back(f);
+            }
+            else if (f.response > held[(size_t)cell].response && f.age >= held[(size_t)cell].age) held[(size_t)cell] = f;
+        }
+    }
+
+    void reset()       // FeatureDetector::reset: the grid and the loads are cleared, the held features are not (reference behaviour)
+    {
+        std::fill(m_cells.begin(), m_cells.end(), -1); m_used = 0;
+        for (Zone& z : zones) z.load = 0;
+    }
+
+    std::vector<Zone> zones;
+    std::vector<Feature> held;               // m_Features: propagated features waiting for the next detect()
+
+private:
+    size_t cell_of(float x, float y) const { return (size_t)(y / m_ch) * (size_t)m_gc + (size_t)(x / m_cw); }
+
+    float quality() const                    // SpatialMap::distribution_quality
+    {
+        if (m_used == 0) return 1.0f;
+        if (m_gc <= 4 || m_gr <= 4) return (float)m_used / (float)m_cells.size();
+        const float sw = (float)m_gc / 4.0f, sh = (float)m_gr / 4.0f;
+        size_t bucket[16] = {0};
+        const size_t ideal = (size_t)((float)m_used / 16.0f);
+        float excess = 0.0f;
+        for (int y = 0; y < m_gr; y++)
+            for (int x = 0; x < m_gc; x++)
+                if (m_cells[(size_t)y * m_gc + x] >= 0)
+                    if (++bucket[(size_t)((float)y / sh) * 4 + (size_t)((float)x / sw)] > ideal) excess += 1.0f;
+        return 1.0f - (excess / (float)(m_used - ideal));
+    }
+
+    int m_w = 0, m_h = 0, m_gc = 0, m_gr = 0, m_zc = 1, m_zr = 1;
+    float m_cw = 1, m_ch = 1, m_zw = 1, m_zh = 1;
+    std::vector<long> m_cells;
+    size_t m_used = 0, m_min_load = 0, m_target = 0;
+    bool m_force = false;
+};
+
+} // namespace lvkh

@@ -91,3 +91,8 @@ struct DevicePyramid
     int build(lvk_hip_ctx* ctx);      // level 0 image must be filled; enqueues pyrDown + Scharr
     void release();
 };
+
+// Robust global motion (motion.hip)
+size_t lvk_ransac_workspace_bytes(int n);
+int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask);

@@ -1,0 +1,396 @@
+// Robust global motion estimation for gfx950: deterministic RANSAC over a fixed hypothesis schedule, one
+// wavefront per hypothesis with exact integer inlier voting, then a single-wave local optimisation whose
+// least-squares sums run in a fixed lane order (so the result is reproducible bit for bit).
+//
+// Replaces cv::findHomography(tracked, matched, mask, UsacParams) and cv::estimateAffinePartial2D as called by
+// FrameTracker::estimate_global_motion (reference: LiveVisionKit/Vision/FrameTracker.cpp:325-375).  The
+// algorithm is the specification of SURVEY.md Appendix A.8 (OpenCV's USAC is not restated):
+//   128 hypotheses, minimal sample from a SplitMix64 stream keyed by the hypothesis index, 8x8 solve /
+//   closed-form similarity, score = sum floor(1024 * max(0, 1 - e^2/t^2)), best score (lowest index on ties),
+//   up to 3 least-squares refits accepted while the score strictly improves.  All math binary64, no contraction.
+#include "lvk_hip_internal.hpp"
+
+namespace {
+
+constexpr int K_HYPOTHESES = 128;
+constexpr int LO_ROUNDS = 3;
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& s)
+{
+    s += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ bool draw_sample(int h, int n, int m, int* idx)
+{
+    unsigned long long s = 0x4C564B31ull ^ ((unsigned long long)(h + 1) * 0xD1B54A32D192ED03ull);
+    int got = 0;
+    for (int draw = 0; draw < 32 && got < m; draw++)
+    {
+        const int c = (int)((splitmix64(s) >> 32) % (unsigned long long)n);
+        bool dup = false;
+        for (int j = 0; j < got; j++) dup = dup || (idx[j] == c);
+        if (!dup) idx[got++] = c;
+    }
+    return got == m;
+}
+
+// Gaussian elimination with partial pivoting on LDS-resident A (n x n) and b, executed by one lane.
+__device__ bool solve_n(double* A, double* b, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        int piv = i;
+        for (int j = i + 1; j < n; j++) if (fabs(A[j * n + i]) > fabs(A[piv * n + i])) piv = j;
+        if (fabs(A[piv * n + i]) < 1e-10) return false;
+        if (piv != i)
+        {
+            for (int q = 0; q < n; q++) { const double t = A[i * n + q]; A[i * n + q] = A[piv * n + q]; A[piv * n + q] = t; }
+            const double t = b[i]; b[i] = b[piv]; b[piv] = t;
+        }
+        const double inv = 1.0 / A[i * n + i];
+        for (int j = i + 1; j < n; j++)
+        {
+            const double f = A[j * n + i] * inv;
+            for (int q = i + 1; q < n; q++) A[j * n + q] = A[j * n + q] - f * A[i * n + q];
+            b[j] = b[j] - f * b[i];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--)
+    {
+        double s = b[i];
+        for (int q = i + 1; q < n; q++) s = s - A[i * n + q] * b[q];
+        b[i] = s / A[i * n + i];
+    }
+    return true;
+}
+
+__device__ __forceinline__ double reproj_err2(const double* H, double x, double y, double u, double v)
+{
+    const double w = H[6] * x + H[7] * y + H[8];
+    if (fabs(w) < 1e-12) return 1e300;
+    const double px = (H[0] * x + H[1] * y + H[2]) / w, py = (H[3] * x + H[4] * y + H[5]) / w;
+    const double ex = px - u, ey = py - v;
+    return ex * ex + ey * ey;
+}
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)          // xor butterfly 32,16,...,1: own + partner
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = v + __shfl_xor(v, o);
+    return v;
+}
+
+// Scores model H over all pairs with the whole wave; optionally writes the inlier mask. Returns (score, #inliers) on every lane.
+__device__ long long score_model(const double* H, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2,
+                                 uint8_t* mask, int* ninl)
+{
+    const int lane = threadIdx.x & 63;
+    long long score = 0; long long cnt = 0;
+    for (int i = lane; i < n; i += 64)
+    {
+        const float2 a = p1[i], b = p2[i];
+        const double e2 = reproj_err2(H, (double)a.x, (double)a.y, (double)b.x, (double)b.y);
+        const bool in = e2 <= t2;
+        if (in) { score += (long long)((1.0 - e2 / t2) * 1024.0); cnt++; }
+        if (mask) mask[i] = in ? 1 : 0;
+    }
+    score = wave_sum_ll(score);
+    cnt = wave_sum_ll(cnt);
+    if (ninl) *ninl = (int)cnt;
+    return score;
+}
+
+__device__ bool model_from_sample(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, const int* idx,
+                                  double* A, double* b, double* H)
+{
+    if (full)
+    {
+        for (int i = 0; i < 4; i++)
+        {
+            const double x = p1[idx[i]].x, y = p1[idx[i]].y, u = p2[idx[i]].x, v = p2[idx[i]].y;
+            double* r0 = A + i * 8; double* r1 = A + (i + 4) * 8;
+            r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x * u; r0[7] = -y * u; b[i] = u;
+            r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * v; r1[7] = -y * v; b[i + 4] = v;
+        }
+        if (!solve_n(A, b, 8)) return false;
+        for (int q = 0; q < 8; q++) H[q] = b[q];
+        H[8] = 1.0;
+        return true;
+    }
+    const double x0 = p1[idx[0]].x, y0 = p1[idx[0]].y, x1 = p1[idx[1]].x, y1 = p1[idx[1]].y;
+    const double u0 = p2[idx[0]].x, v0 = p2[idx[0]].y, u1 = p2[idx[1]].x, v1 = p2[idx[1]].y;
+    const double dx = x1 - x0, dy = y1 - y0, ex = u1 - u0, ey = v1 - v0;
+    const double d2 = dx * dx + dy * dy;
+    if (d2 < 1e-10) return false;
+    const double a = (dx * ex + dy * ey) / d2, bb = (dx * ey - dy * ex) / d2;
+    H[0] = a; H[1] = -bb; H[2] = u0 - (a * x0 - bb * y0);
+    H[3] = bb; H[4] = a;  H[5] = v0 - (bb * x0 + a * y0);
+    H[6] = 0; H[7] = 0;   H[8] = 1;
+    return true;
+}
+
+// One wavefront per hypothesis.
+__global__ __launch_bounds__(64)
+void k_ransac_hypotheses(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2, int full,
+                         double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
+{
+    __shared__ double sA[64], sb[8], sH[9];
+    __shared__ int s_ok;
+    const int h = blockIdx.x;
+    if (threadIdx.x == 0)
+    {
+        int idx[4];
+        bool ok = draw_sample(h, n, full ? 4 : 2, idx);
+        if (ok) ok = model_from_sample(full != 0, p1, p2, idx, sA, sb, sH);
+        s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) { if (threadIdx.x == 0) hyp_score[h] = -1; return; }
+    const long long s = score_model(sH, p1, p2, n, t2, nullptr, nullptr);
+    if (threadIdx.x == 0)
+    {
+        hyp_score[h] = s;
+        for (int q = 0; q < 9; q++) hyp_H[h * 9 + q] = sH[q];
+    }
+}
+
+// Least-squares refit on the masked pairs; sums in wave order (lane = i mod 64, xor butterfly).
+__device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
+                      double cx, double cy, double sc, double* A, double* b, double* H)
+{
+    const int lane = threadIdx.x & 63;
+    if (full)
+    {
+        double N[36], g[8];
+#pragma unroll
+        for (int k = 0; k < 36; k++) N[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) g[k] = 0.0;
+        for (int i = lane; i < n; i += 64)
+        {
+            if (!mask[i]) continue;
+            const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
+            const double u = ((double)p2[i].x - cx) * sc, v = ((double)p2[i].y - cy) * sc;
+            const double r0[8] = {x, y, 1, 0, 0, 0, -x * u, -y * u};
+            const double r1[8] = {0, 0, 0, x, y, 1, -x * v, -y * v};
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int c = a; c < 8; c++, k++)
+                    N[k] = N[k] + (r0[a] * r0[c] + r1[a] * r1[c]);
+#pragma unroll
+            for (int a = 0; a < 8; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
+        }
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int c = a; c < 8; c++, k++)
+            {
+                const double t = wave_sum_f64(N[k]);
+                if (lane == 0) { A[a * 8 + c] = t; A[c * 8 + a] = t; }
+            }
+#pragma unroll
+        for (int a = 0; a < 8; a++) { const double t = wave_sum_f64(g[a]); if (lane == 0) b[a] = t; }
+        __syncthreads();
+        __shared__ int s_ok;
+        if (lane == 0)
+        {
+            bool ok = solve_n(A, b, 8);
+            if (ok)
+            {
+                const double Hn[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
+                const double T[9] = {sc, 0, -cx * sc, 0, sc, -cy * sc, 0, 0, 1};
+                const double Ti[9] = {1.0 / sc, 0, cx, 0, 1.0 / sc, cy, 0, 0, 1};
+                double M[9], R[9];
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r * 3 + c] = (Hn[r * 3] * T[c] + Hn[r * 3 + 1] * T[3 + c]) + Hn[r * 3 + 2] * T[6 + c];
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[r * 3 + c] = (Ti[r * 3] * M[c] + Ti[r * 3 + 1] * M[3 + c]) + Ti[r * 3 + 2] * M[6 + c];
+                if (fabs(R[8]) < 1e-12) ok = false;
+                else for (int q = 0; q < 9; q++) H[q] = R[q] / R[8];
+            }
+            s_ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        return s_ok != 0;
+    }
+    else
+    {
+        double N[10], g[4];
+#pragma unroll
+        for (int k = 0; k < 10; k++) N[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) g[k] = 0.0;
+        for (int i = lane; i < n; i += 64)
+        {
+            if (!mask[i]) continue;
+            const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
+            const double u = ((double)p2[i].x - cx) * sc, v = ((double)p2[i].y - cy) * sc;
+            const double r0[4] = {x, -y, 1, 0};
+            const double r1[4] = {y, x, 0, 1};
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int c = a; c < 4; c++, k++)
+                    N[k] = N[k] + (r0[a] * r0[c] + r1[a] * r1[c]);
+#pragma unroll
+            for (int a = 0; a < 4; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
+        }
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = a; c < 4; c++, k++)
+            {
+                const double t = wave_sum_f64(N[k]);
+                if (lane == 0) { A[a * 4 + c] = t; A[c * 4 + a] = t; }
+            }
+#pragma unroll
+        for (int a = 0; a < 4; a++) { const double t = wave_sum_f64(g[a]); if (lane == 0) b[a] = t; }
+        __syncthreads();
+        __shared__ int s_ok2;
+        if (lane == 0)
+        {
+            const bool ok = solve_n(A, b, 4);
+            if (ok)
+            {
+                const double a = b[0], bb = b[1], tx = b[2], ty = b[3];
+                H[0] = a; H[1] = -bb; H[2] = (tx / sc + cx) - (a * cx - bb * cy);
+                H[3] = bb; H[4] = a;  H[5] = (ty / sc + cy) - (bb * cx + a * cy);
+                H[6] = 0; H[7] = 0; H[8] = 1;
+            }
+            s_ok2 = ok ? 1 : 0;
+        }
+        __syncthreads();
+        return s_ok2 != 0;
+    }
+}
+
+// Single wavefront: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
+__global__ __launch_bounds__(64)
+void k_ransac_finalize(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2, int full,
+                       double cx, double cy, double sc,
+                       const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
+                       uint8_t* __restrict__ mask_a, uint8_t* __restrict__ mask_b,
+                       double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
+{
+    __shared__ double sA[64], sb[8], sH[9], sBest[9];
+    const int lane = threadIdx.x;
+    const int m = full ? 4 : 2;
+    // argmax over the hypotheses: highest score, lowest index on ties
+    long long best = -1; int best_h = -1;
+    for (int h = lane; h < K_HYPOTHESES; h += 64)
+    {
+        const long long s = hyp_score[h];
+        if (s > best) { best = s; best_h = h; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        const long long os = __shfl_xor(best, o); const int oh = __shfl_xor(best_h, o);
+        if (os > best || (os == best && oh >= 0 && (best_h < 0 || oh < best_h))) { best = os; best_h = oh; }
+    }
+    if (best_h < 0 || best < 0)
+    {
+        for (int i = lane; i < n; i += 64) out_mask[i] = 0;
+        if (lane == 0) { for (int q = 0; q < 9; q++) out_H[q] = (q % 4 == 0) ? 1.0 : 0.0; *out_ninl = -2; }
+        return;
+    }
+    if (lane < 9) sBest[lane] = hyp_H[best_h * 9 + lane];
+    __syncthreads();
+    uint8_t* cur = mask_a; uint8_t* trial = mask_b;
+    int ninl = 0;
+    long long best_score = score_model(sBest, p1, p2, n, t2, cur, &ninl);
+    __syncthreads();
+    for (int round = 0; round < LO_ROUNDS; round++)
+    {
+        if (ninl < m) break;
+        if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH)) break;
+        int nt = 0;
+        const long long s = score_model(sH, p1, p2, n, t2, trial, &nt);
+        __syncthreads();
+        if (s <= best_score) break;
+        best_score = s; ninl = nt;
+        if (lane < 9) sBest[lane] = sH[lane];
+        uint8_t* t = cur; cur = trial; trial = t;
+        __syncthreads();
+    }
+    for (int i = lane; i < n; i += 64) out_mask[i] = cur[i];
+    if (lane < 9) out_H[lane] = sBest[lane];
+    if (lane == 0) *out_ninl = ninl;
+}
+
+} // namespace
+
+size_t lvk_ransac_workspace_bytes(int n)
+{
+    // hypotheses (H + score) | mask_a | mask_b
+    return (size_t)K_HYPOTHESES * (9 * sizeof(double) + sizeof(long long)) + 2 * (((size_t)n + 255) & ~(size_t)255);
+}
+
+// d_p1/d_p2: n pairs; d_ws: lvk_ransac_workspace_bytes(n); outputs d_H (9 doubles), d_ninl, d_mask (n bytes).
+int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask)
+{
+    LVK_HIP_REQUIRE(ctx, d_p1 && d_p2 && d_ws && d_H && d_ninl && d_mask && n >= (full_homography ? 4 : 2));
+    double* hyp_H = (double*)d_ws;
+    long long* hyp_score = (long long*)(hyp_H + K_HYPOTHESES * 9);
+    uint8_t* mask_a = (uint8_t*)(hyp_score + K_HYPOTHESES);
+    uint8_t* mask_b = mask_a + (((size_t)n + 255) & ~(size_t)255);
+    const double t2 = threshold * threshold;
+    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(K_HYPOTHESES), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+    hipLaunchKernelGGL(k_ransac_finalize, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+                       region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+extern "C" {
+
+// Synchronous test entry point: host point arrays (n x 2 floats), outputs H (9 doubles, row major), mask (n bytes).
+// Returns the inlier count (>= 0) or a negative status: LVK_HIP_ERR_* or -10 - (reason) when no model was found.
+int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const float* pts2, int n, double threshold,
+                                   double region_w, double region_h, int full_homography, double H[9], uint8_t* mask)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, pts1 && pts2 && H && mask && n >= 0);
+    for (int q = 0; q < 9; q++) H[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < n; i++) mask[i] = 0;
+    if (n < (full_homography ? 4 : 2)) return -11;
+    float2 *d_p1 = nullptr, *d_p2 = nullptr; void* d_ws = nullptr; double* d_H = nullptr; int* d_n = nullptr; uint8_t* d_mask = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_p1); (void)hipFree(d_p2); (void)hipFree(d_ws); (void)hipFree(d_H); (void)hipFree(d_n); (void)hipFree(d_mask); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_p1, n * sizeof(float2))) != hipSuccess || (e = hipMalloc((void**)&d_p2, n * sizeof(float2))) != hipSuccess ||
+        (e = hipMalloc(&d_ws, lvk_ransac_workspace_bytes(n))) != hipSuccess || (e = hipMalloc((void**)&d_H, 9 * sizeof(double))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_n, sizeof(int))) != hipSuccess || (e = hipMalloc((void**)&d_mask, n)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_p1, pts1, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_p2, pts2, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+    { cleanup(); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
+    int rc = lvk_launch_ransac(ctx, d_p1, d_p2, n, threshold, region_w, region_h, full_homography != 0, d_ws, d_H, d_n, d_mask);
+    int ninl = 0;
+    if (rc == LVK_HIP_OK)
+    {
+        if ((e = hipMemcpyAsync(H, d_H, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(&ninl, d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(mask, d_mask, n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+        { cleanup(); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
+    }
+    cleanup();
+    if (rc != LVK_HIP_OK) return rc;
+    return ninl >= 0 ? ninl : -10 + ninl;
+}
+
+} // extern "C"

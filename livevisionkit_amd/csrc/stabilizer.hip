@@ -1,0 +1,463 @@
+// The stabilization filter proper: per-frame orchestration of the HIP kernels plus the host state machines.
+//
+// Replaces (reference, paths relative to LiveVisionKit/):
+//   StabilizationFilter::{configure,filter,restart,ready,reset_context,frame_delay,stable_region}  Filters/StabilizationFilter.cpp:42-206
+//   FrameTracker::{configure,track,restart,estimate_global_motion}                                  Vision/FrameTracker.cpp:57-196,325-375
+//   FeatureDetector::{detect,propagate,reset} bookkeeping                                           Vision/FeatureDetector.cpp:114-214
+//
+// Per frame, on the context's stream:
+//   luma + INTER_AREA downscale -> pyramid (pyrDown x3, Scharr x4)                       [imgproc.hip]
+//   FAST-9/16 + NMS per due region, ordered compaction                                  [fast.hip]      -> host: suppression grid
+//   pyramidal LK, one wavefront per feature                                             [pyrlk.hip]     -> host: swap-erase filter
+//   RANSAC hypotheses + local optimisation                                              [motion.hip]    -> host: ageing, propagate, QA, path smoothing
+//   EASU remap of the delayed frame (homography or in-kernel mesh)                      [remap.hip]
+// Frames are never copied: the filter borrows the caller's device buffer until that frame has been emitted
+// (the reference moves the input frame into its queue, StabilizationFilter.cpp:118).
+#include "lvk_hip_internal.hpp"
+#include "host_logic.hpp"
+
+#include <cstring>
+#include <deque>
+
+using lvkh::Feature;
+using lvkh::WarpMeshF;
+
+namespace {
+
+constexpr int LK_WIN = 11, LK_LEVELS = 3, LK_ITERS = 5;        // FrameTracker.cpp:33-35
+constexpr double LK_EPS = 0.01, LK_MIN_EIG = 1e-4;
+constexpr float HOMOGRAPHY_DISTRIBUTION_THRESHOLD = 0.6f;      // FrameTracker.cpp:37
+constexpr float QA_UPDATE_RATE = 0.1f, QA_BLEND_STEP = 0.05f;   // StabilizationFilter.cpp:30-31
+
+inline float step_toward(float current, float target, float amount)   // Functions/Math.tpp:133-142
+{
+    return current > target ? std::max(current - amount, target) : std::min(current + amount, target);
+}
+
+struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; };
+
+} // namespace
+
+struct lvk_hip_stab
+{
+    lvk_hip_ctx* ctx = nullptr;
+    lvk_stab_settings s{};
+    bool configured = false;
+
+    // ---- tracker device state
+    DevicePyramid pyr[2];
+    int cur = 0;                               // pyr[cur] = current frame, pyr[cur ^ 1] = previous frame
+    int pyr_w = 0, pyr_h = 0;                  // resolution the pyramids are allocated for
+    int prev_w = 0, prev_h = 0, cur_w = 0, cur_h = 0;
+    bool initialized = false;
+    size_t cap_features = 0;                   // suppression-grid capacity (max features)
+    int fast_cap = 0, fast_max_rw = 0, fast_max_rh = 0, fast_regions = 0;
+    FastRegion* d_regions = nullptr; void* d_fast_masks = nullptr; void* d_fast_scores = nullptr;
+    uint32_t* d_fast_out = nullptr; int* d_fast_counts = nullptr;
+    float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr, *d_p2 = nullptr; uint8_t* d_status = nullptr;
+    void* d_ransac_ws = nullptr; double* d_H = nullptr; int* d_ninl = nullptr; uint8_t* d_mask = nullptr;
+    // pinned host mirrors
+    uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
+    float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr, *h_p2 = nullptr; uint8_t* h_status = nullptr;
+    double* h_H = nullptr; int* h_ninl = nullptr; uint8_t* h_mask = nullptr;
+
+    // ---- host state
+    lvkh::FeatureGridH grid;
+    lvkh::PathSmootherH smoother;
+    std::vector<Feature> tracked;
+    std::vector<FastRegion> plan;
+    std::deque<QueuedFrame> queue;
+    size_t queue_capacity = 1;
+    float tracking_stability = 0.0f, scene_quality = 0.0f, trust = 0.0f;
+    // taps for stats / tests
+    float last_distribution = 0.0f; int last_detected = 0, last_matched = 0;
+    double last_H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    WarpMeshF last_motion, last_correction;
+
+    int fail(int code, const std::string& msg) { return ctx->fail(code, msg); }
+    void free_tracker_buffers();
+    int alloc_tracker_buffers();
+    int alloc_pyramids();
+    int configure(const lvk_stab_settings& st);
+    void tracker_restart();
+    void reset_context() { tracker_restart(); smoother.restart(); }
+    int track(const QueuedFrame& f, WarpMeshF& motion, bool& have_motion);
+};
+
+int lvk_hip_stab::alloc_pyramids()
+{
+    int rc;
+    if ((rc = pyr[0].allocate(ctx, s.detection_height, s.detection_width, LK_LEVELS, LK_WIN, LK_WIN)) != LVK_HIP_OK) return rc;
+    if ((rc = pyr[1].allocate(ctx, s.detection_height, s.detection_width, LK_LEVELS, LK_WIN, LK_WIN)) != LVK_HIP_OK) return rc;
+    pyr_w = s.detection_width; pyr_h = s.detection_height;
+    return LVK_HIP_OK;
+}
+
+void lvk_hip_stab::free_tracker_buffers()
+{
+    void* dev[] = {d_regions, d_fast_masks, d_fast_scores, d_fast_out, d_fast_counts, d_pts, d_matched, d_p1, d_p2, d_status, d_ransac_ws, d_H, d_ninl, d_mask};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_p2, h_status, h_H, h_ninl, h_mask};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    d_regions = nullptr; d_fast_masks = d_fast_scores = nullptr; d_fast_out = nullptr; d_fast_counts = nullptr;
+    d_pts = d_matched = d_p1 = d_p2 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_H = nullptr; d_ninl = nullptr; d_mask = nullptr;
+    h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = h_p2 = nullptr; h_status = nullptr;
+    h_H = nullptr; h_ninl = nullptr; h_mask = nullptr;
+}
+
+int lvk_hip_stab::alloc_tracker_buffers()
+{
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    free_tracker_buffers();
+    // the grid holds at most one feature per cell; features left over from before a reset() can add as many again
+    cap_features = 2 * grid.capacity() + 16;
+    fast_regions = (int)grid.zones.size();
+    fast_max_rw = fast_max_rh = 1;
+    grid.plan(plan);
+    for (const FastRegion& r : plan) { fast_max_rw = std::max(fast_max_rw, r.w); fast_max_rh = std::max(fast_max_rh, r.h); }
+    // NMS keeps at most one pixel of every 2x2 block: that bounds the raw corner count of a region.
+    fast_cap = ((fast_max_rw + 1) / 2) * ((fast_max_rh + 1) / 2);
+    size_t mb, sb;
+    lvk_fast_workspace_bytes(fast_regions, fast_max_rw, fast_max_rh, &mb, &sb);
+    const size_t n = cap_features;
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_regions, fast_regions * sizeof(FastRegion)));
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_fast_masks, mb));
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_fast_scores, sb));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_fast_counts, fast_regions * sizeof(int)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_pts, n * sizeof(float2)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_matched, n * sizeof(float2)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p1, n * sizeof(float2)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p2, n * sizeof(float2)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_status, n));
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_ransac_ws, lvk_ransac_workspace_bytes((int)n)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_H, 9 * sizeof(double)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_ninl, sizeof(int)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_mask, n));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_pts, n * sizeof(float2), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_matched, n * sizeof(float2), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, n * sizeof(float2), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p2, n * sizeof(float2), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_status, n, hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocDefault));
+    return LVK_HIP_OK;
+}
+
+void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameTracker.cpp:97-104)
+{
+    tracking_stability = 0.0f;
+    tracked.clear();
+    grid.reset();
+    initialized = false;
+}
+
+int lvk_hip_stab::configure(const lvk_stab_settings& st)
+{
+    // pre-conditions the reference asserts: StabilizationFilter.cpp:44-45, FrameTracker.cpp:59-65, FeatureDetector.cpp:50-57, PathSmoother.cpp:38-44
+    LVK_HIP_REQUIRE(ctx, st.min_tracking_quality >= 0 && st.min_tracking_quality <= 1 && st.min_scene_quality >= 0 && st.min_scene_quality <= 1);
+    LVK_HIP_REQUIRE(ctx, st.motion_width >= 2 && st.motion_height >= 2);
+    LVK_HIP_REQUIRE(ctx, st.acceptance_threshold >= 0 && st.temporal_smoothing >= 0 && st.local_smoothing >= 0 && st.min_motion_samples >= 4);
+    LVK_HIP_REQUIRE(ctx, st.uniformity_threshold >= 0 && st.uniformity_threshold <= 1);
+    LVK_HIP_REQUIRE(ctx, st.detection_regions_x > 0 && st.detection_regions_y > 0);
+    LVK_HIP_REQUIRE(ctx, st.detection_regions_x <= st.detection_width && st.detection_regions_y <= st.detection_height);
+    LVK_HIP_REQUIRE(ctx, st.min_feature_density <= st.max_feature_density && st.min_feature_density > 0 && st.max_feature_density <= 1 && st.accumulation_rate > 0);
+    LVK_HIP_REQUIRE(ctx, st.corrective_limit_x >= 0 && st.corrective_limit_x <= 1 && st.corrective_limit_y >= 0 && st.corrective_limit_y <= 1);
+    LVK_HIP_REQUIRE(ctx, st.predictive_samples > 0 && st.smoothing_steps > 0 && st.response_rate >= 0 && st.response_rate <= 1);
+    LVK_HIP_REQUIRE(ctx, st.detection_width >= 8 && st.detection_height >= 8 && st.detection_width < 4096 && st.detection_height < 4096);
+
+    if (configured && s.stabilize_output && !st.stabilize_output) reset_context();        // StabilizationFilter.cpp:49-52
+    const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
+    const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
+                                || st.max_feature_density != s.max_feature_density;
+    smoother.configure(st);
+    queue_capacity = (size_t)st.predictive_samples + 1;
+    while (queue.size() > queue_capacity) queue.pop_front();
+    grid.configure(st);
+    if (configured && res_changed && initialized) grid.reset();                          // FrameTracker.cpp:86-91
+    s = st;
+    configured = true;
+    if (layout_changed)
+    {
+        // New tracking geometry: the cached frame no longer matches, which costs one nullopt frame exactly as the
+        // reference's size check does (FrameTracker.cpp:120-124).
+        int rc = alloc_tracker_buffers();
+        if (rc != LVK_HIP_OK) return rc;
+        if (res_changed)
+        {
+            if ((rc = alloc_pyramids()) != LVK_HIP_OK) return rc;
+            prev_w = prev_h = cur_w = cur_h = 0;
+        }
+    }
+    return LVK_HIP_OK;
+}
+
+// FrameTracker::track (FrameTracker.cpp:108-196)
+int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_motion)
+{
+    have_motion = false;
+    tracking_stability = 0.0f;
+    last_detected = last_matched = 0; last_distribution = 0.0f;
+    hipStream_t st = ctx->stream;
+    int rc;
+
+    cur ^= 1;
+    std::swap(prev_w, cur_w); std::swap(prev_h, cur_h);
+    cur_w = s.detection_width; cur_h = s.detection_height;
+    DevicePyramid& C = pyr[cur];
+    DevicePyramid& P = pyr[cur ^ 1];
+    if ((rc = lvk_launch_luma_area_resize(ctx, f.d_ptr, f.step, 3, 0, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
+    if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
+    if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return LVK_HIP_OK; }
+
+    // ---- FeatureDetector::detect
+    grid.plan(plan);
+    bool any = false;
+    for (size_t i = 0; i < plan.size(); i++) { h_regions[i] = plan[i]; any = any || plan[i].active; }
+    if (any)
+    {
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_regions, h_regions, plan.size() * sizeof(FastRegion), hipMemcpyHostToDevice, st));
+        if ((rc = lvk_launch_fast(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, d_regions, (int)plan.size(), fast_max_rw, fast_max_rh,
+                                  d_fast_masks, d_fast_scores, d_fast_out, fast_cap, d_fast_counts)) != LVK_HIP_OK) return rc;
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_fast_counts, d_fast_counts, plan.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_fast_out, d_fast_out, plan.size() * (size_t)fast_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    for (size_t i = 0; i < plan.size(); i++)
+        if (plan[i].active) grid.absorb(i, h_fast_out + i * (size_t)fast_cap, std::min(h_fast_counts[i], fast_cap));
+    const float distribution = grid.finish(tracked);
+    last_distribution = distribution; last_detected = (int)tracked.size();
+    if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return LVK_HIP_OK; }
+    if (tracked.size() > cap_features) return fail(LVK_HIP_ERR_RUNTIME, "feature count exceeds the suppression grid capacity");
+
+    // ---- sparse optical flow prev -> cur
+    const int n = (int)tracked.size();
+    for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, h_pts, n * sizeof(float2), hipMemcpyHostToDevice, st));
+    if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_matched, d_matched, n * sizeof(float2), hipMemcpyDeviceToHost, st));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_status, d_status, n, hipMemcpyDeviceToHost, st));
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+
+    // fast_filter(features, tracked points, matched points; keep = status): back-to-front swap-erase (Container.tpp:97-121)
+    int m = n;
+    for (int k = n - 1; k >= 0; k--)
+        if (!h_status[k])
+        {
+            m--;
+            std::swap(tracked[k], tracked[m]);
+            std::swap(h_pts[k], h_pts[m]);
+            std::swap(h_matched[k], h_matched[m]);
+        }
+    tracked.resize(m);
+    last_matched = m;
+    if ((size_t)m < (size_t)s.min_motion_samples) { tracked.clear(); return LVK_HIP_OK; }
+
+    // ---- motion estimate
+    motion = WarpMeshF(s.motion_height, s.motion_width);
+    if (s.track_local_motions)
+        return fail(LVK_HIP_ERR_ARG, "track_local_motions (vector-field preset) is not built yet: SURVEY.md section 8 row a10");
+    const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
+    std::memcpy(h_p1, h_pts, m * sizeof(float2));
+    std::memcpy(h_p2, h_matched, m * sizeof(float2));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, m * sizeof(float2), hipMemcpyHostToDevice, st));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, h_p2, m * sizeof(float2), hipMemcpyHostToDevice, st));
+    if ((rc = lvk_launch_ransac(ctx, d_p1, d_p2, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, d_H, d_ninl, d_mask)) != LVK_HIP_OK) return rc;
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_H, d_H, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_ninl, d_ninl, sizeof(int), hipMemcpyDeviceToHost, st));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, d_mask, m, hipMemcpyDeviceToHost, st));
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    std::memcpy(last_H, h_H, sizeof(last_H));
+    motion.from_homography(last_H, (float)cur_w, (float)cur_h);
+
+    size_t inliers = 0;
+    for (int i = 0; i < m; i++) inliers += h_mask[i] ? 1 : 0;
+    tracking_stability = (float)inliers / (float)m;                                      // ratio_of(inlier_status, 1)
+
+    for (int i = m - 1; i >= 0; i--)                                                     // FrameTracker.cpp:183-192
+    {
+        if (h_mask[i]) { tracked[i].age++; tracked[i].x = h_matched[i].x; tracked[i].y = h_matched[i].y; }
+        else { std::swap(tracked[i], tracked.back()); tracked.pop_back(); }
+    }
+    grid.propagate(tracked);
+    have_motion = true;
+    return LVK_HIP_OK;
+}
+
+extern "C" {
+
+void lvk_stab_default_settings(lvk_stab_settings* s)
+{
+    if (!s) return;
+    // FeatureDetector.hpp:28-37, FrameTracker.hpp:31-44, PathSmoother.hpp:29-39, StabilizationFilter.hpp:28-39
+    s->detection_width = 256; s->detection_height = 256; s->detection_regions_x = 2; s->detection_regions_y = 2; s->force_detection = 0;
+    s->max_feature_density = 0.20f; s->min_feature_density = 0.05f; s->accumulation_rate = 2.0f;
+    s->track_local_motions = 1; s->temporal_smoothing = 1.0f; s->local_smoothing = 20.0f;
+    s->min_motion_samples = 75; s->acceptance_threshold = 8.0f; s->uniformity_threshold = 0.20f;
+    s->predictive_samples = 10; s->corrective_limit_x = 0.1f; s->corrective_limit_y = 0.1f; s->smoothing_steps = 20.0f; s->response_rate = 0.04f;
+    s->motion_width = 2; s->motion_height = 2;
+    s->background[0] = 255; s->background[1] = 0; s->background[2] = 255;
+    s->crop_to_stable_region = 0; s->stabilize_output = 1; s->min_scene_quality = 0.8f; s->min_tracking_quality = 0.3f;
+}
+
+int lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lvk_hip_stab** out)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, settings && out);
+    *out = nullptr;
+    auto* st = new lvk_hip_stab();
+    st->ctx = ctx;
+    const int rc = st->configure(*settings);
+    if (rc != LVK_HIP_OK) { st->free_tracker_buffers(); st->pyr[0].release(); st->pyr[1].release(); delete st; return rc; }
+    *out = st;
+    return LVK_HIP_OK;
+}
+
+void lvk_hip_stab_destroy(lvk_hip_stab* st)
+{
+    if (!st) return;
+    (void)hipStreamSynchronize(st->ctx->stream);
+    st->free_tracker_buffers();
+    st->pyr[0].release(); st->pyr[1].release();
+    delete st;
+}
+
+int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(st->ctx, settings);
+    return st->configure(*settings);
+}
+
+int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::restart (StabilizationFilter.cpp:139-144)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    st->scene_quality = 1.0f;
+    st->queue.clear();
+    st->reset_context();
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_stab_reset_context(lvk_hip_stab* st)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    st->reset_context();
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_stab_ready(const lvk_hip_stab* st) { return st && st->queue.size() == st->queue_capacity ? 1 : 0; }
+int lvk_hip_stab_frame_delay(const lvk_hip_stab* st) { return st ? st->s.predictive_samples : 0; }
+
+// StabilizationFilter::filter (StabilizationFilter.cpp:69-135)
+int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
+                      void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    if (produced) *produced = 0;
+    if (released) *released = nullptr;
+    LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
+    LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV);                                       // other VideoFrame formats: SURVEY.md section 8 "next"
+    const QueuedFrame in{d_frame, step, rows, cols, timestamp};
+    const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
+
+    auto enqueue = [&]() {
+        if (st->queue.size() == st->queue_capacity) { if (released) *released = st->queue.front().d_ptr; st->queue.pop_front(); }
+        st->queue.push_back(in);
+    };
+    auto emit = [&](const WarpMeshF* mesh) -> int {
+        const QueuedFrame f = st->queue.front();
+        st->queue.pop_front();
+        LVK_HIP_REQUIRE(ctx, d_out != nullptr && out_step >= 3 * f.cols);
+        int rc = LVK_HIP_OK;
+        if (mesh) rc = lvk_hip_warpmesh_apply(ctx, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1);
+        else
+        {
+            hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) rc = ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
+        }
+        if (rc != LVK_HIP_OK) return rc;
+        if (produced) *produced = 1;
+        if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222
+        if (released) *released = f.d_ptr;
+        return LVK_HIP_OK;
+    };
+
+    if (!st->s.stabilize_output)                                                          // StabilizationFilter.cpp:77-95
+    {
+        enqueue();
+        if (st->queue.size() != st->queue_capacity) return LVK_HIP_OK;
+        return emit(st->s.crop_to_stable_region ? &st->smoother.scene_crop() : nullptr);
+    }
+
+    WarpMeshF motion(st->s.motion_height, st->s.motion_width);                            // m_NullMotion
+    WarpMeshF est; bool have = false;
+    int rc = st->track(in, est, have);
+    if (rc != LVK_HIP_OK) return rc;
+    if (have) motion = est;
+
+    // quality assurance (StabilizationFilter.cpp:101-115)
+    const float tq = st->tracking_stability;
+    st->scene_quality = st->scene_quality + QA_UPDATE_RATE * (tq - st->scene_quality);
+    if (tq < st->s.min_tracking_quality) st->trust = 0.0f;
+    else if (st->scene_quality < st->s.min_scene_quality) st->trust = step_toward(st->trust, 0.0f, QA_BLEND_STEP);
+    else st->trust = step_toward(st->trust, 1.0f, QA_BLEND_STEP);
+    motion.scale(st->trust);
+    st->last_motion = motion;
+
+    enqueue();
+    WarpMeshF correction = st->smoother.next(motion);
+    if (st->queue.size() != st->queue_capacity) return LVK_HIP_OK;                        // !ready(): output.release()
+    if (st->s.crop_to_stable_region) correction += st->smoother.scene_crop();
+    st->last_correction = correction;
+    return emit(&correction);
+}
+
+int lvk_hip_stab_get_stats(const lvk_hip_stab* st, lvk_stab_stats* o)
+{
+    if (!st || !o) return LVK_HIP_ERR_ARG;
+    o->tracking_stability = st->tracking_stability; o->scene_quality = st->scene_quality; o->trust = st->trust;
+    o->distribution = st->last_distribution; o->n_detected = st->last_detected; o->n_matched = st->last_matched;
+    o->n_tracked = (int)st->tracked.size(); o->frame_delay = st->s.predictive_samples;
+    o->smoothing_factor = st->smoother.smoothing_factor();
+    for (int i = 0; i < 9; i++) o->homography[i] = st->last_H[i];
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_stab_get_meshes(const lvk_hip_stab* st, float* motion, float* correction, int cap_floats)
+{
+    if (!st || !motion || !correction) return LVK_HIP_ERR_ARG;
+    const int n = (int)st->last_motion.off.size();
+    if (n > cap_floats) return LVK_HIP_ERR_ARG;
+    std::memcpy(motion, st->last_motion.off.data(), n * sizeof(float));
+    if ((int)st->last_correction.off.size() == n) std::memcpy(correction, st->last_correction.off.data(), n * sizeof(float));
+    return n;
+}
+
+int lvk_hip_stab_get_features(const lvk_hip_stab* st, float* xy_resp_age, int cap)
+{
+    if (!st || !xy_resp_age) return LVK_HIP_ERR_ARG;
+    const int n = std::min(cap, (int)st->tracked.size());
+    for (int i = 0; i < n; i++)
+    {
+        xy_resp_age[4 * i] = st->tracked[i].x; xy_resp_age[4 * i + 1] = st->tracked[i].y;
+        xy_resp_age[4 * i + 2] = st->tracked[i].response; xy_resp_age[4 * i + 3] = (float)st->tracked[i].age;
+    }
+    return (int)st->tracked.size();
+}
+
+// StabilizationFilter::stable_region (StabilizationFilter.cpp:199-205): margins * frame size -> cv::Rect (rounded)
+int lvk_hip_stab_stable_region(const lvk_hip_stab* st, int rows, int cols, int rect[4])
+{
+    if (!st || !rect) return LVK_HIP_ERR_ARG;
+    float m[4]; st->smoother.margins(m);
+    rect[0] = lvkh::cv_round(m[0] * (float)cols); rect[1] = lvkh::cv_round(m[1] * (float)rows);
+    rect[2] = lvkh::cv_round(m[2] * (float)cols); rect[3] = lvkh::cv_round(m[3] * (float)rows);
+    return LVK_HIP_OK;
+}
+
+} // extern "C"

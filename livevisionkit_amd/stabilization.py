@@ -1,0 +1,193 @@
+"""Host-side mirror of lvk::StabilizationFilter (reference: LiveVisionKit/Filters/StabilizationFilter.hpp:42-78,
+LiveVisionKit/Filters/VideoFilter.hpp:32-61) over the C-ABI.  Same method names and argument meaning:
+configure / reconfigure / settings / apply / restart / ready / reset_context / frame_delay / stable_region / timings.
+Frames are torch uint8 tensors [rows, cols, 3] resident on the GPU (packed YUV, the reference's 8UC3 VideoFrame)."""
+import ctypes
+import time
+
+import numpy as np
+
+from . import _native
+from .context import Context, LvkHipError
+
+_c = ctypes
+
+FORMAT_BGR, FORMAT_BGRA, FORMAT_RGB, FORMAT_RGBA, FORMAT_YUV, FORMAT_GRAY = range(6)
+
+
+class StabilizationFilterSettings(_c.Structure):
+    """lvk::StabilizationFilterSettings flattened (field-for-field lvk_stab_settings of include/lvk_hip.h)."""
+    _fields_ = [("detection_width", _c.c_int), ("detection_height", _c.c_int),
+                ("detection_regions_x", _c.c_int), ("detection_regions_y", _c.c_int), ("force_detection", _c.c_int),
+                ("max_feature_density", _c.c_float), ("min_feature_density", _c.c_float), ("accumulation_rate", _c.c_float),
+                ("track_local_motions", _c.c_int), ("temporal_smoothing", _c.c_float), ("local_smoothing", _c.c_float),
+                ("min_motion_samples", _c.c_int), ("acceptance_threshold", _c.c_float), ("uniformity_threshold", _c.c_float),
+                ("predictive_samples", _c.c_int), ("corrective_limit_x", _c.c_float), ("corrective_limit_y", _c.c_float),
+                ("smoothing_steps", _c.c_float), ("response_rate", _c.c_float),
+                ("motion_width", _c.c_int), ("motion_height", _c.c_int), ("background", _c.c_float * 3),
+                ("crop_to_stable_region", _c.c_int), ("stabilize_output", _c.c_int),
+                ("min_scene_quality", _c.c_float), ("min_tracking_quality", _c.c_float)]
+
+    def __init__(self, **over):
+        super().__init__()
+        _native.load().lvk_stab_default_settings(_c.byref(self))
+        for k, v in over.items():
+            setattr(self, k, v)
+
+    def copy(self):
+        other = StabilizationFilterSettings()
+        _c.memmove(_c.byref(other), _c.byref(self), _c.sizeof(self))
+        return other
+
+    @classmethod
+    def obs_preset(cls, subsystem="homography", strict=True, crop=0.05, predictive_samples=10, apply_crop=True, **over):
+        """The OBS plugin's presets (Modules/OBS-Plugin/Sources/Stabilisation/VSFilter.cpp:235-294)."""
+        s = cls()
+        s.detection_width, s.detection_height = 480, 270
+        if subsystem == "field":
+            s.acceptance_threshold, s.track_local_motions = 10.0, 1
+            s.motion_width, s.motion_height = 16, 16
+            s.detection_regions_x, s.detection_regions_y = 2, 2
+            s.max_feature_density, s.min_feature_density, s.accumulation_rate = 0.12, 0.06, 3.0
+        else:
+            s.acceptance_threshold, s.track_local_motions = 3.0, 0
+            s.motion_width, s.motion_height = 2, 2
+            s.detection_regions_x, s.detection_regions_y = 2, 1
+            s.max_feature_density, s.min_feature_density, s.accumulation_rate = 0.12, 0.04, 3.0
+        s.min_scene_quality, s.min_tracking_quality = (0.95, 0.35) if strict else (0.40, 0.20)
+        s.corrective_limit_x = s.corrective_limit_y = crop
+        s.predictive_samples = predictive_samples
+        s.crop_to_stable_region = 1 if apply_crop else 0
+        s.background[0], s.background[1], s.background[2] = 105, 212, 235
+        for k, v in over.items():
+            setattr(s, k, v)
+        return s
+
+
+class StabStats(_c.Structure):
+    _fields_ = [("tracking_stability", _c.c_float), ("scene_quality", _c.c_float), ("trust", _c.c_float), ("distribution", _c.c_float),
+                ("n_detected", _c.c_int), ("n_matched", _c.c_int), ("n_tracked", _c.c_int), ("frame_delay", _c.c_int),
+                ("smoothing_factor", _c.c_double), ("homography", _c.c_double * 9)]
+
+
+class Stopwatch:
+    """Subset of lvk::Stopwatch the plugin reads: timings().average() / deviation() in milliseconds (Timing/Stopwatch.hpp)."""
+
+    def __init__(self, history=1):
+        self.set_history_size(history)
+
+    def set_history_size(self, n):
+        self._n = max(1, int(n)); self._hist = []
+
+    def _add(self, seconds):
+        self._hist.append(seconds); self._hist = self._hist[-self._n:]
+
+    def average_ms(self):
+        return 1e3 * float(np.mean(self._hist)) if self._hist else 0.0
+
+    def deviation_ms(self):
+        return 1e3 * float(np.std(self._hist)) if self._hist else 0.0
+
+
+class StabilizationFilter:
+    def __init__(self, settings=None, context=None, device=0):
+        self.ctx = context if context is not None else Context(device)
+        self.lib = self.ctx.lib
+        self._settings = (settings or StabilizationFilterSettings()).copy()
+        self._timer = Stopwatch()
+        self._borrowed = {}
+        h = _c.c_void_p()
+        self.ctx._check(self.lib.lvk_hip_stab_create(self.ctx.handle, _c.byref(self._settings), _c.byref(h)))
+        self.handle = h
+
+    # ---- Configurable<StabilizationFilterSettings> (Utility/Configurable.hpp:26-44)
+    def configure(self, settings):
+        self.ctx._check(self.lib.lvk_hip_stab_configure(self.handle, _c.byref(settings)))
+        self._settings = settings.copy()
+
+    def reconfigure(self, updater):
+        s = self._settings.copy()
+        updater(s)
+        self.configure(s)
+
+    def settings(self):
+        return self._settings
+
+    # ---- VideoFilter (Filters/VideoFilter.hpp:32-61)
+    def alias(self):
+        return "Stabilization Filter"
+
+    def set_timing_samples(self, n):
+        self._timer.set_history_size(n)
+
+    def timings(self):
+        return self._timer
+
+    def apply(self, frame, timestamp=0, out=None, profile=False, fmt=FORMAT_YUV):
+        """apply(std::move(input), output, profile): returns (output tensor, its timestamp) or (None, None) while the delay builds.
+        `frame` is borrowed (not copied) until it has been emitted; do not modify it in the meantime."""
+        import torch
+        if profile:
+            self.ctx.sync()
+        t0 = time.perf_counter()
+        if out is None:
+            out = torch.empty_like(frame)
+        produced = _c.c_int(0); ots = _c.c_uint64(0); released = _c.c_void_p()
+        self._borrowed[frame.data_ptr()] = frame
+        rc = self.lib.lvk_hip_stab_push(self.handle, frame.data_ptr(), frame.stride(0), frame.shape[0], frame.shape[1],
+                                        int(timestamp), fmt, out.data_ptr(), out.stride(0),
+                                        _c.byref(produced), _c.byref(ots), _c.byref(released))
+        self.ctx._check(rc)
+        if released.value:
+            self._borrowed.pop(released.value, None)
+        if profile:
+            self.ctx.sync()
+        self._timer._add(time.perf_counter() - t0)
+        return (out, ots.value) if produced.value else (None, None)
+
+    # ---- StabilizationFilter (Filters/StabilizationFilter.hpp:46-62)
+    def restart(self):
+        self.ctx._check(self.lib.lvk_hip_stab_restart(self.handle)); self._borrowed.clear()
+
+    def reset_context(self):
+        self.ctx._check(self.lib.lvk_hip_stab_reset_context(self.handle))
+
+    def ready(self):
+        return bool(self.lib.lvk_hip_stab_ready(self.handle))
+
+    def frame_delay(self):
+        return int(self.lib.lvk_hip_stab_frame_delay(self.handle))
+
+    def stable_region(self, rows, cols):
+        r = (_c.c_int * 4)()
+        self.ctx._check(self.lib.lvk_hip_stab_stable_region(self.handle, rows, cols, r))
+        return tuple(r)
+
+    # ---- taps (tests / HUD)
+    def stats(self):
+        st = StabStats()
+        self.ctx._check(self.lib.lvk_hip_stab_get_stats(self.handle, _c.byref(st)))
+        return st
+
+    def meshes(self):
+        n = self._settings.motion_width * self._settings.motion_height * 2
+        a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+        self.lib.lvk_hip_stab_get_meshes(self.handle, a.ctypes.data_as(_c.POINTER(_c.c_float)), b.ctypes.data_as(_c.POINTER(_c.c_float)), n)
+        shp = (self._settings.motion_height, self._settings.motion_width, 2)
+        return a.reshape(shp), b.reshape(shp)
+
+    def features(self, cap=8192):
+        a = np.zeros((cap, 4), np.float32)
+        n = self.lib.lvk_hip_stab_get_features(self.handle, a.ctypes.data_as(_c.POINTER(_c.c_float)), cap)
+        return a[:max(n, 0)].copy()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lvk_hip_stab_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

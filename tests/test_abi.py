@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "lvk_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lvk_hip_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(lvk_(?:hip|stab)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_what_python_binds():

@@ -1,0 +1,189 @@
+"""End-to-end GPU parity: the HIP stabilization filter vs the CPU oracle on the same synthetic clips, frame by frame,
+through the C-ABI.  Bar: every emitted frame bit-identical, every per-frame statistic / mesh identical."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_settings(o):
+    """oracle_lib.StabSettings -> livevisionkit_amd.StabilizationFilterSettings (same field order)."""
+    import ctypes
+    import livevisionkit_amd as lvk
+    s = lvk.StabilizationFilterSettings()
+    assert ctypes.sizeof(s) == ctypes.sizeof(o)
+    ctypes.memmove(ctypes.byref(s), ctypes.byref(o), ctypes.sizeof(o))
+    return s
+
+
+def _apply(H, p):
+    q = np.c_[p, np.ones(len(p))] @ H.T
+    return q[:, :2] / q[:, 2:]
+
+
+@pytest.mark.parametrize("partial", [False, True])
+def test_global_motion_bit_exact(ctx, oracle, partial):
+    rng = np.random.default_rng(5)
+    for trial, n in enumerate([4, 7, 75, 300, 1856, 3000]):
+        H = np.array([[1.01, 0.012, 3.1], [-0.011, 0.995, -2.2], [2e-5 * (not partial), -1e-5 * (not partial), 1.0]])
+        p1 = np.c_[rng.uniform(0, 480, n), rng.uniform(0, 270, n)].astype(np.float32)
+        p2 = _apply(H, p1) + rng.normal(0, 0.2, p1.shape)
+        out = rng.random(n) < 0.3
+        p2[out] += rng.uniform(-40, 40, (out.sum(), 2))
+        p2 = p2.astype(np.float32)
+        rc_o, H_o, m_o = oracle.find_homography(p1, p2, 3.0, partial=partial)
+        rc_g, H_g, m_g = ctx.estimate_global_motion(p1, p2, 3.0, full_homography=not partial)
+        assert (rc_o < 0) == (rc_g < 0), (n, rc_o, rc_g)
+        if rc_o >= 0:
+            assert rc_o == rc_g, (n, rc_o, rc_g)
+        assert np.array_equal(m_o, m_g), n
+        assert np.array_equal(H_o.view(np.uint64), H_g.view(np.uint64)), (n, np.abs(H_o - H_g).max())
+
+
+def test_global_motion_degenerate_inputs(ctx, oracle):
+    same = np.tile(np.array([[10.0, 20.0]], np.float32), (50, 1))                  # all points identical -> no model
+    line = np.c_[np.arange(50), 2 * np.arange(50)].astype(np.float32)              # collinear -> singular 4-point systems
+    for p in (same, line):
+        for partial in (False, True):
+            rc_o, H_o, m_o = oracle.find_homography(p, p, 3.0, partial=partial)
+            rc_g, H_g, m_g = ctx.estimate_global_motion(p, p, 3.0, full_homography=not partial)
+            assert (rc_o < 0) == (rc_g < 0) and np.array_equal(m_o, m_g)
+            assert np.array_equal(H_o, H_g)
+    rc_g, H_g, m_g = ctx.estimate_global_motion(same[:3], same[:3], 3.0)
+    assert rc_g < 0 and np.array_equal(H_g, np.eye(3))
+
+
+def _run_pair(oracle, ctx, frames, settings, n_check_frames=None, reconfigure_at=None):
+    import torch
+    import livevisionkit_amd as lvk
+    ost = oracle_lib.OracleStabilizer(oracle, settings)
+    gst = lvk.StabilizationFilter(_to_settings(settings), context=ctx)
+    produced = 0
+    for i, f in enumerate(frames):
+        if reconfigure_at and i in reconfigure_at:
+            new = reconfigure_at[i]
+            ost.configure(new); gst.configure(_to_settings(new))
+        want, wts = ost.push(f, ts=100 + i)
+        got, gts = gst.apply(torch.from_numpy(f).cuda(), timestamp=100 + i)
+        ctx.sync()
+        so, sg = ost.stats(), gst.stats()
+        for k in ("n_detected", "n_matched", "n_tracked"):
+            assert getattr(so, k) == getattr(sg, k), (i, k, getattr(so, k), getattr(sg, k))
+        for k in ("tracking_stability", "scene_quality", "trust", "distribution", "smoothing_factor"):
+            assert getattr(so, k) == getattr(sg, k), (i, k, getattr(so, k), getattr(sg, k))
+        assert list(so.homography) == list(sg.homography), (i, list(so.homography), list(sg.homography))
+        mo, co = ost.meshes(); mg, cg = gst.meshes()
+        assert np.array_equal(mo.view(np.uint32), mg.view(np.uint32)), i
+        fo, fg = ost.features(), gst.features()
+        assert np.array_equal(fo.view(np.uint32), fg.view(np.uint32)), i
+        assert (want is None) == (got is None), i
+        if want is not None:
+            assert wts == gts
+            assert np.array_equal(co.view(np.uint32), cg.view(np.uint32)), i
+            g = got.cpu().numpy()
+            if not np.array_equal(g, want):
+                d = np.abs(g.astype(int) - want.astype(int))
+                raise AssertionError(f"frame {i}: {np.count_nonzero(d.max(axis=2))} pixels differ, max {d.max()}")
+            produced += 1
+    ost.close(); gst.close()
+    return produced
+
+
+@pytest.fixture(scope="module")
+def clip():
+    return synth.make_clip(360, 640, 30, seed=11, jitter=1.0)
+
+
+def test_stabilizer_homography_preset_bit_exact(ctx, oracle, clip):
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=4)
+    assert _run_pair(oracle, ctx, frames, s) == len(frames) - 4
+
+
+def test_stabilizer_relaxed_qa_no_crop_bit_exact(ctx, oracle, clip):
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.4, min_tracking_quality=0.2,
+                          crop_to_stable_region=0, corrective_limit_x=0.1, corrective_limit_y=0.08)
+    assert _run_pair(oracle, ctx, frames[:20], s) == 17
+
+
+def test_stabilizer_library_defaults_global_motion(ctx, oracle, clip):
+    """Library default geometry (256x256 tracking, 2x2 regions, density 0.2) with the global-motion estimator."""
+    frames, _ = clip
+    s = oracle_lib.preset("default", track_local_motions=0, predictive_samples=3)
+    assert _run_pair(oracle, ctx, frames[:14], s) == 11
+
+
+def test_stabilizer_affine_fallback_when_badly_distributed(ctx, oracle):
+    """Texture only in one corner: distribution quality <= 0.6 -> partial-affine estimator (FrameTracker.cpp:359-374)."""
+    frames, _ = synth.make_clip(360, 640, 12, seed=13, jitter=0.6)
+    frames = frames.copy()
+    frames[:, :, 330:, :] = 128
+    frames[:, 200:, :, :] = 128
+    s = oracle_lib.preset("homography", predictive_samples=2, uniformity_threshold=0.0, min_motion_samples=20)
+    assert _run_pair(oracle, ctx, frames, s) == 10
+
+
+def test_stabilizer_scene_cut_and_flat_frames(ctx, oracle, clip):
+    """A scene cut drops the trust factor; featureless frames take the nullopt path."""
+    frames, _ = clip
+    other, _ = synth.make_clip(360, 640, 8, seed=99, jitter=1.0)
+    flat = np.full((3, 360, 640, 3), 90, np.uint8)
+    seq = np.concatenate([frames[:10], other, flat, frames[10:16]])
+    s = oracle_lib.preset("homography", predictive_samples=3)
+    assert _run_pair(oracle, ctx, seq, s) == len(seq) - 3
+
+
+def test_stabilizer_reconfigure_and_passthrough(ctx, oracle, clip):
+    frames, _ = clip
+    a = oracle_lib.preset("homography", predictive_samples=3)
+    b = oracle_lib.preset("homography", predictive_samples=3, stabilize_output=0)         # passthrough with delay (+ crop)
+    c = oracle_lib.preset("homography", predictive_samples=5, corrective_limit_x=0.08, corrective_limit_y=0.08)
+    _run_pair(oracle, ctx, frames[:24], a, reconfigure_at={8: b, 13: a, 18: c})
+
+
+def test_stabilizer_restart(ctx, oracle, clip):
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    for i, f in enumerate(frames[:16]):
+        if i == 7:
+            ost.restart(); gst.restart()
+        want, _ = ost.push(f, ts=i)
+        got, _ = gst.apply(torch.from_numpy(f).cuda(), timestamp=i)
+        ctx.sync()
+        assert (want is None) == (got is None), i
+        if want is not None:
+            assert np.array_equal(got.cpu().numpy(), want), i
+        assert ost.stats().scene_quality == gst.stats().scene_quality
+    assert gst.frame_delay() == 2 and gst.stable_region(360, 640) == (16, 9, 608, 342)
+    ost.close(); gst.close()
+
+
+def test_1080p_and_4k_streams_match_oracle(ctx, oracle):
+    """BASELINE configs 2 and 3 (1080p / 4K packed YUV): a short clip each, every emitted frame bit-identical."""
+    import torch
+    import livevisionkit_amd as lvk
+    for (rows, cols, n) in [(1080, 1920, 7), (2160, 3840, 5)]:
+        small, _ = synth.make_clip(rows // 4, cols // 4, n, seed=rows, jitter=1.0)
+        frames = np.ascontiguousarray(small.repeat(4, axis=1).repeat(4, axis=2))            # cheap full-size frames with corners
+        s = oracle_lib.preset("homography", predictive_samples=2)
+        ost = oracle_lib.OracleStabilizer(oracle, s)
+        gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+        emitted = 0
+        for i, f in enumerate(frames):
+            want, _ = ost.push(f, ts=i, nthreads=32)
+            got, _ = gst.apply(torch.from_numpy(f).cuda(), timestamp=i)
+            ctx.sync()
+            assert ost.stats().n_tracked == gst.stats().n_tracked
+            assert (want is None) == (got is None)
+            if want is not None:
+                assert np.array_equal(got.cpu().numpy(), want), (rows, i)
+                emitted += 1
+        assert emitted == n - 2
+        ost.close(); gst.close()
