@@ -410,7 +410,6 @@ struct lvko_stab
     size_t queue_capacity = 1;
     float scene_quality = 0.0f, trust = 0.0f;
     Mesh last_motion, last_correction;
-    int last_tracked = 0;
 
     void reset_context() { tracker.restart(); smoother.restart(); }             // StabilizationFilter.cpp:155-159
 
@@ -489,7 +488,6 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
     Mesh motion(st->s.motion_height, st->s.motion_width);           // m_NullMotion
     Mesh tracked_motion;
     if (st->tracker.track(frame, step, 3, rows, cols, tracked_motion)) motion = tracked_motion;
-    st->last_tracked = (int)st->tracker.tracked.size();
 
     // quality assurance (:101-115); exp_moving_average / step from Functions/Math.tpp:133-142,198-204
     const float tq = st->tracker.stability;
@@ -521,7 +519,7 @@ void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* o)
     o->distribution = st->tracker.last_distribution;
     o->n_detected = st->tracker.last_detected;
     o->n_matched = st->tracker.last_matched;
-    o->n_tracked = st->last_tracked;
+    o->n_tracked = (int)st->tracker.tracked.size();
     o->smoothing_factor = st->smoother.smoothing_factor;
     o->frame_delay = st->s.predictive_samples;
     for (int i = 0; i < 9; i++) o->homography[i] = st->tracker.last_H[i];
