@@ -188,6 +188,18 @@ int  lvk_hip_stab_get_meshes(const lvk_hip_stab* stab, float* motion, float* cor
 /* FrameTracker::features(): (x, y, response, age) per tracked feature; returns the total count */
 int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int cap);
 
+/* ---- timing (reference: VideoFilter::timings() / Stopwatch::sync_gpu, Filters/VideoFilter.cpp:46-51) ---------
+ * Per-stage GPU time from HIP events recorded on the launch stream around each stage's kernels. */
+#define LVK_STAGE_DOWNSCALE 0   /* luma + INTER_AREA */
+#define LVK_STAGE_PYRAMID   1   /* pyrDown x3 + Scharr x4 */
+#define LVK_STAGE_FAST      2   /* FAST-9/16 + NMS + compaction */
+#define LVK_STAGE_PYRLK     3   /* sparse optical flow */
+#define LVK_STAGE_MOTION    4   /* RANSAC + local optimisation */
+#define LVK_STAGE_REMAP     5   /* EASU remap of the delayed frame */
+#define LVK_STAGE_COUNT     6
+int  lvk_hip_stab_set_profiling(lvk_hip_stab* stab, int enable);
+int  lvk_hip_stab_get_profile(lvk_hip_stab* stab, double total_ms[LVK_STAGE_COUNT], long long launches[LVK_STAGE_COUNT]);
+
 #ifdef __cplusplus
 }
 #endif

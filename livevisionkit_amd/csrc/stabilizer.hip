@@ -74,6 +74,15 @@ struct lvk_hip_stab
     double last_H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     WarpMeshF last_motion, last_correction;
 
+    // ---- optional per-stage GPU timing (HIP events on the launch stream)
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> ev_pool; size_t ev_used = 0;
+    double prof_ms[LVK_STAGE_COUNT] = {0}; long prof_n[LVK_STAGE_COUNT] = {0};
+    int prof_begin(int kind);
+    void prof_end(int idx);
+    int prof_collect();
+
     int fail(int code, const std::string& msg) { return ctx->fail(code, msg); }
     void free_tracker_buffers();
     int alloc_tracker_buffers();
@@ -83,6 +92,34 @@ struct lvk_hip_stab
     void reset_context() { tracker_restart(); smoother.restart(); }
     int track(const QueuedFrame& f, WarpMeshF& motion, bool& have_motion);
 };
+
+int lvk_hip_stab::prof_begin(int kind)
+{
+    if (!profiling) return -1;
+    if (ev_used == ev_pool.size())
+    {
+        EvPair p{nullptr, nullptr, kind};
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+        ev_pool.push_back(p);
+    }
+    ev_pool[ev_used].kind = kind;
+    (void)hipEventRecord(ev_pool[ev_used].a, ctx->stream);
+    return (int)ev_used++;
+}
+
+void lvk_hip_stab::prof_end(int idx) { if (idx >= 0) (void)hipEventRecord(ev_pool[(size_t)idx].b, ctx->stream); }
+
+int lvk_hip_stab::prof_collect()
+{
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ev_used; i++)
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev_pool[i].a, ev_pool[i].b) == hipSuccess) { prof_ms[ev_pool[i].kind] += ms; prof_n[ev_pool[i].kind]++; }
+    }
+    ev_used = 0;
+    return LVK_HIP_OK;
+}
 
 int lvk_hip_stab::alloc_pyramids()
 {
@@ -210,8 +247,12 @@ int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_moti
     cur_w = s.detection_width; cur_h = s.detection_height;
     DevicePyramid& C = pyr[cur];
     DevicePyramid& P = pyr[cur ^ 1];
+    int pe = prof_begin(LVK_STAGE_DOWNSCALE);
     if ((rc = lvk_launch_luma_area_resize(ctx, f.d_ptr, f.step, 3, 0, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
+    prof_end(pe);
+    pe = prof_begin(LVK_STAGE_PYRAMID);
     if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
+    prof_end(pe);
     if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return LVK_HIP_OK; }
 
     // ---- FeatureDetector::detect
@@ -221,8 +262,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_moti
     if (any)
     {
         LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_regions, h_regions, plan.size() * sizeof(FastRegion), hipMemcpyHostToDevice, st));
+        pe = prof_begin(LVK_STAGE_FAST);
         if ((rc = lvk_launch_fast(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, d_regions, (int)plan.size(), fast_max_rw, fast_max_rh,
                                   d_fast_masks, d_fast_scores, d_fast_out, fast_cap, d_fast_counts)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
         LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_fast_counts, d_fast_counts, plan.size() * sizeof(int), hipMemcpyDeviceToHost, st));
         LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_fast_out, d_fast_out, plan.size() * (size_t)fast_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -238,7 +281,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_moti
     const int n = (int)tracked.size();
     for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, h_pts, n * sizeof(float2), hipMemcpyHostToDevice, st));
+    pe = prof_begin(LVK_STAGE_PYRLK);
     if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
+    prof_end(pe);
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_matched, d_matched, n * sizeof(float2), hipMemcpyDeviceToHost, st));
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_status, d_status, n, hipMemcpyDeviceToHost, st));
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -266,7 +311,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_moti
     std::memcpy(h_p2, h_matched, m * sizeof(float2));
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, m * sizeof(float2), hipMemcpyHostToDevice, st));
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, h_p2, m * sizeof(float2), hipMemcpyHostToDevice, st));
+    pe = prof_begin(LVK_STAGE_MOTION);
     if ((rc = lvk_launch_ransac(ctx, d_p1, d_p2, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, d_H, d_ninl, d_mask)) != LVK_HIP_OK) return rc;
+    prof_end(pe);
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_H, d_H, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_ninl, d_ninl, sizeof(int), hipMemcpyDeviceToHost, st));
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, d_mask, m, hipMemcpyDeviceToHost, st));
@@ -323,7 +370,28 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     (void)hipStreamSynchronize(st->ctx->stream);
     st->free_tracker_buffers();
     st->pyr[0].release(); st->pyr[1].release();
+    for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete st;
+}
+
+// Per-stage GPU time measured with HIP events on the launch stream.  enable != 0 starts (and resets) the
+// accumulation; lvk_hip_stab_get_profile synchronises the stream and reports, per stage, the summed milliseconds
+// and the number of timed launches (stage ids: LVK_STAGE_*).
+int lvk_hip_stab_set_profiling(lvk_hip_stab* st, int enable)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    const int rc = st->prof_collect();
+    st->profiling = enable != 0;
+    for (int i = 0; i < LVK_STAGE_COUNT; i++) { st->prof_ms[i] = 0; st->prof_n[i] = 0; }
+    return rc;
+}
+
+int lvk_hip_stab_get_profile(lvk_hip_stab* st, double total_ms[LVK_STAGE_COUNT], long long launches[LVK_STAGE_COUNT])
+{
+    if (!st || !total_ms || !launches) return LVK_HIP_ERR_ARG;
+    const int rc = st->prof_collect();
+    for (int i = 0; i < LVK_STAGE_COUNT; i++) { total_ms[i] = st->prof_ms[i]; launches[i] = st->prof_n[i]; }
+    return rc;
 }
 
 int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
@@ -374,12 +442,14 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
         st->queue.pop_front();
         LVK_HIP_REQUIRE(ctx, d_out != nullptr && out_step >= 3 * f.cols);
         int rc = LVK_HIP_OK;
+        const int pe = st->prof_begin(LVK_STAGE_REMAP);
         if (mesh) rc = lvk_hip_warpmesh_apply(ctx, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
             if (e != hipSuccess) rc = ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
         }
+        st->prof_end(pe);
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
         if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222

@@ -181,6 +181,17 @@ class StabilizationFilter:
         n = self.lib.lvk_hip_stab_get_features(self.handle, a.ctypes.data_as(_c.POINTER(_c.c_float)), cap)
         return a[:max(n, 0)].copy()
 
+    STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap")
+
+    def set_profiling(self, enable=True):
+        self.ctx._check(self.lib.lvk_hip_stab_set_profiling(self.handle, 1 if enable else 0))
+
+    def profile(self):
+        """{stage: (total_ms, launches)} measured with HIP events on the launch stream since set_profiling(True)."""
+        ms = (_c.c_double * 6)(); n = (_c.c_longlong * 6)()
+        self.ctx._check(self.lib.lvk_hip_stab_get_profile(self.handle, ms, n))
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(self.STAGES)}
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.lvk_hip_stab_destroy(self.handle)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): kernel-trace stats + HBM traffic counters of the bench command.
+# Counter passes are separate runs (one counter each), as MI355X_MICROARCH.md prescribes.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 120 --warmup 10 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
+find $OUT -name "*.csv" | head -40
+tail -2 $OUT/stats.log
