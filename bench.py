@@ -171,12 +171,7 @@ def main():
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t) * 1e3)
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    t_em = torch.tensor([emitted], dtype=torch.int64, device=device)
-    if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_em, op=dist.ReduceOp.SUM)
-    elapsed_max = float(t_el.item()); total_frames = int(t_em.item())
+    elapsed_max, total_frames = lvk.shard.reduce_timing(elapsed, emitted, device=device)
 
     result = None
     if rank == 0:

@@ -1,0 +1,361 @@
+// C++ facade of the MI355X-native stabilization path: the lvk::VideoFilter / lvk::StabilizationFilter API of
+// LiveVisionKit (reference: LiveVisionKit/Filters/VideoFilter.hpp:32-61, Filters/StabilizationFilter.hpp:28-78,
+// Utility/Configurable.hpp:26-44, Utility/Unique.hpp, Timing/Stopwatch.hpp, Data/VideoFrame.hpp:25-81) as a
+// header-only wrapper over the C-ABI of lvk_hip.h.  Same class names, member names, settings fields and defaults,
+// so the call sites of Modules/OBS-Plugin/Sources/Stabilisation/VSFilter.cpp compile against it unchanged
+// (tests/cpp/plugin_conformance.cpp reproduces them).
+//
+// Differences that a HIP build implies:
+//   * lvk::VideoFrame owns a HIP device buffer (the reference's VideoFrame is a cv::UMat, i.e. an OpenCL buffer).
+//   * errors go through lvk::context::assert_handler exactly as LVK_ASSERT does (Directives.hpp:37-52).
+#pragma once
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../lvk_hip.h"
+#include "cv_min.hpp"
+
+namespace lvk {
+
+// ---------------------------------------------------------------------------------------------- Directives.hpp
+namespace context {
+inline std::function<void(std::string, std::string, std::string)> assert_handler =
+    [](std::string file, std::string function, std::string assertion) {
+        std::cerr << "Failed Assert " << file << "@" << function << "(..) ... " << assertion << std::endl;
+        std::abort();
+    };
+}
+#define LVK_HIP_ASSERT(cond) do { if (!(cond)) lvk::context::assert_handler("LiveVisionKit.hpp", __func__, #cond); } while (0)
+
+// ---------------------------------------------------------------------------------------------- hip context
+namespace hip {
+// One HIP context (stream + staging) per object that needs one; replaces OpenCV's implicit OpenCL queue.
+class Context
+{
+public:
+    explicit Context(int device = 0)
+    {
+        if (lvk_hip_ctx_create(device, &m_ctx) != LVK_HIP_OK)
+            lvk::context::assert_handler("LiveVisionKit.hpp", "Context", std::string("lvk_hip_ctx_create: ") + lvk_hip_last_error(nullptr));
+    }
+    ~Context() { lvk_hip_ctx_destroy(m_ctx); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    lvk_hip_ctx* get() const { return m_ctx; }
+    void check(int rc, const char* what) const
+    {
+        if (rc < 0) lvk::context::assert_handler("LiveVisionKit.hpp", what, lvk_hip_last_error(m_ctx));
+    }
+private:
+    lvk_hip_ctx* m_ctx = nullptr;
+};
+inline std::shared_ptr<Context> shared_context(int device = 0)
+{
+    static thread_local std::weak_ptr<Context> cached;
+    auto c = cached.lock();
+    if (!c) { c = std::make_shared<Context>(device); cached = c; }
+    return c;
+}
+} // namespace hip
+
+// ---------------------------------------------------------------------------------------------- Data/VideoFrame.hpp
+struct VideoFrame
+{
+    enum Format { BGR, BGRA, RGB, RGBA, YUV, GRAY, UNKNOWN };
+
+    uint64_t timestamp = 0;
+    Format format = UNKNOWN;
+    int cols = 0, rows = 0;
+    int& width = cols; int& height = rows;
+    size_t step = 0;
+
+    VideoFrame() = default;
+    explicit VideoFrame(uint64_t ts) : timestamp(ts) {}
+    VideoFrame(const VideoFrame& o) : timestamp(o.timestamp), format(o.format), cols(o.cols), rows(o.rows), step(o.step), m_buf(o.m_buf), m_ctx(o.m_ctx) {}
+    VideoFrame(VideoFrame&& o) noexcept : timestamp(o.timestamp), format(o.format), cols(o.cols), rows(o.rows), step(o.step), m_buf(std::move(o.m_buf)), m_ctx(std::move(o.m_ctx)) { o.cols = o.rows = 0; o.step = 0; }
+    VideoFrame& operator=(const VideoFrame& o) { timestamp = o.timestamp; format = o.format; cols = o.cols; rows = o.rows; step = o.step; m_buf = o.m_buf; m_ctx = o.m_ctx; return *this; }
+    VideoFrame& operator=(VideoFrame&& o) noexcept
+    {
+        timestamp = o.timestamp; format = o.format; cols = o.cols; rows = o.rows; step = o.step; m_buf = std::move(o.m_buf); m_ctx = std::move(o.m_ctx);
+        o.cols = o.rows = 0; o.step = 0; return *this;
+    }
+    virtual ~VideoFrame() = default;
+
+    // cv::UMat subset
+    bool empty() const { return !m_buf || cols == 0 || rows == 0; }
+    cv::Size size() const { return {cols, rows}; }
+    int type() const { return CV_8UC3; }
+    void release() { m_buf.reset(); cols = rows = 0; step = 0; }
+    void create(const cv::Size& sz, int /*type = CV_8UC3*/, const std::shared_ptr<hip::Context>& ctx = nullptr)
+    {
+        if (m_buf && m_buf.use_count() == 1 && cols == sz.width && rows == sz.height) return;
+        m_ctx = ctx ? ctx : (m_ctx ? m_ctx : hip::shared_context());
+        void* p = nullptr;
+        step = (size_t)sz.width * 3;
+        m_ctx->check(lvk_hip_malloc(m_ctx->get(), step * (size_t)sz.height, &p), "VideoFrame::create");
+        auto c = m_ctx;
+        m_buf = std::shared_ptr<void>(p, [c](void* q) { lvk_hip_free(c->get(), q); });
+        cols = sz.width; rows = sz.height;
+    }
+    void* device_ptr() const { return m_buf.get(); }
+    bool has_known_format() const { return format != UNKNOWN; }
+
+    // host <-> device helpers (reference: cv::UMat::copyTo / getMat); packed 8UC3, tight rows
+    void upload(const uint8_t* host, int rows_, int cols_, Format fmt, uint64_t ts, const std::shared_ptr<hip::Context>& ctx = nullptr)
+    {
+        create({cols_, rows_}, CV_8UC3, ctx);
+        m_ctx->check(lvk_hip_upload(m_ctx->get(), m_buf.get(), host, step * (size_t)rows), "VideoFrame::upload");
+        format = fmt; timestamp = ts;
+    }
+    void download(uint8_t* host) const
+    {
+        m_ctx->check(lvk_hip_download(m_ctx->get(), host, m_buf.get(), step * (size_t)rows), "VideoFrame::download");
+        m_ctx->check(lvk_hip_sync(m_ctx->get()), "VideoFrame::download");
+    }
+    const std::shared_ptr<hip::Context>& context() const { return m_ctx; }
+    std::shared_ptr<void> buffer() const { return m_buf; }
+
+private:
+    std::shared_ptr<void> m_buf;
+    std::shared_ptr<hip::Context> m_ctx;
+};
+typedef VideoFrame Frame;
+
+// ---------------------------------------------------------------------------------------------- Timing
+class Time
+{
+public:
+    Time() = default;
+    explicit Time(double seconds) : m_s(seconds) {}
+    double seconds() const { return m_s; }
+    double milliseconds() const { return m_s * 1e3; }
+    double microseconds() const { return m_s * 1e6; }
+private:
+    double m_s = 0.0;
+};
+
+class Stopwatch
+{
+public:
+    explicit Stopwatch(size_t history = 1) : m_cap(history ? history : 1) {}
+    void start() { m_t0 = clock::now(); m_running = true; }
+    Time stop()
+    {
+        const double s = std::chrono::duration<double>(clock::now() - m_t0).count();
+        m_running = false;
+        m_hist.push_back(s);
+        while (m_hist.size() > m_cap) m_hist.pop_front();
+        return Time(s);
+    }
+    Time average() const { return Time(m_hist.empty() ? 0.0 : std::accumulate(m_hist.begin(), m_hist.end(), 0.0) / (double)m_hist.size()); }
+    Time deviation() const
+    {
+        if (m_hist.empty()) return Time(0.0);
+        const double a = average().seconds();
+        double v = 0; for (double s : m_hist) v += (s - a) * (s - a);
+        return Time(std::sqrt(v / (double)m_hist.size()));
+    }
+    void set_history_size(size_t n) { m_cap = n ? n : 1; while (m_hist.size() > m_cap) m_hist.pop_front(); }
+    bool is_running() const { return m_running; }
+private:
+    using clock = std::chrono::steady_clock;
+    clock::time_point m_t0{};
+    bool m_running = false;
+    size_t m_cap;
+    std::deque<double> m_hist;
+};
+
+// ---------------------------------------------------------------------------------------------- Utility
+template <typename Scope> class Unique
+{
+public:
+    Unique() : m_UID(next()++) {}
+    Unique(const Unique&) : m_UID(next()++) {}
+    Unique(Unique&& o) noexcept : m_UID(o.m_UID) {}
+    virtual ~Unique() = default;
+    uint64_t uid() const { return m_UID; }
+private:
+    static uint64_t& next() { static uint64_t n = 1; return n; }
+    uint64_t m_UID;
+};
+
+template <typename T> class Configurable
+{
+public:
+    explicit Configurable(const T& settings = {}) : m_Settings(settings) {}
+    virtual ~Configurable() = default;
+    void configure_default() { configure(T{}); }
+    virtual void configure(const T& settings) = 0;
+    void reconfigure(const std::function<void(T&)>& updater) { T s = m_Settings; updater(s); configure(s); }
+    const T& settings() const { return m_Settings; }
+protected:
+    T m_Settings;
+};
+
+// ---------------------------------------------------------------------------------------------- settings (same names & defaults)
+struct FeatureDetectorSettings                       // Vision/FeatureDetector.hpp:28-37
+{
+    cv::Size detection_resolution = {256, 256};
+    cv::Size detection_regions = {2, 2};
+    bool force_detection = false;
+    float max_feature_density = 0.20f;
+    float min_feature_density = 0.05f;
+    float accumulation_rate = 2.0f;
+};
+
+struct FrameTrackerSettings : public FeatureDetectorSettings   // Vision/FrameTracker.hpp:31-44
+{
+    cv::Size motion_resolution = {16, 16};
+    bool track_local_motions = true;
+    float temporal_smoothing = 1.0f;
+    float local_smoothing = 20.0f;
+    size_t min_motion_samples = 75;
+    float acceptance_threshold = 8.0f;
+    float uniformity_threshold = 0.20f;
+};
+
+struct PathSmootherSettings                          // Vision/PathSmoother.hpp:29-39
+{
+    size_t predictive_samples = 10;
+    cv::Size motion_resolution = {2, 2};
+    cv::Size2f corrective_limits = {0.1f, 0.1f};
+    float smoothing_steps = 20.0f;
+    float response_rate = 0.04f;
+};
+
+struct StabilizationFilterSettings : public FrameTrackerSettings, public PathSmootherSettings   // Filters/StabilizationFilter.hpp:28-39
+{
+    cv::Size motion_resolution = {2, 2};
+    cv::Scalar background_colour = {255, 0, 255};
+    bool crop_to_stable_region = false;
+    bool stabilize_output = true;
+    float min_scene_quality = 0.8f;
+    float min_tracking_quality = 0.3f;
+};
+
+// ---------------------------------------------------------------------------------------------- Filters/VideoFilter.hpp
+class VideoFilter : public Unique<VideoFilter>
+{
+public:
+    explicit VideoFilter(const std::string& filter_name = "Identity Filter") : m_Alias(filter_name + " (" + std::to_string(this->uid()) + ")") {}
+    virtual ~VideoFilter() = default;
+    const std::string& alias() const { return m_Alias; }
+
+    void apply(VideoFrame&& input, VideoFrame& output, const bool profile = false)    // VideoFilter.cpp:46-51
+    {
+        sync_gpu(profile); m_FrameTimer.start();
+        filter(std::move(input), output);
+        sync_gpu(profile); m_FrameTimer.stop();
+    }
+    void apply(const VideoFrame& input, VideoFrame& output, const bool profile = false) { apply(Frame(input), output, profile); }
+    void set_timing_samples(const size_t samples) { LVK_HIP_ASSERT(samples >= 1); m_FrameTimer.set_history_size(samples); }
+    const Stopwatch& timings() const { return m_FrameTimer; }
+
+protected:
+    virtual void filter(VideoFrame&& input, VideoFrame& output) { output = std::move(input); }
+    virtual void sync_gpu(bool /*trigger*/) {}
+private:
+    Stopwatch m_FrameTimer;
+    const std::string m_Alias;
+};
+typedef VideoFilter IdentityFilter;
+
+// ---------------------------------------------------------------------------------------------- Filters/StabilizationFilter.hpp
+class StabilizationFilter final : public VideoFilter, public Configurable<StabilizationFilterSettings>
+{
+public:
+    explicit StabilizationFilter(const StabilizationFilterSettings& settings = {}, int device = 0)
+        : VideoFilter("Stabilization Filter"), m_Ctx(std::make_shared<hip::Context>(device))
+    {
+        configure(settings);
+    }
+    ~StabilizationFilter() override { lvk_hip_stab_destroy(m_Stab); }
+    StabilizationFilter(const StabilizationFilter&) = delete;
+    StabilizationFilter& operator=(const StabilizationFilter&) = delete;
+
+    void configure(const StabilizationFilterSettings& settings) override          // StabilizationFilter.cpp:42-65
+    {
+        const lvk_stab_settings pod = to_pod(settings);
+        if (!m_Stab) m_Ctx->check(lvk_hip_stab_create(m_Ctx->get(), &pod, &m_Stab), "StabilizationFilter::configure");
+        else m_Ctx->check(lvk_hip_stab_configure(m_Stab, &pod), "StabilizationFilter::configure");
+        m_Settings = settings;
+        static_cast<PathSmootherSettings&>(m_Settings).motion_resolution = settings.motion_resolution;
+        static_cast<FrameTrackerSettings&>(m_Settings).motion_resolution = settings.motion_resolution;
+    }
+
+    void restart() { m_Ctx->check(lvk_hip_stab_restart(m_Stab), "restart"); m_Held.clear(); }
+    bool ready() const { return lvk_hip_stab_ready(m_Stab) != 0; }
+    void reset_context() { m_Ctx->check(lvk_hip_stab_reset_context(m_Stab), "reset_context"); }
+    void draw_trackers() {}       // debug overlays: SURVEY.md section 8f row 4 (not built)
+    void draw_motion_mesh() {}    // "
+    size_t frame_delay() const { return (size_t)lvk_hip_stab_frame_delay(m_Stab); }
+    cv::Rect stable_region() const
+    {
+        int r[4] = {0, 0, 0, 0};
+        lvk_hip_stab_stable_region(m_Stab, m_LastRows, m_LastCols, r);
+        return {r[0], r[1], r[2], r[3]};
+    }
+    const std::shared_ptr<hip::Context>& context() const { return m_Ctx; }
+
+private:
+    void filter(VideoFrame&& input, VideoFrame& output) override                    // StabilizationFilter.cpp:69-135
+    {
+        LVK_HIP_ASSERT(input.has_known_format());
+        LVK_HIP_ASSERT(!input.empty());
+        m_LastRows = input.rows; m_LastCols = input.cols;
+        VideoFrame in = std::move(input);                  // input and output may alias the same object (VSFilter.cpp:358,363)
+        VideoFrame result;
+        result.create(in.size(), CV_8UC3, m_Ctx);
+        int produced = 0; uint64_t ts = 0; const void* released = nullptr;
+        m_Held.push_back(in.buffer());                     // keep the borrowed device buffer alive while it is queued
+        m_Ctx->check(lvk_hip_stab_push(m_Stab, in.device_ptr(), (int)in.step, in.rows, in.cols, in.timestamp, (int)in.format,
+                                       result.device_ptr(), (int)result.step, &produced, &ts, &released), "StabilizationFilter::filter");
+        if (released)
+            for (auto it = m_Held.begin(); it != m_Held.end(); ++it)
+                if (it->get() == released) { m_Retired.push_back(*it); m_Held.erase(it); break; }
+        while (m_Retired.size() > 2) m_Retired.pop_front();    // the remap reading it has been followed by later stream work
+        if (produced) { result.timestamp = ts; result.format = in.format; output = std::move(result); }
+        else output.release();
+    }
+    void sync_gpu(bool trigger) override { if (trigger) m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); }
+
+    static lvk_stab_settings to_pod(const StabilizationFilterSettings& s)
+    {
+        lvk_stab_settings p;
+        p.detection_width = s.detection_resolution.width; p.detection_height = s.detection_resolution.height;
+        p.detection_regions_x = s.detection_regions.width; p.detection_regions_y = s.detection_regions.height;
+        p.force_detection = s.force_detection ? 1 : 0;
+        p.max_feature_density = s.max_feature_density; p.min_feature_density = s.min_feature_density; p.accumulation_rate = s.accumulation_rate;
+        p.track_local_motions = s.track_local_motions ? 1 : 0; p.temporal_smoothing = s.temporal_smoothing; p.local_smoothing = s.local_smoothing;
+        p.min_motion_samples = (int)s.min_motion_samples; p.acceptance_threshold = s.acceptance_threshold; p.uniformity_threshold = s.uniformity_threshold;
+        p.predictive_samples = (int)s.predictive_samples; p.corrective_limit_x = s.corrective_limits.width; p.corrective_limit_y = s.corrective_limits.height;
+        p.smoothing_steps = s.smoothing_steps; p.response_rate = s.response_rate;
+        p.motion_width = s.motion_resolution.width; p.motion_height = s.motion_resolution.height;
+        p.background[0] = (float)s.background_colour[0]; p.background[1] = (float)s.background_colour[1]; p.background[2] = (float)s.background_colour[2];
+        p.crop_to_stable_region = s.crop_to_stable_region ? 1 : 0; p.stabilize_output = s.stabilize_output ? 1 : 0;
+        p.min_scene_quality = s.min_scene_quality; p.min_tracking_quality = s.min_tracking_quality;
+        return p;
+    }
+
+    std::shared_ptr<hip::Context> m_Ctx;
+    lvk_hip_stab* m_Stab = nullptr;
+    std::deque<std::shared_ptr<void>> m_Held, m_Retired;
+    int m_LastRows = 0, m_LastCols = 0;
+};
+
+// north-star aliases (BASELINE.json names from another LVK snapshot; SURVEY.md name mapping)
+using PathStabilizerSettings = PathSmootherSettings;
+using GridDetectorSettings = FeatureDetectorSettings;
+
+} // namespace lvk

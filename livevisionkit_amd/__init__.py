@@ -7,5 +7,6 @@ bench driver: it calls the C-ABI through ctypes and uses torch only for device m
 from . import _native
 from .context import Context, LvkHipError
 from .stabilization import StabilizationFilter, StabilizationFilterSettings
+from . import shard
 
 __all__ = ["Context", "LvkHipError", "StabilizationFilter", "StabilizationFilterSettings", "_native"]

@@ -1,0 +1,132 @@
+// API-conformance translation unit: reproduces, against include/lvk/LiveVisionKit.hpp, the way the reference's
+// callers use the stabilizer (libobs is not available here, so the plugin itself cannot be compiled):
+//   Modules/OBS-Plugin/Sources/Stabilisation/VSFilter.hpp:54        StabilizationFilter m_Filter (by value)
+//   Modules/OBS-Plugin/Sources/Stabilisation/VSFilter.cpp:235-294   reconfigure(lambda) with every settings field
+//   .../VSFilter.cpp:304,327-333,347                                 frame_delay(), settings(), set_timing_samples(30)
+//   .../VSFilter.cpp:352-364                                         apply(std::move(frame), frame[, true]), draw_*()
+//   .../VSFilter.cpp:368-383                                         timings().average()/deviation().milliseconds(), stable_region()
+//   Modules/VideoEditor/FilterParser.tpp:51-64                       make_shared<StabilizationFilter>() + Configurable<>::configure
+// With -DRUN_ON_GPU it also runs a short synthetic stream (needs a GPU).
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "lvk/LiveVisionKit.hpp"
+
+namespace lvk {
+
+class VSFilterLike
+{
+public:
+    VSFilterLike() { m_Filter.set_timing_samples(30); }
+
+    void configure(bool field_subsystem, bool strict, float crop_x, float crop_y, int samples, bool apply_crop, bool disabled, bool test_mode)
+    {
+        m_TestMode = test_mode;
+        m_Filter.reconfigure([&](StabilizationFilterSettings& stab_settings) {
+            stab_settings.crop_to_stable_region = apply_crop && !m_TestMode;
+            stab_settings.stabilize_output = !disabled;
+            stab_settings.corrective_limits.height = crop_y;
+            stab_settings.corrective_limits.width = crop_x;
+            stab_settings.predictive_samples = samples;
+            stab_settings.background_colour[0] = 105.0f;
+            stab_settings.background_colour[1] = 212.0f;
+            stab_settings.background_colour[2] = 235.0f;
+            if (field_subsystem)
+            {
+                stab_settings.detection_resolution = {480, 270};
+                stab_settings.acceptance_threshold = 10.0f;
+                stab_settings.track_local_motions = true;
+                stab_settings.motion_resolution = {16, 16};
+                stab_settings.detection_regions = {2, 2};
+                stab_settings.max_feature_density = 0.12f;
+                stab_settings.min_feature_density = 0.06f;
+                stab_settings.accumulation_rate = 3.0f;
+            }
+            else
+            {
+                stab_settings.detection_resolution = {480, 270};
+                stab_settings.acceptance_threshold = 3.0f;
+                stab_settings.track_local_motions = false;
+                stab_settings.motion_resolution = {2, 2};
+                stab_settings.detection_regions = {2, 1};
+                stab_settings.max_feature_density = 0.12f;
+                stab_settings.min_feature_density = 0.04f;
+                stab_settings.accumulation_rate = 3.0f;
+            }
+            if (strict) { stab_settings.min_scene_quality = 0.95f; stab_settings.min_tracking_quality = 0.35f; }
+            else { stab_settings.min_scene_quality = 0.40f; stab_settings.min_tracking_quality = 0.20f; }
+        });
+        const auto new_stream_delay = static_cast<int>((1000.0f / 60.0f) * static_cast<float>(m_Filter.frame_delay()));
+        std::printf("delay %d ms, predictive %zu, crop (%.1f%%, %.1f%%), crop_out %d, disabled %d\n", new_stream_delay,
+                    m_Filter.settings().predictive_samples, m_Filter.settings().corrective_limits.width * 100.0f,
+                    m_Filter.settings().corrective_limits.height * 100.0f, (int)m_Filter.settings().crop_to_stable_region,
+                    (int)!m_Filter.settings().stabilize_output);
+    }
+
+    void filter(Frame& frame)
+    {
+        if (m_TestMode)
+        {
+            m_Filter.apply(std::move(frame), frame, true);
+            m_Filter.draw_motion_mesh();
+            m_Filter.draw_trackers();
+            const double frame_time_ms = m_Filter.timings().average().milliseconds();
+            const double deviation_ms = m_Filter.timings().deviation().milliseconds();
+            const auto& crop_region = m_Filter.stable_region();
+            const cv::Point text_at = crop_region.tl() + cv::Point(5, 40);
+            (void)frame_time_ms; (void)deviation_ms; (void)text_at;
+        }
+        else m_Filter.apply(std::move(frame), frame);
+    }
+
+private:
+    StabilizationFilter m_Filter;      // held BY VALUE, as VSFilter.hpp:54
+    bool m_TestMode = false;
+};
+
+} // namespace lvk
+
+int main()
+{
+#ifdef RUN_ON_GPU
+    lvk::VSFilterLike vs;
+    vs.configure(false, true, 0.05f, 0.05f, 5, true, false, true);
+    const int rows = 360, cols = 640;
+    std::vector<uint8_t> host((size_t)rows * cols * 3);
+    int emitted = 0;
+    for (int i = 0; i < 12; i++)
+    {
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++)
+            {
+                const int xs = x + (i % 3), ys = y + (i % 2);
+                uint8_t* p = &host[((size_t)y * cols + x) * 3];
+                p[0] = (uint8_t)((((xs / 16) + (ys / 16)) % 2) ? 200 : 40 + (xs * 7 + ys * 13) % 23);
+                p[1] = 128; p[2] = 128;
+            }
+        lvk::Frame frame;
+        frame.upload(host.data(), rows, cols, lvk::VideoFrame::YUV, 1000 + i);
+        vs.filter(frame);
+        if (!frame.empty())
+        {
+            if (frame.timestamp != (uint64_t)(1000 + i - 5)) { std::printf("bad timestamp\n"); return 1; }
+            frame.download(host.data());
+            emitted++;
+        }
+    }
+    std::printf("emitted %d frames\n", emitted);
+    return emitted == 7 ? 0 : 1;
+#else
+    // CLI-style construction (FilterParser.tpp:51-64)
+    std::printf("conformance TU compiled; sizeof(StabilizationFilterSettings) = %zu\n", sizeof(lvk::StabilizationFilterSettings));
+    if (false)
+    {
+        auto filter = std::make_shared<lvk::StabilizationFilter>();
+        std::static_pointer_cast<lvk::Configurable<lvk::StabilizationFilterSettings>>(filter)->configure(lvk::StabilizationFilterSettings{});
+        std::printf("%s %f\n", filter->alias().c_str(), filter->timings().average().milliseconds());
+    }
+    return 0;
+#endif
+}

@@ -1,0 +1,44 @@
+"""World-size-2 gloo test (CPU) of the only distributed logic on the path: stream->rank assignment and the
+barrier + max-over-ranks timing reduction used by bench.py."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stream_assignment_is_a_partition():
+    from livevisionkit_amd import shard
+    for world in (1, 2, 4, 8):
+        owned = [shard.streams_for_rank(8, r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(8))
+        assert max(len(o) for o in owned) - min(len(o) for o in owned) == 0
+
+
+def test_timing_reduction_two_ranks_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import torch.distributed as dist
+        from livevisionkit_amd import shard
+        rank, local, world = shard.rank_info()
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        dist.barrier()
+        el, units = shard.reduce_timing(1.0 + rank, 100 * (rank + 1))
+        assert el == 2.0 and units == 300, (el, units)
+        assert shard.streams_for_rank(8, rank, world) == list(range(rank, 8, 2))
+        dist.destroy_process_group()
+        print("ok", rank)
+    """))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
