@@ -295,4 +295,153 @@ private:
     bool m_force = false;
 };
 
+// ------------------------------------------------------------------------------------------------ local motion (vector field)
+// FrameTracker::generate_mesh_constraints + estimate_local_motions (Vision/FrameTracker.cpp:200-321,380-457).
+// The reference hands the sparse least-squares problem to Eigen::LeastSquaresConjugateGradient; this solves the same
+// problem exactly through its normal equations: static rows -> constant band matrix (binary64),
+// feature rows -> Q32 fixed-point sums (exact, order independent), 1e-6 ridge, right-looking banded Cholesky with the
+// forward substitution carried along, column-oriented back substitution; the solution is kept as float.
+// r01 runs it on the host (n = 512 unknowns, half bandwidth 103 for the 16x16 preset).
+class MeshSolverH
+{
+public:
+    void generate(int cols, int rows, float gen_w, float gen_h, float temporal, float local)
+    {
+        m_cols = cols; m_rows = rows; m_n = 2 * cols * rows;
+        m_hb = std::min(m_n - 1, 2 * (3 * cols + 3) + 1);
+        m_ts = temporal;
+        m_mesh.assign((size_t)m_n, 0.0f);
+        m_static.assign((size_t)m_n * (m_hb + 1), 0.0);
+        const float kw = (((float)cols / (float)(cols - 1)) * gen_w) / (float)cols;
+        const float kh = (((float)rows / (float)(rows - 1)) * gen_h) / (float)rows;
+        const double v1 = -((double)kw / (double)kh), v2 = -1.0 / v1;
+        int cidx[4]; float cval[4];
+        auto emit = [&](int n) {                               // one constraint row: add its outer product to the band
+            for (int p = 0; p < n; p++)
+                for (int q = 0; q < n; q++)
+                    if (cidx[p] >= cidx[q]) at(m_static, cidx[p], cidx[q]) = at(m_static, cidx[p], cidx[q]) + (double)cval[p] * (double)cval[q];
+        };
+        m_static_rows = 0;
+        for (int i = 0; i < m_n; i++) { cidx[0] = i; cval[0] = temporal; emit(1); m_static_rows++; }
+        for (int r = 0, index = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++, index++)
+            {
+                int q = 1;
+                if (c % 4 == 0 && r % 4 == 0) q = 3;
+                else if ((c + r) % 2 != 1 && c != 0 && r != 0 && c != cols - 2 && r != rows - 2) continue;
+                if (c >= cols - q || r >= rows - q) continue;
+                const int i00 = 2 * index, i10 = i00 + 2 * q, i01 = 2 * (index + q * cols), i11 = i01 + 2 * q;
+                const float w = local, w1 = (float)(v1 * w), w2 = (float)(v2 * w);
+                auto row = [&](int a, float va, int b, float vb, int c2, float vc, int d, float vd) {
+                    cidx[0] = a; cval[0] = va; cidx[1] = b; cval[1] = vb; cidx[2] = c2; cval[2] = vc; cidx[3] = d; cval[3] = vd;
+                    emit(4); m_static_rows++;
+                };
+                row(i00, -w, i01, w, i01 + 1, -w2, i11 + 1, w2);
+                row(i00 + 1, -w, i01, w2, i01 + 1, w, i11, -w2);
+                row(i00, -w, i10, w, i10 + 1, -w1, i11 + 1, w1);
+                row(i00 + 1, -w, i10, w1, i10 + 1, w, i11, -w1);
+            }
+    }
+
+    bool generated() const { return m_n > 0; }
+    int cols() const { return m_cols; }
+    int rows() const { return m_rows; }
+    void reset() { std::fill(m_mesh.begin(), m_mesh.end(), 0.0f); }
+
+    // tracked/matched: interleaved (x, y).  Returns false when a feature falls outside the mesh or the factorisation breaks down.
+    bool solve(const float* tracked, const float* matched, int count, float region_w, float region_h,
+               float temporal_now, float threshold, uint8_t* inlier, float* offsets)
+    {
+        const int n = m_n, hb = m_hb, W = m_cols;
+        const float kw = (((float)m_cols / (float)(m_cols - 1)) * region_w) / (float)m_cols;
+        const float kh = (((float)m_rows / (float)(m_rows - 1)) * region_h) / (float)m_rows;
+        const double Q = 4294967296.0;
+        m_N = m_static;
+        m_g.assign((size_t)n, 0.0);
+        m_Nq.assign((size_t)n * (hb + 1), 0);
+        m_gq.assign((size_t)n, 0);
+        m_fidx.resize((size_t)count * 4); m_fw.resize((size_t)count * 4);
+        for (int i = 0; i < n; i++) m_g[i] = (double)m_ts * (double)(temporal_now * m_mesh[i]);
+
+        for (int f = 0; f < count; f++)
+        {
+            const float px = tracked[2 * f], py = tracked[2 * f + 1];
+            int kx = (int)(size_t)(px / kw), ky = (int)(size_t)(py / kh);
+            kx = std::min(std::max(kx, 0), m_cols - 1); ky = std::min(std::max(ky, 0), m_rows - 1);
+            const int i00 = 2 * (ky * W + kx), i11 = 2 * ((ky + 1) * W + kx + 1);
+            if (i11 + 1 >= n) return false;
+            const int id[4] = {i00, i11 - 2, i11, i00 + 2};                     // TL, BL, BR, TR
+            const float x1 = (float)kx * kw, y1 = (float)ky * kh;
+            const float cw = (float)(kx + 1) * kw - x1, chh = (float)(ky + 1) * kh - y1;
+            const float inv = 1.0f / (cw * chh);
+            const float rx1 = (x1 + cw) - px, ry1 = (y1 + chh) - py, rx2 = px - x1, ry2 = py - y1;
+            const float wgt[4] = {rx1 * ry1 * inv, rx1 * ry2 * inv, rx2 * ry2 * inv, rx2 * ry1 * inv};
+            for (int a = 0; a < 4; a++) { m_fidx[4 * f + a] = id[a]; m_fw[4 * f + a] = wgt[a]; }
+            for (int comp = 0; comp < 2; comp++)
+            {
+                const float target = matched[2 * f + comp];
+                for (int a = 0; a < 4; a++)
+                {
+                    const int ia = id[a] + comp;
+                    m_gq[ia] += llrint((double)wgt[a] * (double)target * Q);
+                    for (int b = 0; b < 4; b++)
+                    {
+                        const int ib = id[b] + comp;
+                        if (ia >= ib) m_Nq[(size_t)ia * (hb + 1) + (ia - ib)] += llrint((double)wgt[a] * (double)wgt[b] * Q);
+                    }
+                }
+            }
+        }
+        for (size_t k = 0; k < m_N.size(); k++) m_N[k] = m_N[k] + (double)m_Nq[k] / Q;
+        for (int i = 0; i < n; i++) { m_g[i] = m_g[i] + (double)m_gq[i] / Q; at(m_N, i, i) = at(m_N, i, i) + 1e-6; }
+
+        for (int j = 0; j < n; j++)                                            // banded Cholesky + forward substitution
+        {
+            const double d = std::sqrt(at(m_N, j, j));
+            if (!(d > 0.0)) return false;
+            at(m_N, j, j) = d;
+            const int last = std::min(n - 1, j + hb);
+            for (int i = j + 1; i <= last; i++) at(m_N, i, j) = at(m_N, i, j) / d;
+            m_g[j] = m_g[j] / d;
+            for (int i = j + 1; i <= last; i++)
+            {
+                const double l = at(m_N, i, j);
+                m_g[i] = m_g[i] - l * m_g[j];
+                double* row_i = &at(m_N, i, i);                                // entries (i, k) live at row_i[i - k]
+                for (int k = j + 1; k <= i; k++) row_i[i - k] = row_i[i - k] - l * at(m_N, k, j);
+            }
+        }
+        for (int j = n - 1; j >= 0; j--)                                       // back substitution
+        {
+            m_g[j] = m_g[j] / at(m_N, j, j);
+            for (int k = std::max(0, j - hb); k < j; k++) m_g[k] = m_g[k] - at(m_N, j, k) * m_g[j];
+        }
+        for (int i = 0; i < n; i++) m_mesh[i] = (float)m_g[i];
+
+        for (int f = 0; f < count; f++)
+        {
+            const int* id = &m_fidx[4 * f]; const float* w = &m_fw[4 * f];
+            const float x = w[0] * m_mesh[id[0]] + w[1] * m_mesh[id[1]] + w[2] * m_mesh[id[2]] + w[3] * m_mesh[id[3]];
+            const float y = w[0] * m_mesh[id[0] + 1] + w[1] * m_mesh[id[1] + 1] + w[2] * m_mesh[id[2] + 1] + w[3] * m_mesh[id[3] + 1];
+            inlier[f] = (std::fabs(x - matched[2 * f]) + std::fabs(y - matched[2 * f + 1])) < threshold ? 1 : 0;
+        }
+        for (int r = 0, index = 0; r < m_rows; r++)
+            for (int c = 0; c < m_cols; c++, index++)
+            {
+                offsets[2 * index] = ((float)c * kw - m_mesh[2 * index]) / region_w;
+                offsets[2 * index + 1] = ((float)r * kh - m_mesh[2 * index + 1]) / region_h;
+            }
+        return true;
+    }
+
+private:
+    double& at(std::vector<double>& B, int i, int j) { return B[(size_t)i * (m_hb + 1) + (size_t)(i - j)]; }
+    int m_cols = 0, m_rows = 0, m_n = 0, m_hb = 0, m_static_rows = 0;
+    float m_ts = 0.0f;
+    std::vector<float> m_mesh, m_fw;
+    std::vector<double> m_static, m_N, m_g;
+    std::vector<long long> m_Nq, m_gq;
+    std::vector<int> m_fidx;
+};
+
 } // namespace lvkh

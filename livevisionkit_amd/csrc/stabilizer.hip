@@ -64,6 +64,9 @@ struct lvk_hip_stab
     // ---- host state
     lvkh::FeatureGridH grid;
     lvkh::PathSmootherH smoother;
+    lvkh::MeshSolverH solver;                  // FrameTracker's m_MeshConstraints + m_OptimizedMesh
+    lvk_stab_settings tracker_s{};             // FrameTracker::m_Settings (what the tracker was last configured with)
+    std::vector<float> solver_offsets;
     std::vector<Feature> tracked;
     std::vector<FastRegion> plan;
     std::deque<QueuedFrame> queue;
@@ -191,6 +194,7 @@ void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameT
     tracked.clear();
     grid.reset();
     initialized = false;
+    solver.reset();
 }
 
 int lvk_hip_stab::configure(const lvk_stab_settings& st)
@@ -211,6 +215,20 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
     const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
                                 || st.max_feature_density != s.max_feature_density;
+    if (!solver.generated())
+    {
+        // The reference's FrameTracker member is default-constructed first: FrameTracker(FrameTrackerSettings{}) generates the
+        // mesh constraints for a 16x16 mesh over its default 256x256 region with weights 1.0 / 20.0 (FrameTracker.cpp:41-53,
+        // FrameTracker.hpp:31-44).  configure() below then only regenerates them when the motion resolution changes.
+        lvk_stab_default_settings(&tracker_s);
+        tracker_s.motion_width = 16; tracker_s.motion_height = 16;
+        solver.generate(16, 16, 256.0f, 256.0f, tracker_s.temporal_smoothing, tracker_s.local_smoothing);
+    }
+    if (st.motion_width != tracker_s.motion_width || st.motion_height != tracker_s.motion_height)
+        // FrameTracker.cpp:74-82: new region, but the PREVIOUS settings' smoothing weights
+        solver.generate(st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height,
+                        tracker_s.temporal_smoothing, tracker_s.local_smoothing);
+    tracker_s = st;
     smoother.configure(st);
     queue_capacity = (size_t)st.predictive_samples + 1;
     while (queue.size() > queue_capacity) queue.pop_front();
@@ -305,7 +323,23 @@ int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_moti
     // ---- motion estimate
     motion = WarpMeshF(s.motion_height, s.motion_width);
     if (s.track_local_motions)
-        return fail(LVK_HIP_ERR_ARG, "track_local_motions (vector-field preset) is not built yet: SURVEY.md section 8 row a10");
+    {
+        // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the feature matches
+        if (!solver.solve(&h_pts[0].x, &h_matched[0].x, m, (float)cur_w, (float)cur_h, s.temporal_smoothing, s.acceptance_threshold,
+                          h_mask, motion.off.data()))
+            return LVK_HIP_OK;                                                        // no estimate this frame (identity motion)
+        size_t inl = 0;
+        for (int i = 0; i < m; i++) inl += h_mask[i] ? 1 : 0;
+        tracking_stability = (float)inl / (float)m;
+        for (int i = m - 1; i >= 0; i--)
+        {
+            if (h_mask[i]) { tracked[i].age++; tracked[i].x = h_matched[i].x; tracked[i].y = h_matched[i].y; }
+            else { std::swap(tracked[i], tracked.back()); tracked.pop_back(); }
+        }
+        grid.propagate(tracked);
+        have_motion = true;
+        return LVK_HIP_OK;
+    }
     const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
     std::memcpy(h_p1, h_pts, m * sizeof(float2));
     std::memcpy(h_p2, h_matched, m * sizeof(float2));

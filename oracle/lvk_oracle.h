@@ -152,6 +152,20 @@ void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* out);
 int lvko_stab_get_meshes(const lvko_stab* st, float* motion, float* correction, int cap_floats);
 int lvko_stab_get_features(const lvko_stab* st, float* xy_resp_age, int cap);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage a10: local motion (vector-field preset), oracle/mesh_solver.cpp.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lvko_mesh_solver lvko_mesh_solver;
+lvko_mesh_solver* lvko_mesh_solver_create(int cols, int rows, float gen_region_w, float gen_region_h, float temporal_smoothing, float local_smoothing);
+void lvko_mesh_solver_destroy(lvko_mesh_solver* s);
+void lvko_mesh_solver_reset(lvko_mesh_solver* s);
+int lvko_mesh_solver_static_rows(const lvko_mesh_solver* s);
+int lvko_mesh_solver_static_triplets(const lvko_mesh_solver* s);
+const float* lvko_mesh_solver_mesh(const lvko_mesh_solver* s);
+int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const float* matched, int n_pts,
+                           float region_w, float region_h, float temporal_now, float threshold, uint8_t* inliers, float* offsets);
+
 #ifdef __cplusplus
 }
 #endif

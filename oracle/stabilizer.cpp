@@ -215,6 +215,22 @@ struct Tracker
 {
     lvko_stab_settings s{};
     Detector det;
+    lvko_mesh_solver* solver = nullptr;             // m_MeshConstraints + m_OptimizedMesh
+    int solver_cols = 0, solver_rows = 0;
+
+    Tracker()
+    {
+        // FrameTracker(const FrameTrackerSettings& = {}) runs configure(defaults) + restart() (FrameTracker.cpp:41-53):
+        // the static mesh constraints first exist for a 16x16 mesh over a 256x256 region with weights 1.0 / 20.0.
+        lvko_stab_default_settings(&s);
+        s.motion_width = 16; s.motion_height = 16;  // FrameTrackerSettings::motion_resolution default (FrameTracker.hpp:33)
+        solver = lvko_mesh_solver_create(16, 16, 256.0f, 256.0f, s.temporal_smoothing, s.local_smoothing);
+        solver_cols = solver_rows = 16;
+        det.configure(s);
+    }
+    ~Tracker() { lvko_mesh_solver_destroy(solver); }
+    Tracker(const Tracker&) = delete;
+    Tracker& operator=(const Tracker&) = delete;
     bool initialized = false;
     std::vector<uint8_t> prev, cur;                                 // tracking-resolution gray frames
     int prev_w = 0, prev_h = 0, cur_w = 0, cur_h = 0;
@@ -231,6 +247,14 @@ struct Tracker
     {
         const bool res_changed = (st.detection_width != s.detection_width || st.detection_height != s.detection_height);
         det.configure(st);
+        if (st.motion_width != s.motion_width || st.motion_height != s.motion_height)
+        {
+            // FrameTracker.cpp:74-82: regenerated for the NEW region with the PREVIOUS settings' smoothing weights
+            lvko_mesh_solver_destroy(solver);
+            solver = lvko_mesh_solver_create(st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height,
+                                             s.temporal_smoothing, s.local_smoothing);
+            solver_cols = st.motion_width; solver_rows = st.motion_height;
+        }
         if (res_changed && initialized)
         {
             matched_pts.clear();
@@ -247,6 +271,7 @@ struct Tracker
         tracked.clear();
         det.reset();
         initialized = false;
+        lvko_mesh_solver_reset(solver);
     }
 
     // returns true and fills `motion` when a motion estimate exists (std::optional<WarpMesh>)
@@ -291,7 +316,9 @@ struct Tracker
         inlier_status.assign(m, 0);
         if (s.track_local_motions)
         {
-            return false;   // estimate_local_motions (field preset) is specified in oracle/mesh_solver.cpp (not built yet)
+            if (lvko_mesh_solver_solve(solver, tracked_pts.data(), matched_pts.data(), m, (float)cur_w, (float)cur_h,
+                                       s.temporal_smoothing, s.acceptance_threshold, inlier_status.data(), motion.v.data()) != 0)
+                return false;
         }
         else
         {

@@ -225,6 +225,41 @@ def preset(name="homography", **over):
     return s
 
 
+class OracleMeshSolver:
+    def __init__(self, oracle, cols, rows, gen_region=(480, 270), temporal=1.0, local=20.0):
+        L = self.L = oracle.lib
+        L.lvko_mesh_solver_create.restype = _c.c_void_p
+        L.lvko_mesh_solver_create.argtypes = [_c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_float]
+        L.lvko_mesh_solver_destroy.argtypes = [_c.c_void_p]
+        L.lvko_mesh_solver_reset.argtypes = [_c.c_void_p]
+        L.lvko_mesh_solver_static_rows.argtypes = [_c.c_void_p]
+        L.lvko_mesh_solver_static_triplets.argtypes = [_c.c_void_p]
+        L.lvko_mesh_solver_mesh.restype = _f32p
+        L.lvko_mesh_solver_mesh.argtypes = [_c.c_void_p]
+        L.lvko_mesh_solver_solve.restype = _c.c_int
+        L.lvko_mesh_solver_solve.argtypes = [_c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _u8p, _f32p]
+        self.cols, self.rows = cols, rows
+        self.h = L.lvko_mesh_solver_create(cols, rows, gen_region[0], gen_region[1], temporal, local)
+
+    def static_counts(self):
+        return self.L.lvko_mesh_solver_static_rows(self.h), self.L.lvko_mesh_solver_static_triplets(self.h)
+
+    def solve(self, tracked, matched, region=(480, 270), temporal=1.0, threshold=10.0):
+        t = np.ascontiguousarray(tracked, np.float32).reshape(-1, 2); m = np.ascontiguousarray(matched, np.float32).reshape(-1, 2)
+        inl = np.zeros(len(t), np.uint8); off = np.zeros((self.rows, self.cols, 2), np.float32)
+        rc = self.L.lvko_mesh_solver_solve(self.h, _p(t, _f32p), _p(m, _f32p), len(t), region[0], region[1], temporal, threshold,
+                                           _p(inl, _u8p), _p(off, _f32p))
+        return rc, inl, off
+
+    def mesh(self):
+        ptr = self.L.lvko_mesh_solver_mesh(self.h)
+        return np.ctypeslib.as_array(ptr, shape=(self.rows, self.cols, 2)).copy()
+
+    def close(self):
+        if self.h:
+            self.L.lvko_mesh_solver_destroy(self.h); self.h = None
+
+
 class OracleStabilizer:
     def __init__(self, oracle, settings):
         self.L = oracle.lib

@@ -125,3 +125,81 @@ def test_passthrough_mode_keeps_the_delay(oracle, clip):
         else:
             assert ts == i - 3 and np.array_equal(out, frames[i - 3])
     st.close()
+
+
+# ---- row a10: local motion (vector-field preset) ---------------------------------------------------------------
+def test_mesh_constraint_counts_match_the_reference_generator(oracle):
+    """16x16: 512 temporal rows + 4 x (133 unit quads + 16 3x3 quads) = 1108 rows / 2896 triplets."""
+    s = oracle_lib.OracleMeshSolver(oracle, 16, 16)
+    assert s.static_counts() == (1108, 2896)
+    s.close()
+    s = oracle_lib.OracleMeshSolver(oracle, 2, 2)                 # CLI default: no quad passes the tests -> temporal rows only
+    assert s.static_counts() == (8, 8)
+    s.close()
+
+
+def test_mesh_solver_converges_to_a_pure_translation(oracle):
+    rng = np.random.default_rng(3)
+    src = np.c_[rng.uniform(0, 479, 900), rng.uniform(0, 269, 900)].astype(np.float32)
+    t = np.array([3.5, -2.25], np.float32)
+    s = oracle_lib.OracleMeshSolver(oracle, 16, 16)
+    for it in range(60):                                          # the temporal rows pull towards the previous solution
+        rc, inl, off = s.solve(src, src + t)
+        assert rc == 0
+    grid = np.stack(np.meshgrid(np.arange(16) * 32.0, np.arange(16) * 18.0), -1)
+    assert np.abs(s.mesh() - (grid + t)).max() < 0.02
+    assert np.abs(off * np.array([480, 270]) + t).max() < 0.02    # offsets are backwards and normalised
+    assert inl.all()
+    s.close()
+
+
+def test_mesh_solver_flags_outliers_and_is_deterministic(oracle):
+    rng = np.random.default_rng(4)
+    src = np.c_[rng.uniform(0, 479, 600), rng.uniform(0, 269, 600)].astype(np.float32)
+    dst = src + np.array([1.0, 0.5], np.float32)
+    dst[:40] += 60
+    outs = []
+    for rep in range(2):
+        s = oracle_lib.OracleMeshSolver(oracle, 16, 16)
+        for it in range(40):
+            rc, inl, off = s.solve(src, dst, threshold=10.0)
+        outs.append((inl.copy(), off.copy()))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # plain least squares is not robust: gross outliers drag their neighbourhood, but are themselves rejected
+    assert outs[0][0][40:].mean() > 0.8 and outs[0][0][:40].mean() < 0.2
+
+
+def test_field_preset_stabilizer_tracks_and_emits(oracle, clip):
+    frames, path = clip
+    # OBS flow: the filter is default-constructed (2x2 mesh) and THEN reconfigured to the field preset (VSFilter.cpp:235-294),
+    # which regenerates the mesh constraints for the 480x270 region.  (Constructing it directly with a 16x16 mesh keeps the
+    # constraints the FrameTracker constructor generated for its default 256x256 region -- reference behaviour, see
+    # test_field_preset_direct_construction_keeps_stale_constraints.)
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default"))
+    st.configure(oracle_lib.preset("field", predictive_samples=4, min_scene_quality=0.4, min_tracking_quality=0.2))
+    n_out = 0
+    for i, f in enumerate(frames[:24]):
+        out, ts = st.push(f, ts=i)
+        s = st.stats()
+        if i >= 8:                                                  # the mesh starts at zero and converges over a few frames
+            assert s.n_matched > 100 and s.tracking_stability > 0.7, (i, s.n_matched, s.tracking_stability)
+        if out is not None:
+            assert ts == i - 4
+            n_out += 1
+    motion, corr = st.meshes()
+    assert motion.shape == (16, 16, 2) and np.isfinite(motion).all()
+    assert n_out == 20
+    st.close()
+
+
+def test_field_preset_direct_construction_keeps_stale_constraints(oracle, clip):
+    """FrameTracker's constructor generates the constraints for its default 256x256 region (aspect 1); configure() only
+    regenerates them when motion_resolution changes (FrameTracker.cpp:74-82), so a filter constructed directly with a
+    16x16 mesh solves with square-cell similarity rows on a 16:9 region and never reaches a usable inlier ratio."""
+    frames, _ = clip
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("field", predictive_samples=4))
+    for i, f in enumerate(frames[:12]):
+        st.push(f, ts=i)
+    assert st.stats().tracking_stability < 0.3
+    st.close()
