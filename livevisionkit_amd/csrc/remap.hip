@@ -9,18 +9,15 @@
 // binary32 IEEE ops, no implicit contraction (the file is compiled with -ffp-contract=off), fused
 // multiply-adds exactly where written as fma(), correctly rounded division.
 //
-// Work decomposition: a thread produces PXT horizontally adjacent output pixels so that the packed
-// 3-byte pixels leave as aligned dwords; a 256-thread block covers a (64*PXT) x 4 output tile.
+// Work decomposition: see remap_strip() -- 256 x 4 output strips, 4 pixels per thread, taps gathered with unaligned
+// dwordx2/x4 loads, XCD-aware strip order.
 #include "lvk_hip_internal.hpp"
 
+#include <climits>
 #include <cstring>
 #include <cmath>
 
 namespace {
-
-constexpr int PXT = 4;          // output pixels per thread (4 px * 3 B = 3 aligned dwords)
-constexpr int BLOCK_X = 64;     // threads along x  -> tile width  = 256 px
-constexpr int BLOCK_Y = 4;      // threads along y  -> tile height = 4 rows
 
 struct HomographyArgs { float h[9]; };
 
@@ -92,45 +89,35 @@ __device__ __forceinline__ void tap(F3& aC, float& aW, float offx, float offy, f
 }
 
 // Unaligned little-endian loads straight from global memory (gfx950 runs in unaligned access mode;
-// these lower to single global_load_dwordx{2,4}).
+// these lower to single global_load_dword / dwordx2 / dwordx4).
 struct __attribute__((packed, aligned(1))) U16B { uint32_t w[4]; };
 struct __attribute__((packed, aligned(1))) U8B { uint32_t w[2]; };
+struct __attribute__((packed, aligned(1))) U4B { uint32_t w; };
 
 __device__ __forceinline__ uint32_t byte_window(uint32_t lo, uint32_t hi, int shift_bytes)
 {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * shift_bytes));
 }
 
-// FSR.cl:181-318.  Returns the output pixel as 0x00ZZYYXX.
+// One source pixel as the kernel consumes it: the three normalised channels and the EASU luma.
 template <bool YUV>
-__device__ __forceinline__ uint32_t easu(const uint8_t* __restrict__ src, int step, int sx, int sy, float ppx, float ppy)
+__device__ __forceinline__ float4 make_tap(uint32_t lo_bytes)
 {
-    const uint8_t* r0p = src + (long)(sy - 1) * step + 3 * sx;      // b, c        (8 bytes read, 6 used)
-    const uint8_t* r1p = r0p + step - 3;                            // e, f, g, h  (16 bytes read, 12 used)
-    const uint8_t* r2p = r1p + step;                                // i, j, k, l
-    const uint8_t* r3p = r0p + 3 * (long)step;                      // n, o
-    const U8B r0 = *reinterpret_cast<const U8B*>(r0p);
-    const U16B r1 = *reinterpret_cast<const U16B*>(r1p);
-    const U16B r2 = *reinterpret_cast<const U16B*>(r2p);
-    const U8B r3 = *reinterpret_cast<const U8B*>(r3p);
+    const F3 p = unpack3(lo_bytes);
+    return make_float4(p.x, p.y, p.z, luma<YUV>(p));
+}
 
-    const F3 b = unpack3(r0.w[0]), c = unpack3(byte_window(r0.w[0], r0.w[1], 3));
-    const F3 e = unpack3(r1.w[0]), f = unpack3(byte_window(r1.w[0], r1.w[1], 3));
-    const F3 g = unpack3(byte_window(r1.w[1], r1.w[2], 2)), h = unpack3(byte_window(r1.w[2], 0u, 1));
-    const F3 i = unpack3(r2.w[0]), j = unpack3(byte_window(r2.w[0], r2.w[1], 3));
-    const F3 k = unpack3(byte_window(r2.w[1], r2.w[2], 2)), l = unpack3(byte_window(r2.w[2], 0u, 1));
-    const F3 n = unpack3(r3.w[0]), o = unpack3(byte_window(r3.w[0], r3.w[1], 3));
-
-    const float bL = luma<YUV>(b), cL = luma<YUV>(c), eL = luma<YUV>(e), fL = luma<YUV>(f), gL = luma<YUV>(g), hL = luma<YUV>(h);
-    const float iL = luma<YUV>(i), jL = luma<YUV>(j), kL = luma<YUV>(k), lL = luma<YUV>(l), nL = luma<YUV>(n), oL = luma<YUV>(o);
-
+// FSR.cl:181-318 on the 12 taps  b c / e f g h / i j k l / n o  (order of the array below).  Returns 0x00ZZYYXX.
+enum { TB, TC, TE, TF, TG, TH_, TI, TJ, TK, TL, TN, TO };
+__device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, float ppy)
+{
     // FSR.cl:244-249
     float len = 0.0f, dirx = 0.0f, diry = 0.0f;
     const float omx = 1.0f - ppx, omy = 1.0f - ppy;
-    accumulate(dirx, diry, len, omx * omy, bL, eL, fL, gL, jL);
-    accumulate(dirx, diry, len, ppx * omy, cL, fL, gL, hL, kL);
-    accumulate(dirx, diry, len, omx * ppy, fL, iL, jL, kL, nL);
-    accumulate(dirx, diry, len, ppx * ppy, gL, jL, kL, lL, oL);
+    accumulate(dirx, diry, len, omx * omy, t[TB].w, t[TE].w, t[TF].w, t[TG].w, t[TJ].w);
+    accumulate(dirx, diry, len, ppx * omy, t[TC].w, t[TF].w, t[TG].w, t[TH_].w, t[TK].w);
+    accumulate(dirx, diry, len, omx * ppy, t[TF].w, t[TI].w, t[TJ].w, t[TK].w, t[TN].w);
+    accumulate(dirx, diry, len, ppx * ppy, t[TG].w, t[TJ].w, t[TK].w, t[TL].w, t[TO].w);
 
     // FSR.cl:252-258
     float dirR = fma_(dirx, dirx, diry * diry);
@@ -151,24 +138,27 @@ __device__ __forceinline__ uint32_t easu(const uint8_t* __restrict__ src, int st
     const float clp = rcp_lo(lob);
 
     // FSR.cl:284-296
+    const float4 &f = t[TF], &g = t[TG], &j = t[TJ], &k = t[TK];
     const F3 mi4{ min_(f.x, min_(g.x, min_(j.x, k.x))), min_(f.y, min_(g.y, min_(j.y, k.y))), min_(f.z, min_(g.z, min_(j.z, k.z))) };
     const F3 ma4{ max_(f.x, max_(g.x, max_(j.x, k.x))), max_(f.y, max_(g.y, max_(j.y, k.y))), max_(f.z, max_(g.z, max_(j.z, k.z))) };
 
     // FSR.cl:299-313
     F3 aC{0.0f, 0.0f, 0.0f};
     float aW = 0.0f;
-    tap(aC, aW,  0.0f - ppx, -1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, b);
-    tap(aC, aW,  1.0f - ppx, -1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, c);
-    tap(aC, aW, -1.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, i);
-    tap(aC, aW,  0.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, j);
-    tap(aC, aW,  0.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, f);
-    tap(aC, aW, -1.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, e);
-    tap(aC, aW,  1.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, k);
-    tap(aC, aW,  2.0f - ppx,  1.0f - ppy, dirx, diry, len2x, len2y, lob, clp, l);
-    tap(aC, aW,  2.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, h);
-    tap(aC, aW,  1.0f - ppx,  0.0f - ppy, dirx, diry, len2x, len2y, lob, clp, g);
-    tap(aC, aW,  0.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, n);
-    tap(aC, aW,  1.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, o);
+#define LVK_TAP(ox, oy, T) tap(aC, aW, (ox) - ppx, (oy) - ppy, dirx, diry, len2x, len2y, lob, clp, F3{t[T].x, t[T].y, t[T].z})
+    LVK_TAP( 0.0f, -1.0f, TB);
+    LVK_TAP( 1.0f, -1.0f, TC);
+    LVK_TAP(-1.0f,  1.0f, TI);
+    LVK_TAP( 0.0f,  1.0f, TJ);
+    LVK_TAP( 0.0f,  0.0f, TF);
+    LVK_TAP(-1.0f,  0.0f, TE);
+    LVK_TAP( 1.0f,  1.0f, TK);
+    LVK_TAP( 2.0f,  1.0f, TL);
+    LVK_TAP( 2.0f,  0.0f, TH_);
+    LVK_TAP( 1.0f,  0.0f, TG);
+    LVK_TAP( 0.0f,  2.0f, TN);
+    LVK_TAP( 1.0f,  2.0f, TO);
+#undef LVK_TAP
 
     // FSR.cl:316-317
     const float rW = 1.0f / aW;
@@ -181,58 +171,114 @@ __device__ __forceinline__ uint32_t easu(const uint8_t* __restrict__ src, int st
     return ux | (uy << 8) | (uz << 16);
 }
 
-// Shared tail of FSR.cl:380-402 / 429-451.  Returns the pixel as 0x00ZZYYXX.
+// EASU with the 12 taps gathered straight from global memory (8 + 16 + 16 + 8 byte loads like FSR.cl:196-202).
 template <bool YUV>
-__device__ __forceinline__ uint32_t remap_pixel(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
-                                                float subx, float suby, uint32_t bg)
+__device__ __forceinline__ uint32_t easu_gather(const uint8_t* __restrict__ src, int step, int sx, int sy, float ppx, float ppy)
 {
-    const int sx = (int)subx;                 // v_cvt_i32_f32: truncates, saturates, NaN -> 0
-    const int sy = (int)suby;
-    const float ppx = subx - __builtin_floorf(subx);
-    const float ppy = suby - __builtin_floorf(suby);
-    if (sx < 1 || sy < 1 || sx >= src_cols - 4 || sy >= src_rows - 4)
-    {
-        if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)
-        {
-            const uint8_t* s = src + (long)sy * src_step + 3 * sx;
-            return (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-        }
-        return bg;
-    }
-    return easu<YUV>(src, src_step, sx, sy, ppx, ppy);
+    const uint8_t* r0p = src + (long)(sy - 1) * step + 3 * sx;      // b, c
+    const uint8_t* r1p = r0p + step - 3;                            // e, f, g, h
+    const uint8_t* r2p = r1p + step;                                // i, j, k, l
+    const uint8_t* r3p = r0p + 3 * (long)step;                      // n, o
+    const U8B r0 = *reinterpret_cast<const U8B*>(r0p);
+    const U16B r1 = *reinterpret_cast<const U16B*>(r1p);
+    const U16B r2 = *reinterpret_cast<const U16B*>(r2p);
+    const U8B r3 = *reinterpret_cast<const U8B*>(r3p);
+    float4 t[12];
+    t[TB] = make_tap<YUV>(r0.w[0]);                                t[TC] = make_tap<YUV>(byte_window(r0.w[0], r0.w[1], 3));
+    t[TE] = make_tap<YUV>(r1.w[0]);                                t[TF] = make_tap<YUV>(byte_window(r1.w[0], r1.w[1], 3));
+    t[TG] = make_tap<YUV>(byte_window(r1.w[1], r1.w[2], 2));       t[TH_] = make_tap<YUV>(byte_window(r1.w[2], 0u, 1));
+    t[TI] = make_tap<YUV>(r2.w[0]);                                t[TJ] = make_tap<YUV>(byte_window(r2.w[0], r2.w[1], 3));
+    t[TK] = make_tap<YUV>(byte_window(r2.w[1], r2.w[2], 2));       t[TL] = make_tap<YUV>(byte_window(r2.w[2], 0u, 1));
+    t[TN] = make_tap<YUV>(r3.w[0]);                                t[TO] = make_tap<YUV>(byte_window(r3.w[0], r3.w[1], 3));
+    return easu_core(t, ppx, ppy);
 }
+
+// ---- coordinate generators: destination pixel -> source coordinate -------------------------------------------
+struct HomographyCoord      // FSR.cl:422-430
+{
+    HomographyArgs H; int off_x, off_y;
+    __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
+    {
+        const float fx = (float)x, fy = (float)y;
+        const float dz = 1.0f / fma_(H.h[6], fx, fma_(H.h[7], fy, H.h[8]));
+        const float ox = fma_(H.h[0], fx, fma_(H.h[1], fy, H.h[2])) * dz - fx;
+        const float oy = fma_(H.h[3], fx, fma_(H.h[4], fy, H.h[5])) * dz - fy;
+        subx = (float)(x + off_x) + ox;
+        suby = (float)(y + off_y) + oy;
+    }
+};
+
+struct MeshCoord            // WarpMesh.cpp:190-191 per pixel (HResizeLinear, VResizeLinear, * (cols, rows)) + FSR.cl:381
+{
+    const float* __restrict__ mesh; int mesh_cols;
+    const LinTabEntry* __restrict__ xtab; const LinTabEntry* __restrict__ ytab;
+    float sw, sh;
+    __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
+    {
+        const LinTabEntry ty = ytab[y], tx = xtab[x];
+        const float* __restrict__ m0 = mesh + (long)ty.s0 * mesh_cols * 2;
+        const float* __restrict__ m1 = mesh + (long)ty.s1 * mesh_cols * 2;
+        float off[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+        {
+            const float h0 = (tx.s1 == tx.s0) ? m0[2 * tx.s0 + ch] * 1.0f : m0[2 * tx.s0 + ch] * tx.a0 + m0[2 * tx.s1 + ch] * tx.a1;
+            const float h1 = (tx.s1 == tx.s0) ? m1[2 * tx.s0 + ch] * 1.0f : m1[2 * tx.s0 + ch] * tx.a0 + m1[2 * tx.s1 + ch] * tx.a1;
+            off[ch] = (h0 * ty.a0 + h1 * ty.a1) * (ch == 0 ? sw : sh);
+        }
+        subx = (float)x + off[0];
+        suby = (float)y + off[1];
+    }
+};
+
+// ---- kernel body ---------------------------------------------------------------------------------------------------
+// rocprofv3 (profiles/r01_remap_pmc_sq.txt) shows this kernel is VALU-issue bound, not memory bound: ~510 VALU
+// instructions per output pixel, SQ_ACTIVE_INST_VALU ~ the whole SIMD time.  Two alternatives were built and
+// measured on MI355X at 4K and rejected: (a) staging the source window in LDS as pre-converted float4 (saves the
+// 72 unpack + 24 luma ops per pixel but needs 4 block barriers and 31-36 KB LDS -> 4 waves/SIMD: 126 us), and
+// (b) two pixels per lane on packed v_pk_fma/mul/add_f32 (those issue at half rate on gfx950, scripts/valu_peak.hip:
+// 126 us).  The barrier-free gather below keeps 5 waves/SIMD resident and runs at 108 us.
+//
+// A thread produces PXT horizontally adjacent output pixels so that the packed 3-byte pixels leave as three aligned
+// dwords; a 256-thread block covers a 256 x 4 strip.  Strips are handed out so that the blocks one XCD receives
+// (block b -> XCD b mod 8) form a contiguous band of the frame: vertically adjacent strips re-read 3 of their 7
+// source rows, and with this order those re-reads hit that XCD's L2 instead of going back to HBM.
+constexpr int PXT = 4, STRIP_W = 64 * PXT, STRIP_H = 4;
+constexpr int NUM_XCD = 8;
 
 __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
 {
     if (npx == PXT && aligned)
     {
-        // 4 packed pixels = 12 bytes = 3 dwords
-        uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);
+        uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);      // 4 packed pixels = 12 bytes = 3 dwords
         d[0] = px[0] | (px[1] << 24);
         d[1] = (px[1] >> 8) | (px[2] << 16);
         d[2] = (px[2] >> 16) | (px[3] << 8);
     }
     else
-    {
         for (int p = 0; p < npx; p++)
         {
             uint8_t* d = drow + 3 * (x0 + p);
             d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16);
         }
-    }
 }
 
-template <bool YUV>
-__global__ __launch_bounds__(BLOCK_X * BLOCK_Y)
-void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
-                        uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
-                        int off_x, int off_y, HomographyArgs H, uint32_t bg)
+template <bool YUV, class Coord>
+__device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                                            uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
+                                            const Coord& coord, uint32_t bg)
 {
-    const int x0 = (blockIdx.x * BLOCK_X + threadIdx.x) * PXT;
-    const int y = blockIdx.y * BLOCK_Y + threadIdx.y;
+    const int strips_x = (dst_cols + STRIP_W - 1) / STRIP_W, strips_y = (dst_rows + STRIP_H - 1) / STRIP_H;
+    const int nstrips = strips_x * strips_y;
+    const int band = (nstrips + NUM_XCD - 1) / NUM_XCD;
+    const int k = (int)(blockIdx.x / NUM_XCD);
+    const int strip = (int)(blockIdx.x % NUM_XCD) * band + k;
+    if (k >= band || strip >= nstrips) return;
+    const int sy_ = strip / strips_x, sx_ = strip - sy_ * strips_x;
+    const int x0 = sx_ * STRIP_W + (int)(threadIdx.x & 63) * PXT;
+    const int y = sy_ * STRIP_H + (int)(threadIdx.x >> 6);
     if (x0 >= dst_cols || y >= dst_rows) return;
     const int npx = min(PXT, dst_cols - x0);
-    const float fy = (float)y;
     uint32_t px[PXT];
 #pragma unroll
     for (int p = 0; p < PXT; p++)
@@ -240,14 +286,23 @@ void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_r
         px[p] = 0;
         if (p < npx)
         {
-            // FSR.cl:422-430
-            const float fx = (float)(x0 + p);
-            const float dz = 1.0f / fma_(H.h[6], fx, fma_(H.h[7], fy, H.h[8]));
-            const float ox = fma_(H.h[0], fx, fma_(H.h[1], fy, H.h[2])) * dz - fx;
-            const float oy = fma_(H.h[3], fx, fma_(H.h[4], fy, H.h[5])) * dz - fy;
-            const float subx = (float)(x0 + p + off_x) + ox;
-            const float suby = (float)(y + off_y) + oy;
-            px[p] = remap_pixel<YUV>(src, src_step, src_rows, src_cols, subx, suby, bg);
+            float subx, suby;
+            coord(x0 + p, y, subx, suby);
+            // shared tail of FSR.cl:380-402 / 429-451
+            const int sx = (int)subx;                 // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+            const int sy = (int)suby;
+            const float ppx = subx - __builtin_floorf(subx);
+            const float ppy = suby - __builtin_floorf(suby);
+            if (sx < 1 || sy < 1 || sx >= src_cols - 4 || sy >= src_rows - 4)
+            {
+                if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)
+                {
+                    const uint8_t* s = src + (long)sy * src_step + 3 * sx;
+                    px[p] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                }
+                else px[p] = bg;
+            }
+            else px[p] = easu_gather<YUV>(src, src_step, sx, sy, ppx, ppy);
         }
     }
     uint8_t* drow = dst + (long)y * dst_step;
@@ -255,44 +310,30 @@ void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_r
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(BLOCK_X * BLOCK_Y)
+__global__ __launch_bounds__(256)
+void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                        uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
+                        int off_x, int off_y, HomographyArgs H, uint32_t bg)
+{
+    const HomographyCoord coord{H, off_x, off_y};
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, coord, bg);
+}
+
+template <bool YUV>
+__global__ __launch_bounds__(256)
 void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                   uint8_t* __restrict__ dst, int dst_step,
                   const float* __restrict__ mesh, int mesh_cols,
                   const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
-    const int x0 = (blockIdx.x * BLOCK_X + threadIdx.x) * PXT;
-    const int y = blockIdx.y * BLOCK_Y + threadIdx.y;
-    if (x0 >= src_cols || y >= src_rows) return;
-    const int npx = min(PXT, src_cols - x0);
-    const LinTabEntry ty = ytab[y];
-    const float* __restrict__ m0 = mesh + (long)ty.s0 * mesh_cols * 2;
-    const float* __restrict__ m1 = mesh + (long)ty.s1 * mesh_cols * 2;
-    const float sw = (float)src_cols, sh = (float)src_rows;
-    uint32_t px[PXT];
-#pragma unroll
-    for (int p = 0; p < PXT; p++)
-    {
-        px[p] = 0;
-        if (p < npx)
-        {
-            // WarpMesh.cpp:190-191 evaluated per pixel: HResizeLinear then VResizeLinear on the float2 mesh, then * (cols, rows)
-            const LinTabEntry tx = xtab[x0 + p];
-            float off[2];
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++)
-            {
-                const float h0 = (tx.s1 == tx.s0) ? m0[2 * tx.s0 + ch] * 1.0f : m0[2 * tx.s0 + ch] * tx.a0 + m0[2 * tx.s1 + ch] * tx.a1;
-                const float h1 = (tx.s1 == tx.s0) ? m1[2 * tx.s0 + ch] * 1.0f : m1[2 * tx.s0 + ch] * tx.a0 + m1[2 * tx.s1 + ch] * tx.a1;
-                off[ch] = (h0 * ty.a0 + h1 * ty.a1) * (ch == 0 ? sw : sh);
-            }
-            const float subx = (float)(x0 + p) + off[0];      // FSR.cl:381
-            const float suby = (float)y + off[1];
-            px[p] = remap_pixel<YUV>(src, src_step, src_rows, src_cols, subx, suby, bg);
-        }
-    }
-    uint8_t* drow = dst + (long)y * dst_step;
-    store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
+    const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows};
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+}
+
+inline dim3 remap_grid(int dst_rows, int dst_cols)
+{
+    const int nstrips = ((dst_cols + STRIP_W - 1) / STRIP_W) * ((dst_rows + STRIP_H - 1) / STRIP_H);
+    return dim3((unsigned)(((nstrips + NUM_XCD - 1) / NUM_XCD) * NUM_XCD));
 }
 
 inline uint32_t pack_bg(const uint8_t bg[3]) { return (uint32_t)bg[0] | ((uint32_t)bg[1] << 8) | ((uint32_t)bg[2] << 16); }
@@ -351,8 +392,7 @@ int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
     LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * dst_cols);
     HomographyArgs args;
     std::memcpy(args.h, H, sizeof(args.h));
-    const dim3 block(BLOCK_X, BLOCK_Y);
-    const dim3 grid((dst_cols + BLOCK_X * PXT - 1) / (BLOCK_X * PXT), (dst_rows + BLOCK_Y - 1) / BLOCK_Y);
+    const dim3 block(256), grid = remap_grid(dst_rows, dst_cols);
     if (yuv)
         hipLaunchKernelGGL(k_remap_homography<true>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, pack_bg(bg));
@@ -384,8 +424,7 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
     if ((rc = lvk_get_lintab(ctx, mesh_cols, src_cols, false, &xtab)) != LVK_HIP_OK) return rc;
     if ((rc = lvk_get_lintab(ctx, mesh_rows, src_rows, true, &ytab)) != LVK_HIP_OK) return rc;
 
-    const dim3 block(BLOCK_X, BLOCK_Y);
-    const dim3 grid((src_cols + BLOCK_X * PXT - 1) / (BLOCK_X * PXT), (src_rows + BLOCK_Y - 1) / BLOCK_Y);
+    const dim3 block(256), grid = remap_grid(src_rows, src_cols);
     if (yuv)
         hipLaunchKernelGGL(k_remap_mesh<true>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));

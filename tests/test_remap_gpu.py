@@ -131,3 +131,27 @@ def test_full_size_4k_properties(ctx, oracle):
     got = ctx.remap_homography(band, H, yuv=True)
     ctx.sync()
     _assert_same(got, want, "4K band")
+
+
+def test_remap_strong_distortions_take_the_gather_path(ctx, oracle):
+    """Zoom-out / rotation large enough that a tile's source window exceeds the LDS staging capacity: the kernel
+    then gathers taps from global memory -- same bits either way."""
+    src = synth.textured_frame(300, 400, seed=31)
+    dsrc = _to_gpu(src)
+    cases = []
+    H = np.eye(3, dtype=np.float32); H[0, 0] = 3.0; H[1, 1] = 3.0; cases.append(H)                      # 3x minification
+    th = 0.6; c, s_ = np.cos(th), np.sin(th)
+    H = np.array([[c, -s_, 120], [s_, c, -60], [0, 0, 1]], np.float32); cases.append(H)                # 34 degree rotation
+    H = np.array([[1, 0.4, 0], [0.3, 1, 0], [1e-3, 5e-4, 1]], np.float32); cases.append(H)            # shear + strong perspective
+    H = np.array([[0.2, 0, 50], [0, 0.2, 40], [0, 0, 1]], np.float32); cases.append(H)                # 5x magnification (tiny window)
+    for i, H in enumerate(cases):
+        for yuv in (True, False):
+            want = oracle.remap_homography(src, H, bg=(7, 8, 9), yuv=yuv)
+            got = ctx.remap_homography(dsrc, H, bg=(7, 8, 9), yuv=yuv)
+            ctx.sync()
+            _assert_same(got, want, f"distortion case {i} yuv={yuv}")
+    mesh = synth.random_mesh(6, 6, np.random.default_rng(1), amp=0.35)                                  # violent mesh
+    want = oracle.remap_mesh(src, mesh, yuv=True)
+    got = ctx.remap_mesh(dsrc, mesh, yuv=True)
+    ctx.sync()
+    _assert_same(got, want, "violent mesh")
