@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--preset", default="homography", choices=["homography", "field"])
     ap.add_argument("--pool", type=int, default=24, help="distinct source frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the output remap on the tracking stream")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline: one pass over the frame pool instead of a 12 s budget")
     return ap.parse_args()
 
@@ -122,19 +123,21 @@ def main():
     ctx = lvk.Context(local_rank)
     settings = lvk.StabilizationFilterSettings.obs_preset(args.preset)
     filt = lvk.StabilizationFilter(settings, context=ctx)
+    if not args.no_overlap:
+        filt.set_overlap(True)          # remap of frame n-N on a second stream, concurrent with the tracking of frame n+1
     delay = filt.frame_delay()
 
     rows, cols = args.rows, args.cols
     pool = max(args.pool, delay + 3)
     frames = make_frame_pool(rows, cols, pool, seed=0x4C564B31 + rank, device=device)
-    outs = [torch.empty_like(frames[0]) for _ in range(2)]
+    outs = [torch.empty_like(frames[0]) for _ in range(4)]
     torch.cuda.synchronize()
 
     step_no = [0]
 
     def step():
         i = step_no[0]; step_no[0] += 1
-        return filt.apply(frames[i % pool], timestamp=i, out=outs[i & 1])
+        return filt.apply(frames[i % pool], timestamp=i, out=outs[i & 3])
 
     # fill the delay (untimed, before the warmup): every timed step then emits one stabilized frame
     for _ in range(delay + 2):

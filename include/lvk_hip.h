@@ -182,6 +182,12 @@ int  lvk_hip_stab_stable_region(const lvk_hip_stab* stab, int rows, int cols, in
 int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
                        void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released);
 
+/* Optional: run the output remap on a second HIP stream so that it overlaps the tracking of the next frame
+ * (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches, Functions/Image.cpp:76).
+ * With overlap enabled d_out is complete only after lvk_hip_sync(), and *released reports a borrowed frame one
+ * push later (after its remap has finished). */
+int  lvk_hip_stab_set_overlap(lvk_hip_stab* stab, int enable);
+
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
 /* last frame motion (after the trust factor) and last applied correction; each motion_height x motion_width x 2 floats */
 int  lvk_hip_stab_get_meshes(const lvk_hip_stab* stab, float* motion, float* correction, int cap_floats);

@@ -55,6 +55,7 @@ _SIG = {
     "lvk_hip_stab_get_stats": (_c.c_int, [_P, _P]),
     "lvk_hip_stab_get_meshes": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int]),
     "lvk_hip_stab_get_features": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.c_int]),
+    "lvk_hip_stab_set_overlap": (_c.c_int, [_P, _c.c_int]),
     "lvk_hip_stab_set_profiling": (_c.c_int, [_P, _c.c_int]),
     "lvk_hip_stab_get_profile": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),
 }

@@ -78,6 +78,7 @@ int lvk_hip_sync(lvk_hip_ctx* ctx)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t s : ctx->aux_streams) LVK_HIP_CHECK(ctx, hipStreamSynchronize(s));
     return LVK_HIP_OK;
 }
 
@@ -116,7 +117,7 @@ int lvk_hip_download(lvk_hip_ctx* ctx, void* h_dst, const void* d_src, size_t by
 
 } // extern "C"
 
-int lvk_stage_params(lvk_hip_ctx* ctx, const void* host, size_t bytes, void** d_out)
+int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, size_t bytes, void** d_out)
 {
     LVK_HIP_REQUIRE(ctx, bytes <= lvk_hip_ctx::kStageBytes);
     const int slot = ctx->stage_next;
@@ -126,8 +127,8 @@ int lvk_stage_params(lvk_hip_ctx* ctx, const void* host, size_t bytes, void** d_
     uint8_t* h = ctx->stage_host + (size_t)slot * lvk_hip_ctx::kStageBytes;
     uint8_t* d = ctx->stage_dev + (size_t)slot * lvk_hip_ctx::kStageBytes;
     std::memcpy(h, host, bytes);
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    LVK_HIP_CHECK(ctx, hipEventRecord(ctx->stage_done[slot], ctx->stream));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+    LVK_HIP_CHECK(ctx, hipEventRecord(ctx->stage_done[slot], stream));
     *d_out = d;
     return LVK_HIP_OK;
 }

@@ -34,6 +34,9 @@ struct lvk_hip_ctx
     hipEvent_t stage_done[kStageSlots] = {};
     int stage_next = 0;
 
+    // extra streams owned by objects of this context (synchronised by lvk_hip_sync as well)
+    std::vector<hipStream_t> aux_streams;
+
     // Cached INTER_LINEAR tables: key = (mesh extent, frame extent, vertical?)
     std::map<std::tuple<int, int, int>, LinTabEntry*> lintabs;
 
@@ -56,7 +59,7 @@ struct lvk_hip_ctx
 
 // Copies `bytes` (<= kStageBytes) of host data into a device staging slot, asynchronously on the
 // context's stream, and returns the device address.  The slot is recycled after kStageSlots uses.
-int lvk_stage_params(lvk_hip_ctx* ctx, const void* host, size_t bytes, void** d_out);
+int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, size_t bytes, void** d_out);
 
 // Device-resident INTER_LINEAR table for resizing a mesh axis of `msize` vertices to `fsize` pixels.
 int lvk_get_lintab(lvk_hip_ctx* ctx, int msize, int fsize, bool vertical, const LinTabEntry** d_out);
@@ -96,3 +99,12 @@ struct DevicePyramid
 size_t lvk_ransac_workspace_bytes(int n);
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
                       bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask);
+
+// Dense remap on an explicit stream (remap.hip)
+int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
+                                void* d_dst, int dst_step, int dst_rows, int dst_cols, int off_x, int off_y,
+                                const float H[9], const uint8_t bg[3], int yuv);
+int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
+                          void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
+int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
+                              void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);

@@ -378,14 +378,11 @@ bool perspective_transform(const float src[8], const float dst[8], double M[9])
 
 } // namespace
 
-extern "C" {
-
-int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
-                             const void* d_src, int src_step, int src_rows, int src_cols,
-                             void* d_dst, int dst_step, int dst_rows, int dst_cols,
-                             int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv)
+int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream,
+                                const void* d_src, int src_step, int src_rows, int src_cols,
+                                void* d_dst, int dst_step, int dst_rows, int dst_cols,
+                                int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
     // Image.cpp:93-98
     LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && H != nullptr && bg != nullptr);
     LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0 && dst_cols > 0 && dst_rows > 0);
@@ -394,21 +391,20 @@ int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
     std::memcpy(args.h, H, sizeof(args.h));
     const dim3 block(256), grid = remap_grid(dst_rows, dst_cols);
     if (yuv)
-        hipLaunchKernelGGL(k_remap_homography<true>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+        hipLaunchKernelGGL(k_remap_homography<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, pack_bg(bg));
     else
-        hipLaunchKernelGGL(k_remap_homography<false>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+        hipLaunchKernelGGL(k_remap_homography<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, pack_bg(bg));
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
 
-int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
-                       const void* d_src, int src_step, int src_rows, int src_cols,
-                       void* d_dst, int dst_step,
-                       const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
+                          const void* d_src, int src_step, int src_rows, int src_cols,
+                          void* d_dst, int dst_step,
+                          const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
     // Image.cpp:30-34
     LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && mesh != nullptr && bg != nullptr);
     LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0);
@@ -418,7 +414,7 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
     LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
 
     void* d_mesh = nullptr;
-    int rc = lvk_stage_params(ctx, mesh, mesh_bytes, &d_mesh);
+    int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh);
     if (rc != LVK_HIP_OK) return rc;
     const LinTabEntry *xtab = nullptr, *ytab = nullptr;
     if ((rc = lvk_get_lintab(ctx, mesh_cols, src_cols, false, &xtab)) != LVK_HIP_OK) return rc;
@@ -426,21 +422,20 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
 
     const dim3 block(256), grid = remap_grid(src_rows, src_cols);
     if (yuv)
-        hipLaunchKernelGGL(k_remap_mesh<true>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+        hipLaunchKernelGGL(k_remap_mesh<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
     else
-        hipLaunchKernelGGL(k_remap_mesh<false>, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+        hipLaunchKernelGGL(k_remap_mesh<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
 
-int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
-                           const void* d_src, int src_step, int rows, int cols,
-                           void* d_dst, int dst_step,
-                           const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream,
+                              const void* d_src, int src_step, int rows, int cols,
+                              void* d_dst, int dst_step,
+                              const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
     LVK_HIP_REQUIRE(ctx, mesh != nullptr && mesh_rows >= 2 && mesh_cols >= 2);
     if (mesh_rows == 2 && mesh_cols == 2)
     {
@@ -461,9 +456,38 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
             for (int q = 0; q < 9; q++) M[q] = (q % 4 == 0) ? 1.0 : 0.0;
         float H[9];
         for (int q = 0; q < 9; q++) H[q] = (float)M[q];              // Image.cpp:137-139
-        return lvk_hip_remap_homography(ctx, d_src, src_step, rows, cols, d_dst, dst_step, rows, cols, 0, 0, H, bg, yuv);
+        return lvk_launch_remap_homography(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, rows, cols, 0, 0, H, bg, yuv);
     }
-    return lvk_hip_remap_mesh(ctx, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
+    return lvk_launch_remap_mesh(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
+}
+
+extern "C" {
+
+int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
+                             const void* d_src, int src_step, int src_rows, int src_cols,
+                             void* d_dst, int dst_step, int dst_rows, int dst_cols,
+                             int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_remap_homography(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, H, bg, yuv);
+}
+
+int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
+                       const void* d_src, int src_step, int src_rows, int src_cols,
+                       void* d_dst, int dst_step,
+                       const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_remap_mesh(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
+}
+
+int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
+                           const void* d_src, int src_step, int rows, int cols,
+                           void* d_dst, int dst_step,
+                           const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_warpmesh_apply(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
 }
 
 } // extern "C"

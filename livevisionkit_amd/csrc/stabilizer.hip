@@ -77,13 +77,21 @@ struct lvk_hip_stab
     double last_H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     WarpMeshF last_motion, last_correction;
 
+    // ---- optional overlap of the output remap with the next frame's tracking (second stream)
+    bool overlap = false;
+    hipStream_t remap_stream = nullptr;
+    hipEvent_t remap_done[2] = {nullptr, nullptr};
+    int remap_slot = 0;
+    const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
+    int pending_slot = -1;
+
     // ---- optional per-stage GPU timing (HIP events on the launch stream)
     bool profiling = false;
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
     double prof_ms[LVK_STAGE_COUNT] = {0}; long prof_n[LVK_STAGE_COUNT] = {0};
-    int prof_begin(int kind);
-    void prof_end(int idx);
+    int prof_begin(int kind, hipStream_t stream = nullptr);
+    void prof_end(int idx, hipStream_t stream = nullptr);
     int prof_collect();
 
     int fail(int code, const std::string& msg) { return ctx->fail(code, msg); }
@@ -96,8 +104,9 @@ struct lvk_hip_stab
     int track(const QueuedFrame& f, WarpMeshF& motion, bool& have_motion);
 };
 
-int lvk_hip_stab::prof_begin(int kind)
+int lvk_hip_stab::prof_begin(int kind, hipStream_t stream)
 {
+    if (!stream) stream = ctx->stream;
     if (!profiling) return -1;
     if (ev_used == ev_pool.size())
     {
@@ -106,15 +115,16 @@ int lvk_hip_stab::prof_begin(int kind)
         ev_pool.push_back(p);
     }
     ev_pool[ev_used].kind = kind;
-    (void)hipEventRecord(ev_pool[ev_used].a, ctx->stream);
+    (void)hipEventRecord(ev_pool[ev_used].a, stream);
     return (int)ev_used++;
 }
 
-void lvk_hip_stab::prof_end(int idx) { if (idx >= 0) (void)hipEventRecord(ev_pool[(size_t)idx].b, ctx->stream); }
+void lvk_hip_stab::prof_end(int idx, hipStream_t stream) { if (idx >= 0) (void)hipEventRecord(ev_pool[(size_t)idx].b, stream ? stream : ctx->stream); }
 
 int lvk_hip_stab::prof_collect()
 {
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
     for (size_t i = 0; i < ev_used; i++)
     {
         float ms = 0.f;
@@ -404,8 +414,37 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     (void)hipStreamSynchronize(st->ctx->stream);
     st->free_tracker_buffers();
     st->pyr[0].release(); st->pyr[1].release();
+    if (st->remap_stream)
+    {
+        (void)hipStreamSynchronize(st->remap_stream);
+        auto& aux = st->ctx->aux_streams;
+        aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
+        (void)hipStreamDestroy(st->remap_stream);
+        (void)hipEventDestroy(st->remap_done[0]); (void)hipEventDestroy(st->remap_done[1]);
+    }
     for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete st;
+}
+
+// Overlap mode: the EASU remap of the delayed frame runs on a second stream, concurrently with the tracking of the
+// next frame (the two are independent: the delayed frame was uploaded at least one push earlier).  The output of a
+// push is then complete only after lvk_hip_sync(), and a borrowed frame is handed back (*released) one push later,
+// after its remap has finished.
+int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (st->remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st->remap_stream));
+    if (enable && !st->remap_stream)
+    {
+        LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&st->remap_stream, hipStreamNonBlocking));
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[0], hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[1], hipEventDisableTiming));
+        ctx->aux_streams.push_back(st->remap_stream);
+    }
+    st->overlap = enable != 0;
+    return LVK_HIP_OK;
 }
 
 // Per-stage GPU time measured with HIP events on the launch stream.  enable != 0 starts (and resets) the
@@ -440,6 +479,7 @@ int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::rest
     if (!st) return LVK_HIP_ERR_ARG;
     st->scene_quality = 1.0f;
     st->queue.clear();
+    st->pending_release = nullptr; st->pending_slot = -1;
     st->reset_context();
     return LVK_HIP_OK;
 }
@@ -476,18 +516,35 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
         st->queue.pop_front();
         LVK_HIP_REQUIRE(ctx, d_out != nullptr && out_step >= 3 * f.cols);
         int rc = LVK_HIP_OK;
-        const int pe = st->prof_begin(LVK_STAGE_REMAP);
-        if (mesh) rc = lvk_hip_warpmesh_apply(ctx, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1);
+        // overlap mode: the delayed frame was pushed >= 1 push ago and the tracker has synchronised the main stream since,
+        // so the remap may run on its own stream concurrently with the next frame's tracking
+        const bool side = st->overlap && mesh && st->s.stabilize_output;
+        hipStream_t rs = side ? st->remap_stream : ctx->stream;
+        const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
+        if (mesh) rc = lvk_launch_warpmesh_apply(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
             if (e != hipSuccess) rc = ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
         }
-        st->prof_end(pe);
+        st->prof_end(pe, rs);
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
         if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222
-        if (released) *released = f.d_ptr;
+        if (side)
+        {
+            // the frame stays borrowed until its remap has finished: hand back the previous one instead
+            const int slot = st->remap_slot; st->remap_slot ^= 1;
+            hipError_t e = hipEventRecord(st->remap_done[slot], rs);
+            if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
+            if (st->pending_release)
+            {
+                if ((e = hipEventSynchronize(st->remap_done[st->pending_slot])) != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
+                if (released) *released = st->pending_release;
+            }
+            st->pending_release = f.d_ptr; st->pending_slot = slot;
+        }
+        else if (released) *released = f.d_ptr;
         return LVK_HIP_OK;
     };
 

@@ -181,6 +181,10 @@ class StabilizationFilter:
         n = self.lib.lvk_hip_stab_get_features(self.handle, a.ctypes.data_as(_c.POINTER(_c.c_float)), cap)
         return a[:max(n, 0)].copy()
 
+    def set_overlap(self, enable=True):
+        """Run the output remap on a second stream, overlapping the next frame's tracking (output valid after ctx.sync())."""
+        self.ctx._check(self.lib.lvk_hip_stab_set_overlap(self.handle, 1 if enable else 0))
+
     STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap")
 
     def set_profiling(self, enable=True):

@@ -55,11 +55,13 @@ def test_global_motion_degenerate_inputs(ctx, oracle):
     assert rc_g < 0 and np.array_equal(H_g, np.eye(3))
 
 
-def _run_pair(oracle, ctx, frames, settings, n_check_frames=None, reconfigure_at=None, then_configure=None):
+def _run_pair(oracle, ctx, frames, settings, n_check_frames=None, reconfigure_at=None, then_configure=None, overlap=False):
     import torch
     import livevisionkit_amd as lvk
     ost = oracle_lib.OracleStabilizer(oracle, settings)
     gst = lvk.StabilizationFilter(_to_settings(settings), context=ctx)
+    if overlap:
+        gst.set_overlap(True)
     if then_configure is not None:                      # OBS flow: default-constructed filter, then reconfigure(preset)
         ost.configure(then_configure); gst.configure(_to_settings(then_configure))
     produced = 0
@@ -102,6 +104,39 @@ def test_stabilizer_homography_preset_bit_exact(ctx, oracle, clip):
     frames, _ = clip
     s = oracle_lib.preset("homography", predictive_samples=4)
     assert _run_pair(oracle, ctx, frames, s) == len(frames) - 4
+
+
+def test_stabilizer_overlap_mode_bit_exact(ctx, oracle, clip):
+    """Remap on the second stream (overlapping the next frame's tracking): same frames, same order, same bits."""
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=4)
+    assert _run_pair(oracle, ctx, frames, s, overlap=True) == len(frames) - 4
+    field = oracle_lib.preset("field", predictive_samples=3, min_scene_quality=0.4, min_tracking_quality=0.2)
+    assert _run_pair(oracle, ctx, frames[:20], oracle_lib.preset("default"), then_configure=field, overlap=True) == 17
+
+
+def test_overlap_mode_without_per_frame_sync(ctx, oracle, clip):
+    """Free-running overlap mode (no sync between pushes, outputs in distinct buffers, borrowed inputs reused only after
+    release): every output still equals the oracle's."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=3)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    gst.set_overlap(True)
+    wants, gots = [], []
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    for i, f in enumerate(frames):
+        want, _ = ost.push(f, ts=i)
+        got, _ = gst.apply(dev[i], timestamp=i)
+        if want is not None:
+            wants.append(want); gots.append(got)
+    ctx.sync()
+    assert len(gots) == len(frames) - 3
+    for i, (w, g) in enumerate(zip(wants, gots)):
+        assert np.array_equal(g.cpu().numpy(), w), i
+    ost.close(); gst.close()
 
 
 def test_stabilizer_relaxed_qa_no_crop_bit_exact(ctx, oracle, clip):
