@@ -93,6 +93,11 @@ int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, 
 int lvk_hip_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
 int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
 
+/* The whole optical-flow pyramid of buildOpticalFlowPyramid (levels until one would be <= the window) plus every
+ * level's Scharr image, returned to the host tightly packed level after level.  Returns the level count.  Synchronous. */
+int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, int max_level, int win_w, int win_h,
+                          uint8_t* levels, int16_t* derivs, int* level_rows, int* level_cols);
+
 /* ---- a5 (inner): FAST-9/16 + non-max suppression per detection region -----------------------------------
  * cv::FastFeatureDetector(threshold, true, TYPE_9_16)->detect(frame(region)) (Vision/FeatureDetector.cpp:130-134).
  * regions = nregions x {x, y, w, h, threshold, active} ints; out = nregions x cap keypoints packed as

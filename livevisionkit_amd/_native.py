@@ -34,6 +34,8 @@ _SIG = {
     "lvk_hip_luma_area_resize": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int]),
     "lvk_hip_pyr_down": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int]),
     "lvk_hip_scharr": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "lvk_hip_build_pyramid": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                         _c.POINTER(_c.c_uint8), _c.POINTER(_c.c_int16), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "lvk_hip_fast_detect": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int,
                                        _c.POINTER(_c.c_uint32), _c.c_int, _c.POINTER(_c.c_int)]),
     "lvk_hip_pyrlk": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _c.c_int,

@@ -122,6 +122,22 @@ class Context:
         self._check(self.lib.lvk_hip_scharr(self.handle, img.data_ptr(), img.stride(0), img.shape[0], img.shape[1], out.data_ptr()))
         return out
 
+    def build_pyramid(self, img, max_level=3, win=(11, 11)):
+        """Returns [(level uint8 [r, c], deriv int16 [r, c, 2]), ...] as the LK tracker sees them."""
+        rows, cols = img.shape
+        lv = np.zeros(rows * cols * 2, np.uint8); dv = np.zeros(rows * cols * 4, np.int16)
+        lr = np.zeros(8, np.int32); lc = np.zeros(8, np.int32)
+        n = self.lib.lvk_hip_build_pyramid(self.handle, img.data_ptr(), img.stride(0), rows, cols, max_level, win[0], win[1],
+                                           lv.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), dv.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)),
+                                           lr.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), lc.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        self._check(min(n, 0))
+        out, lo, do = [], 0, 0
+        for i in range(n):
+            r, c = int(lr[i]), int(lc[i])
+            out.append((lv[lo:lo + r * c].reshape(r, c).copy(), dv[do:do + r * c * 2].reshape(r, c, 2).copy()))
+            lo += r * c; do += r * c * 2
+        return out
+
     # ---- a5 / a7 ----------------------------------------------------------------------------------------
     def fast_detect(self, img, regions, cap=None):
         """regions: list of (x, y, w, h, threshold, active). Returns a list of [n, 3] int32 (x, y, score) arrays, region-local."""

@@ -45,6 +45,42 @@ void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, 
     dst[(long)y * dst_step + x] = out;
 }
 
+// Same arithmetic, specialised for the stabilizer's cases (4K: 8x8, 1080p: 4x4; packed 8UC3 channel 0 or planar): every
+// source row segment of a destination pixel is SX * PIX contiguous bytes = whole aligned dwords, so the SY * SX * PIX / 4
+// loads of a thread are independent and issued back to back (the generic kernel's byte loads in a runtime-bound loop
+// serialise on memory latency: rocprofv3 showed 88 % of its wave time in s_waitcnt).
+template <int SX, int SY, int PIX>
+__global__ __launch_bounds__(256)
+void k_area_fast_dw(const uint8_t* __restrict__ src, int src_step, uint8_t* __restrict__ dst, int dst_step, int drows, int dcols)
+{
+    constexpr int NW = SX * PIX / 4;
+    static_assert((SX * PIX) % 4 == 0, "row segment must be whole dwords");
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dcols || y >= drows) return;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (long)(y * SY) * src_step) + (long)x * NW;
+    uint32_t w[SY][NW];
+#pragma unroll
+    for (int ky = 0; ky < SY; ky++)
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+            w[ky][k] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + (long)ky * src_step)[k];
+    int sum = 0;
+#pragma unroll
+    for (int ky = 0; ky < SY; ky++)
+#pragma unroll
+        for (int kx = 0; kx < SX; kx++)
+        {
+            constexpr int dummy = 0; (void)dummy;
+            const int b = kx * PIX;                       // byte of channel 0 of source pixel kx inside the segment
+            sum += (int)((w[ky][b >> 2] >> ((b & 3) * 8)) & 0xffu);
+        }
+    uint8_t out;
+    if (SX == 2 && SY == 2) out = (uint8_t)((sum + 2) >> 2);
+    else out = sat_u8_rint((float)sum * (1.f / (float)(SX * SY)));
+    dst[(long)y * dst_step + x] = out;
+}
+
 // ---- INTER_AREA, general scale (resizeArea_ + computeResizeAreaTab) ----
 __global__ __launch_bounds__(256)
 void k_area_general(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
@@ -112,6 +148,104 @@ void k_scharr(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
     dst[(long)y * cols + x] = o;
 }
 
+// ---- pyramid levels 1..3 in ONE launch -----------------------------------------------------------------------------
+// The pyramid images are tiny (240x135, 120x68, 60x34 for the 480x270 tracking frame), so seven dependent launches
+// (3 x pyrDown + 4 x Scharr) cost far more in launch gaps than in work.  Here a block owns an 8x8 tile of level 3 and
+// the matching 16x16 / 32x32 tiles of levels 2 / 1: it stages the 85x85 window of level 0 those need in LDS, computes
+// the 41x41 level-1 window (halo recomputed redundantly by neighbouring blocks), from it the 19x19 level-2 window and
+// from that its level-3 tile, writing only the pixels it owns.  Same integer arithmetic as k_pyr_down
+// ((sum + 128) >> 8, reflect-101 applied on each level's own index range).
+constexpr int F0 = 85, F0P = 88, F1 = 41, F1P = 44, F2 = 19, F2P = 20;
+
+__device__ __forceinline__ int pyr_tap(const uint8_t* t, int pitch, int ox, int oy, int x, int y, int cols, int rows)
+{
+    // 5x5 [1 4 6 4 1] around (2x, 2y) of the source level (size cols x rows), samples fetched from tile t whose (0,0) is (ox, oy)
+    int xi[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xi[k] = reflect101(2 * x - 2 + k, cols) - ox;
+    int acc = 0;
+#pragma unroll
+    for (int ky = 0; ky < 5; ky++)
+    {
+        const uint8_t* row = t + (reflect101(2 * y - 2 + ky, rows) - oy) * pitch;
+        const int h = row[xi[0]] + row[xi[4]] + 4 * (row[xi[1]] + row[xi[3]]) + 6 * row[xi[2]];
+        acc += ((ky == 0 || ky == 4) ? 1 : (ky == 2 ? 6 : 4)) * h;
+    }
+    return (acc + 128) >> 8;
+}
+
+__global__ __launch_bounds__(256)
+void k_pyr_fused3(PyrArgs a)
+{
+    __shared__ uint8_t t0[F0 * F0P], t1[F1 * F1P], t2[F2 * F2P];
+    const int tid = threadIdx.x;
+    const int x3 = blockIdx.x * 8, y3 = blockIdx.y * 8;
+    const int o2x = 2 * x3 - 2, o2y = 2 * y3 - 2, o1x = 2 * o2x - 2, o1y = 2 * o2y - 2, o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
+    const PyrLevel L0 = a.lv[0], L1 = a.lv[1], L2 = a.lv[2], L3 = a.lv[3];
+
+    for (int i = tid; i < F0 * F0; i += 256)
+    {
+        const int ty = i / F0, tx = i - ty * F0;
+        const int gx = o0x + tx, gy = o0y + ty;
+        if (gx >= 0 && gy >= 0 && gx < L0.cols && gy < L0.rows) t0[ty * F0P + tx] = L0.img[(long)gy * L0.step + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < F1 * F1; i += 256)
+    {
+        const int ty = i / F1, tx = i - ty * F1;
+        const int gx = o1x + tx, gy = o1y + ty;
+        if (gx >= 0 && gy >= 0 && gx < L1.cols && gy < L1.rows)
+        {
+            const int v = pyr_tap(t0, F0P, o0x, o0y, gx, gy, L0.cols, L0.rows);
+            t1[ty * F1P + tx] = (uint8_t)v;
+            if (gx >= 4 * x3 && gx < 4 * x3 + 32 && gy >= 4 * y3 && gy < 4 * y3 + 32)
+                const_cast<uint8_t*>(L1.img)[(long)gy * L1.step + gx] = (uint8_t)v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < F2 * F2; i += 256)
+    {
+        const int ty = i / F2, tx = i - ty * F2;
+        const int gx = o2x + tx, gy = o2y + ty;
+        if (gx >= 0 && gy >= 0 && gx < L2.cols && gy < L2.rows)
+        {
+            const int v = pyr_tap(t1, F1P, o1x, o1y, gx, gy, L1.cols, L1.rows);
+            t2[ty * F2P + tx] = (uint8_t)v;
+            if (gx >= 2 * x3 && gx < 2 * x3 + 16 && gy >= 2 * y3 && gy < 2 * y3 + 16)
+                const_cast<uint8_t*>(L2.img)[(long)gy * L2.step + gx] = (uint8_t)v;
+        }
+    }
+    __syncthreads();
+    if (tid < 64)
+    {
+        const int gx = x3 + (tid & 7), gy = y3 + (tid >> 3);
+        if (gx < L3.cols && gy < L3.rows)
+            const_cast<uint8_t*>(L3.img)[(long)gy * L3.step + gx] = (uint8_t)pyr_tap(t2, F2P, o2x, o2y, gx, gy, L2.cols, L2.rows);
+    }
+}
+
+// Scharr derivative images of all pyramid levels in one launch (blockIdx.z = level).
+__global__ __launch_bounds__(256)
+void k_scharr_all(PyrArgs a)
+{
+    const PyrLevel L = a.lv[blockIdx.z];
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= L.cols || y >= L.rows) return;
+    const int rows = L.rows, cols = L.cols;
+    const uint8_t* r0 = L.img + (long)(y > 0 ? y - 1 : (rows > 1 ? 1 : 0)) * L.step;
+    const uint8_t* r1 = L.img + (long)y * L.step;
+    const uint8_t* r2 = L.img + (long)(y < rows - 1 ? y + 1 : (rows > 1 ? rows - 2 : 0)) * L.step;
+    const int xm = x > 0 ? x - 1 : (cols > 1 ? 1 : 0);
+    const int xp = x < cols - 1 ? x + 1 : (cols > 1 ? cols - 2 : 0);
+    const int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10, t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
+    const int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
+    short2 o;
+    o.x = (short)(t0p - t0m);
+    o.y = (short)((t1p + t1m) * 3 + t1c * 10);
+    const_cast<short2*>(L.deriv)[(long)y * cols + x] = o;
+}
+
 // imgproc/resize.cpp computeResizeAreaTab, grouped per destination index.
 void build_area_tab(int ssize, int dsize, std::vector<int2>& range, std::vector<AreaTabEntry>& tab)
 {
@@ -162,7 +296,18 @@ int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_ste
     LVK_HIP_REQUIRE(ctx, pix_stride >= 1 && channel >= 0 && channel < pix_stride);
     LVK_HIP_REQUIRE(ctx, drows <= srows && dcols <= scols);          // the tracker only downscales (FrameTracker.cpp:117)
     const dim3 block(64, 4), grid((dcols + 63) / 64, (drows + 3) / 4);
-    if (scols % dcols == 0 && srows % drows == 0)
+    const int isx = scols / dcols, isy = srows / drows;
+    const bool exact = scols % dcols == 0 && srows % drows == 0;
+    const bool dw_ok = exact && channel == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && (src_step & 3) == 0;
+    if (dw_ok && isx == 8 && isy == 8 && pix_stride == 3)
+        hipLaunchKernelGGL((k_area_fast_dw<8, 8, 3>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_ok && isx == 4 && isy == 4 && pix_stride == 3)
+        hipLaunchKernelGGL((k_area_fast_dw<4, 4, 3>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_ok && isx == 8 && isy == 8 && pix_stride == 1)
+        hipLaunchKernelGGL((k_area_fast_dw<8, 8, 1>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_ok && isx == 4 && isy == 4 && pix_stride == 1)
+        hipLaunchKernelGGL((k_area_fast_dw<4, 4, 1>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (exact)
     {
         hipLaunchKernelGGL(k_area_fast, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, pix_stride, channel,
                            (uint8_t*)d_dst, dst_step, drows, dcols, scols / dcols, srows / drows);
@@ -195,6 +340,25 @@ int lvk_launch_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int row
     LVK_HIP_REQUIRE(ctx, d_src && d_dst && rows > 0 && cols > 0);
     const dim3 block(64, 4), grid((cols + 63) / 64, (rows + 3) / 4);
     hipLaunchKernelGGL(k_scharr, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, rows, cols, (short2*)d_dst);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+// Levels 1.. and all derivative images of a pyramid whose level 0 is filled: two launches for the usual 4-level pyramid.
+int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args)
+{
+    int rc;
+    if (args.nlevels == 4)
+    {
+        const dim3 grid((args.lv[3].cols + 7) / 8, (args.lv[3].rows + 7) / 8);
+        hipLaunchKernelGGL(k_pyr_fused3, grid, dim3(256), 0, ctx->stream, args);
+    }
+    else
+        for (int i = 1; i < args.nlevels; i++)
+            if ((rc = lvk_launch_pyr_down(ctx, args.lv[i - 1].img, args.lv[i - 1].step, args.lv[i - 1].rows, args.lv[i - 1].cols,
+                                          const_cast<uint8_t*>(args.lv[i].img), args.lv[i].step)) != LVK_HIP_OK) return rc;
+    const dim3 sgrid((args.lv[0].cols + 63) / 64, (args.lv[0].rows + 3) / 4, args.nlevels);
+    hipLaunchKernelGGL(k_scharr_all, sgrid, dim3(64, 4), 0, ctx->stream, args);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

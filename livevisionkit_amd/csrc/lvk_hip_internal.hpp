@@ -72,6 +72,8 @@ int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_ste
                                 int srows, int scols, void* d_dst, int dst_step, int drows, int dcols);
 int lvk_launch_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
 int lvk_launch_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
+struct PyrArgs;
+int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args);
 
 // FAST-9/16 + NMS per region (fast.hip)
 int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks_bytes, size_t* scores_bytes);

@@ -14,6 +14,7 @@ namespace {
 
 constexpr int K_HYPOTHESES = 128;
 constexpr int LO_ROUNDS = 3;
+constexpr int LDS_POINTS = 2048;     // point pairs staged in LDS (16 B each); larger sets are read from global memory
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& s)
 {
@@ -38,33 +39,43 @@ __device__ bool draw_sample(int h, int n, int m, int* idx)
     return got == m;
 }
 
-// Gaussian elimination with partial pivoting on LDS-resident A (n x n) and b, executed by one lane.
+// Gaussian elimination with partial pivoting on LDS-resident A (n x n, n <= 8) and b, executed by one wavefront:
+// the row operations of each pivot step run one element per lane (each element sees exactly the operations of the
+// sequential algorithm, so the result is bit-identical to it); the short back substitution runs on lane 0.
+// All lanes return the same verdict.  Must be called by all 64 lanes of a single-wave block.
 __device__ bool solve_n(double* A, double* b, int n)
 {
+    const int lane = threadIdx.x & 63;
     for (int i = 0; i < n; i++)
     {
         int piv = i;
-        for (int j = i + 1; j < n; j++) if (fabs(A[j * n + i]) > fabs(A[piv * n + i])) piv = j;
+        for (int j = i + 1; j < n; j++) if (fabs(A[j * n + i]) > fabs(A[piv * n + i])) piv = j;     // uniform: every lane reads the same column
         if (fabs(A[piv * n + i]) < 1e-10) return false;
+        __syncthreads();
         if (piv != i)
         {
-            for (int q = 0; q < n; q++) { const double t = A[i * n + q]; A[i * n + q] = A[piv * n + q]; A[piv * n + q] = t; }
-            const double t = b[i]; b[i] = b[piv]; b[piv] = t;
+            if (lane < n) { const double t = A[i * n + lane]; A[i * n + lane] = A[piv * n + lane]; A[piv * n + lane] = t; }
+            else if (lane == n) { const double t = b[i]; b[i] = b[piv]; b[piv] = t; }
         }
+        __syncthreads();
         const double inv = 1.0 / A[i * n + i];
-        for (int j = i + 1; j < n; j++)
+        const int j = i + 1 + lane / (n + 1), q = i + 1 + lane % (n + 1);     // q == n stands for the right-hand side
+        if (j < n && q <= n)
         {
             const double f = A[j * n + i] * inv;
-            for (int q = i + 1; q < n; q++) A[j * n + q] = A[j * n + q] - f * A[i * n + q];
-            b[j] = b[j] - f * b[i];
+            if (q < n) A[j * n + q] = A[j * n + q] - f * A[i * n + q];
+            else b[j] = b[j] - f * b[i];
         }
+        __syncthreads();
     }
-    for (int i = n - 1; i >= 0; i--)
-    {
-        double s = b[i];
-        for (int q = i + 1; q < n; q++) s = s - A[i * n + q] * b[q];
-        b[i] = s / A[i * n + i];
-    }
+    if (lane == 0)
+        for (int i = n - 1; i >= 0; i--)
+        {
+            double s = b[i];
+            for (int q = i + 1; q < n; q++) s = s - A[i * n + q] * b[q];
+            b[i] = s / A[i * n + i];
+        }
+    __syncthreads();
     return true;
 }
 
@@ -111,11 +122,14 @@ __device__ long long score_model(const double* H, const float2* __restrict__ p1,
     return score;
 }
 
+// Whole-wave: lane 0 assembles the system / closed form, all lanes take part in the solve.
 __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, const int* idx,
                                   double* A, double* b, double* H)
 {
+    const int lane = threadIdx.x & 63;
     if (full)
     {
+        if (lane == 0)
         for (int i = 0; i < 4; i++)
         {
             const double x = p1[idx[i]].x, y = p1[idx[i]].y, u = p2[idx[i]].x, v = p2[idx[i]].y;
@@ -123,9 +137,11 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
             r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x * u; r0[7] = -y * u; b[i] = u;
             r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * v; r1[7] = -y * v; b[i + 4] = v;
         }
+        __syncthreads();
         if (!solve_n(A, b, 8)) return false;
-        for (int q = 0; q < 8; q++) H[q] = b[q];
-        H[8] = 1.0;
+        if (lane < 8) H[lane] = b[lane];
+        if (lane == 8) H[8] = 1.0;
+        __syncthreads();
         return true;
     }
     const double x0 = p1[idx[0]].x, y0 = p1[idx[0]].y, x1 = p1[idx[1]].x, y1 = p1[idx[1]].y;
@@ -134,29 +150,39 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
     const double d2 = dx * dx + dy * dy;
     if (d2 < 1e-10) return false;
     const double a = (dx * ex + dy * ey) / d2, bb = (dx * ey - dy * ex) / d2;
-    H[0] = a; H[1] = -bb; H[2] = u0 - (a * x0 - bb * y0);
-    H[3] = bb; H[4] = a;  H[5] = v0 - (bb * x0 + a * y0);
-    H[6] = 0; H[7] = 0;   H[8] = 1;
+    if (lane == 0)
+    {
+        H[0] = a; H[1] = -bb; H[2] = u0 - (a * x0 - bb * y0);
+        H[3] = bb; H[4] = a;  H[5] = v0 - (bb * x0 + a * y0);
+        H[6] = 0; H[7] = 0;   H[8] = 1;
+    }
+    __syncthreads();
     return true;
 }
 
-// One wavefront per hypothesis.
+// One wavefront per hypothesis.  STAGED: the point pairs are first copied into LDS with one coalesced sweep, so the
+// voting loop is not a chain of dependent global-memory round trips.
+template <bool STAGED>
 __global__ __launch_bounds__(64)
-void k_ransac_hypotheses(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2, int full,
+void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, double t2, int full,
                          double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
 {
     __shared__ double sA[64], sb[8], sH[9];
     __shared__ int s_ok;
-    const int h = blockIdx.x;
-    if (threadIdx.x == 0)
+    __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
+    if (STAGED)
     {
-        int idx[4];
-        bool ok = draw_sample(h, n, full ? 4 : 2, idx);
-        if (ok) ok = model_from_sample(full != 0, p1, p2, idx, sA, sb, sH);
-        s_ok = ok ? 1 : 0;
+        for (int i = threadIdx.x; i < n; i += 64) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+        __syncthreads();
     }
-    __syncthreads();
-    if (!s_ok) { if (threadIdx.x == 0) hyp_score[h] = -1; return; }
+    const float2* p1 = STAGED ? s_p1 : g1;
+    const float2* p2 = STAGED ? s_p2 : g2;
+    const int h = blockIdx.x;
+    int idx[4];
+    bool ok = draw_sample(h, n, full ? 4 : 2, idx);                 // uniform: every lane draws the same sample
+    if (ok) ok = model_from_sample(full != 0, p1, p2, idx, sA, sb, sH);
+    (void)s_ok;
+    if (!ok) { if (threadIdx.x == 0) hyp_score[h] = -1; return; }
     const long long s = score_model(sH, p1, p2, n, t2, nullptr, nullptr);
     if (threadIdx.x == 0)
     {
@@ -166,8 +192,26 @@ void k_ransac_hypotheses(const float2* __restrict__ p1, const float2* __restrict
 }
 
 // Least-squares refit on the masked pairs; sums in wave order (lane = i mod 64, xor butterfly).
+// Wave-order sums of NS partials per lane: part[k * 64 + lane] holds lane's partial of sum k.  The xor butterfly
+// (32, 16, ..., 1; own + partner) reaches lane 0 through the tree  v[l] += v[l + o]  for l < o, which is evaluated
+// here with all 64 lanes spread over the NS sums.  Totals end up in part[k * 64].
+__device__ __forceinline__ void tree_reduce(double* part, int ns)
+{
+    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        for (int i = lane; i < ns * o; i += 64)
+        {
+            const int k = i / o, l = i - k * o;
+            part[k * 64 + l] = part[k * 64 + l] + part[k * 64 + l + o];
+        }
+        __syncthreads();
+    }
+}
+
 __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
-                      double cx, double cy, double sc, double* A, double* b, double* H)
+                      double cx, double cy, double sc, double* A, double* b, double* H, double* part)
 {
     const int lane = threadIdx.x & 63;
     if (full)
@@ -193,22 +237,28 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 #pragma unroll
             for (int a = 0; a < 8; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
         }
-        int k = 0;
 #pragma unroll
-        for (int a = 0; a < 8; a++)
+        for (int k = 0; k < 36; k++) part[k * 64 + lane] = N[k];
 #pragma unroll
-            for (int c = a; c < 8; c++, k++)
+        for (int k = 0; k < 8; k++) part[(36 + k) * 64 + lane] = g[k];
+        tree_reduce(part, 44);
+        if (lane < 44)
+        {
+            const double t = part[lane * 64];
+            if (lane < 36)
             {
-                const double t = wave_sum_f64(N[k]);
-                if (lane == 0) { A[a * 8 + c] = t; A[c * 8 + a] = t; }
+                int a = 0, rem = lane;
+                while (rem >= 8 - a) { rem -= 8 - a; a++; }
+                const int c = a + rem;
+                A[a * 8 + c] = t; A[c * 8 + a] = t;
             }
-#pragma unroll
-        for (int a = 0; a < 8; a++) { const double t = wave_sum_f64(g[a]); if (lane == 0) b[a] = t; }
+            else b[lane - 36] = t;
+        }
         __syncthreads();
         __shared__ int s_ok;
+        bool ok = solve_n(A, b, 8);
         if (lane == 0)
         {
-            bool ok = solve_n(A, b, 8);
             if (ok)
             {
                 const double Hn[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
@@ -248,22 +298,28 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 #pragma unroll
             for (int a = 0; a < 4; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
         }
-        int k = 0;
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int k = 0; k < 10; k++) part[k * 64 + lane] = N[k];
 #pragma unroll
-            for (int c = a; c < 4; c++, k++)
+        for (int k = 0; k < 4; k++) part[(10 + k) * 64 + lane] = g[k];
+        tree_reduce(part, 14);
+        if (lane < 14)
+        {
+            const double t = part[lane * 64];
+            if (lane < 10)
             {
-                const double t = wave_sum_f64(N[k]);
-                if (lane == 0) { A[a * 4 + c] = t; A[c * 4 + a] = t; }
+                int a = 0, rem = lane;
+                while (rem >= 4 - a) { rem -= 4 - a; a++; }
+                const int c = a + rem;
+                A[a * 4 + c] = t; A[c * 4 + a] = t;
             }
-#pragma unroll
-        for (int a = 0; a < 4; a++) { const double t = wave_sum_f64(g[a]); if (lane == 0) b[a] = t; }
+            else b[lane - 10] = t;
+        }
         __syncthreads();
         __shared__ int s_ok2;
+        const bool ok = solve_n(A, b, 4);
         if (lane == 0)
         {
-            const bool ok = solve_n(A, b, 4);
             if (ok)
             {
                 const double a = b[0], bb = b[1], tx = b[2], ty = b[3];
@@ -279,15 +335,28 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 }
 
 // Single wavefront: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
+template <bool STAGED>
 __global__ __launch_bounds__(64)
-void k_ransac_finalize(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2, int full,
+void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, double t2, int full,
                        double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
-                       uint8_t* __restrict__ mask_a, uint8_t* __restrict__ mask_b,
+                       uint8_t* __restrict__ gmask_a, uint8_t* __restrict__ gmask_b,
                        double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
 {
     __shared__ double sA[64], sb[8], sH[9], sBest[9];
+    __shared__ double s_part[44 * 64];
+    __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
+    __shared__ uint8_t s_mask[2][STAGED ? LDS_POINTS : 1];
     const int lane = threadIdx.x;
+    if (STAGED)
+    {
+        for (int i = lane; i < n; i += 64) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+        __syncthreads();
+    }
+    const float2* p1 = STAGED ? s_p1 : g1;
+    const float2* p2 = STAGED ? s_p2 : g2;
+    uint8_t* mask_a = STAGED ? s_mask[0] : gmask_a;
+    uint8_t* mask_b = STAGED ? s_mask[1] : gmask_b;
     const int m = full ? 4 : 2;
     // argmax over the hypotheses: highest score, lowest index on ties
     long long best = -1; int best_h = -1;
@@ -317,7 +386,7 @@ void k_ransac_finalize(const float2* __restrict__ p1, const float2* __restrict__
     for (int round = 0; round < LO_ROUNDS; round++)
     {
         if (ninl < m) break;
-        if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH)) break;
+        if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH, s_part)) break;
         int nt = 0;
         const long long s = score_model(sH, p1, p2, n, t2, trial, &nt);
         __syncthreads();
@@ -350,9 +419,18 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     uint8_t* mask_a = (uint8_t*)(hyp_score + K_HYPOTHESES);
     uint8_t* mask_b = mask_a + (((size_t)n + 255) & ~(size_t)255);
     const double t2 = threshold * threshold;
-    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(K_HYPOTHESES), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
-    hipLaunchKernelGGL(k_ransac_finalize, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
-                       region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+    if (n <= LDS_POINTS)
+    {
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+                           region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+                           region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+    }
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

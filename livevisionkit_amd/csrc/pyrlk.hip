@@ -9,6 +9,8 @@
 // so results are bit-identical to the specification regardless of lane order.
 #include "lvk_hip_internal.hpp"
 
+#include <climits>
+
 namespace {
 
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -18,6 +20,16 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+constexpr int LK_MARGIN = 3;     // search margin (pixels) of the staged next-frame window
+
+// byte offset of the reduction scratch inside the dynamic LDS block (after the tiles and cached patches), 16-byte aligned
+__host__ __device__ inline size_t lvk_pyrlk_part_offset(int win_w, int win_h)
+{
+    const size_t tarea = (size_t)(win_w + 1) * (win_h + 1), area = (size_t)win_w * win_h;
+    const size_t jarea = (size_t)(win_w + 1 + 2 * LK_MARGIN) * (win_h + 1 + 2 * LK_MARGIN);
+    return ((tarea * 4 + area * 6 + tarea + jarea) + 15) & ~(size_t)15;
+}
+
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 __device__ __forceinline__ long long wave_sum(long long v)
@@ -25,6 +37,30 @@ __device__ __forceinline__ long long wave_sum(long long v)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// Exact integer sums of K per-lane partials over the wavefront through LDS: lanes 0..K-1 each add up one column.
+// (Integer addition is associative, so the order is free; this is ~2x cheaper than K xor-butterflies of 64-bit
+// ds_bpermute pairs.)  part: K * 64 int64 in LDS.  Every lane returns all K totals in v[].
+template <int K>
+__device__ __forceinline__ void wave_sums(long long (&v)[K], long long* part)
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; k++) part[k * 64 + lane] = v[k];
+    __syncthreads();
+    if (lane < K)
+    {
+        long long acc = 0;
+        const long long* col = part + lane * 64;
+#pragma unroll 16
+        for (int i = 0; i < 64; i++) acc += col[i];
+        part[lane * 64] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = part[k * 64];
+    __syncthreads();
 }
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11)
@@ -47,11 +83,17 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, in
     if (pt >= n) return;
     const int lane = threadIdx.x;
     const int tw = win_w + 1, th = win_h + 1, area = win_w * win_h, tarea = tw * th;
+    const int jw = tw + 2 * LK_MARGIN, jh = th + 2 * LK_MARGIN;               // next-frame window incl. search margin
     short2* dtile = reinterpret_cast<short2*>(smem);                          // tarea * 4 B
     short* Iw = reinterpret_cast<short*>(smem + (size_t)tarea * 4);           // area * 2 B
     short* Ixw = Iw + area;
     short* Iyw = Ixw + area;
     uint8_t* tile = reinterpret_cast<uint8_t*>(Iyw + area);                   // tarea B
+    uint8_t* jtile = tile + tarea;                                            // jw * jh B
+    long long* part = reinterpret_cast<long long*>(smem + lvk_pyrlk_part_offset(win_w, win_h));   // 3 * 64 int64
+    // division-free walk over the window: pixel p = lane + 64 r  ->  (y, x) advances by (64 / win_w, 64 % win_w)
+    const int py0 = lane / win_w, px0 = lane - py0 * win_w, pdy_ = 64 / win_w, pdx_ = 64 - pdy_ * win_w;
+    const int lx = lane & 15, ly = lane >> 4;                                 // 16 x 4 lane grid for the staging loops
 
     const float2 p0 = prev_pts[pt];
     const float halfx = (win_w - 1) * 0.5f, halfy = (win_h - 1) * 0.5f;
@@ -82,33 +124,49 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, in
         int w00, w01, w10, w11;
         bilinear_weights(a, b, w00, w01, w10, w11);
 
-        // stage the (win+1)^2 window of the previous image (reflect-101 border) and its derivatives (zero border)
+        // stage the (win+1)^2 window of the previous image (reflect-101 border) and its derivatives (zero border), and --
+        // in the same round trip -- the next-frame window around the starting point plus a LK_MARGIN search margin, so
+        // that the iterations below normally run out of LDS without touching global memory again
+        int jx0 = (int)__builtin_floorf(nx - halfx), jy0 = (int)__builtin_floorf(ny - halfy);
+        // only positions that pass the tracker's own bounds test are staged (anything else never samples the image)
+        const bool j_valid = !(jx0 < -win_w || jx0 >= J.cols || jy0 < -win_h || jy0 >= J.rows);
+        jx0 = j_valid ? jx0 - LK_MARGIN : INT_MIN / 2; jy0 = j_valid ? jy0 - LK_MARGIN : INT_MIN / 2;
         __syncthreads();
-        for (int i = lane; i < tarea; i += 64)
+        for (int ty = ly; ty < th; ty += 4)
         {
-            const int ty = i / tw, tx = i - ty * tw;
-            const int yy = ipy + ty, xx = ipx + tx;
-            tile[i] = I.img[(long)reflect101(yy, I.rows) * I.step + reflect101(xx, I.cols)];
-            short2 d = make_short2(0, 0);
-            if (xx >= 0 && yy >= 0 && xx < I.cols && yy < I.rows) d = I.deriv[(long)yy * I.cols + xx];
-            dtile[i] = d;
+            const int yy = ipy + ty;
+            const uint8_t* irow = I.img + (long)reflect101(yy, I.rows) * I.step;
+            for (int tx = lx; tx < tw; tx += 16)
+            {
+                const int xx = ipx + tx;
+                tile[ty * tw + tx] = irow[reflect101(xx, I.cols)];
+                short2 d = make_short2(0, 0);
+                if (xx >= 0 && yy >= 0 && xx < I.cols && yy < I.rows) d = I.deriv[(long)yy * I.cols + xx];
+                dtile[ty * tw + tx] = d;
+            }
         }
+        if (j_valid)
+            for (int ty = ly; ty < jh; ty += 4)
+            {
+                const uint8_t* jrow = J.img + (long)reflect101(jy0 + ty, J.rows) * J.step;
+                for (int tx = lx; tx < jw; tx += 16) jtile[ty * jw + tx] = jrow[reflect101(jx0 + tx, J.cols)];
+            }
         __syncthreads();
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
-        for (int p = lane; p < area; p += 64)
+        long long sA[3] = {0, 0, 0};
+        for (int p = lane, y = py0, x = px0; p < area; p += 64)
         {
-            const int y = p / win_w, x = p - y * win_w;
             const int i00 = y * tw + x, i01 = i00 + 1, i10 = i00 + tw, i11 = i10 + 1;
             const int ival = descale(tile[i00] * w00 + tile[i01] * w01 + tile[i10] * w10 + tile[i11] * w11, 14 - 5);
             const int ixval = descale(dtile[i00].x * w00 + dtile[i01].x * w01 + dtile[i10].x * w10 + dtile[i11].x * w11, 14);
             const int iyval = descale(dtile[i00].y * w00 + dtile[i01].y * w01 + dtile[i10].y * w10 + dtile[i11].y * w11, 14);
             Iw[p] = (short)ival; Ixw[p] = (short)ixval; Iyw[p] = (short)iyval;
-            sA11 += (long long)ixval * ixval;
-            sA12 += (long long)ixval * iyval;
-            sA22 += (long long)iyval * iyval;
+            sA[0] += (long long)ixval * ixval;
+            sA[1] += (long long)ixval * iyval;
+            sA[2] += (long long)iyval * iyval;
+            y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
         }
-        sA11 = wave_sum(sA11); sA12 = wave_sum(sA12); sA22 = wave_sum(sA22);
-        const float A11 = (float)(double)sA11 * FLT_SCALE, A12 = (float)(double)sA12 * FLT_SCALE, A22 = (float)(double)sA22 * FLT_SCALE;
+        wave_sums<3>(sA, part);
+        const float A11 = (float)(double)sA[0] * FLT_SCALE, A12 = (float)(double)sA[1] * FLT_SCALE, A22 = (float)(double)sA[2] * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - __builtin_sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win_w * win_h);
         if (minEig < min_eig_threshold || D < 1.1920928955078125e-07f)
@@ -129,24 +187,30 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, in
             }
             a = nx - inx; b = ny - iny;
             bilinear_weights(a, b, w00, w01, w10, w11);
-            __syncthreads();
-            for (int i = lane; i < tarea; i += 64)
+            if (inx < jx0 || iny < jy0 || inx + tw > jx0 + jw || iny + th > jy0 + jh)
             {
-                const int ty = i / tw, tx = i - ty * tw;
-                tile[i] = J.img[(long)reflect101(iny + ty, J.rows) * J.step + reflect101(inx + tx, J.cols)];
+                // the track left the staged window: re-centre it on the current position
+                jx0 = inx - LK_MARGIN; jy0 = iny - LK_MARGIN;
+                __syncthreads();
+                for (int ty = ly; ty < jh; ty += 4)
+                {
+                    const uint8_t* jrow = J.img + (long)reflect101(jy0 + ty, J.rows) * J.step;
+                    for (int tx = lx; tx < jw; tx += 16) jtile[ty * jw + tx] = jrow[reflect101(jx0 + tx, J.cols)];
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            long long sb1 = 0, sb2 = 0;
-            for (int p = lane; p < area; p += 64)
+            const uint8_t* jt = jtile + (iny - jy0) * jw + (inx - jx0);
+            long long sb[2] = {0, 0};
+            for (int p = lane, y = py0, x = px0; p < area; p += 64)
             {
-                const int y = p / win_w, x = p - y * win_w;
-                const int i00 = y * tw + x, i01 = i00 + 1, i10 = i00 + tw, i11 = i10 + 1;
-                const int diff = descale(tile[i00] * w00 + tile[i01] * w01 + tile[i10] * w10 + tile[i11] * w11, 14 - 5) - Iw[p];
-                sb1 += (long long)diff * Ixw[p];
-                sb2 += (long long)diff * Iyw[p];
+                const int i00 = y * jw + x, i01 = i00 + 1, i10 = i00 + jw, i11 = i10 + 1;
+                const int diff = descale(jt[i00] * w00 + jt[i01] * w01 + jt[i10] * w10 + jt[i11] * w11, 14 - 5) - Iw[p];
+                sb[0] += (long long)diff * Ixw[p];
+                sb[1] += (long long)diff * Iyw[p];
+                y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
             }
-            sb1 = wave_sum(sb1); sb2 = wave_sum(sb2);
-            const float b1 = (float)(double)sb1 * FLT_SCALE, b2 = (float)(double)sb2 * FLT_SCALE;
+            wave_sums<2>(sb, part);
+            const float b1 = (float)(double)sb[0] * FLT_SCALE, b2 = (float)(double)sb[1] * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;
@@ -169,11 +233,7 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, in
 
 } // namespace
 
-size_t lvk_pyrlk_lds_bytes(int win_w, int win_h)
-{
-    const size_t tarea = (size_t)(win_w + 1) * (win_h + 1), area = (size_t)win_w * win_h;
-    return ((tarea * 4 + area * 6 + tarea) + 15) & ~(size_t)15;
-}
+size_t lvk_pyrlk_lds_bytes(int win_w, int win_h) { return lvk_pyrlk_part_offset(win_w, win_h) + 3 * 64 * sizeof(long long); }
 
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
                      float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig)
@@ -235,17 +295,7 @@ void DevicePyramid::release()
 }
 
 // Level 0 must already hold the tracking-resolution image; builds levels 1.. and all derivative images.
-int DevicePyramid::build(lvk_hip_ctx* ctx)
-{
-    int rc;
-    for (int i = 1; i < args.nlevels; i++)
-        if ((rc = lvk_launch_pyr_down(ctx, args.lv[i - 1].img, args.lv[i - 1].step, args.lv[i - 1].rows, args.lv[i - 1].cols,
-                                      const_cast<uint8_t*>(args.lv[i].img), args.lv[i].step)) != LVK_HIP_OK) return rc;
-    for (int i = 0; i < args.nlevels; i++)
-        if ((rc = lvk_launch_scharr(ctx, args.lv[i].img, args.lv[i].step, args.lv[i].rows, args.lv[i].cols,
-                                    const_cast<short2*>(args.lv[i].deriv))) != LVK_HIP_OK) return rc;
-    return LVK_HIP_OK;
-}
+int DevicePyramid::build(lvk_hip_ctx* ctx) { return lvk_launch_pyramid(ctx, args); }
 
 extern "C" {
 
@@ -283,6 +333,37 @@ int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const voi
     cleanup();
     if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
     return P.args.nlevels >= 0 ? LVK_HIP_OK : LVK_HIP_ERR_RUNTIME;
+}
+
+
+// Synchronous test entry point: builds the optical-flow pyramid (levels + Scharr derivative images) of a device image and
+// returns it to the host, tightly packed level after level.  Returns the level count (or a negative status).
+int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, int max_level, int win_w, int win_h,
+                          uint8_t* levels, int16_t* derivs, int* level_rows, int* level_cols)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, d_img && levels && derivs && level_rows && level_cols && rows > 0 && cols > 0);
+    DevicePyramid P;
+    int rc;
+    if ((rc = P.allocate(ctx, rows, cols, max_level, win_w, win_h)) != LVK_HIP_OK) return rc;
+    hipError_t e = hipMemcpy2DAsync(const_cast<uint8_t*>(P.args.lv[0].img), P.args.lv[0].step, d_img, step, cols, rows, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && (rc = P.build(ctx)) == LVK_HIP_OK)
+    {
+        size_t lo = 0, dofs = 0;
+        for (int i = 0; i < P.args.nlevels && e == hipSuccess; i++)
+        {
+            const PyrLevel& L = P.args.lv[i];
+            level_rows[i] = L.rows; level_cols[i] = L.cols;
+            e = hipMemcpy2DAsync(levels + lo, L.cols, L.img, L.step, L.cols, L.rows, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(derivs + dofs, L.deriv, (size_t)L.rows * L.cols * 4, hipMemcpyDeviceToHost, ctx->stream);
+            lo += (size_t)L.rows * L.cols; dofs += (size_t)L.rows * L.cols * 2;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    const int n = P.args.nlevels;
+    P.release();
+    if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
+    return rc == LVK_HIP_OK ? n : rc;
 }
 
 } // extern "C"

@@ -45,6 +45,22 @@ def test_pyr_down_and_scharr(ctx, oracle, shape):
     assert np.array_equal(got_s.cpu().numpy(), oracle.scharr_deriv(img))
 
 
+@pytest.mark.parametrize("shape", [(270, 480), (256, 256), (143, 211), (97, 100), (40, 40)])
+def test_whole_pyramid_matches_oracle(ctx, oracle, shape):
+    """The fused pyramid launch (levels 1-3 from one LDS window) and the generic per-level path: every level and every
+    derivative image identical to the pyrDown / Scharr chain of the oracle."""
+    img = np.random.default_rng(shape[0] * 7 + shape[1]).integers(0, 256, shape, dtype=np.uint8)
+    got = ctx.build_pyramid(_gpu(img))
+    sizes = oracle.pyramid_levels(*shape)
+    assert [g[0].shape for g in got] == sizes
+    cur = img
+    for lvl, (g_img, g_der) in enumerate(got):
+        if lvl > 0:
+            cur = oracle.pyr_down(cur)
+        assert np.array_equal(g_img, cur), (shape, lvl)
+        assert np.array_equal(g_der, oracle.scharr_deriv(cur)), (shape, lvl)
+
+
 @pytest.mark.parametrize("layout", ["2x1", "2x2", "1x1", "odd"])
 def test_fast_detect_regions(ctx, oracle, layout):
     rows, cols = 270, 480
