@@ -113,6 +113,16 @@ int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const voi
                   const float* prev_pts, int n, float* next_pts, uint8_t* status,
                   int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
 
+/* ---- section 8f row 2: YUV420 <-> packed YUV444 either side of the filter --------------------------------------
+ * I4XXIngest::to_ocl / NV12Ingest::to_ocl (Modules/OBS-Plugin/Interop/FrameIngest.cpp:494-522,567-585): chroma
+ * cv::resize(INTER_LINEAR) + merge into the packed 8UC3 frame the filter consumes; and ::to_obs (:526-557,589-602):
+ * split + cv::resize(0.5, 0.5, INTER_AREA).  nv12 != 0: d_u is the interleaved UV plane and d_v is ignored.
+ * rows and cols must be even. */
+int lvk_hip_ingest_yuv420(lvk_hip_ctx* ctx, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
+                          int rows, int cols, void* d_dst, int dst_step);
+int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
+                          void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
+
 /* ---- a9: robust global motion --------------------------------------------------------------------------
  * cv::findHomography(tracked, matched, mask, UsacParams{threshold}) (full_homography != 0) or
  * cv::estimateAffinePartial2D(..., RANSAC, threshold, 50) + Homography::FromAffineMatrix (full_homography == 0)
@@ -187,6 +197,15 @@ int  lvk_hip_stab_stable_region(const lvk_hip_stab* stab, int rows, int cols, in
 int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
                        void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released);
 
+/* The OBS asynchronous path in one call (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-212): YUV 4:2:0 planes in
+ * (I420, or NV12 with nv12 != 0 and d_u = interleaved UV), ingest -> filter -> egress, 4:2:0 planes out.  The packed
+ * frames the filter queues live in an internal pool.  Input planes are consumed when the call returns (stream order);
+ * output planes are complete after lvk_hip_sync(). */
+int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
+                              int rows, int cols, uint64_t timestamp,
+                              void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,
+                              int* produced, uint64_t* out_timestamp);
+
 /* Optional: run the output remap on a second HIP stream so that it overlaps the tracking of the next frame
  * (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches, Functions/Image.cpp:76).
  * With overlap enabled d_out is complete only after lvk_hip_sync(), and *released reports a borrowed frame one
@@ -207,7 +226,9 @@ int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int
 #define LVK_STAGE_PYRLK     3   /* sparse optical flow */
 #define LVK_STAGE_MOTION    4   /* RANSAC + local optimisation */
 #define LVK_STAGE_REMAP     5   /* EASU remap of the delayed frame */
-#define LVK_STAGE_COUNT     6
+#define LVK_STAGE_INGEST    6   /* YUV420 -> packed 444 (lvk_hip_stab_push_yuv420 only) */
+#define LVK_STAGE_EGRESS    7   /* packed 444 -> YUV420 */
+#define LVK_STAGE_COUNT     8
 int  lvk_hip_stab_set_profiling(lvk_hip_stab* stab, int enable);
 int  lvk_hip_stab_get_profile(lvk_hip_stab* stab, double total_ms[LVK_STAGE_COUNT], long long launches[LVK_STAGE_COUNT]);
 

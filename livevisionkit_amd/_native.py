@@ -41,6 +41,8 @@ _SIG = {
     "lvk_hip_pyrlk": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _c.c_int,
                                  _c.POINTER(_c.c_float), _c.POINTER(_c.c_uint8), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                  _c.c_double, _c.c_double]),
+    "lvk_hip_ingest_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int]),
+    "lvk_hip_egress_yuv420": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int]),
     "lvk_hip_estimate_global_motion": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int, _c.c_double,
                                                   _c.c_double, _c.c_double, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint8)]),
     "lvk_stab_default_settings": (None, [_P]),
@@ -54,6 +56,8 @@ _SIG = {
     "lvk_hip_stab_stable_region": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
     "lvk_hip_stab_push": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _P, _c.c_int,
                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_P)]),
+    "lvk_hip_stab_push_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,
+                                            _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64)]),
     "lvk_hip_stab_get_stats": (_c.c_int, [_P, _P]),
     "lvk_hip_stab_get_meshes": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int]),
     "lvk_hip_stab_get_features": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.c_int]),

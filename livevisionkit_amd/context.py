@@ -180,3 +180,31 @@ class Context:
         if rc in (-1, -2, -3):
             self._check(rc)
         return rc, H.reshape(3, 3), mask
+
+    # ---- YUV420 <-> packed 444 ----------------------------------------------------------
+    def ingest_yuv420(self, y, u, v=None, out=None):
+        """I420 (y, u, v) or NV12 (y, uv[r/2, c/2, 2]) torch uint8 planes -> packed [rows, cols, 3]."""
+        import torch
+        rows, cols = y.shape
+        if out is None:
+            out = torch.empty((rows, cols, 3), dtype=torch.uint8, device=y.device)
+        nv12 = v is None
+        vv = u if nv12 else v
+        self._check(self.lib.lvk_hip_ingest_yuv420(self.handle, y.data_ptr(), y.stride(0), u.data_ptr(), u.stride(0), vv.data_ptr(), vv.stride(0),
+                                                   1 if nv12 else 0, rows, cols, out.data_ptr(), out.stride(0)))
+        return out
+
+    def egress_yuv420(self, frame, nv12=False, out=None):
+        import torch
+        rows, cols = frame.shape[:2]
+        if out is None:
+            y = torch.empty((rows, cols), dtype=torch.uint8, device=frame.device)
+            if nv12:
+                u = torch.empty((rows // 2, cols // 2, 2), dtype=torch.uint8, device=frame.device); v = u
+            else:
+                u = torch.empty((rows // 2, cols // 2), dtype=torch.uint8, device=frame.device); v = torch.empty_like(u)
+        else:
+            y, u, v = out if not nv12 else (out[0], out[1], out[1])
+        self._check(self.lib.lvk_hip_egress_yuv420(self.handle, frame.data_ptr(), frame.stride(0), rows, cols, y.data_ptr(), y.stride(0),
+                                                   u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), 1 if nv12 else 0))
+        return (y, u) if nv12 else (y, u, v)

@@ -66,6 +66,7 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->lintabs) (void)hipFree(kv.second);
+    for (auto& kv : ctx->lin8tabs) (void)hipFree(kv.second);
     for (auto& kv : ctx->areatabs) { (void)hipFree(kv.second.range); (void)hipFree(kv.second.tab); }
     for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);

@@ -12,6 +12,7 @@
 #include "lvk_hip.h"
 
 struct LinTabEntry { int s0, s1; float a0, a1; };   // one column/row of the INTER_LINEAR mesh->frame table
+struct Lin8Entry { int s0, s1, a0, a1; };            // 8-bit INTER_LINEAR table entry: two source indices, 11-bit coefficients
 struct AreaTabEntry { int si; float alpha; };        // one source tap of the INTER_AREA "decimate alpha" table
 struct FastRegion { int x, y, w, h, threshold, active; };   // one FAST detection region (integer ROI of the tracking frame)
 
@@ -39,6 +40,8 @@ struct lvk_hip_ctx
 
     // Cached INTER_LINEAR tables: key = (mesh extent, frame extent, vertical?)
     std::map<std::tuple<int, int, int>, LinTabEntry*> lintabs;
+
+    std::map<std::tuple<int, int, int>, Lin8Entry*> lin8tabs;     // 8-bit INTER_LINEAR tables (chroma upsampling)
 
     // Cached INTER_AREA tables: key = (source extent, destination extent)
     struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; };
@@ -110,3 +113,9 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_sr
                           void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                               void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
+
+// YUV420 <-> packed 444 (ingest.hip)
+int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_y, int y_step, const void* d_u, int u_step,
+                             const void* d_v, int v_step, int nv12, int rows, int cols, void* d_dst, int dst_step);
+int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
+                             void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);

@@ -101,7 +101,14 @@ struct lvk_hip_stab
     int configure(const lvk_stab_settings& st);
     void tracker_restart();
     void reset_context() { tracker_restart(); smoother.restart(); }
-    int track(const QueuedFrame& f, WarpMeshF& motion, bool& have_motion);
+    int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, WarpMeshF& motion, bool& have_motion);
+
+    // ---- YUV420 front/back end: pool of packed frames the planes are converted into
+    std::vector<void*> pool_all, pool_free;
+    void* pool_out = nullptr;
+    int pool_rows = 0, pool_cols = 0;
+    int ensure_pool(int rows, int cols);
+    void free_pool();
 };
 
 int lvk_hip_stab::prof_begin(int kind, hipStream_t stream)
@@ -262,7 +269,7 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
 }
 
 // FrameTracker::track (FrameTracker.cpp:108-196)
-int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_motion)
+int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, WarpMeshF& motion, bool& have_motion)
 {
     have_motion = false;
     tracking_stability = 0.0f;
@@ -276,7 +283,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, WarpMeshF& motion, bool& have_moti
     DevicePyramid& C = pyr[cur];
     DevicePyramid& P = pyr[cur ^ 1];
     int pe = prof_begin(LVK_STAGE_DOWNSCALE);
-    if ((rc = lvk_launch_luma_area_resize(ctx, f.d_ptr, f.step, 3, 0, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
+    if ((rc = lvk_launch_luma_area_resize(ctx, luma, luma_step, luma_pix, 0, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
     prof_end(pe);
     pe = prof_begin(LVK_STAGE_PYRAMID);
     if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
@@ -414,6 +421,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     (void)hipStreamSynchronize(st->ctx->stream);
     st->free_tracker_buffers();
     st->pyr[0].release(); st->pyr[1].release();
+    st->free_pool();
     if (st->remap_stream)
     {
         (void)hipStreamSynchronize(st->remap_stream);
@@ -494,11 +502,14 @@ int lvk_hip_stab_reset_context(lvk_hip_stab* st)
 int lvk_hip_stab_ready(const lvk_hip_stab* st) { return st && st->queue.size() == st->queue_capacity ? 1 : 0; }
 int lvk_hip_stab_frame_delay(const lvk_hip_stab* st) { return st ? st->s.predictive_samples : 0; }
 
-// StabilizationFilter::filter (StabilizationFilter.cpp:69-135)
-int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
-                      void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
+} // extern "C"
+
+// StabilizationFilter::filter (StabilizationFilter.cpp:69-135).  (luma, luma_step, luma_pix): where the tracker reads the
+// luma of this frame from -- the packed frame itself (pix 3) or, on the YUV420 path, the caller's planar Y (pix 1).
+static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
+                     const void* luma, int luma_step, int luma_pix,
+                     void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
 {
-    if (!st) return LVK_HIP_ERR_ARG;
     lvk_hip_ctx* ctx = st->ctx;
     if (produced) *produced = 0;
     if (released) *released = nullptr;
@@ -557,7 +568,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
 
     WarpMeshF motion(st->s.motion_height, st->s.motion_width);                            // m_NullMotion
     WarpMeshF est; bool have = false;
-    int rc = st->track(in, est, have);
+    int rc = st->track(in, luma, luma_step, luma_pix, est, have);
     if (rc != LVK_HIP_OK) return rc;
     if (have) motion = est;
 
@@ -576,6 +587,94 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     if (st->s.crop_to_stable_region) correction += st->smoother.scene_crop();
     st->last_correction = correction;
     return emit(&correction);
+}
+
+int lvk_hip_stab::ensure_pool(int rows, int cols)
+{
+    const size_t want = (size_t)s.predictive_samples + 4;
+    if (rows == pool_rows && cols == pool_cols && pool_all.size() >= want) return LVK_HIP_OK;
+    if (rows != pool_rows || cols != pool_cols)
+    {
+        // new geometry: queued pool frames of the old size stay valid until they are emitted, so only grow lazily
+        LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
+        LVK_HIP_REQUIRE(ctx, queue.empty() || pool_all.empty());          // mixed-size YUV420 streams need a restart() in between
+        free_pool();
+        pool_rows = rows; pool_cols = cols;
+        LVK_HIP_CHECK(ctx, hipMalloc(&pool_out, (size_t)rows * cols * 3));
+    }
+    while (pool_all.size() < want)
+    {
+        void* p = nullptr;
+        LVK_HIP_CHECK(ctx, hipMalloc(&p, (size_t)rows * cols * 3));
+        pool_all.push_back(p); pool_free.push_back(p);
+    }
+    return LVK_HIP_OK;
+}
+
+void lvk_hip_stab::free_pool()
+{
+    for (void* p : pool_all) (void)hipFree(p);
+    pool_all.clear(); pool_free.clear();
+    if (pool_out) { (void)hipFree(pool_out); pool_out = nullptr; }
+    pool_rows = pool_cols = 0;
+}
+
+extern "C" {
+
+int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
+                      void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    return push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+}
+
+// The OBS asynchronous path in one call: I4XXIngest / NV12Ingest::to_ocl -> StabilizationFilter::filter -> ::to_obs
+// (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-212, FrameIngest.cpp:494-602).  Planar (or NV12) 4:2:0 in, 4:2:0 out;
+// the packed 8UC3 frames the filter works on live in an internal pool (predictive_samples + 4 frames).  The input planes
+// are consumed before the call returns; the output planes are complete after lvk_hip_sync().
+int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
+                             int rows, int cols, uint64_t timestamp,
+                             void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,
+                             int* produced, uint64_t* out_timestamp)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    if (produced) *produced = 0;
+    int rc = st->ensure_pool(rows, cols);
+    if (rc != LVK_HIP_OK) return rc;
+    if (st->pool_free.empty())
+    {
+        // frames dropped by restart() / a shrinking queue never came back through *released: reclaim them
+        for (void* p : st->pool_all)
+        {
+            bool used = (p == st->pending_release);
+            for (const QueuedFrame& q : st->queue) used = used || (q.d_ptr == p);
+            if (!used) st->pool_free.push_back(p);
+        }
+        LVK_HIP_REQUIRE(ctx, !st->pool_free.empty());
+    }
+    void* slot = st->pool_free.back(); st->pool_free.pop_back();
+    int pe = st->prof_begin(LVK_STAGE_INGEST);
+    rc = lvk_launch_ingest_yuv420(ctx, ctx->stream, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
+    st->prof_end(pe);
+    if (rc != LVK_HIP_OK) { st->pool_free.push_back(slot); return rc; }
+    int prod = 0; const void* released = nullptr;
+    rc = push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released);
+    if (released) st->pool_free.push_back(const_cast<void*>(released));
+    if (rc != LVK_HIP_OK) return rc;
+    if (prod)
+    {
+        // the emitted frame has the geometry of the pool (all pooled frames share it)
+        LVK_HIP_REQUIRE(ctx, o_y && o_u && (nv12 || o_v));
+        hipStream_t es = (st->overlap && st->s.stabilize_output) ? st->remap_stream : ctx->stream;
+        pe = st->prof_begin(LVK_STAGE_EGRESS, es);
+        rc = lvk_launch_egress_yuv420(ctx, es, st->pool_out, 3 * cols, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12);
+        st->prof_end(pe, es);
+        if (rc != LVK_HIP_OK) return rc;
+        if (produced) *produced = 1;
+    }
+    return LVK_HIP_OK;
 }
 
 int lvk_hip_stab_get_stats(const lvk_hip_stab* st, lvk_stab_stats* o)

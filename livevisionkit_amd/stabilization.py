@@ -145,6 +145,27 @@ class StabilizationFilter:
         self._timer._add(time.perf_counter() - t0)
         return (out, ots.value) if produced.value else (None, None)
 
+    def apply_yuv420(self, planes, timestamp=0, out=None):
+        """The OBS async path in one call: planes = (y, u, v) I420 or (y, uv) NV12 torch uint8 tensors on the GPU.
+        Returns (output planes, timestamp) or (None, None) while the delay builds."""
+        import torch
+        t0 = time.perf_counter()
+        nv12 = len(planes) == 2
+        y, u = planes[0], planes[1]
+        v = u if nv12 else planes[2]
+        if out is None:
+            out = tuple(torch.empty_like(p) for p in planes)
+        oy, ou = out[0], out[1]
+        ov = ou if nv12 else out[2]
+        produced = _c.c_int(0); ots = _c.c_uint64(0)
+        rc = self.lib.lvk_hip_stab_push_yuv420(self.handle, y.data_ptr(), y.stride(0), u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0),
+                                               1 if nv12 else 0, y.shape[0], y.shape[1], int(timestamp),
+                                               oy.data_ptr(), oy.stride(0), ou.data_ptr(), ou.stride(0), ov.data_ptr(), ov.stride(0),
+                                               _c.byref(produced), _c.byref(ots))
+        self.ctx._check(rc)
+        self._timer._add(time.perf_counter() - t0)
+        return (out, ots.value) if produced.value else (None, None)
+
     # ---- StabilizationFilter (Filters/StabilizationFilter.hpp:46-62)
     def restart(self):
         self.ctx._check(self.lib.lvk_hip_stab_restart(self.handle)); self._borrowed.clear()
@@ -185,14 +206,14 @@ class StabilizationFilter:
         """Run the output remap on a second stream, overlapping the next frame's tracking (output valid after ctx.sync())."""
         self.ctx._check(self.lib.lvk_hip_stab_set_overlap(self.handle, 1 if enable else 0))
 
-    STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap")
+    STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap", "ingest", "egress")
 
     def set_profiling(self, enable=True):
         self.ctx._check(self.lib.lvk_hip_stab_set_profiling(self.handle, 1 if enable else 0))
 
     def profile(self):
         """{stage: (total_ms, launches)} measured with HIP events on the launch stream since set_profiling(True)."""
-        ms = (_c.c_double * 6)(); n = (_c.c_longlong * 6)()
+        ms = (_c.c_double * 8)(); n = (_c.c_longlong * 8)()
         self.ctx._check(self.lib.lvk_hip_stab_get_profile(self.handle, ms, n))
         return {k: (ms[i], int(n[i])) for i, k in enumerate(self.STAGES)}
 

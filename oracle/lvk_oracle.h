@@ -166,6 +166,16 @@ const float* lvko_mesh_solver_mesh(const lvko_mesh_solver* s);
 int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const float* matched, int n_pts,
                            float region_w, float region_h, float temporal_now, float threshold, uint8_t* inliers, float* offsets);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * YUV420 <-> packed YUV444 either side of the filter (oracle/ingest.cpp;
+ * reference Modules/OBS-Plugin/Interop/FrameIngest.cpp:494-602).
+ * ---------------------------------------------------------------------------------------------- */
+int lvko_ingest_yuv420(const uint8_t* y, int y_step, const uint8_t* u, int u_step, const uint8_t* v, int v_step, int nv12,
+                       int rows, int cols, uint8_t* dst, int dst_step);
+int lvko_egress_yuv420(const uint8_t* src, int src_step, int rows, int cols,
+                       uint8_t* y, int y_step, uint8_t* u, int u_step, uint8_t* v, int v_step, int nv12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,37 @@ class Oracle:
         assert lv >= 0
         return out, st
 
+    def ingest_yuv420(self, y, u, v=None):
+        """I420 (y, u, v planes) or NV12 (y, interleaved uv [r/2, c/2, 2]) -> packed [rows, cols, 3]."""
+        y = np.ascontiguousarray(y, np.uint8); u = np.ascontiguousarray(u, np.uint8)
+        nv12 = v is None
+        vv = u if nv12 else np.ascontiguousarray(v, np.uint8)
+        rows, cols = y.shape
+        dst = np.zeros((rows, cols, 3), np.uint8)
+        fn = self.lib.lvko_ingest_yuv420
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _u8p, _c.c_int, _u8p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int]
+        rc = fn(_p(y, _u8p), y.strides[0], _p(u, _u8p), u.strides[0], _p(vv, _u8p), vv.strides[0], 1 if nv12 else 0, rows, cols,
+                _p(dst, _u8p), dst.strides[0])
+        assert rc == 0
+        return dst
+
+    def egress_yuv420(self, frame, nv12=False):
+        frame = np.ascontiguousarray(frame, np.uint8)
+        rows, cols = frame.shape[:2]
+        y = np.zeros((rows, cols), np.uint8)
+        if nv12:
+            u = np.zeros((rows // 2, cols // 2, 2), np.uint8); v = u
+        else:
+            u = np.zeros((rows // 2, cols // 2), np.uint8); v = np.zeros_like(u)
+        fn = self.lib.lvko_egress_yuv420
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int, _u8p, _c.c_int, _u8p, _c.c_int, _c.c_int]
+        rc = fn(_p(frame, _u8p), frame.strides[0], rows, cols, _p(y, _u8p), y.strides[0], _p(u, _u8p), u.strides[0],
+                _p(v, _u8p), v.strides[0], 1 if nv12 else 0)
+        assert rc == 0
+        return (y, u) if nv12 else (y, u, v)
+
     def find_homography(self, p1, p2, threshold, region=(480, 270), partial=False):
         p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
         H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8)

@@ -160,3 +160,39 @@ def test_pyrlk_status_rules(oracle):
     assert st[1] == 0 and st[3] == 0                                # window origin left of -winSize / beyond the image
     out, st = oracle.pyrlk(flat, flat, pts[:1])
     assert st[0] == 0                                               # minEig below threshold on a flat patch
+
+
+# ---- YUV420 <-> packed 444 ------------------------------------------------------------
+def test_ingest_constant_chroma_and_luma_passthrough(oracle):
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 256, (36, 48), dtype=np.uint8)
+    u = np.full((18, 24), 77, np.uint8); v = np.full((18, 24), 201, np.uint8)
+    f = oracle.ingest_yuv420(y, u, v)
+    assert np.array_equal(f[..., 0], y) and (f[..., 1] == 77).all() and (f[..., 2] == 201).all()
+
+
+def test_ingest_bilinear_phase_and_roundtrip(oracle):
+    """2x upsampling samples at phases .25/.75 (fx = dx/2 - 0.25); egress (2x2 area mean) of ingest(x) stays within 1 LSB of x
+    away from the borders for a smooth chroma plane."""
+    yy, xx = np.mgrid[0:20, 0:30]
+    u = (40 + 5 * xx + 2 * yy).astype(np.uint8); v = (200 - 3 * xx).astype(np.uint8)
+    y = np.zeros((40, 60), np.uint8)
+    f = oracle.ingest_yuv420(y, u, v)
+    # interior column 2k+1 = .75*u[k] + .25*u[k+1] (exact here: multiples of 5 * .25 ...), checked loosely
+    exp = 0.75 * u[:, :-1].astype(float) + 0.25 * u[:, 1:].astype(float)
+    assert np.abs(f[1::2, 1:-1:2, 1][:-1] - (0.75 * exp[:-1] + 0.25 * exp[1:])).max() <= 1.0
+    y2, u2, v2 = oracle.egress_yuv420(f)
+    assert np.array_equal(y2, y)
+    assert np.abs(u2[1:-1, 1:-1].astype(int) - u[1:-1, 1:-1]).max() <= 1 and np.abs(v2[1:-1, 1:-1].astype(int) - v[1:-1, 1:-1]).max() <= 1
+
+
+def test_nv12_equals_i420(oracle):
+    rng = np.random.default_rng(5)
+    y = rng.integers(0, 256, (32, 40), dtype=np.uint8)
+    u = rng.integers(0, 256, (16, 20), dtype=np.uint8); v = rng.integers(0, 256, (16, 20), dtype=np.uint8)
+    a = oracle.ingest_yuv420(y, u, v)
+    b = oracle.ingest_yuv420(y, np.stack([u, v], -1))
+    assert np.array_equal(a, b)
+    ya, ua, va = oracle.egress_yuv420(a)
+    yb, uvb = oracle.egress_yuv420(a, nv12=True)
+    assert np.array_equal(ya, yb) and np.array_equal(ua, uvb[..., 0]) and np.array_equal(va, uvb[..., 1])

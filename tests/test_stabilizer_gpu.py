@@ -245,3 +245,59 @@ def test_1080p_and_4k_streams_match_oracle(ctx, oracle):
                 emitted += 1
         assert emitted == n - 2
         ost.close(); gst.close()
+
+
+# ---- YUV420 in / out -----------------------------------------------------------------------
+@pytest.mark.parametrize("nv12", [False, True])
+@pytest.mark.parametrize("size", [(36, 48), (270, 480), (1080, 1920), (38, 50)])
+def test_ingest_egress_yuv420_bit_exact(ctx, oracle, nv12, size):
+    import torch
+    rows, cols = size
+    rng = np.random.default_rng(rows + cols)
+    y = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    u = rng.integers(0, 256, (rows // 2, cols // 2), dtype=np.uint8)
+    v = rng.integers(0, 256, (rows // 2, cols // 2), dtype=np.uint8)
+    if nv12:
+        uv = np.ascontiguousarray(np.stack([u, v], -1))
+        want = oracle.ingest_yuv420(y, uv)
+        got = ctx.ingest_yuv420(torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda())
+    else:
+        want = oracle.ingest_yuv420(y, u, v)
+        got = ctx.ingest_yuv420(torch.from_numpy(y).cuda(), torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda())
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
+    frame = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    wp = oracle.egress_yuv420(frame, nv12=nv12)
+    gp = ctx.egress_yuv420(torch.from_numpy(frame).cuda(), nv12=nv12)
+    ctx.sync()
+    for a, b in zip(gp, wp):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+@pytest.mark.parametrize("nv12,overlap", [(False, False), (True, True)])
+def test_stabilizer_yuv420_in_out_bit_exact(ctx, oracle, clip, nv12, overlap):
+    """The OBS async path in one call: 4:2:0 planes -> ingest -> filter -> egress -> 4:2:0 planes, vs the oracle chain."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=3)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    if overlap:
+        gst.set_overlap(True)
+    emitted = 0
+    for i, f in enumerate(frames[:18]):
+        planes = oracle.egress_yuv420(f, nv12=nv12)                    # the 4:2:0 source material
+        packed = oracle.ingest_yuv420(*planes)
+        want, wts = ost.push(packed, ts=i)
+        got, gts = gst.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)
+        ctx.sync()
+        assert ost.stats().n_tracked == gst.stats().n_tracked, i
+        assert (want is None) == (got is None), i
+        if want is not None:
+            assert wts == gts
+            for a, b in zip(got, oracle.egress_yuv420(want, nv12=nv12)):
+                assert np.array_equal(a.cpu().numpy(), b), i
+            emitted += 1
+    assert emitted == 15
+    ost.close(); gst.close()
