@@ -14,6 +14,7 @@ namespace {
 
 constexpr int K_HYPOTHESES = 128;
 constexpr int LO_ROUNDS = 3;
+constexpr int NT = 256;              // threads per block of both kernels (the least-squares sums use NT strided partials)
 constexpr int LDS_POINTS = 2048;     // point pairs staged in LDS (16 B each); larger sets are read from global memory
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& s)
@@ -42,10 +43,10 @@ __device__ bool draw_sample(int h, int n, int m, int* idx)
 // Gaussian elimination with partial pivoting on LDS-resident A (n x n, n <= 8) and b, executed by one wavefront:
 // the row operations of each pivot step run one element per lane (each element sees exactly the operations of the
 // sequential algorithm, so the result is bit-identical to it); the short back substitution runs on lane 0.
-// All lanes return the same verdict.  Must be called by all 64 lanes of a single-wave block.
+// All threads return the same verdict.  Must be called by every thread of the block.
 __device__ bool solve_n(double* A, double* b, int n)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;          // only the first (n-1)*(n+1) <= 63 threads carry elements; all threads hit the barriers
     for (int i = 0; i < n; i++)
     {
         int piv = i;
@@ -95,6 +96,19 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
     return v;
 }
 
+// Exact integer sum over the whole block (order free).  scratch: NT / 64 int64 in LDS.
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* scratch)
+{
+    v = wave_sum_ll(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) t += scratch[w];
+    return t;
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v)          // xor butterfly 32,16,...,1: own + partner
 {
 #pragma unroll
@@ -104,11 +118,10 @@ __device__ __forceinline__ double wave_sum_f64(double v)          // xor butterf
 
 // Scores model H over all pairs with the whole wave; optionally writes the inlier mask. Returns (score, #inliers) on every lane.
 __device__ long long score_model(const double* H, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2,
-                                 uint8_t* mask, int* ninl)
+                                 uint8_t* mask, int* ninl, long long* scratch)
 {
-    const int lane = threadIdx.x & 63;
     long long score = 0; long long cnt = 0;
-    for (int i = lane; i < n; i += 64)
+    for (int i = threadIdx.x; i < n; i += NT)
     {
         const float2 a = p1[i], b = p2[i];
         const double e2 = reproj_err2(H, (double)a.x, (double)a.y, (double)b.x, (double)b.y);
@@ -116,8 +129,8 @@ __device__ long long score_model(const double* H, const float2* __restrict__ p1,
         if (in) { score += (long long)((1.0 - e2 / t2) * 1024.0); cnt++; }
         if (mask) mask[i] = in ? 1 : 0;
     }
-    score = wave_sum_ll(score);
-    cnt = wave_sum_ll(cnt);
+    score = block_sum_ll(score, scratch);
+    cnt = block_sum_ll(cnt, scratch);
     if (ninl) *ninl = (int)cnt;
     return score;
 }
@@ -126,7 +139,7 @@ __device__ long long score_model(const double* H, const float2* __restrict__ p1,
 __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, const int* idx,
                                   double* A, double* b, double* H)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     if (full)
     {
         if (lane == 0)
@@ -163,16 +176,17 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
 // One wavefront per hypothesis.  STAGED: the point pairs are first copied into LDS with one coalesced sweep, so the
 // voting loop is not a chain of dependent global-memory round trips.
 template <bool STAGED>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(NT)
 void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, double t2, int full,
                          double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
 {
     __shared__ double sA[64], sb[8], sH[9];
     __shared__ int s_ok;
+    __shared__ long long s_scratch[NT / 64];
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
     if (STAGED)
     {
-        for (int i = threadIdx.x; i < n; i += 64) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+        for (int i = threadIdx.x; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
         __syncthreads();
     }
     const float2* p1 = STAGED ? s_p1 : g1;
@@ -183,7 +197,7 @@ void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict
     if (ok) ok = model_from_sample(full != 0, p1, p2, idx, sA, sb, sH);
     (void)s_ok;
     if (!ok) { if (threadIdx.x == 0) hyp_score[h] = -1; return; }
-    const long long s = score_model(sH, p1, p2, n, t2, nullptr, nullptr);
+    const long long s = score_model(sH, p1, p2, n, t2, nullptr, nullptr, s_scratch);
     if (threadIdx.x == 0)
     {
         hyp_score[h] = s;
@@ -192,19 +206,18 @@ void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict
 }
 
 // Least-squares refit on the masked pairs; sums in wave order (lane = i mod 64, xor butterfly).
-// Wave-order sums of NS partials per lane: part[k * 64 + lane] holds lane's partial of sum k.  The xor butterfly
-// (32, 16, ..., 1; own + partner) reaches lane 0 through the tree  v[l] += v[l + o]  for l < o, which is evaluated
-// here with all 64 lanes spread over the NS sums.  Totals end up in part[k * 64].
+// Block-order sums: part[k * NT + t] holds thread t's partial of sum k (pairs i = t, t + NT, ... in increasing i).  The
+// NT partials of each sum are combined by the tree  v[j] += v[j + o]  for j < o, o = NT/2 ... 1, with all threads spread
+// over the NS sums.  Totals end up in part[k * NT].
 __device__ __forceinline__ void tree_reduce(double* part, int ns)
 {
-    const int lane = threadIdx.x & 63;
     __syncthreads();
-    for (int o = 32; o >= 1; o >>= 1)
+    for (int o = NT / 2; o >= 1; o >>= 1)
     {
-        for (int i = lane; i < ns * o; i += 64)
+        for (int i = threadIdx.x; i < ns * o; i += NT)
         {
             const int k = i / o, l = i - k * o;
-            part[k * 64 + l] = part[k * 64 + l] + part[k * 64 + l + o];
+            part[k * NT + l] = part[k * NT + l] + part[k * NT + l + o];
         }
         __syncthreads();
     }
@@ -213,7 +226,7 @@ __device__ __forceinline__ void tree_reduce(double* part, int ns)
 __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
                       double cx, double cy, double sc, double* A, double* b, double* H, double* part)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     if (full)
     {
         double N[36], g[8];
@@ -221,7 +234,7 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
         for (int k = 0; k < 36; k++) N[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; k++) g[k] = 0.0;
-        for (int i = lane; i < n; i += 64)
+        for (int i = lane; i < n; i += NT)
         {
             if (!mask[i]) continue;
             const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
@@ -237,24 +250,32 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 #pragma unroll
             for (int a = 0; a < 8; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
         }
+        // 44 block-order sums, reduced 11 at a time through the 22 KB scratch
 #pragma unroll
-        for (int k = 0; k < 36; k++) part[k * 64 + lane] = N[k];
-#pragma unroll
-        for (int k = 0; k < 8; k++) part[(36 + k) * 64 + lane] = g[k];
-        tree_reduce(part, 44);
-        if (lane < 44)
+        for (int chunk = 0; chunk < 4; chunk++)
         {
-            const double t = part[lane * 64];
-            if (lane < 36)
+#pragma unroll
+            for (int k = 0; k < 11; k++)
             {
-                int a = 0, rem = lane;
-                while (rem >= 8 - a) { rem -= 8 - a; a++; }
-                const int c = a + rem;
-                A[a * 8 + c] = t; A[c * 8 + a] = t;
+                const int id = chunk * 11 + k;
+                part[k * NT + lane] = id < 36 ? N[id < 36 ? id : 0] : g[id >= 36 ? id - 36 : 0];
             }
-            else b[lane - 36] = t;
+            tree_reduce(part, 11);
+            if (lane < 11)
+            {
+                const int id = chunk * 11 + lane;
+                const double t = part[lane * NT];
+                if (id < 36)
+                {
+                    int a = 0, rem = id;
+                    while (rem >= 8 - a) { rem -= 8 - a; a++; }
+                    const int c = a + rem;
+                    A[a * 8 + c] = t; A[c * 8 + a] = t;
+                }
+                else b[id - 36] = t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         __shared__ int s_ok;
         bool ok = solve_n(A, b, 8);
         if (lane == 0)
@@ -282,7 +303,7 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
         for (int k = 0; k < 10; k++) N[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; k++) g[k] = 0.0;
-        for (int i = lane; i < n; i += 64)
+        for (int i = lane; i < n; i += NT)
         {
             if (!mask[i]) continue;
             const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
@@ -299,13 +320,13 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
             for (int a = 0; a < 4; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
         }
 #pragma unroll
-        for (int k = 0; k < 10; k++) part[k * 64 + lane] = N[k];
+        for (int k = 0; k < 10; k++) part[k * NT + lane] = N[k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) part[(10 + k) * 64 + lane] = g[k];
+        for (int k = 0; k < 4; k++) part[(10 + k) * NT + lane] = g[k];
         tree_reduce(part, 14);
         if (lane < 14)
         {
-            const double t = part[lane * 64];
+            const double t = part[lane * NT];
             if (lane < 10)
             {
                 int a = 0, rem = lane;
@@ -336,7 +357,7 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 
 // Single wavefront: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
 template <bool STAGED>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(NT)
 void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, double t2, int full,
                        double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
@@ -344,13 +365,15 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
                        double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
 {
     __shared__ double sA[64], sb[8], sH[9], sBest[9];
-    __shared__ double s_part[44 * 64];
+    __shared__ double s_part[14 * NT];                                       // block-order reduction scratch (<= 14 sums at a time)
+    __shared__ long long s_scratch[NT / 64];
+    __shared__ long long s_best[NT / 64]; __shared__ int s_best_h[NT / 64];
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
     __shared__ uint8_t s_mask[2][STAGED ? LDS_POINTS : 1];
     const int lane = threadIdx.x;
     if (STAGED)
     {
-        for (int i = lane; i < n; i += 64) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+        for (int i = lane; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
         __syncthreads();
     }
     const float2* p1 = STAGED ? s_p1 : g1;
@@ -360,7 +383,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     const int m = full ? 4 : 2;
     // argmax over the hypotheses: highest score, lowest index on ties
     long long best = -1; int best_h = -1;
-    for (int h = lane; h < K_HYPOTHESES; h += 64)
+    for (int h = lane; h < K_HYPOTHESES; h += NT)
     {
         const long long s = hyp_score[h];
         if (s > best) { best = s; best_h = h; }
@@ -371,9 +394,17 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
         const long long os = __shfl_xor(best, o); const int oh = __shfl_xor(best_h, o);
         if (os > best || (os == best && oh >= 0 && (best_h < 0 || oh < best_h))) { best = os; best_h = oh; }
     }
+    if ((lane & 63) == 0) { s_best[lane >> 6] = best; s_best_h[lane >> 6] = best_h; }
+    __syncthreads();
+    best = s_best[0]; best_h = s_best_h[0];
+    for (int w = 1; w < NT / 64; w++)
+    {
+        const long long os = s_best[w]; const int oh = s_best_h[w];
+        if (os > best || (os == best && oh >= 0 && (best_h < 0 || oh < best_h))) { best = os; best_h = oh; }
+    }
     if (best_h < 0 || best < 0)
     {
-        for (int i = lane; i < n; i += 64) out_mask[i] = 0;
+        for (int i = lane; i < n; i += NT) out_mask[i] = 0;
         if (lane == 0) { for (int q = 0; q < 9; q++) out_H[q] = (q % 4 == 0) ? 1.0 : 0.0; *out_ninl = -2; }
         return;
     }
@@ -381,14 +412,14 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     __syncthreads();
     uint8_t* cur = mask_a; uint8_t* trial = mask_b;
     int ninl = 0;
-    long long best_score = score_model(sBest, p1, p2, n, t2, cur, &ninl);
+    long long best_score = score_model(sBest, p1, p2, n, t2, cur, &ninl, s_scratch);
     __syncthreads();
     for (int round = 0; round < LO_ROUNDS; round++)
     {
         if (ninl < m) break;
         if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH, s_part)) break;
         int nt = 0;
-        const long long s = score_model(sH, p1, p2, n, t2, trial, &nt);
+        const long long s = score_model(sH, p1, p2, n, t2, trial, &nt, s_scratch);
         __syncthreads();
         if (s <= best_score) break;
         best_score = s; ninl = nt;
@@ -396,7 +427,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
         uint8_t* t = cur; cur = trial; trial = t;
         __syncthreads();
     }
-    for (int i = lane; i < n; i += 64) out_mask[i] = cur[i];
+    for (int i = lane; i < n; i += NT) out_mask[i] = cur[i];
     if (lane < 9) out_H[lane] = sBest[lane];
     if (lane == 0) *out_ninl = ninl;
 }
@@ -421,14 +452,14 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     const double t2 = threshold * threshold;
     if (n <= LDS_POINTS)
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
-        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     else
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
-        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     LVK_HIP_CHECK(ctx, hipGetLastError());

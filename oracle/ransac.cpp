@@ -15,8 +15,8 @@
 //      an MSAC/MAGSAC-style truncated quadratic, accumulated as an exact integer.  Best score wins, ties go to
 //      the lower hypothesis index.
 //   4. Local optimisation: up to 3 rounds of least squares on the current inliers (e^2 <= t^2), accepted while
-//      the score strictly improves.  The normal-equation sums are taken in "wave order" (64 strided partial sums
-//      combined by an xor butterfly) so that a 64-lane GPU wavefront reproduces them bit for bit.
+//      the score strictly improves.  The normal-equation sums are taken in "block order" (256 strided partial sums
+//      combined by a binary tree) so that a 256-thread GPU block reproduces them bit for bit.
 //   All arithmetic is binary64, separately rounded (no contraction).
 #include "lvk_oracle.h"
 
@@ -134,23 +134,20 @@ long long score_model(const double H[9], const float* p1, const float* p2, int n
     return score;
 }
 
-// "Wave order" sum: term i goes to partial (k mod 64) where k counts the contributing terms in index order...
-// NO: to keep the GPU mapping trivial the partial is chosen by the POINT index i (i mod 64), terms of
-// non-inliers are skipped; partials are then combined by an xor butterfly (32, 16, 8, 4, 2, 1).
+// "Block order" sum: the term of pair i goes to partial (i mod 256) -- chosen by the POINT index, terms of non-inliers
+// are skipped, each partial accumulates in increasing i -- and the 256 partials are combined by the binary tree
+// v[j] += v[j + o] for j < o, o = 128, 64, ..., 1.  A 256-thread GPU block reproduces exactly this order.
 struct WaveAcc
 {
-    double part[64];
+    static constexpr int P = 256;
+    double part[P];
     WaveAcc() { for (double& p : part) p = 0.0; }
-    void add(int i, double v) { part[i & 63] = part[i & 63] + v; }
+    void add(int i, double v) { part[i % P] = part[i % P] + v; }
     double total() const
     {
-        double v[64]; std::memcpy(v, part, sizeof(v));
-        for (int o = 32; o >= 1; o >>= 1)
-        {
-            double t[64];
-            for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ o];
-            std::memcpy(v, t, sizeof(v));
-        }
+        double v[P]; std::memcpy(v, part, sizeof(v));
+        for (int o = P / 2; o >= 1; o >>= 1)
+            for (int l = 0; l < o; l++) v[l] = v[l] + v[l + o];
         return v[0];
     }
 };
