@@ -155,7 +155,9 @@ void k_scharr(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
 // the 41x41 level-1 window (halo recomputed redundantly by neighbouring blocks), from it the 19x19 level-2 window and
 // from that its level-3 tile, writing only the pixels it owns.  Same integer arithmetic as k_pyr_down
 // ((sum + 128) >> 8, reflect-101 applied on each level's own index range).
-constexpr int F0 = 85, F0P = 88, F1 = 41, F1P = 44, F2 = 19, F2P = 20;
+constexpr int T3 = 4;                                   // level-3 tile edge owned by a block (level 2: 2*T3, level 1: 4*T3)
+constexpr int F2 = 2 * (T3 - 1) + 5, F1 = 2 * (F2 - 1) + 5, F0 = 2 * (F1 - 1) + 5;     // 11, 25, 53: windows incl. filter halo
+constexpr int F0P = F0 + 3, F1P = F1 + 3, F2P = F2 + 1;
 
 __device__ __forceinline__ int pyr_tap(const uint8_t* t, int pitch, int ox, int oy, int x, int y, int cols, int rows)
 {
@@ -179,7 +181,7 @@ void k_pyr_fused3(PyrArgs a)
 {
     __shared__ uint8_t t0[F0 * F0P], t1[F1 * F1P], t2[F2 * F2P];
     const int tid = threadIdx.x;
-    const int x3 = blockIdx.x * 8, y3 = blockIdx.y * 8;
+    const int x3 = blockIdx.x * T3, y3 = blockIdx.y * T3;
     const int o2x = 2 * x3 - 2, o2y = 2 * y3 - 2, o1x = 2 * o2x - 2, o1y = 2 * o2y - 2, o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
     const PyrLevel L0 = a.lv[0], L1 = a.lv[1], L2 = a.lv[2], L3 = a.lv[3];
 
@@ -198,7 +200,7 @@ void k_pyr_fused3(PyrArgs a)
         {
             const int v = pyr_tap(t0, F0P, o0x, o0y, gx, gy, L0.cols, L0.rows);
             t1[ty * F1P + tx] = (uint8_t)v;
-            if (gx >= 4 * x3 && gx < 4 * x3 + 32 && gy >= 4 * y3 && gy < 4 * y3 + 32)
+            if (gx >= 4 * x3 && gx < 4 * x3 + 4 * T3 && gy >= 4 * y3 && gy < 4 * y3 + 4 * T3)
                 const_cast<uint8_t*>(L1.img)[(long)gy * L1.step + gx] = (uint8_t)v;
         }
     }
@@ -211,14 +213,14 @@ void k_pyr_fused3(PyrArgs a)
         {
             const int v = pyr_tap(t1, F1P, o1x, o1y, gx, gy, L1.cols, L1.rows);
             t2[ty * F2P + tx] = (uint8_t)v;
-            if (gx >= 2 * x3 && gx < 2 * x3 + 16 && gy >= 2 * y3 && gy < 2 * y3 + 16)
+            if (gx >= 2 * x3 && gx < 2 * x3 + 2 * T3 && gy >= 2 * y3 && gy < 2 * y3 + 2 * T3)
                 const_cast<uint8_t*>(L2.img)[(long)gy * L2.step + gx] = (uint8_t)v;
         }
     }
     __syncthreads();
-    if (tid < 64)
+    if (tid < T3 * T3)
     {
-        const int gx = x3 + (tid & 7), gy = y3 + (tid >> 3);
+        const int gx = x3 + (tid % T3), gy = y3 + (tid / T3);
         if (gx < L3.cols && gy < L3.rows)
             const_cast<uint8_t*>(L3.img)[(long)gy * L3.step + gx] = (uint8_t)pyr_tap(t2, F2P, o2x, o2y, gx, gy, L2.cols, L2.rows);
     }
@@ -350,7 +352,7 @@ int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args)
     int rc;
     if (args.nlevels == 4)
     {
-        const dim3 grid((args.lv[3].cols + 7) / 8, (args.lv[3].rows + 7) / 8);
+        const dim3 grid((args.lv[3].cols + T3 - 1) / T3, (args.lv[3].rows + T3 - 1) / T3);
         hipLaunchKernelGGL(k_pyr_fused3, grid, dim3(256), 0, ctx->stream, args);
     }
     else

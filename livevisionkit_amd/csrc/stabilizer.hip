@@ -184,7 +184,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_fast_counts, fast_regions * sizeof(int)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_pts, n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_matched, n * sizeof(float2)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p1, n * sizeof(float2)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p1, 2 * n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p2, n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_status, n));
     LVK_HIP_CHECK(ctx, hipMalloc(&d_ransac_ws, lvk_ransac_workspace_bytes((int)n)));
@@ -196,7 +196,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_pts, n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_matched, n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, n * sizeof(float2), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, 2 * n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p2, n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_status, n, hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocDefault));
@@ -296,13 +296,13 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     for (size_t i = 0; i < plan.size(); i++) { h_regions[i] = plan[i]; any = any || plan[i].active; }
     if (any)
     {
-        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_regions, h_regions, plan.size() * sizeof(FastRegion), hipMemcpyHostToDevice, st));
+        // The small per-frame parameter / result blocks live in pinned, device-visible host memory: the kernels read the
+        // region descriptors from it and write the keypoint list straight into it (posted PCIe writes), so the only host
+        // call besides the launches is the stream synchronisation.
         pe = prof_begin(LVK_STAGE_FAST);
-        if ((rc = lvk_launch_fast(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, d_regions, (int)plan.size(), fast_max_rw, fast_max_rh,
-                                  d_fast_masks, d_fast_scores, d_fast_out, fast_cap, d_fast_counts)) != LVK_HIP_OK) return rc;
+        if ((rc = lvk_launch_fast(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, h_regions, (int)plan.size(), fast_max_rw, fast_max_rh,
+                                  d_fast_masks, d_fast_scores, h_fast_out, fast_cap, h_fast_counts)) != LVK_HIP_OK) return rc;
         prof_end(pe);
-        LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_fast_counts, d_fast_counts, plan.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-        LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_fast_out, d_fast_out, plan.size() * (size_t)fast_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
     for (size_t i = 0; i < plan.size(); i++)
@@ -317,10 +317,8 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, h_pts, n * sizeof(float2), hipMemcpyHostToDevice, st));
     pe = prof_begin(LVK_STAGE_PYRLK);
-    if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
+    if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, h_matched, h_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
     prof_end(pe);
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_matched, d_matched, n * sizeof(float2), hipMemcpyDeviceToHost, st));
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_status, d_status, n, hipMemcpyDeviceToHost, st));
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
 
     // fast_filter(features, tracked points, matched points; keep = status): back-to-front swap-erase (Container.tpp:97-121)
@@ -358,16 +356,14 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         return LVK_HIP_OK;
     }
     const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
+    // both point sets travel in one copy (h_p1 | h_p2 and d_p1 | d_p2 are each one allocation); results come back through
+    // the pinned host block the kernel writes directly
     std::memcpy(h_p1, h_pts, m * sizeof(float2));
-    std::memcpy(h_p2, h_matched, m * sizeof(float2));
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, m * sizeof(float2), hipMemcpyHostToDevice, st));
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p2, h_p2, m * sizeof(float2), hipMemcpyHostToDevice, st));
+    std::memcpy(h_p1 + m, h_matched, m * sizeof(float2));
+    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, 2 * (size_t)m * sizeof(float2), hipMemcpyHostToDevice, st));
     pe = prof_begin(LVK_STAGE_MOTION);
-    if ((rc = lvk_launch_ransac(ctx, d_p1, d_p2, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, d_H, d_ninl, d_mask)) != LVK_HIP_OK) return rc;
+    if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + m, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
     prof_end(pe);
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_H, d_H, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_ninl, d_ninl, sizeof(int), hipMemcpyDeviceToHost, st));
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, d_mask, m, hipMemcpyDeviceToHost, st));
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     std::memcpy(last_H, h_H, sizeof(last_H));
     motion.from_homography(last_H, (float)cur_w, (float)cur_h);
