@@ -240,7 +240,10 @@ def main():
             "roofline": {"kernel": "k_remap_homography<yuv>" if args.preset == "homography" else "k_remap_mesh<yuv>",
                          "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": remap_ms / remap_n * 1e3 if remap_n else None, "launches": remap_n},
+                         "avg_launch_us": remap_ms / remap_n * 1e3 if remap_n else None, "launches": remap_n,
+                         # the kernel is VALU-issue bound: 487 VALU wave-instructions per output pixel (rocprofv3 SQ_INSTS_VALU,
+                         # profiles/r01_sq_counters_per_kernel.txt) against 64.6 T lane-instr/s measured with scripts/valu_peak.hip
+                         "valu_frac": (487.0 * rows * cols / (remap_ms / remap_n * 1e-3)) / 64.6e12 if remap_n else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             ncpu = os.cpu_count() or 1
