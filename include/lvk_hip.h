@@ -73,6 +73,18 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
                        void* d_dst, int dst_step,
                        const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 
+/* lvk::remap(src, dst, offset_map, background) with a materialised map (Functions/Image.cpp:28-81, FSR.cl:362-403):
+ * d_map = rows x cols float2 offsets in pixels resident in HBM (pitch map_step bytes); dst has the size of src. */
+int lvk_hip_remap_map(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
+                      const void* d_map, int map_step, const uint8_t bg[3], int yuv);
+
+/* Lens correction: the offset map LCFilter::prepare_undistort_maps builds
+ * (Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-171) for a camera profile in the plugin's format
+ * (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153); LCFilter::filter == lvk_hip_remap_map with it. */
+typedef struct lvk_camera_params { double fx, fy, cx, cy, k1, k2, p1, p2, k3; } lvk_camera_params;
+int lvk_hip_lens_map_create(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, void** d_map, int view_xywh[4]);
+int lvk_hip_lens_map_destroy(lvk_hip_ctx* ctx, void* d_map);
+
 /* WarpMesh::apply(src, dst, background) (Math/WarpMesh.cpp:183-223): a 2x2 mesh goes through
  * cv::getPerspectiveTransform + the homography kernel, anything larger through the mesh kernel. */
 int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,

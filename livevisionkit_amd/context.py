@@ -208,3 +208,29 @@ class Context:
         self._check(self.lib.lvk_hip_egress_yuv420(self.handle, frame.data_ptr(), frame.stride(0), rows, cols, y.data_ptr(), y.stride(0),
                                                    u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), 1 if nv12 else 0))
         return (y, u) if nv12 else (y, u, v)
+
+    # ---- lens correction --------------------------------------------------------------------
+    def remap_map(self, src, offsets, bg=(255, 0, 255), yuv=True, out=None):
+        """lvk::remap(src, dst, offset_map): offsets = torch float32 [rows, cols, 2] on the GPU (pixels)."""
+        import torch
+        rows, cols = src.shape[:2]
+        if out is None:
+            out = torch.empty_like(src)
+        bga, bgp = _u8x3(bg)
+        self._check(self.lib.lvk_hip_remap_map(self.handle, src.data_ptr(), src.stride(0), rows, cols, out.data_ptr(), out.stride(0),
+                                               offsets.data_ptr(), offsets.stride(0) * 4, bgp, 1 if yuv else 0))
+        return out
+
+    def lens_map(self, params, rows, cols):
+        """Device offset map of LCFilter for camera params (fx, fy, cx, cy, k1, k2, p1, p2, k3): (torch view [rows, cols, 2], view_xywh)."""
+        import torch
+        arr = (ctypes.c_double * 9)(*[float(v) for v in params])
+        d = ctypes.c_void_p(); view = (ctypes.c_int * 4)()
+        self._check(self.lib.lvk_hip_lens_map_create(self.handle, arr, rows, cols, ctypes.byref(d), view))
+        # hand ownership to torch: stage through host once (the map is static per profile / frame size)
+        tmp = np.zeros((rows, cols, 2), np.float32)
+        self._check(self.lib.lvk_hip_download(self.handle, tmp.ctypes.data_as(ctypes.c_void_p), d, tmp.nbytes))
+        self.sync()
+        t = torch.from_numpy(tmp).to("cuda")
+        self._check(self.lib.lvk_hip_lens_map_destroy(self.handle, d))
+        return t, tuple(view)

@@ -231,6 +231,17 @@ struct MeshCoord            // WarpMesh.cpp:190-191 per pixel (HResizeLinear, VR
     }
 };
 
+struct MapCoord             // FSR.cl:376-381: a materialised offset map (pixels), e.g. the lens-correction warp
+{
+    const uint8_t* __restrict__ map; int map_step;
+    __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
+    {
+        const float2 o = *reinterpret_cast<const float2*>(map + (long)y * map_step + 8 * (long)x);
+        subx = (float)x + o.x;
+        suby = (float)y + o.y;
+    }
+};
+
 // ---- kernel body ---------------------------------------------------------------------------------------------------
 // rocprofv3 (profiles/r01_remap_pmc_sq.txt) shows this kernel is VALU-issue bound, not memory bound: ~510 VALU
 // instructions per output pixel, SQ_ACTIVE_INST_VALU ~ the whole SIMD time.  Two alternatives were built and
@@ -327,6 +338,15 @@ void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, i
                   const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
     const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows};
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+}
+
+template <bool YUV>
+__global__ __launch_bounds__(256)
+void k_remap_map(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                 uint8_t* __restrict__ dst, int dst_step, const uint8_t* __restrict__ map, int map_step, uint32_t bg)
+{
+    const MapCoord coord{map, map_step};
     remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
 }
 
@@ -431,6 +451,21 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
     return LVK_HIP_OK;
 }
 
+// lvk::remap(src, dst, offset_map, background) with the map resident in HBM (Functions/Image.cpp:28-81): dst and map have
+// the size of src (the path never uses map ROIs).  d_map: rows x cols float2 offsets in pixels, pitch map_step bytes.
+int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
+                         void* d_dst, int dst_step, const void* d_map, int map_step, const uint8_t bg[3], int yuv)
+{
+    LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && d_map != nullptr && bg != nullptr);     // Image.cpp:30-34
+    LVK_HIP_REQUIRE(ctx, cols > 0 && rows > 0 && src_step >= 3 * cols && dst_step >= 3 * cols && map_step >= 8 * cols);
+    LVK_HIP_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_map) | (uintptr_t)map_step) & 7u) == 0);
+    const dim3 block(256), grid = remap_grid(rows, cols);
+    if (yuv) hipLaunchKernelGGL(k_remap_map<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, (const uint8_t*)d_map, map_step, pack_bg(bg));
+    else hipLaunchKernelGGL(k_remap_map<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, (const uint8_t*)d_map, map_step, pack_bg(bg));
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
 int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream,
                               const void* d_src, int src_step, int rows, int cols,
                               void* d_dst, int dst_step,
@@ -479,6 +514,13 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     return lvk_launch_remap_mesh(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
+}
+
+int lvk_hip_remap_map(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
+                      const void* d_map, int map_step, const uint8_t bg[3], int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_remap_map(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, d_map, map_step, bg, yuv);
 }
 
 int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,

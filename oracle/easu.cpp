@@ -338,6 +338,22 @@ int lvko_remap_mesh(const uint8_t* src, int src_step, int src_rows, int src_cols
     return 0;
 }
 
+int lvko_remap_map(const uint8_t* src, int src_step, int src_rows, int src_cols, uint8_t* dst, int dst_step,
+                   const float* offsets, const uint8_t bg[3], int yuv, int nthreads)
+{
+    // FSR.cl:362-403 easu_remap with a materialised offset map (dst size == map size == src size, no ROI)
+    if (!src || !dst || !offsets) return -1;
+    parallel_rows(src_rows, nthreads, [=](int r0, int r1) {
+        for (int y = r0; y < r1; y++)
+            for (int x = 0; x < src_cols; x++)
+            {
+                const float* o = offsets + ((size_t)y * src_cols + x) * 2;
+                remap_pixel(src, src_step, src_rows, src_cols, dst + (size_t)y * dst_step + 3 * x, (float)x + o[0], (float)y + o[1], bg, yuv != 0);
+            }
+    });
+    return 0;
+}
+
 int lvko_get_perspective_transform(const float src[8], const float dst[8], double M[9])
 {
     // OpenCV imgproc getPerspectiveTransform: rows i<4 [x y 1 0 0 0 -x*u -y*u | u], rows i+4 [0 0 0 x y 1 -x*v -y*v | v]

@@ -176,6 +176,15 @@ int lvko_ingest_yuv420(const uint8_t* y, int y_step, const uint8_t* u, int u_ste
 int lvko_egress_yuv420(const uint8_t* src, int src_step, int rows, int cols,
                        uint8_t* y, int y_step, uint8_t* u, int u_step, uint8_t* v, int v_step, int nv12);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * lens correction (oracle/lens.cpp; reference Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-192)
+ * and lvk::remap(src, dst, offset_map) with a materialised per-pixel offset map (Functions/Image.cpp:28-81).
+ * ---------------------------------------------------------------------------------------------- */
+int lvko_lens_offset_map(const double params[9], int rows, int cols, float* offsets, int view_xywh[4]);
+int lvko_remap_map(const uint8_t* src, int src_step, int src_rows, int src_cols, uint8_t* dst, int dst_step,
+                   const float* offsets /* rows x cols x 2, pixels */, const uint8_t bg[3], int yuv, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,26 @@ class Oracle:
         assert rc == 0
         return (y, u) if nv12 else (y, u, v)
 
+    def lens_offset_map(self, params, rows, cols):
+        """params = (fx, fy, cx, cy, k1, k2, p1, p2, k3). Returns (offsets [rows, cols, 2] float32 in pixels, view (x, y, w, h))."""
+        pr = np.ascontiguousarray(params, np.float64).reshape(9)
+        off = np.zeros((rows, cols, 2), np.float32); view = np.zeros(4, np.int32)
+        fn = self.lib.lvko_lens_offset_map
+        fn.restype = _c.c_int
+        fn.argtypes = [_f64p, _c.c_int, _c.c_int, _f32p, _c.POINTER(_c.c_int32)]
+        assert fn(_p(pr, _f64p), rows, cols, _p(off, _f32p), _p(view, _c.POINTER(_c.c_int32))) == 0
+        return off, tuple(int(v) for v in view)
+
+    def remap_map(self, src, offsets, bg=(255, 0, 255), yuv=True, nthreads=8):
+        src = np.ascontiguousarray(src, np.uint8); offsets = np.ascontiguousarray(offsets, np.float32)
+        dst = np.zeros_like(src); bg = np.ascontiguousarray(bg, np.uint8)
+        fn = self.lib.lvko_remap_map
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int, _f32p, _u8p, _c.c_int, _c.c_int]
+        assert fn(_p(src, _u8p), src.strides[0], src.shape[0], src.shape[1], _p(dst, _u8p), dst.strides[0], _p(offsets, _f32p),
+                  _p(bg, _u8p), 1 if yuv else 0, nthreads) == 0
+        return dst
+
     def find_homography(self, p1, p2, threshold, region=(480, 270), partial=False):
         p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
         H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8)

@@ -1,0 +1,93 @@
+"""CPU tests pinning the oracle's lens-correction map (no GPU).  The reference holds no
+golden vectors for LCFilter and OpenCV is absent from the image, so this row is pinned by known-answer cases and a second,
+independently written numpy statement of the undistort-rectify model (parity vs OpenCV itself: unpinned)."""
+import numpy as np
+
+from tests import synth
+
+
+def _np_map(params, rows, cols):
+    """Vectorised binary64 statement of getOptimalNewCameraMatrix(alpha 0) + initUndistortRectifyMap, written from the
+    published Brown-Conrady model, not from oracle/lens.cpp: returns (map_x, map_y, P)."""
+    fx, fy, cx, cy, k1, k2, p1, p2, k3 = [float(v) for v in params]
+
+    def undist(u, v):
+        x0 = (u - cx) / fx; y0 = (v - cy) / fy
+        x, y = x0.copy(), y0.copy()
+        for _ in range(5):
+            r2 = x * x + y * y
+            ic = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x = (x0 - dx) * ic; y = (y0 - dy) * ic
+        return x, y
+
+    gx, gy = np.meshgrid(np.arange(9) * cols / 8.0, np.arange(9) * rows / 8.0)
+    ux, uy = undist(gx.astype(np.float32).astype(np.float64), gy.astype(np.float32).astype(np.float64))
+    ux = ux.astype(np.float32); uy = uy.astype(np.float32)
+    ix0, ix1 = ux[:, 0].max(), ux[:, 8].min(); iy0, iy1 = uy[0, :].max(), uy[8, :].min()
+    nfx = (cols - 1) / float(ix1 - ix0); nfy = (rows - 1) / float(iy1 - iy0)
+    ncx = -nfx * float(ix0); ncy = -nfy * float(iy0)
+    jj, ii = np.meshgrid(np.arange(cols, dtype=np.float64), np.arange(rows, dtype=np.float64))
+    x = (jj - ncx) / nfx; y = (ii - ncy) / nfy
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return fx * xd + cx, fy * yd + cy, (nfx, nfy, ncx, ncy)
+
+
+def _offsets_from_map(mx, my, view, rows, cols):
+    """WarpMesh set_to(absolute map) -> normalise -> crop_in(view) -> pixels, in binary64."""
+    jj, ii = np.meshgrid(np.arange(cols, dtype=np.float64), np.arange(rows, dtype=np.float64))
+    vx, vy, vw, vh = [float(v) for v in view]
+    ox = (mx - jj) / cols + (jj * ((vw / cols - 1) / (cols - 1)) + vx / cols)
+    oy = (my - ii) / rows + (ii * ((vh / rows - 1) / (rows - 1)) + vy / rows)
+    return np.stack([ox * cols, oy * rows], axis=2)
+
+
+def test_zero_distortion_is_a_near_identity_map(oracle):
+    rows, cols = 270, 480
+    off, view = oracle.lens_offset_map((400, 400, 239.5, 134.5, 0, 0, 0, 0, 0), rows, cols)
+    assert view[0] == 0 and view[1] == 0 and view[2] >= cols - 1 and view[3] >= rows - 1
+    # the [0, cols] x [0, rows] sample grid of getOptimalNewCameraMatrix leaves a (cols-1)/cols zoom: <= 1 px at the far edge
+    assert np.abs(off).max() <= 1.01
+    assert np.abs(off[0, 0]).max() < 1e-3
+
+
+def test_matches_independent_numpy_model(oracle):
+    rows, cols = 135, 240
+    for params in [(0.8 * cols, 0.8 * cols, cols / 2, rows / 2, -0.12, 0.03, 0, 0, 0),
+                   (0.9 * cols, 0.85 * cols, cols / 2 + 3, rows / 2 - 2, -0.2, 0.05, 1e-3, -2e-3, 0.01),
+                   (1.1 * cols, 1.1 * cols, cols / 2, rows / 2, 0.08, -0.01, 0, 0, 0)]:
+        off, view = oracle.lens_offset_map(params, rows, cols)
+        mx, my, _ = _np_map(params, rows, cols)
+        want = _offsets_from_map(mx, my, view, rows, cols)
+        assert np.abs(off - want).max() < 2e-3, params
+        assert 0 <= view[0] and 0 <= view[1] and view[0] + view[2] <= cols and view[1] + view[3] <= rows
+        assert view[2] >= cols - 2 and view[3] >= rows - 2        # alpha = 0: the whole output is valid
+
+
+def test_barrel_correction_pulls_corners_inwards(oracle):
+    rows, cols = 270, 480
+    off, _ = oracle.lens_offset_map((0.8 * cols, 0.8 * cols, cols / 2, rows / 2, -0.12, 0.03, 0, 0, 0), rows, cols)
+    assert off[0, 0, 0] > 1 and off[0, 0, 1] > 1 and off[-1, -1, 0] < -1 and off[-1, -1, 1] < -1
+    assert np.abs(off[rows // 2, cols // 2]).max() < 0.1
+
+
+def test_remap_map_zero_offsets_equals_identity_homography(oracle):
+    src = synth.textured_frame(60, 84, seed=4)
+    zero = np.zeros((60, 84, 2), np.float32)
+    for yuv in (True, False):
+        assert np.array_equal(oracle.remap_map(src, zero, yuv=yuv), oracle.remap_homography(src, np.eye(3, dtype=np.float32), yuv=yuv))
+
+
+def test_remap_map_matches_mesh_path_on_its_materialised_map(oracle):
+    """A mesh warp rendered through its per-pixel map (Image.cpp:28-81 path) equals remap_mesh when the map is the oracle's
+    own mesh_to_map (same binary32 interpolation)."""
+    rows, cols = 72, 96
+    src = synth.textured_frame(rows, cols, seed=9)
+    rng = np.random.default_rng(5)
+    mesh = synth.random_mesh(5, 7, rng)
+    m = oracle.mesh_to_map(mesh, rows, cols)
+    assert np.array_equal(oracle.remap_map(src, m), oracle.remap_mesh(src, mesh))
