@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--format", default="i420", choices=["i420", "nv12", "packed"],
                     help="frame format resident in HBM: 4:2:0 planes in and out (BASELINE metric) or the packed 8UC3 boundary format")
+    ap.add_argument("--lens", default="off", choices=["off", "fused", "two-pass"],
+                    help="BASELINE config 5: lens-correction pre-warp (profile of SURVEY.md section 8d) fused into the stabilizing remap, "
+                         "or as the reference chain's separate LC pass (two-pass; --format packed only)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the output remap on the tracking stream")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline: one pass over the frame pool instead of a 12 s budget")
     return ap.parse_args()
@@ -77,13 +80,16 @@ def make_frame_pool(rows, cols, count, seed, device):
     return frames
 
 
-def cpu_baseline(rows, cols, preset_name, frames_host, nthreads, budget_s=12.0, fmt="packed"):
+def cpu_baseline(rows, cols, preset_name, frames_host, nthreads, budget_s=12.0, fmt="packed", lens_params=None):
     """The CPU oracle (a port: CPU restatement of the reference, see oracle/lvk_oracle.h) timed on the host cores on a
     bounded sample of the same workload."""
     from tests import oracle_lib
     oracle = oracle_lib.load()
     s = oracle_lib.preset(preset_name)
-    st = oracle_lib.OracleStabilizer(oracle, s)
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default"))      # same OBS flow as the GPU leg
+    st.configure(s)
+    if lens_params is not None:
+        st.set_lens(lens_params)
     delay = s.predictive_samples
     n = len(frames_host)
     yuv420 = fmt != "packed"
@@ -137,12 +143,23 @@ def main():
     import livevisionkit_amd as lvk
     ctx = lvk.Context(local_rank)
     settings = lvk.StabilizationFilterSettings.obs_preset(args.preset)
-    filt = lvk.StabilizationFilter(settings, context=ctx)
+    # the OBS plugin's flow (VSFilter.cpp:255-293): a default-constructed filter that is then configured with the preset --
+    # constructing the "field" preset directly would keep FrameTracker's constructor-time 256x256 mesh constraints (reference quirk)
+    filt = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
+    filt.configure(settings)
     if not args.no_overlap:
         filt.set_overlap(True)          # remap of frame n-N on a second stream, concurrent with the tracking of frame n+1
     delay = filt.frame_delay()
 
     rows, cols = args.rows, args.cols
+    lens_params = (0.8 * cols, 0.8 * cols, cols / 2, rows / 2, -0.12, 0.03, 0.0, 0.0, 0.0)
+    lens_map = lens_bufs = None
+    if args.lens == "fused":
+        filt.set_lens(lens_params)
+    elif args.lens == "two-pass":
+        if args.format != "packed":
+            raise SystemExit("--lens two-pass needs --format packed")
+        lens_map, _ = ctx.lens_map(lens_params, rows, cols)
     pool = max(args.pool, delay + 3)
     frames = make_frame_pool(rows, cols, pool, seed=0x4C564B31 + rank, device=device)
     yuv420 = args.format != "packed"
@@ -154,6 +171,8 @@ def main():
         outs = [tuple(torch.empty_like(p) for p in planes[0]) for _ in range(4)]
     else:
         outs = [torch.empty_like(frames[0]) for _ in range(4)]
+    if lens_map is not None:
+        lens_bufs = [torch.empty_like(frames[0]) for _ in range(delay + 4)]       # corrected frames stay borrowed for `delay` pushes
     torch.cuda.synchronize()
 
     step_no = [0]
@@ -162,6 +181,9 @@ def main():
         i = step_no[0]; step_no[0] += 1
         if yuv420:
             return filt.apply_yuv420(planes[i % pool], timestamp=i, out=outs[i & 3])
+        if lens_map is not None:
+            corrected = ctx.remap_map(frames[i % pool], lens_map, bg=(0, 0, 0), out=lens_bufs[i % len(lens_bufs)])     # LCFilter::filter
+            return filt.apply(corrected, timestamp=i, out=outs[i & 3])
         return filt.apply(frames[i % pool], timestamp=i, out=outs[i & 3])
 
     # fill the delay (untimed, before the warmup): every timed step then emits one stabilized frame
@@ -231,13 +253,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{cols}x{rows} {args.format.upper()} (YUV 4:2:0) stream per GPU, planes resident in HBM, ingest -> lvk::StabilizationFilter -> egress, "
                                     if yuv420 else f"{cols}x{rows} packed YUV444 8UC3 stream per GPU (lvk::StabilizationFilter boundary format), ")
-                                   + f"OBS '{args.preset}' preset, tracking 480x270, predictive_samples={delay}, crop 5%",
+                                   + f"OBS '{args.preset}' preset, tracking 480x270, predictive_samples={delay}, crop 5%"
+                                   + ("" if args.lens == "off" else f", lens correction {args.lens} (fx=fy=0.8W, k1=-0.12, k2=0.03)"),
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",
                        "frames_in_hbm": pool},
             "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))},
             "stage_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof.items()},
             "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked},
-            "roofline": {"kernel": "k_remap_homography<yuv>" if args.preset == "homography" else "k_remap_mesh<yuv>",
+            "roofline": {"kernel": ("k_remap_homography" if args.preset == "homography" else "k_remap_mesh") + ("_lens<yuv>" if args.lens == "fused" else "<yuv>"),
                          "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": remap_ms / remap_n * 1e3 if remap_n else None, "launches": remap_n,
@@ -250,7 +273,8 @@ def main():
             nthreads = min(ncpu, 64)
             host_frames = [f.cpu().numpy() for f in frames]
             fps, dt, done = cpu_baseline(rows, cols, args.preset, host_frames, nthreads,
-                                         budget_s=0.0 if args.cpu_frames else 12.0, fmt=args.format)
+                                         budget_s=0.0 if args.cpu_frames else 12.0, fmt=args.format,
+                                         lens_params=lens_params if args.lens == "fused" else None)
             result["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nthreads, "kind": "port",
                                       "sample": f"{done} steady-state frames of the same workload ({dt:.1f} s of CPU work; "
                                                 f"oracle = CPU restatement of the reference, remap row-parallel over {nthreads} threads, "

@@ -84,6 +84,14 @@ int lvk_hip_remap_map(lvk_hip_ctx* ctx, const void* d_src, int src_step, int row
 typedef struct lvk_camera_params { double fx, fy, cx, cy, k1, k2, p1, p2, k3; } lvk_camera_params;
 int lvk_hip_lens_map_create(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, void** d_map, int view_xywh[4]);
 int lvk_hip_lens_map_destroy(lvk_hip_ctx* ctx, void* d_map);
+/* FUSED lens mode (BASELINE config 5; this library's design, the reference only has the two-pass chain): the same warp in
+ * closed form, composed into the coordinate of the stabilizing remap -> one EASU resampling, no map traffic.
+ * lvk_hip_warpmesh_apply_lens == WarpMesh::apply applied to the lens-corrected frame, sampled from the RAW frame d_src;
+ * lvk_hip_lens_undistort_points = raw tracking-frame points (scale sx, sy = frame / tracking size) -> corrected positions. */
+int lvk_hip_warpmesh_apply_lens(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
+                                const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv, const lvk_camera_params* lens);
+int lvk_hip_lens_undistort_points(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, double sx, double sy,
+                                  const float* pts, int n, float* out);
 
 /* WarpMesh::apply(src, dst, background) (Math/WarpMesh.cpp:183-223): a 2x2 mesh goes through
  * cv::getPerspectiveTransform + the homography kernel, anything larger through the mesh kernel. */
@@ -194,6 +202,10 @@ int  lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lv
 void lvk_hip_stab_destroy(lvk_hip_stab* stab);
 int  lvk_hip_stab_configure(lvk_hip_stab* stab, const lvk_stab_settings* settings);
 int  lvk_hip_stab_restart(lvk_hip_stab* stab);            /* :139-144 */
+/* Fused lens pre-warp for the stream this filter stabilizes: frames are pushed RAW (uncorrected); the tracker estimates the
+ * motion between lens-corrected feature positions and the output remap composes lens map and stabilizing warp.
+ * params = NULL switches it off.  Restarts the filter (queued frames are dropped). */
+int  lvk_hip_stab_set_lens(lvk_hip_stab* stab, const lvk_camera_params* params);
 int  lvk_hip_stab_reset_context(lvk_hip_stab* stab);      /* :155-159 */
 int  lvk_hip_stab_ready(const lvk_hip_stab* stab);        /* :148-151 */
 int  lvk_hip_stab_frame_delay(const lvk_hip_stab* stab);  /* :192-195 */

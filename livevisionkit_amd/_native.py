@@ -32,6 +32,9 @@ _SIG = {
     "lvk_hip_remap_map": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
     "lvk_hip_lens_map_create": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.POINTER(_P), _c.POINTER(_c.c_int)]),
     "lvk_hip_lens_map_destroy": (_c.c_int, [_P, _P]),
+    "lvk_hip_warpmesh_apply_lens": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int, _P]),
+    "lvk_hip_lens_undistort_points": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.POINTER(_c.c_float), _c.c_int, _c.POINTER(_c.c_float)]),
+    "lvk_hip_stab_set_lens": (_c.c_int, [_P, _P]),
     "lvk_hip_warpmesh_apply": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                           _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
     "lvk_hip_luma_area_resize": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int]),

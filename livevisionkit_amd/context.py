@@ -234,3 +234,26 @@ class Context:
         t = torch.from_numpy(tmp).to("cuda")
         self._check(self.lib.lvk_hip_lens_map_destroy(self.handle, d))
         return t, tuple(view)
+
+    def warpmesh_apply_lens(self, src, mesh, params, bg=(255, 0, 255), yuv=True, out=None):
+        """WarpMesh::apply on the lens-corrected frame, sampled from the RAW frame `src` in one pass (fused lens mode)."""
+        import torch
+        rows, cols = src.shape[0], src.shape[1]
+        if out is None:
+            out = torch.empty((rows, cols, 3), dtype=torch.uint8, device=src.device)
+        m = np.ascontiguousarray(mesh, dtype=np.float32)
+        ma, mp = _f32(m)
+        bga, bgp = _u8x3(bg)
+        arr = (ctypes.c_double * 9)(*[float(v) for v in params])
+        self._check(self.lib.lvk_hip_warpmesh_apply_lens(self.handle, src.data_ptr(), src.stride(0), rows, cols, out.data_ptr(), out.stride(0),
+                                                         mp, m.shape[0], m.shape[1], bgp, 1 if yuv else 0, arr))
+        return out
+
+    def lens_undistort_points(self, params, rows, cols, sx, sy, pts):
+        """Raw tracking-frame points -> lens-corrected positions (binary64 on the GPU)."""
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(p)
+        arr = (ctypes.c_double * 9)(*[float(v) for v in params])
+        fp = ctypes.POINTER(ctypes.c_float)
+        self._check(self.lib.lvk_hip_lens_undistort_points(self.handle, arr, rows, cols, float(sx), float(sy), p.ctypes.data_as(fp), len(p), out.ctypes.data_as(fp)))
+        return out

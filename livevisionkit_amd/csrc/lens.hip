@@ -54,20 +54,27 @@ void inscribed(const lvk_camera_params& c, const double* P, int w, int h, float 
     out[0] = oX0; out[1] = oY0; out[2] = oX1 - oX0; out[3] = oY1 - oY0;
 }
 
-void build_offsets(const lvk_camera_params& c, int rows, int cols, std::vector<float>& off, int view[4])
+// cv::getOptimalNewCameraMatrix(alpha 0, same size) -> P = (fx', fy', cx', cy') and the valid-pixel ROI
+void optimal_matrix(const lvk_camera_params& c, int rows, int cols, double P[4], int view[4])
 {
     float in[4], out[4];
     inscribed(c, nullptr, cols, rows, in, out);
     const double fx0 = (cols - 1) / (double)in[2], fy0 = (rows - 1) / (double)in[3], cx0 = -fx0 * in[0], cy0 = -fy0 * in[1];
     const double fx1 = (cols - 1) / (double)out[2], fy1 = (rows - 1) / (double)out[3], cx1 = -fx1 * out[0], cy1 = -fy1 * out[1];
     const double alpha = 0.0;
-    const double P[4] = {fx0 * (1 - alpha) + fx1 * alpha, fy0 * (1 - alpha) + fy1 * alpha, cx0 * (1 - alpha) + cx1 * alpha, cy0 * (1 - alpha) + cy1 * alpha};
+    P[0] = fx0 * (1 - alpha) + fx1 * alpha; P[1] = fy0 * (1 - alpha) + fy1 * alpha;
+    P[2] = cx0 * (1 - alpha) + cx1 * alpha; P[3] = cy0 * (1 - alpha) + cy1 * alpha;
     inscribed(c, P, cols, rows, in, out);
     const int rx = (int)lrint(in[0]), ry = (int)lrint(in[1]), rw = (int)lrint(in[2]), rh = (int)lrint(in[3]);
     const int x1 = std::max(rx, 0), y1 = std::max(ry, 0), x2 = std::min(rx + rw, cols), y2 = std::min(ry + rh, rows);
     view[0] = x1; view[1] = y1; view[2] = std::max(x2 - x1, 0); view[3] = std::max(y2 - y1, 0);
     if (view[2] <= 0 || view[3] <= 0) view[0] = view[1] = view[2] = view[3] = 0;
+}
 
+void build_offsets(const lvk_camera_params& c, int rows, int cols, std::vector<float>& off, int view[4])
+{
+    double P[4];
+    optimal_matrix(c, rows, cols, P, view);
     const double ir[9] = {1. / P[0], 0, -P[2] / P[0], 0, 1. / P[1], -P[3] / P[1], 0, 0, 1};
     const float nfx = 1.0f / (float)cols, nfy = 1.0f / (float)rows;
     const float vx = (float)view[0] / (float)cols, vy = (float)view[1] / (float)rows;
@@ -93,9 +100,95 @@ void build_offsets(const lvk_camera_params& c, int rows, int cols, std::vector<f
     }
 }
 
+// One thread per point: F^-1 of the fused lens map in binary64 (two passes of {remove the crop_in term, the 5 fixed-point
+// iterations of cv::undistortPoints, apply P}); tracked points live at tracking resolution, the model at frame resolution.
+struct LensModelD { double d[17]; };
+
+__global__ void k_lens_undistort(LensModelD M, double sx, double sy, const float2* __restrict__ a, int na,
+                                 const float2* __restrict__ b, int nb, float2* __restrict__ out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= na + nb) return;
+    const float2 p = i < na ? a[i] : b[i - na];
+    const double nfx = M.d[0], nfy = M.d[1], ncx = M.d[2], ncy = M.d[3], fx = M.d[4], fy = M.d[5], cx = M.d[6], cy = M.d[7];
+    const double k1 = M.d[8], k2 = M.d[9], p1 = M.d[10], p2 = M.d[11], k3 = M.d[12];
+    const double kxc = M.d[13], vxc = M.d[14], kyc = M.d[15], vyc = M.d[16];
+    const double s = (double)p.x * sx, t = (double)p.y * sy;
+    double u = s, v = t;
+    for (int pass = 0; pass < 2; pass++)
+    {
+        const double s1 = s - (u * kxc + vxc), t1 = t - (v * kyc + vyc);
+        const double x0 = (s1 - cx) / fx, y0 = (t1 - cy) / fy;
+        double x = x0, y = y0;
+        for (int j = 0; j < 5; j++)
+        {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            if (icdist < 0) { x = x0; y = y0; break; }
+            const double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+        u = x * nfx + ncx; v = y * nfy + ncy;
+    }
+    out[i] = make_float2((float)(u / sx), (float)(v / sy));
+}
+
 } // namespace
 
+int lvk_lens_model_build(const lvk_camera_params& c, int rows, int cols, LensModel& out)
+{
+    if (rows <= 1 || cols <= 1 || c.fx == 0.0 || c.fy == 0.0) return LVK_HIP_ERR_ARG;
+    double P[4];
+    optimal_matrix(c, rows, cols, P, out.view);
+    const float vx = (float)out.view[0] / (float)cols, vy = (float)out.view[1] / (float)rows;
+    const float vw = (float)out.view[2] / (float)cols, vh = (float)out.view[3] / (float)rows;
+    const float kx = (vw - 1.0f) / (float)(cols - 1), ky = (vh - 1.0f) / (float)(rows - 1);
+    double* d = out.d;
+    d[0] = P[0]; d[1] = P[1]; d[2] = P[2]; d[3] = P[3];
+    d[4] = c.fx; d[5] = c.fy; d[6] = c.cx; d[7] = c.cy; d[8] = c.k1; d[9] = c.k2; d[10] = c.p1; d[11] = c.p2; d[12] = c.k3;
+    d[13] = (double)kx * cols; d[14] = (double)vx * cols; d[15] = (double)ky * rows; d[16] = (double)vy * rows;
+    out.f[0] = (float)(1.0 / d[0]); out.f[1] = (float)(1.0 / d[1]);
+    for (int i = 2; i < 17; i++) out.f[i] = (float)d[i];
+    return LVK_HIP_OK;
+}
+
+int lvk_launch_lens_undistort(lvk_hip_ctx* ctx, hipStream_t stream, const LensModel& model, double sx, double sy,
+                              const float2* a, int na, const float2* b, int nb, float2* out)
+{
+    if (na + nb <= 0) return LVK_HIP_OK;
+    LensModelD M;
+    for (int i = 0; i < 17; i++) M.d[i] = model.d[i];
+    hipLaunchKernelGGL(k_lens_undistort, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, stream, M, sx, sy, a, na, b, nb, out);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
 extern "C" {
+
+// test / tooling entry: corrected positions of n raw points (host arrays)
+int lvk_hip_lens_undistort_points(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, double sx, double sy,
+                                  const float* pts, int n, float* out)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, params && pts && out && n >= 0);
+    if (n == 0) return LVK_HIP_OK;
+    LensModel m;
+    if (lvk_lens_model_build(*params, rows, cols, m) != LVK_HIP_OK) return ctx->fail(LVK_HIP_ERR_ARG, "invalid camera profile");
+    float2 *d_in = nullptr, *d_out = nullptr;
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_in, 2 * (size_t)n * sizeof(float2)));
+    d_out = d_in + n;
+    int rc = LVK_HIP_OK;
+    hipError_t e = hipMemcpyAsync(d_in, pts, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = lvk_launch_lens_undistort(ctx, ctx->stream, m, sx, sy, d_in, n, nullptr, 0, d_out);
+    if (e == hipSuccess && rc == LVK_HIP_OK) e = hipMemcpyAsync(out, d_out, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
+    return rc;
+}
+
 
 int lvk_hip_lens_map_create(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, void** d_map, int view_xywh[4])
 {

@@ -105,12 +105,14 @@ size_t lvk_ransac_workspace_bytes(int n);
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
                       bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask);
 
+struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)
 int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
                                 void* d_dst, int dst_step, int dst_rows, int dst_cols, int off_x, int off_y,
-                                const float H[9], const uint8_t bg[3], int yuv);
+                                const float H[9], const uint8_t bg[3], int yuv, const LensArgs* lens = nullptr);
 int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
-                          void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
+                          void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv,
+                          const LensArgs* lens = nullptr);
 int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                               void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 
@@ -122,3 +124,17 @@ int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
 
 int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                          void* d_dst, int dst_step, const void* d_map, int map_step, const uint8_t bg[3], int yuv);
+
+// Fused lens pre-warp (lens.hip): the camera profile reduced to what the closed-form map needs for one frame size.
+// d = nfx, nfy, ncx, ncy (new camera matrix), fx, fy, cx, cy, k1, k2, p1, p2, k3, kxc, vxc, kyc, vyc (crop_in term, pixels);
+// f = the binary32 kernel parameters: 1/nfx, 1/nfy, then d[2..16] rounded.
+struct LensModel { double d[17]; float f[17]; int view[4]; };
+struct LensArgs { float f[17]; };
+int lvk_lens_model_build(const lvk_camera_params& params, int rows, int cols, LensModel& out);
+// (a | b)[i] raw tracking-frame points -> lens-corrected positions, binary64, written to out[0 .. na + nb)
+int lvk_launch_lens_undistort(lvk_hip_ctx* ctx, hipStream_t stream, const LensModel& model, double sx, double sy,
+                              const float2* a, int na, const float2* b, int nb, float2* out);
+// lens != nullptr composes the closed-form lens map into the coordinate (fused mode)
+int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
+                                   void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv,
+                                   const LensArgs* lens);

@@ -242,6 +242,32 @@ struct MapCoord             // FSR.cl:376-381: a materialised offset map (pixels
     }
 };
 
+// Fused lens pre-warp (BASELINE config 5): the inner functor yields the position (u, v) the
+// stabilizing warp asks for in the LENS-CORRECTED frame; the closed-form Brown-Conrady map (LCFilter.cpp:133-171 reduced by
+// lens.hip to 17 floats) carries it on to the raw frame, so the chain LC -> VS costs one EASU resampling and no map traffic.
+// (u, v) outside the corrected frame is background, as the second pass of the reference chain would decide.
+template <class Inner>
+struct LensCoord
+{
+    Inner inner; LensArgs L; int rows, cols;
+    __device__ __forceinline__ void operator()(int px, int py, float& subx, float& suby) const
+    {
+        float u, v;
+        inner(px, py, u, v);
+        const int ux = (int)u, vy = (int)v;
+        if (ux < 0 || ux >= cols || vy < 0 || vy >= rows) { subx = -16.0f; suby = -16.0f; return; }
+        const float* f = L.f;
+        const float x = (u - f[2]) * f[0], y = (v - f[3]) * f[1];
+        const float r2 = __builtin_fmaf(x, x, y * y);
+        const float kr = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(f[12], r2, f[9]), r2, f[8]), r2, 1.0f);
+        const float xy2 = (x + x) * y;
+        const float xd = __builtin_fmaf(x, kr, __builtin_fmaf(f[10], xy2, f[11] * __builtin_fmaf(x + x, x, r2)));
+        const float yd = __builtin_fmaf(y, kr, __builtin_fmaf(f[10], __builtin_fmaf(y + y, y, r2), f[11] * xy2));
+        subx = __builtin_fmaf(f[4], xd, f[6]) + __builtin_fmaf(u, f[13], f[14]);
+        suby = __builtin_fmaf(f[5], yd, f[7]) + __builtin_fmaf(v, f[15], f[16]);
+    }
+};
+
 // ---- kernel body ---------------------------------------------------------------------------------------------------
 // rocprofv3 (profiles/r01_remap_pmc_sq.txt) shows this kernel is VALU-issue bound, not memory bound: ~510 VALU
 // instructions per output pixel, SQ_ACTIVE_INST_VALU ~ the whole SIMD time.  Two alternatives were built and
@@ -343,6 +369,27 @@ void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, i
 
 template <bool YUV>
 __global__ __launch_bounds__(256)
+void k_remap_homography_lens(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                             uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
+                             int off_x, int off_y, HomographyArgs H, LensArgs L, uint32_t bg)
+{
+    const LensCoord<HomographyCoord> coord{HomographyCoord{H, off_x, off_y}, L, src_rows, src_cols};
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, coord, bg);
+}
+
+template <bool YUV>
+__global__ __launch_bounds__(256)
+void k_remap_mesh_lens(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                       uint8_t* __restrict__ dst, int dst_step,
+                       const float* __restrict__ mesh, int mesh_cols,
+                       const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, LensArgs L, uint32_t bg)
+{
+    const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols};
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+}
+
+template <bool YUV>
+__global__ __launch_bounds__(256)
 void k_remap_map(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                  uint8_t* __restrict__ dst, int dst_step, const uint8_t* __restrict__ map, int map_step, uint32_t bg)
 {
@@ -401,7 +448,7 @@ bool perspective_transform(const float src[8], const float dst[8], double M[9])
 int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream,
                                 const void* d_src, int src_step, int src_rows, int src_cols,
                                 void* d_dst, int dst_step, int dst_rows, int dst_cols,
-                                int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv)
+                                int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv, const LensArgs* lens)
 {
     // Image.cpp:93-98
     LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && H != nullptr && bg != nullptr);
@@ -410,7 +457,16 @@ int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream,
     HomographyArgs args;
     std::memcpy(args.h, H, sizeof(args.h));
     const dim3 block(256), grid = remap_grid(dst_rows, dst_cols);
-    if (yuv)
+    if (lens)
+    {
+        if (yuv)
+            hipLaunchKernelGGL(k_remap_homography_lens<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                               (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, *lens, pack_bg(bg));
+        else
+            hipLaunchKernelGGL(k_remap_homography_lens<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                               (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, *lens, pack_bg(bg));
+    }
+    else if (yuv)
         hipLaunchKernelGGL(k_remap_homography<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, args, pack_bg(bg));
     else
@@ -423,7 +479,7 @@ int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream,
 int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
                           const void* d_src, int src_step, int src_rows, int src_cols,
                           void* d_dst, int dst_step,
-                          const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
+                          const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv, const LensArgs* lens)
 {
     // Image.cpp:30-34
     LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && mesh != nullptr && bg != nullptr);
@@ -441,7 +497,16 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
     if ((rc = lvk_get_lintab(ctx, mesh_rows, src_rows, true, &ytab)) != LVK_HIP_OK) return rc;
 
     const dim3 block(256), grid = remap_grid(src_rows, src_cols);
-    if (yuv)
+    if (lens)
+    {
+        if (yuv)
+            hipLaunchKernelGGL(k_remap_mesh_lens<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                               (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
+        else
+            hipLaunchKernelGGL(k_remap_mesh_lens<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
+                               (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
+    }
+    else if (yuv)
         hipLaunchKernelGGL(k_remap_mesh<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols,
                            (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
     else
@@ -471,6 +536,14 @@ int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream,
                               void* d_dst, int dst_step,
                               const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
 {
+    return lvk_launch_warpmesh_apply_lens(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, nullptr);
+}
+
+int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream,
+                                   const void* d_src, int src_step, int rows, int cols,
+                                   void* d_dst, int dst_step,
+                                   const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv, const LensArgs* lens)
+{
     LVK_HIP_REQUIRE(ctx, mesh != nullptr && mesh_rows >= 2 && mesh_cols >= 2);
     if (mesh_rows == 2 && mesh_cols == 2)
     {
@@ -491,9 +564,9 @@ int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream,
             for (int q = 0; q < 9; q++) M[q] = (q % 4 == 0) ? 1.0 : 0.0;
         float H[9];
         for (int q = 0; q < 9; q++) H[q] = (float)M[q];              // Image.cpp:137-139
-        return lvk_launch_remap_homography(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, rows, cols, 0, 0, H, bg, yuv);
+        return lvk_launch_remap_homography(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, rows, cols, 0, 0, H, bg, yuv, lens);
     }
-    return lvk_launch_remap_mesh(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
+    return lvk_launch_remap_mesh(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, lens);
 }
 
 extern "C" {
@@ -521,6 +594,18 @@ int lvk_hip_remap_map(lvk_hip_ctx* ctx, const void* d_src, int src_step, int row
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     return lvk_launch_remap_map(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, d_map, map_step, bg, yuv);
+}
+
+int lvk_hip_warpmesh_apply_lens(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
+                                const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv, const lvk_camera_params* lens)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, lens != nullptr && rows > 1 && cols > 1);
+    LensModel m; LensArgs a;
+    const int rc = lvk_lens_model_build(*lens, rows, cols, m);
+    if (rc != LVK_HIP_OK) return ctx->fail(rc, "invalid camera profile");
+    std::memcpy(a.f, m.f, sizeof(a.f));
+    return lvk_launch_warpmesh_apply_lens(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, &a);
 }
 
 int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,

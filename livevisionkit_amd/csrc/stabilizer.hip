@@ -60,6 +60,21 @@ struct lvk_hip_stab
     uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
     float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr, *h_p2 = nullptr; uint8_t* h_status = nullptr;
     double* h_H = nullptr; int* h_ninl = nullptr; uint8_t* h_mask = nullptr;
+    float2* h_und = nullptr;                   // fused lens mode: lens-corrected (previous | matched) point positions
+
+    // ---- fused lens pre-warp (lvk_hip_stab_set_lens): model of the current frame size
+    bool lens = false;
+    lvk_camera_params lens_params{};
+    LensModel lens_model{}; LensArgs lens_args{};
+    int lens_rows = 0, lens_cols = 0;
+    int ensure_lens(int rows, int cols)
+    {
+        if (!lens || (rows == lens_rows && cols == lens_cols)) return LVK_HIP_OK;
+        if (lvk_lens_model_build(lens_params, rows, cols, lens_model) != LVK_HIP_OK) return fail(LVK_HIP_ERR_ARG, "invalid camera profile for this frame size");
+        std::memcpy(lens_args.f, lens_model.f, sizeof(lens_args.f));
+        lens_rows = rows; lens_cols = cols;
+        return LVK_HIP_OK;
+    }
 
     // ---- host state
     lvkh::FeatureGridH grid;
@@ -154,12 +169,12 @@ void lvk_hip_stab::free_tracker_buffers()
 {
     void* dev[] = {d_regions, d_fast_masks, d_fast_scores, d_fast_out, d_fast_counts, d_pts, d_matched, d_p1, d_p2, d_status, d_ransac_ws, d_H, d_ninl, d_mask};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_p2, h_status, h_H, h_ninl, h_mask};
+    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_p2, h_status, h_H, h_ninl, h_mask, h_und};
     for (void* p : host) if (p) (void)hipHostFree(p);
     d_regions = nullptr; d_fast_masks = d_fast_scores = nullptr; d_fast_out = nullptr; d_fast_counts = nullptr;
     d_pts = d_matched = d_p1 = d_p2 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_H = nullptr; d_ninl = nullptr; d_mask = nullptr;
     h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = h_p2 = nullptr; h_status = nullptr;
-    h_H = nullptr; h_ninl = nullptr; h_mask = nullptr;
+    h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr;
 }
 
 int lvk_hip_stab::alloc_tracker_buffers()
@@ -202,6 +217,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_und, 2 * n * sizeof(float2), hipHostMallocDefault));
     return LVK_HIP_OK;
 }
 
@@ -319,8 +335,22 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     pe = prof_begin(LVK_STAGE_PYRLK);
     if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, h_matched, h_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
     prof_end(pe);
+    if (lens)
+    {
+        // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks)
+        if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
+                                            d_pts, n, h_matched, n, h_und)) != LVK_HIP_OK) return rc;
+    }
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
 
+    if (lens)
+    {
+        // a match whose corrected positions leave the tracking region is not visible in the lens-corrected frame: drop it
+        const float w = (float)cur_w, h = (float)cur_h;
+        auto inside = [&](const float2& p) { return p.x >= 0.0f && p.x < w && p.y >= 0.0f && p.y < h; };
+        for (int k = 0; k < n; k++)
+            if (!(inside(h_und[k]) && inside(h_und[n + k]))) h_status[k] = 0;
+    }
     // fast_filter(features, tracked points, matched points; keep = status): back-to-front swap-erase (Container.tpp:97-121)
     int m = n;
     for (int k = n - 1; k >= 0; k--)
@@ -330,6 +360,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
             std::swap(tracked[k], tracked[m]);
             std::swap(h_pts[k], h_pts[m]);
             std::swap(h_matched[k], h_matched[m]);
+            if (lens) { std::swap(h_und[k], h_und[m]); std::swap(h_und[n + k], h_und[n + m]); }
         }
     tracked.resize(m);
     last_matched = m;
@@ -337,10 +368,12 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
 
     // ---- motion estimate
     motion = WarpMeshF(s.motion_height, s.motion_width);
+    const float2* e1 = lens ? h_und : h_pts;
+    const float2* e2 = lens ? h_und + n : h_matched;
     if (s.track_local_motions)
     {
         // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the feature matches
-        if (!solver.solve(&h_pts[0].x, &h_matched[0].x, m, (float)cur_w, (float)cur_h, s.temporal_smoothing, s.acceptance_threshold,
+        if (!solver.solve(&e1[0].x, &e2[0].x, m, (float)cur_w, (float)cur_h, s.temporal_smoothing, s.acceptance_threshold,
                           h_mask, motion.off.data()))
             return LVK_HIP_OK;                                                        // no estimate this frame (identity motion)
         size_t inl = 0;
@@ -358,8 +391,8 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
     // both point sets travel in one copy (h_p1 | h_p2 and d_p1 | d_p2 are each one allocation); results come back through
     // the pinned host block the kernel writes directly
-    std::memcpy(h_p1, h_pts, m * sizeof(float2));
-    std::memcpy(h_p1 + m, h_matched, m * sizeof(float2));
+    std::memcpy(h_p1, e1, m * sizeof(float2));
+    std::memcpy(h_p1 + m, e2, m * sizeof(float2));
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, 2 * (size_t)m * sizeof(float2), hipMemcpyHostToDevice, st));
     pe = prof_begin(LVK_STAGE_MOTION);
     if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + m, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
@@ -478,6 +511,17 @@ int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
     return st->configure(*settings);
 }
 
+int lvk_hip_stab_restart(lvk_hip_stab* st);
+int lvk_hip_stab_set_lens(lvk_hip_stab* st, const lvk_camera_params* params)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    if (params && (params->fx == 0.0 || params->fy == 0.0)) return st->fail(LVK_HIP_ERR_ARG, "camera profile with zero focal length");
+    st->lens = params != nullptr;
+    if (params) st->lens_params = *params;
+    st->lens_rows = st->lens_cols = 0;
+    return lvk_hip_stab_restart(st);
+}
+
 int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::restart (StabilizationFilter.cpp:139-144)
 {
     if (!st) return LVK_HIP_ERR_ARG;
@@ -512,6 +556,8 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
     LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV);                                       // other VideoFrame formats: SURVEY.md section 8 "next"
     const QueuedFrame in{d_frame, step, rows, cols, timestamp};
+    { const int lrc = st->ensure_lens(rows, cols); if (lrc != LVK_HIP_OK) return lrc; }
+    static const WarpMeshF identity_mesh(2, 2);
     const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
 
     auto enqueue = [&]() {
@@ -528,7 +574,9 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         const bool side = st->overlap && mesh && st->s.stabilize_output;
         hipStream_t rs = side ? st->remap_stream : ctx->stream;
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
-        if (mesh) rc = lvk_launch_warpmesh_apply(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1);
+        if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
+        if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1,
+                                                      st->lens ? &st->lens_args : nullptr);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
@@ -559,7 +607,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     {
         enqueue();
         if (st->queue.size() != st->queue_capacity) return LVK_HIP_OK;
-        return emit(st->s.crop_to_stable_region ? &st->smoother.scene_crop() : nullptr);
+        return emit(st->s.crop_to_stable_region ? &st->smoother.scene_crop() : st->lens ? &identity_mesh : nullptr);
     }
 
     WarpMeshF motion(st->s.motion_height, st->s.motion_width);                            // m_NullMotion

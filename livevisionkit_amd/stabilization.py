@@ -202,6 +202,12 @@ class StabilizationFilter:
         n = self.lib.lvk_hip_stab_get_features(self.handle, a.ctypes.data_as(_c.POINTER(_c.c_float)), cap)
         return a[:max(n, 0)].copy()
 
+    def set_lens(self, params):
+        """Fused lens pre-warp: params = (fx, fy, cx, cy, k1, k2, p1, p2, k3) of the plugin's camera profile
+        (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153) or None.  Frames are then pushed RAW; restarts the filter."""
+        arr = (ctypes.c_double * 9)(*[float(v) for v in params]) if params is not None else None
+        self.ctx._check(self.lib.lvk_hip_stab_set_lens(self.handle, arr))
+
     def set_overlap(self, enable=True):
         """Run the output remap on a second stream, overlapping the next frame's tracking (output valid after ctx.sync())."""
         self.ctx._check(self.lib.lvk_hip_stab_set_overlap(self.handle, 1 if enable else 0))

@@ -191,6 +191,34 @@ inline void remap_pixel(const uint8_t* src, int src_step, int src_rows, int src_
     easu(src, src_step, sx, sy, ppx, ppy, yuv, dpx);
 }
 
+// Fused lens pre-warp (oracle/lens.cpp lvko_lens_model, rounded to binary32): (u, v) = position in the lens-corrected frame
+// the stabilizing warp asks for -> (subx, suby) = position in the RAW frame.  Returns false when (u, v) itself is outside the
+// corrected frame (background, as the second pass of the reference chain would decide).
+// L[17] = 1/nfx, 1/nfy, ncx, ncy, fx, fy, cx, cy, k1, k2, p1, p2, k3, kxc, vxc, kyc, vyc.
+inline bool lens_forward(const float* L, int rows, int cols, float u, float v, float& subx, float& suby)
+{
+    const int ux = cvt_int_rtz_sat(u), vy = cvt_int_rtz_sat(v);
+    if (ux < 0 || ux >= cols || vy < 0 || vy >= rows) return false;
+    const float x = (u - L[2]) * L[0], y = (v - L[3]) * L[1];
+    const float r2 = fmaf(x, x, y * y);
+    const float kr = fmaf(fmaf(fmaf(L[12], r2, L[9]), r2, L[8]), r2, 1.0f);
+    const float xy2 = (x + x) * y;
+    const float xd = fmaf(x, kr, fmaf(L[10], xy2, L[11] * fmaf(x + x, x, r2)));
+    const float yd = fmaf(y, kr, fmaf(L[10], fmaf(y + y, y, r2), L[11] * xy2));
+    subx = fmaf(L[4], xd, L[6]) + fmaf(u, L[13], L[14]);
+    suby = fmaf(L[5], yd, L[7]) + fmaf(v, L[15], L[16]);
+    return true;
+}
+
+inline void remap_pixel_lens(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dpx, float u, float v,
+                             const uint8_t bg[3], bool yuv, const float* L)
+{
+    float sx, sy;
+    if (!L) { remap_pixel(src, src_step, rows, cols, dpx, u, v, bg, yuv); return; }
+    if (!lens_forward(L, rows, cols, u, v, sx, sy)) { dpx[0] = bg[0]; dpx[1] = bg[1]; dpx[2] = bg[2]; return; }
+    remap_pixel(src, src_step, rows, cols, dpx, sx, sy, bg, yuv);
+}
+
 template <class Fn>
 void parallel_rows(int rows, int nthreads, Fn fn)
 {
@@ -249,10 +277,10 @@ LinTab make_lintab(int ssize, int dsize, bool vertical)
 
 extern "C" {
 
-int lvko_remap_homography(const uint8_t* src, int src_step, int src_rows, int src_cols,
+static int remap_homography_impl(const uint8_t* src, int src_step, int src_rows, int src_cols,
                           uint8_t* dst, int dst_step, int dst_rows, int dst_cols,
                           int off_x, int off_y, const float H[9], const uint8_t bg[3],
-                          int yuv, int nthreads)
+                          int yuv, int nthreads, const float* L)
 {
     if (!src || !dst || src_rows <= 0 || src_cols <= 0) return -1;
     parallel_rows(dst_rows, nthreads, [=](int r0, int r1) {
@@ -269,11 +297,19 @@ int lvko_remap_homography(const uint8_t* src, int src_step, int src_rows, int sr
                 // FSR.cl:430
                 const float subx = (float)(x + off_x) + ox;
                 const float suby = (float)(y + off_y) + oy;
-                remap_pixel(src, src_step, src_rows, src_cols, drow + 3 * x, subx, suby, bg, yuv != 0);
+                remap_pixel_lens(src, src_step, src_rows, src_cols, drow + 3 * x, subx, suby, bg, yuv != 0, L);
             }
         }
     });
     return 0;
+}
+
+int lvko_remap_homography(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                          uint8_t* dst, int dst_step, int dst_rows, int dst_cols,
+                          int off_x, int off_y, const float H[9], const uint8_t bg[3],
+                          int yuv, int nthreads)
+{
+    return remap_homography_impl(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, off_x, off_y, H, bg, yuv, nthreads, nullptr);
 }
 
 void lvko_mesh_to_map(const float* mesh, int mesh_rows, int mesh_cols, int rows, int cols, float* map)
@@ -302,10 +338,10 @@ void lvko_mesh_to_map(const float* mesh, int mesh_rows, int mesh_cols, int rows,
     }
 }
 
-int lvko_remap_mesh(const uint8_t* src, int src_step, int src_rows, int src_cols,
+static int remap_mesh_impl(const uint8_t* src, int src_step, int src_rows, int src_cols,
                     uint8_t* dst, int dst_step,
                     const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
-                    int yuv, int nthreads)
+                    int yuv, int nthreads, const float* L)
 {
     if (!src || !dst || !mesh || mesh_rows < 2 || mesh_cols < 2) return -1;
     const LinTab tx = make_lintab(mesh_cols, src_cols, false), ty = make_lintab(mesh_rows, src_rows, true);
@@ -331,11 +367,19 @@ int lvko_remap_mesh(const uint8_t* src, int src_step, int src_rows, int src_cols
                 // FSR.cl:381 (dst_bounds.xy == 0: the map is never an ROI on this path)
                 const float subx = (float)x + off[0];
                 const float suby = (float)y + off[1];
-                remap_pixel(src, src_step, src_rows, src_cols, drow + 3 * x, subx, suby, bg, yuv != 0);
+                remap_pixel_lens(src, src_step, src_rows, src_cols, drow + 3 * x, subx, suby, bg, yuv != 0, L);
             }
         }
     });
     return 0;
+}
+
+int lvko_remap_mesh(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                    uint8_t* dst, int dst_step,
+                    const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                    int yuv, int nthreads)
+{
+    return remap_mesh_impl(src, src_step, src_rows, src_cols, dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, nthreads, nullptr);
 }
 
 int lvko_remap_map(const uint8_t* src, int src_step, int src_rows, int src_cols, uint8_t* dst, int dst_step,
@@ -426,6 +470,27 @@ int lvko_warpmesh_apply(const uint8_t* src, int src_step, int rows, int cols, ui
         return lvko_remap_homography(src, src_step, rows, cols, dst, dst_step, rows, cols, 0, 0, H, bg, yuv, nthreads);
     }
     return lvko_remap_mesh(src, src_step, rows, cols, dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, nthreads);
+}
+
+// WarpMesh::apply with the lens pre-warp composed into the coordinate (fused mode; model from lvko_lens_model, NULL = plain)
+int lvko_warpmesh_apply_lens(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step,
+                             const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                             int yuv, int nthreads, const double* model)
+{
+    float L[17]; const float* Lp = nullptr;
+    if (model)
+    {
+        L[0] = (float)(1.0 / model[0]); L[1] = (float)(1.0 / model[1]);
+        for (int i = 2; i < 17; i++) L[i] = (float)model[i];
+        Lp = L;
+    }
+    if (mesh_rows == 2 && mesh_cols == 2)
+    {
+        float H[9];
+        lvko_mesh2x2_to_homography(mesh, rows, cols, H);
+        return remap_homography_impl(src, src_step, rows, cols, dst, dst_step, rows, cols, 0, 0, H, bg, yuv, nthreads, Lp);
+    }
+    return remap_mesh_impl(src, src_step, rows, cols, dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, nthreads, Lp);
 }
 
 } // extern "C"

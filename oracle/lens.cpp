@@ -65,6 +65,31 @@ inline int round_sat(double v) { return (int)lrint(v); }
 
 } // namespace
 
+namespace {
+
+// cvGetOptimalNewCameraMatrix(alpha = 0, newImgSize = imgSize, centerPrincipalPoint = false) + valid-pixel ROI
+void optimal_matrix(const Cam& c, int rows, int cols, double P[4], int view_xywh[4])
+{
+    float inner[4], outer[4];
+    get_rectangles(c, nullptr, cols, rows, inner, outer);
+    const double fx0 = (cols - 1) / (double)inner[2], fy0 = (rows - 1) / (double)inner[3];
+    const double cx0 = -fx0 * inner[0], cy0 = -fy0 * inner[1];
+    const double fx1 = (cols - 1) / (double)outer[2], fy1 = (rows - 1) / (double)outer[3];
+    const double cx1 = -fx1 * outer[0], cy1 = -fy1 * outer[1];
+    const double alpha = 0.0;
+    P[0] = fx0 * (1 - alpha) + fx1 * alpha; P[1] = fy0 * (1 - alpha) + fy1 * alpha;
+    P[2] = cx0 * (1 - alpha) + cx1 * alpha; P[3] = cy0 * (1 - alpha) + cy1 * alpha;
+    float in2[4], out2[4];
+    get_rectangles(c, P, cols, rows, in2, out2);
+    // cv::Rect r = inner (Rect_<float> -> Rect: members rounded); r &= Rect(0, 0, w, h)
+    int rx = round_sat(in2[0]), ry = round_sat(in2[1]), rw = round_sat(in2[2]), rh = round_sat(in2[3]);
+    const int x1 = std::max(rx, 0), y1 = std::max(ry, 0), x2 = std::min(rx + rw, cols), y2 = std::min(ry + rh, rows);
+    view_xywh[0] = x1; view_xywh[1] = y1; view_xywh[2] = std::max(x2 - x1, 0); view_xywh[3] = std::max(y2 - y1, 0);
+    if (view_xywh[2] <= 0 || view_xywh[3] <= 0) { view_xywh[0] = view_xywh[1] = view_xywh[2] = view_xywh[3] = 0; }
+}
+
+} // namespace
+
 extern "C" {
 
 // LCFilter::prepare_undistort_maps (LCFilter.cpp:133-171).  params = fx, fy, cx, cy, k1, k2, p1, p2, k3.
@@ -74,24 +99,8 @@ int lvko_lens_offset_map(const double params[9], int rows, int cols, float* offs
 {
     if (!params || !offsets || rows <= 1 || cols <= 1) return -1;
     const Cam c{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8]};
-    // cvGetOptimalNewCameraMatrix, alpha = 0, newImgSize = imgSize, centerPrincipalPoint = false
-    float inner[4], outer[4];
-    get_rectangles(c, nullptr, cols, rows, inner, outer);
-    const double fx0 = (cols - 1) / (double)inner[2], fy0 = (rows - 1) / (double)inner[3];
-    const double cx0 = -fx0 * inner[0], cy0 = -fy0 * inner[1];
-    const double fx1 = (cols - 1) / (double)outer[2], fy1 = (rows - 1) / (double)outer[3];
-    const double cx1 = -fx1 * outer[0], cy1 = -fy1 * outer[1];
-    const double alpha = 0.0;
-    const double P[4] = {fx0 * (1 - alpha) + fx1 * alpha, fy0 * (1 - alpha) + fy1 * alpha, cx0 * (1 - alpha) + cx1 * alpha, cy0 * (1 - alpha) + cy1 * alpha};
-    {
-        float in2[4], out2[4];
-        get_rectangles(c, P, cols, rows, in2, out2);
-        // cv::Rect r = inner (Rect_<float> -> Rect: members rounded); r &= Rect(0, 0, w, h)
-        int rx = round_sat(in2[0]), ry = round_sat(in2[1]), rw = round_sat(in2[2]), rh = round_sat(in2[3]);
-        const int x1 = std::max(rx, 0), y1 = std::max(ry, 0), x2 = std::min(rx + rw, cols), y2 = std::min(ry + rh, rows);
-        view_xywh[0] = x1; view_xywh[1] = y1; view_xywh[2] = std::max(x2 - x1, 0); view_xywh[3] = std::max(y2 - y1, 0);
-        if (view_xywh[2] <= 0 || view_xywh[3] <= 0) { view_xywh[0] = view_xywh[1] = view_xywh[2] = view_xywh[3] = 0; }
-    }
+    double P[4];
+    optimal_matrix(c, rows, cols, P, view_xywh);
     // initUndistortRectifyMap(K, D, R = I, newK = P, size, CV_32FC2): ir = inverse(newK)
     const double ir[9] = {1. / P[0], 0, -P[2] / P[0], 0, 1. / P[1], -P[3] / P[1], 0, 0, 1};
     // WarpMesh::set_to(map, false, false): offsets = map - identity grid, then * (1/cols, 1/rows); crop_in(norm view region);
@@ -118,6 +127,61 @@ int lvko_lens_offset_map(const double params[9], int rows, int cols, float* offs
         }
     }
     return 0;
+}
+
+// ---- fused lens model (this repo's design for BASELINE config 5) ---------------------------
+// The same warp as lvko_lens_offset_map, but evaluated in closed form at a fractional position of the corrected frame so
+// that it can be composed with the stabilizing warp (one resampling instead of the reference chain's two):
+//   F(u, v) = K * distort(P^-1 (u, v)) + crop_in term (u * kxc + vxc, v * kyc + vyc).
+// model[17] = nfx, nfy, ncx, ncy (new camera matrix P), fx, fy, cx, cy, k1, k2, p1, p2, k3, kxc, vxc, kyc, vyc.
+int lvko_lens_model(const double params[9], int rows, int cols, double model[17])
+{
+    if (!params || !model || rows <= 1 || cols <= 1) return -1;
+    const Cam c{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8]};
+    double P[4]; int view[4];
+    optimal_matrix(c, rows, cols, P, view);
+    const float vrx = (float)view[0] / (float)cols, vry = (float)view[1] / (float)rows;
+    const float vrw = (float)view[2] / (float)cols, vrh = (float)view[3] / (float)rows;
+    const float csx = (vrw - 1.0f) / (float)(cols - 1), csy = (vrh - 1.0f) / (float)(rows - 1);
+    model[0] = P[0]; model[1] = P[1]; model[2] = P[2]; model[3] = P[3];
+    for (int i = 0; i < 9; i++) model[4 + i] = params[i];
+    model[13] = (double)csx * cols; model[14] = (double)vrx * cols;
+    model[15] = (double)csy * rows; model[16] = (double)vry * rows;
+    return 0;
+}
+
+// F^-1 for tracked points: a point of the RAW tracking frame (scale sx, sy = frame / tracking resolution) -> the same
+// point of the lens-corrected tracking frame, binary64: two passes of {remove the crop_in term, 5 undistortPoints
+// iterations, apply P}.  out may alias pts.
+void lvko_lens_undistort_points(const double model[17], double sx, double sy, const float* pts, int n, float* out)
+{
+    const double nfx = model[0], nfy = model[1], ncx = model[2], ncy = model[3];
+    const double fx = model[4], fy = model[5], cx = model[6], cy = model[7];
+    const double k1 = model[8], k2 = model[9], p1 = model[10], p2 = model[11], k3 = model[12];
+    const double kxc = model[13], vxc = model[14], kyc = model[15], vyc = model[16];
+    for (int i = 0; i < n; i++)
+    {
+        const double s = (double)pts[2 * i] * sx, t = (double)pts[2 * i + 1] * sy;
+        double u = s, v = t;
+        for (int pass = 0; pass < 2; pass++)
+        {
+            const double s1 = s - (u * kxc + vxc), t1 = t - (v * kyc + vyc);
+            const double x0 = (s1 - cx) / fx, y0 = (t1 - cy) / fy;
+            double x = x0, y = y0;
+            for (int j = 0; j < 5; j++)
+            {
+                const double r2 = x * x + y * y;
+                const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+                if (icdist < 0) { x = x0; y = y0; break; }
+                const double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+                const double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+                x = (x0 - dX) * icdist;
+                y = (y0 - dY) * icdist;
+            }
+            u = x * nfx + ncx; v = y * nfy + ncy;
+        }
+        out[2 * i] = (float)(u / sx); out[2 * i + 1] = (float)(v / sy);
+    }
 }
 
 } // extern "C"

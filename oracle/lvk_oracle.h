@@ -146,6 +146,7 @@ lvko_stab* lvko_stab_create(const lvko_stab_settings* settings);
 void lvko_stab_destroy(lvko_stab* st);
 void lvko_stab_configure(lvko_stab* st, const lvko_stab_settings* settings);
 void lvko_stab_restart(lvko_stab* st);
+void lvko_stab_set_lens(lvko_stab* st, const double* params /* 9 doubles or NULL; fused lens mode, restarts */);
 int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts,
                    uint8_t* out, int out_step, uint64_t* out_ts, int nthreads);
 void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* out);
@@ -184,6 +185,14 @@ int lvko_egress_yuv420(const uint8_t* src, int src_step, int rows, int cols,
 int lvko_lens_offset_map(const double params[9], int rows, int cols, float* offsets, int view_xywh[4]);
 int lvko_remap_map(const uint8_t* src, int src_step, int src_rows, int src_cols, uint8_t* dst, int dst_step,
                    const float* offsets /* rows x cols x 2, pixels */, const uint8_t bg[3], int yuv, int nthreads);
+
+/* Fused lens mode (this repo's design for BASELINE config 5: one resampling instead of the reference chain's two).
+ * model[17] = nfx, nfy, ncx, ncy, fx, fy, cx, cy, k1, k2, p1, p2, k3, kxc, vxc, kyc, vyc. */
+int lvko_lens_model(const double params[9], int rows, int cols, double model[17]);
+void lvko_lens_undistort_points(const double model[17], double sx, double sy, const float* pts, int n, float* out);
+int lvko_warpmesh_apply_lens(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step,
+                             const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                             int yuv, int nthreads, const double* model /* NULL = no lens */);
 
 #ifdef __cplusplus
 }

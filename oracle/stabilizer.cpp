@@ -275,6 +275,8 @@ struct Tracker
     }
 
     // returns true and fills `motion` when a motion estimate exists (std::optional<WarpMesh>)
+    const double* lens_model = nullptr;        // fused lens mode: estimate motion between lens-corrected point positions
+
     bool track(const uint8_t* frame, int step, int pix_stride, int rows, int cols, Mesh& motion)     // :108-196
     {
         stability = 0.0f;
@@ -295,6 +297,21 @@ struct Tracker
         lvko_pyrlk(prev.data(), prev_w, cur.data(), cur_w, cur_h, cur_w, tracked_pts.data(), n, matched_pts.data(), match_status.data(),
                    11, 11, 3, 5, 0.01, 1e-4);                       // :33-35,42-48
 
+        // fused lens mode: the motion is estimated between lens-corrected positions; a match whose corrected positions leave the
+        // tracking region is not visible in the corrected frame (the reference chain LC -> VS could not have tracked it): drop it
+        std::vector<float> und_t, und_m;
+        if (lens_model)
+        {
+            const double sx = (double)cols / (double)cur_w, sy = (double)rows / (double)cur_h;
+            und_t.resize((size_t)n * 2); und_m.resize((size_t)n * 2);
+            lvko_lens_undistort_points(lens_model, sx, sy, tracked_pts.data(), n, und_t.data());
+            lvko_lens_undistort_points(lens_model, sx, sy, matched_pts.data(), n, und_m.data());
+            const float w = (float)cur_w, h = (float)cur_h;
+            auto inside = [&](const float* p) { return p[0] >= 0.0f && p[0] < w && p[1] >= 0.0f && p[1] < h; };
+            for (int k = 0; k < n; k++)
+                if (!(inside(&und_t[2 * k]) && inside(&und_m[2 * k]))) match_status[k] = 0;
+        }
+
         // fast_filter(features, tracked, matched, status): back-to-front swap-erase (Container.tpp:97-121)
         {
             size_t m = (size_t)n;
@@ -305,8 +322,14 @@ struct Tracker
                     std::swap(tracked[k], tracked[m]);
                     std::swap(tracked_pts[2 * k], tracked_pts[2 * m]); std::swap(tracked_pts[2 * k + 1], tracked_pts[2 * m + 1]);
                     std::swap(matched_pts[2 * k], matched_pts[2 * m]); std::swap(matched_pts[2 * k + 1], matched_pts[2 * m + 1]);
+                    if (lens_model)
+                    {
+                        std::swap(und_t[2 * k], und_t[2 * m]); std::swap(und_t[2 * k + 1], und_t[2 * m + 1]);
+                        std::swap(und_m[2 * k], und_m[2 * m]); std::swap(und_m[2 * k + 1], und_m[2 * m + 1]);
+                    }
                 }
             tracked.resize(m); tracked_pts.resize(m * 2); matched_pts.resize(m * 2);
+            if (lens_model) { und_t.resize(m * 2); und_m.resize(m * 2); }
         }
         const int m = (int)tracked.size();
         last_matched = m;
@@ -314,6 +337,8 @@ struct Tracker
 
         motion = Mesh(s.motion_height, s.motion_width);
         inlier_status.assign(m, 0);
+        const std::vector<float> raw_matched = matched_pts;                      // propagation stays in raw coordinates
+        if (lens_model) { tracked_pts = und_t; matched_pts = und_m; }
         if (s.track_local_motions)
         {
             if (lvko_mesh_solver_solve(solver, tracked_pts.data(), matched_pts.data(), m, (float)cur_w, (float)cur_h,
@@ -334,7 +359,7 @@ struct Tracker
 
         for (int i = m - 1; i >= 0; i--)                            // :183-192
         {
-            if (inlier_status[i]) { tracked[i].class_id++; tracked[i].x = matched_pts[2 * i]; tracked[i].y = matched_pts[2 * i + 1]; }
+            if (inlier_status[i]) { tracked[i].class_id++; tracked[i].x = raw_matched[2 * i]; tracked[i].y = raw_matched[2 * i + 1]; }
             else { std::swap(tracked[i], tracked.back()); tracked.pop_back(); }
         }
         det.propagate(tracked);
@@ -437,6 +462,16 @@ struct lvko_stab
     size_t queue_capacity = 1;
     float scene_quality = 0.0f, trust = 0.0f;
     Mesh last_motion, last_correction;
+    bool lens = false;                                              // fused lens mode (lvko_stab_set_lens)
+    double lens_params[9] = {}, lens_model[17] = {};
+    int lens_rows = 0, lens_cols = 0;
+
+    const double* model_for(int rows, int cols)
+    {
+        if (!lens) return nullptr;
+        if (rows != lens_rows || cols != lens_cols) { lvko_lens_model(lens_params, rows, cols, lens_model); lens_rows = rows; lens_cols = cols; }
+        return lens_model;
+    }
 
     void reset_context() { tracker.restart(); smoother.restart(); }             // StabilizationFilter.cpp:155-159
 
@@ -479,6 +514,16 @@ void lvko_stab_destroy(lvko_stab* st) { delete st; }
 
 void lvko_stab_configure(lvko_stab* st, const lvko_stab_settings* settings) { st->configure(*settings); }
 
+// Fused lens mode (this repo's design, BASELINE config 5): params = camera profile or NULL (off).  Restarts the filter.
+void lvko_stab_restart(lvko_stab* st);
+void lvko_stab_set_lens(lvko_stab* st, const double* params)
+{
+    st->lens = params != nullptr;
+    if (params) std::memcpy(st->lens_params, params, sizeof(st->lens_params));
+    st->lens_rows = st->lens_cols = 0;
+    lvko_stab_restart(st);
+}
+
 void lvko_stab_restart(lvko_stab* st)                               // StabilizationFilter::restart :139-144
 {
     st->scene_quality = 1.0f;
@@ -502,10 +547,12 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
         st->queue.push_back(std::move(qf));
         if (st->queue.size() != st->queue_capacity) return 0;
         lvko_stab::QFrame f = std::move(st->queue.front()); st->queue.pop_front();
-        if (st->s.crop_to_stable_region)
+        if (st->s.crop_to_stable_region || st->lens)
         {
-            const Mesh& m = st->smoother.scene_crop;
-            lvko_warpmesh_apply(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, m.v.data(), m.rows, m.cols, bg, 1, nthreads);
+            const Mesh ident(2, 2);
+            const Mesh& m = st->s.crop_to_stable_region ? st->smoother.scene_crop : ident;
+            lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, m.v.data(), m.rows, m.cols, bg, 1, nthreads,
+                                     st->model_for(f.rows, f.cols));
         }
         else for (int y = 0; y < f.rows; y++) std::memcpy(out + (size_t)y * out_step, &f.px[(size_t)y * f.cols * 3], (size_t)f.cols * 3);
         if (out_ts) *out_ts = f.ts;
@@ -514,6 +561,7 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
 
     Mesh motion(st->s.motion_height, st->s.motion_width);           // m_NullMotion
     Mesh tracked_motion;
+    st->tracker.lens_model = st->model_for(rows, cols);
     if (st->tracker.track(frame, step, 3, rows, cols, tracked_motion)) motion = tracked_motion;
 
     // quality assurance (:101-115); exp_moving_average / step from Functions/Math.tpp:133-142,198-204
@@ -533,7 +581,8 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
     lvko_stab::QFrame f = std::move(st->queue.front()); st->queue.pop_front();
     if (st->s.crop_to_stable_region) correction.add(st->smoother.scene_crop);
     st->last_correction = correction;
-    lvko_warpmesh_apply(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, correction.v.data(), correction.rows, correction.cols, bg, 1, nthreads);
+    lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, correction.v.data(), correction.rows, correction.cols, bg, 1, nthreads,
+                             st->model_for(f.rows, f.cols));
     if (out_ts) *out_ts = f.ts;
     return 1;
 }

@@ -181,6 +181,33 @@ class Oracle:
         assert fn(_p(pr, _f64p), rows, cols, _p(off, _f32p), _p(view, _c.POINTER(_c.c_int32))) == 0
         return off, tuple(int(v) for v in view)
 
+    def lens_model(self, params, rows, cols):
+        pr = np.ascontiguousarray(params, np.float64).reshape(9); m = np.zeros(17, np.float64)
+        fn = self.lib.lvko_lens_model
+        fn.restype = _c.c_int; fn.argtypes = [_f64p, _c.c_int, _c.c_int, _f64p]
+        assert fn(_p(pr, _f64p), rows, cols, _p(m, _f64p)) == 0
+        return m
+
+    def lens_undistort_points(self, params, rows, cols, sx, sy, pts):
+        m = self.lens_model(params, rows, cols)
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2); out = np.zeros_like(p)
+        fn = self.lib.lvko_lens_undistort_points
+        fn.restype = None; fn.argtypes = [_f64p, _c.c_double, _c.c_double, _f32p, _c.c_int, _f32p]
+        fn(_p(m, _f64p), float(sx), float(sy), _p(p, _f32p), len(p), _p(out, _f32p))
+        return out
+
+    def warpmesh_apply_lens(self, src, mesh, params, bg=(255, 0, 255), yuv=True, nthreads=8):
+        src = np.ascontiguousarray(src, np.uint8); mesh = np.ascontiguousarray(mesh, np.float32)
+        rows, cols = src.shape[:2]
+        m = self.lens_model(params, rows, cols)
+        dst = np.zeros_like(src); bg = np.ascontiguousarray(bg, np.uint8)
+        fn = self.lib.lvko_warpmesh_apply_lens
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int, _f32p, _c.c_int, _c.c_int, _u8p, _c.c_int, _c.c_int, _f64p]
+        assert fn(_p(src, _u8p), src.strides[0], rows, cols, _p(dst, _u8p), dst.strides[0], _p(mesh, _f32p), mesh.shape[0], mesh.shape[1],
+                  _p(bg, _u8p), 1 if yuv else 0, nthreads, _p(m, _f64p)) == 0
+        return dst
+
     def remap_map(self, src, offsets, bg=(255, 0, 255), yuv=True, nthreads=8):
         src = np.ascontiguousarray(src, np.uint8); offsets = np.ascontiguousarray(offsets, np.float32)
         dst = np.zeros_like(src); bg = np.ascontiguousarray(bg, np.uint8)
@@ -342,6 +369,15 @@ class OracleStabilizer:
 
     def restart(self):
         self.L.lvko_stab_restart(self.h)
+
+    def set_lens(self, params):
+        self.L.lvko_stab_set_lens.argtypes = [_c.c_void_p, _f64p]
+        self.L.lvko_stab_set_lens.restype = None
+        if params is None:
+            self.L.lvko_stab_set_lens(self.h, None)
+        else:
+            pr = np.ascontiguousarray(params, np.float64).reshape(9)
+            self.L.lvko_stab_set_lens(self.h, _p(pr, _f64p))
 
     def push(self, frame, ts=0, nthreads=8):
         frame = np.ascontiguousarray(frame, np.uint8)

@@ -81,3 +81,24 @@ def make_clip(rows, cols, nframes, seed=0x4C564B31, jitter=1.0):
         for ch in range(3):
             frames[i, ..., ch] = np.clip(np.rint(ndimage.affine_transform(canvas[..., ch], A, offset=off, output_shape=(rows, cols), order=1, mode="nearest")), 0, 255)
     return frames, path
+
+
+def lens_distort(frames, corrected_xy):
+    """Render what a distorting camera would have recorded: raw(s, t) = ideal(F^-1(s, t)) (bilinear), where
+    corrected_xy [rows, cols, 2] holds F^-1 of every raw pixel (e.g. Oracle.lens_undistort_points of the pixel grid)."""
+    from scipy import ndimage
+    frames = np.asarray(frames)
+    single = frames.ndim == 3
+    fr = frames[None] if single else frames
+    out = np.empty_like(fr)
+    coords = np.stack([corrected_xy[..., 1], corrected_xy[..., 0]]).astype(np.float64)
+    for i in range(len(fr)):
+        for ch in range(3):
+            out[i, ..., ch] = np.clip(np.rint(ndimage.map_coordinates(fr[i, ..., ch].astype(np.float32), coords, order=1, mode="nearest")), 0, 255)
+    return out[0] if single else out
+
+
+def psnr(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float(np.mean(d * d))
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)

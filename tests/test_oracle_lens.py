@@ -91,3 +91,105 @@ def test_remap_map_matches_mesh_path_on_its_materialised_map(oracle):
     mesh = synth.random_mesh(5, 7, rng)
     m = oracle.mesh_to_map(mesh, rows, cols)
     assert np.array_equal(oracle.remap_map(src, m), oracle.remap_mesh(src, mesh))
+
+
+# ---- fused lens mode (closed-form map composed with the stabilizing warp; this repo's design for BASELINE config 5) ----------
+LENS = lambda r, c: (0.8 * c, 0.8 * c, c / 2, r / 2, -0.12, 0.03, 0, 0, 0)
+
+
+def _grid(rows, cols):
+    jj, ii = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
+    return np.stack([jj, ii], axis=2)
+
+
+def test_undistort_points_inverts_the_offset_map(oracle):
+    rows, cols = 135, 240
+    for params in [LENS(rows, cols), (0.9 * cols, 0.85 * cols, cols / 2 + 3, rows / 2 - 2, -0.2, 0.05, 1e-3, -2e-3, 0.01)]:
+        off, _ = oracle.lens_offset_map(params, rows, cols)
+        g = _grid(rows, cols)
+        raw = (g + off).reshape(-1, 2)                      # F(corrected pixel) by the reference-restated map
+        back = oracle.lens_undistort_points(params, rows, cols, 1.0, 1.0, raw).reshape(rows, cols, 2)
+        assert np.abs(back - g).max() < 5e-3
+        # tracking-resolution points: scale, invert, scale back
+        half = oracle.lens_undistort_points(params, rows, cols, 2.0, 2.0, raw / 2).reshape(rows, cols, 2)
+        assert np.abs(half * 2 - g).max() < 5e-3
+
+
+def test_fused_identity_equals_map_remap_up_to_coordinate_rounding(oracle):
+    """Identity stabilizing warp: the closed-form binary32 coordinate and the binary64-built offset map differ by ~1e-4 px,
+    so the two EASU renders agree except for isolated +-few-LSB pixels."""
+    rows, cols = 135, 240
+    src = synth.textured_frame(rows, cols, seed=3)
+    params = LENS(rows, cols)
+    off, _ = oracle.lens_offset_map(params, rows, cols)
+    a = oracle.remap_map(src, off, bg=(0, 0, 0))
+    b = oracle.warpmesh_apply_lens(src, np.zeros((2, 2, 2), np.float32), params, bg=(0, 0, 0))
+    assert synth.psnr(a, b) > 55.0
+    assert np.mean(a != b) < 0.02
+
+
+def test_fused_chain_beats_two_pass_against_the_ideal_render(oracle):
+    """raw = ideal seen through the lens.  Reference chain: raw -LC-> corrected -warp-> out (two EASU resamplings).
+    Fused: raw -> out in one.  Both are compared with the warp applied to the ideal frame itself."""
+    rows, cols = 180, 320
+    ideal = synth.textured_frame(rows, cols, seed=8)
+    params = LENS(rows, cols)
+    corrected_of_raw = oracle.lens_undistort_points(params, rows, cols, 1.0, 1.0, _grid(rows, cols).reshape(-1, 2)).reshape(rows, cols, 2)
+    raw = synth.lens_distort(ideal, corrected_of_raw)
+    off, _ = oracle.lens_offset_map(params, rows, cols)
+    rng = np.random.default_rng(3)
+    for mesh in (rng.uniform(-0.01, 0.01, (2, 2, 2)).astype(np.float32), synth.random_mesh(9, 9, rng, amp=0.006)):
+        want = oracle.warpmesh_apply(ideal, mesh, bg=(0, 0, 0))
+        two = oracle.warpmesh_apply(oracle.remap_map(raw, off, bg=(0, 0, 0)), mesh, bg=(0, 0, 0))
+        one = oracle.warpmesh_apply_lens(raw, mesh, params, bg=(0, 0, 0))
+        m = 12                                                  # ignore the border band / background
+        p_two = synth.psnr(two[m:-m, m:-m], want[m:-m, m:-m]); p_one = synth.psnr(one[m:-m, m:-m], want[m:-m, m:-m])
+        assert synth.psnr(one[m:-m, m:-m], two[m:-m, m:-m]) > 28.0      # same picture
+        assert p_one >= p_two - 0.1, (p_one, p_two)             # BASELINE: within 0.1 dB of the reference chain (it is better)
+
+
+def test_fused_stabilizer_tracks_like_the_two_pass_chain(oracle):
+    """End to end on a lens-distorted shaky clip: the fused filter's per-frame motion meshes stay close to those of the
+    reference chain (LC remap, then the plain filter), and its output is the same picture."""
+    from tests import oracle_lib
+    rows, cols, n = 180, 320, 12
+    frames, _ = synth.make_clip(rows, cols, n, seed=5)
+    params = LENS(rows, cols)
+    corrected_of_raw = oracle.lens_undistort_points(params, rows, cols, 1.0, 1.0, _grid(rows, cols).reshape(-1, 2)).reshape(rows, cols, 2)
+    raw = synth.lens_distort(frames, corrected_of_raw)
+    off, _ = oracle.lens_offset_map(params, rows, cols)
+    s = oracle_lib.preset("homography", predictive_samples=3)
+    two = oracle_lib.OracleStabilizer(oracle, s); one = oracle_lib.OracleStabilizer(oracle, s)
+    one.set_lens(params)
+    produced = 0
+    for i in range(n):
+        a, _ = two.push(oracle.remap_map(raw[i], off, bg=(0, 0, 0)), ts=i)
+        b, _ = one.push(raw[i], ts=i)
+        assert (a is None) == (b is None)
+        ma, _ = two.meshes(); mb, _ = one.meshes()
+        assert np.abs(ma - mb).max() < 2e-3, i                  # normalised offsets: < 0.7 px at this width
+        if a is not None:
+            produced += 1
+            assert synth.psnr(a[16:-16, 16:-16], b[16:-16, 16:-16]) > 27.0, i
+    assert produced == n - 3
+    two.close(); one.close()
+
+
+def test_fused_field_preset_converges(oracle):
+    """Lens-corrected positions of border features leave the tracking region; they must be dropped (not handed to the mesh
+    solver, which rejects the whole frame for an out-of-grid sample)."""
+    from tests import oracle_lib
+    rows, cols, n = 270, 480, 10
+    frames, _ = synth.make_clip(rows, cols, n, seed=6)
+    params = LENS(rows, cols)
+    cr = oracle.lens_undistort_points(params, rows, cols, 1.0, 1.0, _grid(rows, cols).reshape(-1, 2)).reshape(rows, cols, 2)
+    raw = synth.lens_distort(frames, cr)
+    st = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default"))
+    st.configure(oracle_lib.preset("field", predictive_samples=3))
+    st.set_lens(params)
+    stab = []
+    for i in range(n):
+        st.push(raw[i], ts=i)
+        stab.append(st.stats().tracking_stability)
+    st.close()
+    assert min(stab[4:]) > 0.8, stab
