@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblvk_hip.so")
+LIB_PATH = os.environ.get("LVK_HIP_LIB") or os.path.join(_HERE, "liblvk_hip.so")      # override: kernel-variant experiments only
 
 # every symbol include/lvk_hip.h declares: (name, restype, argtypes)
 _c = ctypes

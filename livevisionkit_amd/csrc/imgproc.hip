@@ -26,6 +26,15 @@ __device__ __forceinline__ uint8_t sat_u8_rint(float v)
     return (uint8_t)(int)__builtin_fminf(__builtin_fmaxf(r, 0.0f), 255.0f);
 }
 
+// gray value of one source pixel: channel >= 0 extracts it (YUV: channel 0, VideoFrame.cpp:260); -1 / -2 = cv::cvtColor
+// BGR2GRAY / RGB2GRAY (VideoFrame.cpp:194; OpenCV 4.8 RGB2Gray<uchar>, 15-bit fixed point, round to nearest)
+__device__ __forceinline__ int gray_of(const uint8_t* __restrict__ p, int channel)
+{
+    if (channel >= 0) return p[channel];
+    const int b = channel == -1 ? p[0] : p[2], g = p[1], r = channel == -1 ? p[2] : p[0];
+    return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15;
+}
+
 // ---- INTER_AREA, integer scale (resizeAreaFast_): box sum * (1.f/area), round half to even; 2x2 -> (s+2)>>2 ----
 __global__ __launch_bounds__(256)
 void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
@@ -34,11 +43,11 @@ void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, 
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= dcols || y >= drows) return;
-    const uint8_t* p = src + (long)(y * sy) * src_step + (long)(x * sx) * pix_stride + channel;
+    const uint8_t* p = src + (long)(y * sy) * src_step + (long)(x * sx) * pix_stride;
     int sum = 0;
     for (int ky = 0; ky < sy; ky++, p += src_step)
         for (int kx = 0; kx < sx; kx++)
-            sum += p[kx * pix_stride];
+            sum += gray_of(p + kx * pix_stride, channel);
     uint8_t out;
     if (sx == 2 && sy == 2) out = (uint8_t)((sum + 2) >> 2);
     else out = sat_u8_rint((float)sum * (1.f / (float)(sx * sy)));
@@ -49,7 +58,7 @@ void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, 
 // source row segment of a destination pixel is SX * PIX contiguous bytes = whole aligned dwords, so the SY * SX * PIX / 4
 // loads of a thread are independent and issued back to back (the generic kernel's byte loads in a runtime-bound loop
 // serialise on memory latency: rocprofv3 showed 88 % of its wave time in s_waitcnt).
-template <int SX, int SY, int PIX>
+template <int SX, int SY, int PIX, int MODE = 0>          // MODE 0: channel 0; 1: BGR -> gray; 2: RGB -> gray (PIX == 3)
 __global__ __launch_bounds__(256)
 void k_area_fast_dw(const uint8_t* __restrict__ src, int src_step, uint8_t* __restrict__ dst, int dst_step, int drows, int dcols)
 {
@@ -73,7 +82,15 @@ void k_area_fast_dw(const uint8_t* __restrict__ src, int src_step, uint8_t* __re
         {
             constexpr int dummy = 0; (void)dummy;
             const int b = kx * PIX;                       // byte of channel 0 of source pixel kx inside the segment
-            sum += (int)((w[ky][b >> 2] >> ((b & 3) * 8)) & 0xffu);
+            const int c0 = (int)((w[ky][b >> 2] >> ((b & 3) * 8)) & 0xffu);
+            if (MODE == 0) sum += c0;
+            else
+            {
+                const int c1 = (int)((w[ky][(b + 1) >> 2] >> (((b + 1) & 3) * 8)) & 0xffu);
+                const int c2 = (int)((w[ky][(b + 2) >> 2] >> (((b + 2) & 3) * 8)) & 0xffu);
+                const int bl = MODE == 1 ? c0 : c2, rd = MODE == 1 ? c2 : c0;
+                sum += (bl * 3735 + c1 * 19235 + rd * 9798 + (1 << 14)) >> 15;
+            }
         }
     uint8_t out;
     if (SX == 2 && SY == 2) out = (uint8_t)((sum + 2) >> 2);
@@ -95,10 +112,10 @@ void k_area_general(const uint8_t* __restrict__ src, int src_step, int pix_strid
     float sum = 0.0f;
     for (int j = yr.x; j < yr.x + yr.y; j++)
     {
-        const uint8_t* row = src + (long)ytab[j].si * src_step + channel;
+        const uint8_t* row = src + (long)ytab[j].si * src_step;
         float buf = 0.0f;
         for (int k = xr.x; k < xr.x + xr.y; k++)
-            buf = buf + (float)row[(long)xtab[k].si * pix_stride] * xtab[k].alpha;
+            buf = buf + (float)gray_of(row + (long)xtab[k].si * pix_stride, channel) * xtab[k].alpha;
         sum = sum + ytab[j].alpha * buf;
     }
     dst[(long)y * dst_step + x] = sat_u8_rint(sum);
@@ -295,13 +312,23 @@ int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_ste
                                 int srows, int scols, void* d_dst, int dst_step, int drows, int dcols)
 {
     LVK_HIP_REQUIRE(ctx, d_src && d_dst && srows > 0 && scols > 0 && drows > 0 && dcols > 0);
-    LVK_HIP_REQUIRE(ctx, pix_stride >= 1 && channel >= 0 && channel < pix_stride);
+    LVK_HIP_REQUIRE(ctx, pix_stride >= 1 && channel >= -2 && channel < pix_stride && (channel >= 0 || pix_stride >= 3));
     LVK_HIP_REQUIRE(ctx, drows <= srows && dcols <= scols);          // the tracker only downscales (FrameTracker.cpp:117)
     const dim3 block(64, 4), grid((dcols + 63) / 64, (drows + 3) / 4);
     const int isx = scols / dcols, isy = srows / drows;
     const bool exact = scols % dcols == 0 && srows % drows == 0;
-    const bool dw_ok = exact && channel == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && (src_step & 3) == 0;
-    if (dw_ok && isx == 8 && isy == 8 && pix_stride == 3)
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && (src_step & 3) == 0;
+    const bool dw_ok = exact && channel == 0 && aligned;
+    const bool dw_rgb = exact && channel < 0 && aligned && pix_stride == 3;
+    if (dw_rgb && isx == 8 && isy == 8 && channel == -1)
+        hipLaunchKernelGGL((k_area_fast_dw<8, 8, 3, 1>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_rgb && isx == 8 && isy == 8)
+        hipLaunchKernelGGL((k_area_fast_dw<8, 8, 3, 2>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_rgb && isx == 4 && isy == 4 && channel == -1)
+        hipLaunchKernelGGL((k_area_fast_dw<4, 4, 3, 1>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_rgb && isx == 4 && isy == 4)
+        hipLaunchKernelGGL((k_area_fast_dw<4, 4, 3, 2>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
+    else if (dw_ok && isx == 8 && isy == 8 && pix_stride == 3)
         hipLaunchKernelGGL((k_area_fast_dw<8, 8, 3>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);
     else if (dw_ok && isx == 4 && isy == 4 && pix_stride == 3)
         hipLaunchKernelGGL((k_area_fast_dw<4, 4, 3>), grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, (uint8_t*)d_dst, dst_step, drows, dcols);

@@ -274,7 +274,10 @@ struct LensCoord
 // measured on MI355X at 4K and rejected: (a) staging the source window in LDS as pre-converted float4 (saves the
 // 72 unpack + 24 luma ops per pixel but needs 4 block barriers and 31-36 KB LDS -> 4 waves/SIMD: 126 us), and
 // (b) two pixels per lane on packed v_pk_fma/mul/add_f32 (those issue at half rate on gfx950, scripts/valu_peak.hip:
-// 126 us).  The barrier-free gather below keeps 5 waves/SIMD resident and runs at 108 us.
+// 126 us), (c) hoisting the tap gathers of all 4 (or 2) pixels of a thread ahead of the arithmetic so that one memory round
+// trip is exposed per thread instead of four (113 VGPRs, 4 waves/SIMD: 114-117 us; forcing 5-6 waves spills: 125-159 us).
+// None of load batching, occupancy or LDS staging moves the time: the kernel runs at the rate its ~500 VALU
+// instructions per pixel issue.  The barrier-free gather below keeps 5 waves/SIMD resident and runs at 108 us.
 //
 // A thread produces PXT horizontally adjacent output pixels so that the packed 3-byte pixels leave as three aligned
 // dwords; a 256-thread block covers a 256 x 4 strip.  Strips are handed out so that the blocks one XCD receives

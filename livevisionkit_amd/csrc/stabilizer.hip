@@ -34,7 +34,7 @@ inline float step_toward(float current, float target, float amount)   // Functio
     return current > target ? std::max(current - amount, target) : std::min(current + amount, target);
 }
 
-struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; };
+struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; int format; };
 
 } // namespace
 
@@ -116,7 +116,7 @@ struct lvk_hip_stab
     int configure(const lvk_stab_settings& st);
     void tracker_restart();
     void reset_context() { tracker_restart(); smoother.restart(); }
-    int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, WarpMeshF& motion, bool& have_motion);
+    int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion);
 
     // ---- YUV420 front/back end: pool of packed frames the planes are converted into
     std::vector<void*> pool_all, pool_free;
@@ -285,7 +285,7 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
 }
 
 // FrameTracker::track (FrameTracker.cpp:108-196)
-int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, WarpMeshF& motion, bool& have_motion)
+int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion)
 {
     have_motion = false;
     tracking_stability = 0.0f;
@@ -299,7 +299,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     DevicePyramid& C = pyr[cur];
     DevicePyramid& P = pyr[cur ^ 1];
     int pe = prof_begin(LVK_STAGE_DOWNSCALE);
-    if ((rc = lvk_launch_luma_area_resize(ctx, luma, luma_step, luma_pix, 0, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
+    if ((rc = lvk_launch_luma_area_resize(ctx, luma, luma_step, luma_pix, luma_channel, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
     prof_end(pe);
     pe = prof_begin(LVK_STAGE_PYRAMID);
     if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
@@ -554,8 +554,12 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     if (produced) *produced = 0;
     if (released) *released = nullptr;
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
-    LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV);                                       // other VideoFrame formats: SURVEY.md section 8 "next"
-    const QueuedFrame in{d_frame, step, rows, cols, timestamp};
+    // 3-channel VideoFrame formats (VideoFrame.cpp:170-306): YUV tracks channel 0, BGR / RGB track cvtColor(..2GRAY); the remap
+    // runs the YUV or the RGB EASU program by the frame's format (Image.cpp:36-41).  GRAY / 4-channel frames are not on this path.
+    LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
+    const int luma_channel = format == LVK_FORMAT_YUV ? 0 : (format == LVK_FORMAT_BGR ? -1 : -2);
+    LVK_HIP_REQUIRE(ctx, luma_pix == 3 || format == LVK_FORMAT_YUV);
+    const QueuedFrame in{d_frame, step, rows, cols, timestamp, format};
     { const int lrc = st->ensure_lens(rows, cols); if (lrc != LVK_HIP_OK) return lrc; }
     static const WarpMeshF identity_mesh(2, 2);
     const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
@@ -575,8 +579,8 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         hipStream_t rs = side ? st->remap_stream : ctx->stream;
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
-        if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg, 1,
-                                                      st->lens ? &st->lens_args : nullptr);
+        if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
+                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
@@ -612,7 +616,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
 
     WarpMeshF motion(st->s.motion_height, st->s.motion_width);                            // m_NullMotion
     WarpMeshF est; bool have = false;
-    int rc = st->track(in, luma, luma_step, luma_pix, est, have);
+    int rc = st->track(in, luma, luma_step, luma_pix, luma_channel, est, have);
     if (rc != LVK_HIP_OK) return rc;
     if (have) motion = est;
 

@@ -60,13 +60,20 @@ std::vector<AreaTab> area_tab(int ssize, int dsize, double scale)
 
 extern "C" {
 
-// a3 + a4: gray = channel `channel` of a packed frame with `pix_stride` bytes per pixel (3 for 8UC3, 1 for planar),
-// then cv::resize(gray, dst, (dcols, drows), INTER_AREA).
+// a3 + a4: gray = channel `channel` of a packed frame with `pix_stride` bytes per pixel (3 for 8UC3, 1 for planar), or for
+// channel -1 (BGR) / -2 (RGB) cv::cvtColor(COLOR_BGR2GRAY / COLOR_RGB2GRAY) (VideoFrame.cpp:194; OpenCV 4.8 RGB2Gray<uchar>:
+// (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15), then cv::resize(gray, dst, (dcols, drows), INTER_AREA).
 int lvko_luma_area_resize(const uint8_t* src, int src_step, int pix_stride, int channel, int srows, int scols,
                           uint8_t* dst, int dst_step, int drows, int dcols)
 {
     if (!src || !dst || srows <= 0 || scols <= 0 || drows <= 0 || dcols <= 0) return -1;
-    auto S = [&](int y, int x) -> int { return src[(size_t)y * src_step + (size_t)x * pix_stride + channel]; };
+    if (channel < -2 || channel >= pix_stride || (channel < 0 && pix_stride < 3)) return -1;
+    auto S = [&](int y, int x) -> int {
+        const uint8_t* p = src + (size_t)y * src_step + (size_t)x * pix_stride;
+        if (channel >= 0) return p[channel];
+        const int b = channel == -1 ? p[0] : p[2], g = p[1], r = channel == -1 ? p[2] : p[0];
+        return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15;
+    };
     if (drows == srows && dcols == scols)
     {
         for (int y = 0; y < drows; y++) for (int x = 0; x < dcols; x++) dst[(size_t)y * dst_step + x] = (uint8_t)S(y, x);

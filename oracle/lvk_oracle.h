@@ -149,6 +149,9 @@ void lvko_stab_restart(lvko_stab* st);
 void lvko_stab_set_lens(lvko_stab* st, const double* params /* 9 doubles or NULL; fused lens mode, restarts */);
 int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts,
                    uint8_t* out, int out_step, uint64_t* out_ts, int nthreads);
+/* same, for a 3-channel frame of VideoFrame::Format `format` (0 = BGR, 2 = RGB, 4 = YUV) */
+int lvko_stab_push_fmt(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts, int format,
+                       uint8_t* out, int out_step, uint64_t* out_ts, int nthreads);
 void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* out);
 int lvko_stab_get_meshes(const lvko_stab* st, float* motion, float* correction, int cap_floats);
 int lvko_stab_get_features(const lvko_stab* st, float* xy_resp_age, int cap);

@@ -277,13 +277,13 @@ struct Tracker
     // returns true and fills `motion` when a motion estimate exists (std::optional<WarpMesh>)
     const double* lens_model = nullptr;        // fused lens mode: estimate motion between lens-corrected point positions
 
-    bool track(const uint8_t* frame, int step, int pix_stride, int rows, int cols, Mesh& motion)     // :108-196
+    bool track(const uint8_t* frame, int step, int pix_stride, int rows, int cols, Mesh& motion, int luma_channel = 0)     // :108-196
     {
         stability = 0.0f;
         prev.swap(cur); std::swap(prev_w, cur_w); std::swap(prev_h, cur_h);
         cur_w = s.detection_width; cur_h = s.detection_height;
         cur.resize((size_t)cur_w * cur_h);
-        lvko_luma_area_resize(frame, step, pix_stride, 0, rows, cols, cur.data(), cur_w, cur_h, cur_w);
+        lvko_luma_area_resize(frame, step, pix_stride, luma_channel, rows, cols, cur.data(), cur_w, cur_h, cur_w);
         last_detected = last_matched = 0; last_distribution = 0.0f;
         if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return false; }
 
@@ -457,7 +457,7 @@ struct lvko_stab
     bool configured = false;
     Tracker tracker;
     Smoother smoother;
-    struct QFrame { std::vector<uint8_t> px; int rows, cols; uint64_t ts; };
+    struct QFrame { std::vector<uint8_t> px; int rows, cols; uint64_t ts; int format = 4; };
     std::deque<QFrame> queue;                                       // m_FrameQueue (capacity predictive_samples + 1)
     size_t queue_capacity = 1;
     float scene_quality = 0.0f, trust = 0.0f;
@@ -536,8 +536,17 @@ void lvko_stab_restart(lvko_stab* st)                               // Stabiliza
 int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts,
                    uint8_t* out, int out_step, uint64_t* out_ts, int nthreads)
 {
-    if (!st || !frame || rows <= 0 || cols <= 0) return -1;
-    lvko_stab::QFrame qf; qf.rows = rows; qf.cols = cols; qf.ts = ts; qf.px.resize((size_t)rows * cols * 3);
+    return lvko_stab_push_fmt(st, frame, step, rows, cols, ts, 4, out, out_step, out_ts, nthreads);
+}
+
+// format: VideoFrame::Format of the 3-channel frame (0 = BGR, 2 = RGB, 4 = YUV; VideoFrame.hpp) -- selects the tracking luma
+// (VideoFrame.cpp:194,260) and the EASU program (Image.cpp:36-41)
+int lvko_stab_push_fmt(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts, int format,
+                       uint8_t* out, int out_step, uint64_t* out_ts, int nthreads)
+{
+    if (!st || !frame || rows <= 0 || cols <= 0 || !(format == 0 || format == 2 || format == 4)) return -1;
+    const int luma_channel = format == 4 ? 0 : (format == 0 ? -1 : -2);
+    lvko_stab::QFrame qf; qf.rows = rows; qf.cols = cols; qf.ts = ts; qf.format = format; qf.px.resize((size_t)rows * cols * 3);
     for (int y = 0; y < rows; y++) std::memcpy(&qf.px[(size_t)y * cols * 3], frame + (size_t)y * step, (size_t)cols * 3);
     const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
 
@@ -551,7 +560,7 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
         {
             const Mesh ident(2, 2);
             const Mesh& m = st->s.crop_to_stable_region ? st->smoother.scene_crop : ident;
-            lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, m.v.data(), m.rows, m.cols, bg, 1, nthreads,
+            lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, m.v.data(), m.rows, m.cols, bg, f.format == 4 ? 1 : 0, nthreads,
                                      st->model_for(f.rows, f.cols));
         }
         else for (int y = 0; y < f.rows; y++) std::memcpy(out + (size_t)y * out_step, &f.px[(size_t)y * f.cols * 3], (size_t)f.cols * 3);
@@ -562,7 +571,7 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
     Mesh motion(st->s.motion_height, st->s.motion_width);           // m_NullMotion
     Mesh tracked_motion;
     st->tracker.lens_model = st->model_for(rows, cols);
-    if (st->tracker.track(frame, step, 3, rows, cols, tracked_motion)) motion = tracked_motion;
+    if (st->tracker.track(frame, step, 3, rows, cols, tracked_motion, luma_channel)) motion = tracked_motion;
 
     // quality assurance (:101-115); exp_moving_average / step from Functions/Math.tpp:133-142,198-204
     const float tq = st->tracker.stability;
@@ -581,7 +590,7 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
     lvko_stab::QFrame f = std::move(st->queue.front()); st->queue.pop_front();
     if (st->s.crop_to_stable_region) correction.add(st->smoother.scene_crop);
     st->last_correction = correction;
-    lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, correction.v.data(), correction.rows, correction.cols, bg, 1, nthreads,
+    lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, correction.v.data(), correction.rows, correction.cols, bg, f.format == 4 ? 1 : 0, nthreads,
                              st->model_for(f.rows, f.cols));
     if (out_ts) *out_ts = f.ts;
     return 1;

@@ -379,12 +379,15 @@ class OracleStabilizer:
             pr = np.ascontiguousarray(params, np.float64).reshape(9)
             self.L.lvko_stab_set_lens(self.h, _p(pr, _f64p))
 
-    def push(self, frame, ts=0, nthreads=8):
+    def push(self, frame, ts=0, nthreads=8, fmt=4):
         frame = np.ascontiguousarray(frame, np.uint8)
         out = np.zeros_like(frame)
         ots = _c.c_uint64(0)
-        rc = self.L.lvko_stab_push(self.h, _p(frame, _u8p), frame.strides[0], frame.shape[0], frame.shape[1], ts,
-                                   _p(out, _u8p), out.strides[0], _c.byref(ots), nthreads)
+        self.L.lvko_stab_push_fmt.restype = _c.c_int
+        self.L.lvko_stab_push_fmt.argtypes = [_c.c_void_p, _u8p, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _u8p, _c.c_int,
+                                              _c.POINTER(_c.c_uint64), _c.c_int]
+        rc = self.L.lvko_stab_push_fmt(self.h, _p(frame, _u8p), frame.strides[0], frame.shape[0], frame.shape[1], ts, fmt,
+                                       _p(out, _u8p), out.strides[0], _c.byref(ots), nthreads)
         assert rc >= 0
         return (out, ots.value) if rc == 1 else (None, None)
 

@@ -196,3 +196,23 @@ def test_nv12_equals_i420(oracle):
     ya, ua, va = oracle.egress_yuv420(a)
     yb, uvb = oracle.egress_yuv420(a, nv12=True)
     assert np.array_equal(ya, yb) and np.array_equal(ua, uvb[..., 0]) and np.array_equal(va, uvb[..., 1])
+
+
+def test_bgr_and_rgb_gray_known_answers(oracle):
+    """cv::cvtColor(BGR2GRAY / RGB2GRAY) on 8U (OpenCV 4.8 RGB2Gray<uchar>: 15-bit coefficients 3735 / 19235 / 9798, round to
+    nearest): primaries, white, and agreement with the float luma 0.114 B + 0.587 G + 0.299 R to 1 LSB."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 200, 30]]], np.uint8)
+    bgr = oracle.luma_area_resize(px, 1, 6, channel=-1)[0]
+    rgb = oracle.luma_area_resize(px, 1, 6, channel=-2)[0]
+    assert list(bgr[:5]) == [29, 150, 76, 255, 0] and list(rgb[:5]) == [76, 150, 29, 255, 0]
+    assert bgr[5] == (10 * 3735 + 200 * 19235 + 30 * 9798 + 16384) >> 15
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    g = oracle.luma_area_resize(img, 32, 48, channel=-1).astype(np.float64)
+    ref = 0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]
+    assert np.abs(g - ref).max() <= 1.0
+    assert np.array_equal(oracle.luma_area_resize(img[..., ::-1], 32, 48, channel=-2), g.astype(np.uint8))
+    # downscale of the gray image == gray then box average
+    small = oracle.luma_area_resize(img, 8, 12, channel=-1)
+    want = oracle.luma_area_resize(np.ascontiguousarray(g.astype(np.uint8)), 8, 12)
+    assert np.array_equal(small, want)

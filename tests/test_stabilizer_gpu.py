@@ -301,3 +301,33 @@ def test_stabilizer_yuv420_in_out_bit_exact(ctx, oracle, clip, nv12, overlap):
             emitted += 1
     assert emitted == 15
     ost.close(); gst.close()
+
+
+@pytest.mark.parametrize("fmt", [0, 2])
+def test_stabilizer_bgr_rgb_frames_bit_exact(ctx, oracle, clip, fmt):
+    """VideoFrame formats BGR (0) / RGB (2): tracking luma = cvtColor(..2GRAY), remap = the RGB EASU program."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    s = oracle_lib.preset("homography", predictive_samples=3)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    produced = 0
+    for i, f in enumerate(frames[:12]):
+        want, wts = ost.push(f, ts=i, fmt=fmt)
+        got, gts = gst.apply(torch.from_numpy(f).cuda(), timestamp=i, fmt=fmt)
+        ctx.sync()
+        so, sg = ost.stats(), gst.stats()
+        assert (so.n_detected, so.n_matched, so.n_tracked, so.tracking_stability) == (sg.n_detected, sg.n_matched, sg.n_tracked, sg.tracking_stability), i
+        assert (want is None) == (got is None)
+        if want is not None:
+            assert np.array_equal(got.cpu().numpy(), want), i
+            produced += 1
+    assert produced == 9
+    # the formats really differ: the same clip pushed as YUV tracks another luma and resamples with another program
+    ost2 = oracle_lib.OracleStabilizer(oracle, s)
+    outs = [ost2.push(f, ts=i)[0] for i, f in enumerate(frames[:5])]
+    ost3 = oracle_lib.OracleStabilizer(oracle, s)
+    outs_f = [ost3.push(f, ts=i, fmt=fmt)[0] for i, f in enumerate(frames[:5])]
+    assert not np.array_equal(outs[4], outs_f[4])
+    ost.close(); gst.close(); ost2.close(); ost3.close()

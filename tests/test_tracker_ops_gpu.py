@@ -132,3 +132,16 @@ def test_pyrlk_other_geometry(ctx, oracle):
         got_p, got_s = ctx.pyrlk(_gpu(prev), _gpu(nxt), pts, win=win, max_level=lv)
         assert np.array_equal(got_s, want_s), (rows, cols, win)
         assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)), (rows, cols, win)
+
+
+@pytest.mark.parametrize("channel", [-1, -2])
+@pytest.mark.parametrize("src_size,dst_size", [((2160, 3840), (270, 480)), ((1080, 1920), (270, 480)), ((720, 1280), (270, 480)),
+                                                 ((270, 480), (270, 480)), ((90, 130), (45, 65)), ((61, 97), (20, 31))])
+def test_luma_area_resize_bgr_rgb(ctx, oracle, src_size, dst_size, channel):
+    """a3 second half: cvtColor(BGR2GRAY / RGB2GRAY) fused with the INTER_AREA downscale."""
+    rng = np.random.default_rng(src_size[0] + channel)
+    frame = rng.integers(0, 256, (*src_size, 3), dtype=np.uint8)
+    want = oracle.luma_area_resize(frame, *dst_size, channel=channel)
+    got = ctx.luma_area_resize(_gpu(frame), *dst_size, channel=channel)
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
