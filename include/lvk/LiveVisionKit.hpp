@@ -297,8 +297,8 @@ public:
     void restart() { m_Ctx->check(lvk_hip_stab_restart(m_Stab), "restart"); m_Held.clear(); }
     bool ready() const { return lvk_hip_stab_ready(m_Stab) != 0; }
     void reset_context() { m_Ctx->check(lvk_hip_stab_reset_context(m_Stab), "reset_context"); }
-    void draw_trackers() {}       // debug overlays: SURVEY.md section 8f row 4 (not built)
-    void draw_motion_mesh() {}    // "
+    void draw_trackers() { m_Ctx->check(lvk_hip_stab_draw_trackers(m_Stab), "draw_trackers"); }          // StabilizationFilter.cpp:163-175
+    void draw_motion_mesh() { m_Ctx->check(lvk_hip_stab_draw_motion_mesh(m_Stab), "draw_motion_mesh"); }    // StabilizationFilter.cpp:179-188
     size_t frame_delay() const { return (size_t)lvk_hip_stab_frame_delay(m_Stab); }
     cv::Rect stable_region() const
     {

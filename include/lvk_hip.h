@@ -202,6 +202,16 @@ int  lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lv
 void lvk_hip_stab_destroy(lvk_hip_stab* stab);
 int  lvk_hip_stab_configure(lvk_hip_stab* stab, const lvk_stab_settings* settings);
 int  lvk_hip_stab_restart(lvk_hip_stab* stab);            /* :139-144 */
+/* Debug overlays into the newest queued frame, i.e. the caller's borrowed buffer of the last push (StabilizationFilter.cpp:163-188;
+ * kernels Functions/OpenCL/Sources/Drawing.cl:22-39,75-105): crosses at the tracked features coloured lerp(RED, GREEN, trust);
+ * BLUE grid with motion_resolution - 1 cells.  Asynchronous on the context's stream. */
+int  lvk_hip_stab_draw_trackers(lvk_hip_stab* stab);
+int  lvk_hip_stab_draw_motion_mesh(lvk_hip_stab* stab);
+/* lvk::draw_grid / lvk::draw_crosses on a packed 8UC3 device frame (Functions/Drawing.tpp:53-93,146-196); pts_xy = n host (x, y)
+ * floats, scaled by (scale_x, scale_y) and rounded to pixels like cv::multiply(.., CV_32S). */
+int  lvk_hip_draw_grid(lvk_hip_ctx* ctx, void* d_dst, int dst_step, int rows, int cols, int grid_w, int grid_h, const uint8_t colour[3], int thickness);
+int  lvk_hip_draw_crosses(lvk_hip_ctx* ctx, void* d_dst, int dst_step, int rows, int cols, const float* pts_xy, int n,
+                          float scale_x, float scale_y, const uint8_t colour[3], int cross_size, int thickness);
 /* Fused lens pre-warp for the stream this filter stabilizes: frames are pushed RAW (uncorrected); the tracker estimates the
  * motion between lens-corrected feature positions and the output remap composes lens map and stabilizing warp.
  * params = NULL switches it off.  Restarts the filter (queued frames are dropped). */

@@ -257,3 +257,19 @@ class Context:
         fp = ctypes.POINTER(ctypes.c_float)
         self._check(self.lib.lvk_hip_lens_undistort_points(self.handle, arr, rows, cols, float(sx), float(sy), p.ctypes.data_as(fp), len(p), out.ctypes.data_as(fp)))
         return out
+
+    # ---- debug overlays ---------------------------------------------------------------------
+    def draw_grid(self, frame, grid, colour, thickness=1):
+        """lvk::draw_grid(dst, grid = (w, h) cells, colour, thickness): draws into `frame` in place."""
+        ca, cp = _u8x3(colour)
+        self._check(self.lib.lvk_hip_draw_grid(self.handle, frame.data_ptr(), frame.stride(0), frame.shape[0], frame.shape[1], int(grid[0]), int(grid[1]), cp, thickness))
+        return frame
+
+    def draw_crosses(self, frame, points, colour, cross_size, thickness, scaling=(1.0, 1.0)):
+        """lvk::draw_crosses(dst, points, colour, size, thickness, coord_scaling): draws into `frame` in place."""
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        ca, cp = _u8x3(colour)
+        self._check(self.lib.lvk_hip_draw_crosses(self.handle, frame.data_ptr(), frame.stride(0), frame.shape[0], frame.shape[1],
+                                                  p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(p), float(scaling[0]), float(scaling[1]), cp,
+                                                  int(cross_size), int(thickness)))
+        return frame

@@ -138,3 +138,9 @@ int lvk_launch_lens_undistort(lvk_hip_ctx* ctx, hipStream_t stream, const LensMo
 int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                    void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv,
                                    const LensArgs* lens);
+
+// Debug overlays (draw.hip)
+int lvk_launch_draw_grid(lvk_hip_ctx* ctx, hipStream_t stream, void* d_dst, int dst_step, int rows, int cols, int grid_w, int grid_h,
+                         const uint8_t colour[3], int thickness);
+int lvk_launch_draw_crosses(lvk_hip_ctx* ctx, hipStream_t stream, void* d_dst, int dst_step, int rows, int cols, const float* pts, int n,
+                            float scale_x, float scale_y, const uint8_t colour[3], int cross_size, int thickness);

@@ -511,6 +511,46 @@ int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
     return st->configure(*settings);
 }
 
+// lvk::col::{RED, GREEN, BLUE}[format] (Functions/Drawing.hpp:27-71)
+static void overlay_colours(int format, double red[3], double green[3], double blue[3])
+{
+    const double R[3][3] = {{0, 0, 255}, {255, 0, 0}, {76, 84, 255}}, G[3][3] = {{0, 255, 0}, {0, 255, 0}, {149, 43, 21}},
+                 B[3][3] = {{255, 0, 0}, {0, 0, 255}, {29, 255, 107}};
+    const int k = format == LVK_FORMAT_YUV ? 2 : (format == LVK_FORMAT_RGB || format == LVK_FORMAT_RGBA ? 1 : 0);
+    for (int i = 0; i < 3; i++) { red[i] = R[k][i]; green[i] = G[k][i]; blue[i] = B[k][i]; }
+}
+
+// StabilizationFilter::draw_trackers (StabilizationFilter.cpp:163-175): crosses (size 7, thickness 4 -- FrameTracker.cpp:498-503
+// passes a literal 4, not its `thickness` argument) at the tracked features, coloured lerp(RED, GREEN, trust), into the newest
+// queued frame (the caller's borrowed buffer).
+int lvk_hip_stab_draw_trackers(lvk_hip_stab* st)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());                                           // StreamBuffer::newest: !is_empty()
+    const QueuedFrame& f = st->queue.back();
+    double r[3], g[3], b[3];
+    overlay_colours(f.format, r, g, b);
+    uint8_t col[3];
+    for (int i = 0; i < 3; i++) col[i] = (uint8_t)(r[i] + (double)st->trust * (g[i] - r[i]));      // Math.tpp:124-129, Drawing.tpp:184-189
+    std::vector<float> pts(st->tracked.size() * 2);
+    for (size_t i = 0; i < st->tracked.size(); i++) { pts[2 * i] = st->tracked[i].x; pts[2 * i + 1] = st->tracked[i].y; }
+    const float sx = (float)f.cols / (float)st->tracker_s.detection_width, sy = (float)f.rows / (float)st->tracker_s.detection_height;
+    return lvk_launch_draw_crosses(st->ctx, st->ctx->stream, const_cast<void*>(f.d_ptr), f.step, f.rows, f.cols, pts.data(), (int)st->tracked.size(),
+                                   sx, sy, col, 7, 4);
+}
+
+// StabilizationFilter::draw_motion_mesh (:179-188): BLUE grid of motion_resolution - 1 cells, thickness 1
+int lvk_hip_stab_draw_motion_mesh(lvk_hip_stab* st)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());
+    const QueuedFrame& f = st->queue.back();
+    double r[3], g[3], b[3];
+    overlay_colours(f.format, r, g, b);
+    const uint8_t col[3] = {(uint8_t)b[0], (uint8_t)b[1], (uint8_t)b[2]};
+    return lvk_launch_draw_grid(st->ctx, st->ctx->stream, const_cast<void*>(f.d_ptr), f.step, f.rows, f.cols, st->s.motion_width - 1, st->s.motion_height - 1, col, 1);
+}
+
 int lvk_hip_stab_restart(lvk_hip_stab* st);
 int lvk_hip_stab_set_lens(lvk_hip_stab* st, const lvk_camera_params* params)
 {

@@ -202,6 +202,14 @@ class StabilizationFilter:
         n = self.lib.lvk_hip_stab_get_features(self.handle, a.ctypes.data_as(_c.POINTER(_c.c_float)), cap)
         return a[:max(n, 0)].copy()
 
+    def draw_trackers(self):
+        """StabilizationFilter::draw_trackers: crosses at the tracked features, into the frame of the last apply() (in place)."""
+        self.ctx._check(self.lib.lvk_hip_stab_draw_trackers(self.handle))
+
+    def draw_motion_mesh(self):
+        """StabilizationFilter::draw_motion_mesh: the motion-mesh grid, into the frame of the last apply() (in place)."""
+        self.ctx._check(self.lib.lvk_hip_stab_draw_motion_mesh(self.handle))
+
     def set_lens(self, params):
         """Fused lens pre-warp: params = (fx, fy, cx, cy, k1, k2, p1, p2, k3) of the plugin's camera profile
         (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153) or None.  Frames are then pushed RAW; restarts the filter."""

@@ -197,6 +197,14 @@ int lvko_warpmesh_apply_lens(const uint8_t* src, int src_step, int rows, int col
                              const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
                              int yuv, int nthreads, const double* model /* NULL = no lens */);
 
+/* Debug overlays (oracle/draw.cpp; reference Functions/Drawing.tpp:53-93,146-196, Functions/OpenCL/Sources/Drawing.cl:22-39,75-105,
+ * Filters/StabilizationFilter.cpp:163-188): drawn into the newest queued frame. */
+int lvko_draw_grid(uint8_t* dst, int dst_step, int rows, int cols, int grid_w, int grid_h, const uint8_t colour[3], int thickness);
+int lvko_draw_crosses(uint8_t* dst, int dst_step, int rows, int cols, const float* pts, int n, float scale_x, float scale_y,
+                      const uint8_t colour[3], int cross_size, int cross_thickness);
+void lvko_stab_draw_trackers(lvko_stab* st);
+void lvko_stab_draw_motion_mesh(lvko_stab* st);
+
 #ifdef __cplusplus
 }
 #endif

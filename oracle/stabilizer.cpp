@@ -514,6 +514,39 @@ void lvko_stab_destroy(lvko_stab* st) { delete st; }
 
 void lvko_stab_configure(lvko_stab* st, const lvko_stab_settings* settings) { st->configure(*settings); }
 
+// StabilizationFilter::draw_trackers / draw_motion_mesh (StabilizationFilter.cpp:163-188); colours Functions/Drawing.hpp:27-71
+static void overlay_colours(int format, double red[3], double green[3], double blue[3])
+{
+    const double R[3][3] = {{0, 0, 255}, {255, 0, 0}, {76, 84, 255}}, G[3][3] = {{0, 255, 0}, {0, 255, 0}, {149, 43, 21}},
+                 B[3][3] = {{255, 0, 0}, {0, 0, 255}, {29, 255, 107}};
+    const int k = format == 4 ? 2 : (format == 2 || format == 3 ? 1 : 0);
+    for (int i = 0; i < 3; i++) { red[i] = R[k][i]; green[i] = G[k][i]; blue[i] = B[k][i]; }
+}
+
+void lvko_stab_draw_trackers(lvko_stab* st)
+{
+    if (!st || st->queue.empty()) return;
+    lvko_stab::QFrame& f = st->queue.back();
+    double r[3], g[3], b[3];
+    overlay_colours(f.format, r, g, b);
+    uint8_t col[3];
+    for (int i = 0; i < 3; i++) col[i] = (uint8_t)(r[i] + (double)st->trust * (g[i] - r[i]));      // lerp (Math.tpp:124-129), Vec4b cast
+    std::vector<float> pts;
+    for (const KeyPoint& k : st->tracker.tracked) { pts.push_back(k.x); pts.push_back(k.y); }
+    const float sx = (float)f.cols / (float)st->tracker.s.detection_width, sy = (float)f.rows / (float)st->tracker.s.detection_height;
+    lvko_draw_crosses(f.px.data(), f.cols * 3, f.rows, f.cols, pts.data(), (int)(pts.size() / 2), sx, sy, col, 7, 4);    // FrameTracker.cpp:498-503
+}
+
+void lvko_stab_draw_motion_mesh(lvko_stab* st)
+{
+    if (!st || st->queue.empty()) return;
+    lvko_stab::QFrame& f = st->queue.back();
+    double r[3], g[3], b[3];
+    overlay_colours(f.format, r, g, b);
+    const uint8_t col[3] = {(uint8_t)b[0], (uint8_t)b[1], (uint8_t)b[2]};
+    lvko_draw_grid(f.px.data(), f.cols * 3, f.rows, f.cols, st->s.motion_width - 1, st->s.motion_height - 1, col, 1);
+}
+
 // Fused lens mode (this repo's design, BASELINE config 5): params = camera profile or NULL (off).  Restarts the filter.
 void lvko_stab_restart(lvko_stab* st);
 void lvko_stab_set_lens(lvko_stab* st, const double* params)

@@ -181,6 +181,23 @@ class Oracle:
         assert fn(_p(pr, _f64p), rows, cols, _p(off, _f32p), _p(view, _c.POINTER(_c.c_int32))) == 0
         return off, tuple(int(v) for v in view)
 
+    def draw_grid(self, frame, grid, colour, thickness=1):
+        frame = np.ascontiguousarray(frame, np.uint8).copy(); c = np.ascontiguousarray(colour, np.uint8)
+        fn = self.lib.lvko_draw_grid
+        fn.restype = _c.c_int; fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int]
+        assert fn(_p(frame, _u8p), frame.strides[0], frame.shape[0], frame.shape[1], int(grid[0]), int(grid[1]), _p(c, _u8p), thickness) == 0
+        return frame
+
+    def draw_crosses(self, frame, points, colour, cross_size, thickness, scaling=(1.0, 1.0)):
+        frame = np.ascontiguousarray(frame, np.uint8).copy(); c = np.ascontiguousarray(colour, np.uint8)
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        fn = self.lib.lvko_draw_crosses
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_int, _c.c_float, _c.c_float, _u8p, _c.c_int, _c.c_int]
+        assert fn(_p(frame, _u8p), frame.strides[0], frame.shape[0], frame.shape[1], _p(p, _f32p), len(p), scaling[0], scaling[1], _p(c, _u8p),
+                  cross_size, thickness) == 0
+        return frame
+
     def lens_model(self, params, rows, cols):
         pr = np.ascontiguousarray(params, np.float64).reshape(9); m = np.zeros(17, np.float64)
         fn = self.lib.lvko_lens_model
@@ -369,6 +386,14 @@ class OracleStabilizer:
 
     def restart(self):
         self.L.lvko_stab_restart(self.h)
+
+    def draw_trackers(self):
+        self.L.lvko_stab_draw_trackers.argtypes = [_c.c_void_p]; self.L.lvko_stab_draw_trackers.restype = None
+        self.L.lvko_stab_draw_trackers(self.h)
+
+    def draw_motion_mesh(self):
+        self.L.lvko_stab_draw_motion_mesh.argtypes = [_c.c_void_p]; self.L.lvko_stab_draw_motion_mesh.restype = None
+        self.L.lvko_stab_draw_motion_mesh(self.h)
 
     def set_lens(self, params):
         self.L.lvko_stab_set_lens.argtypes = [_c.c_void_p, _f64p]
