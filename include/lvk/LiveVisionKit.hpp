@@ -16,7 +16,13 @@
 #include <cstdlib>
 #include <deque>
 #include <functional>
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <iostream>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -244,6 +250,62 @@ struct StabilizationFilterSettings : public FrameTrackerSettings, public PathSmo
     float min_tracking_quality = 0.3f;
 };
 
+} // namespace lvk
+
+#ifndef LVK_WITH_OPENCV
+// Stand-in for the one cv::VideoCapture use on the path (VideoFilter::stream, Filters/VideoFilter.cpp:62-209): a pull source
+// of frames.  Subclass it (file reader, camera, synthetic generator).
+namespace cv {
+enum { CAP_PROP_POS_MSEC = 0 };
+class VideoCapture
+{
+public:
+    virtual ~VideoCapture() = default;
+    virtual bool isOpened() const = 0;
+    virtual bool read(lvk::VideoFrame& frame) = 0;             // false at the end of the stream
+    virtual double get(int /*prop*/) const { return 0.0; }     // CAP_PROP_POS_MSEC of the frame just read
+};
+} // namespace cv
+#endif
+
+namespace lvk {
+
+namespace detail {
+// bounded hand-off queue between two pipeline stages of VideoFilter::stream
+template <typename T>
+class StageQueue
+{
+public:
+    explicit StageQueue(size_t capacity) : m_Capacity(capacity) {}
+    bool push(T&& v)                                            // false once the consumer has gone away
+    {
+        std::unique_lock<std::mutex> lock(m_Mutex);
+        m_Space.wait(lock, [&] { return m_Items.size() < m_Capacity || m_Abandoned; });
+        if (m_Abandoned) return false;
+        m_Items.push_back(std::move(v));
+        m_Ready.notify_one();
+        return true;
+    }
+    bool pop(T& v)                                              // false when drained and the producer has finished
+    {
+        std::unique_lock<std::mutex> lock(m_Mutex);
+        m_Ready.wait(lock, [&] { return !m_Items.empty() || m_Finished; });
+        if (m_Items.empty()) return false;
+        v = std::move(m_Items.front()); m_Items.pop_front();
+        m_Space.notify_one();
+        return true;
+    }
+    void finish() { std::lock_guard<std::mutex> lock(m_Mutex); m_Finished = true; m_Ready.notify_all(); }
+    void abandon() { std::lock_guard<std::mutex> lock(m_Mutex); m_Abandoned = true; m_Items.clear(); m_Space.notify_all(); }
+private:
+    const size_t m_Capacity;
+    std::mutex m_Mutex;
+    std::condition_variable m_Space, m_Ready;
+    std::deque<T> m_Items;
+    bool m_Finished = false, m_Abandoned = false;
+};
+} // namespace detail
+
 // ---------------------------------------------------------------------------------------------- Filters/VideoFilter.hpp
 class VideoFilter : public Unique<VideoFilter>
 {
@@ -259,6 +321,53 @@ public:
         sync_gpu(profile); m_FrameTimer.stop();
     }
     void apply(const VideoFrame& input, VideoFrame& output, const bool profile = false) { apply(Frame(input), output, profile); }
+
+    // VideoFilter.cpp:62-209: reader thread -> filter thread -> callback on the calling thread, at most 15 frames buffered between
+    // stages; frames the filter holds back (empty output) are skipped; callback returning true ends the stream early.
+    // Each stage works on its own HIP stream (thread-local context), so a frame is completed (stream sync) before it is handed on.
+    void stream(cv::VideoCapture& input, const std::function<bool(Frame&)>& callback, const bool profile = false)
+    {
+        LVK_HIP_ASSERT(input.isOpened());
+        constexpr size_t max_buffer_frames = 15;
+        detail::StageQueue<Frame> input_queue(max_buffer_frames), output_queue(max_buffer_frames);
+
+        std::thread input_thread([&] {
+            Frame read_frame;
+            while (input.read(read_frame))
+            {
+                if (!read_frame.has_known_format()) read_frame.format = VideoFrame::BGR;          // "assume the input frame is BGR"
+                const double stream_position = std::max(0.0, input.get(cv::CAP_PROP_POS_MSEC));
+                if (read_frame.timestamp == 0) read_frame.timestamp = static_cast<uint64_t>(stream_position * 1.0e6);    // ms -> ns
+                if (read_frame.context()) read_frame.context()->check(lvk_hip_sync(read_frame.context()->get()), "VideoFilter::stream");
+                if (!input_queue.push(std::move(read_frame))) break;
+                read_frame = Frame();
+            }
+            input_queue.finish();
+        });
+        std::thread filter_thread([&] {
+            Frame input_frame, filtered_frame;
+            while (input_queue.pop(input_frame))
+            {
+                this->apply(std::move(input_frame), filtered_frame, profile);
+                if (filtered_frame.empty()) continue;
+                sync_gpu(true);                                                                    // complete before it changes threads
+                if (!output_queue.push(std::move(filtered_frame))) break;
+                filtered_frame = Frame();
+            }
+            output_queue.finish();
+        });
+        Frame output_frame;
+        while (output_queue.pop(output_frame))
+            if (callback(output_frame))
+            {
+                // terminated by the user: starve both stages, as the reference does
+                input_queue.abandon();
+                output_queue.abandon();
+                break;
+            }
+        input_thread.join();
+        filter_thread.join();
+    }
     void set_timing_samples(const size_t samples) { LVK_HIP_ASSERT(samples >= 1); m_FrameTimer.set_history_size(samples); }
     const Stopwatch& timings() const { return m_FrameTimer; }
 

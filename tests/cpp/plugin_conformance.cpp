@@ -91,6 +91,47 @@ private:
 int main()
 {
 #ifdef RUN_ON_GPU
+    {
+        // VideoFilter::stream (Filters/VideoFilter.cpp:62-209; CLI use Modules/VideoEditor/VideoProcessor.cpp:148-230): reader thread ->
+        // filter thread -> callback, frames the filter holds back are skipped, callback returning true stops early
+        struct Synthetic : cv::VideoCapture
+        {
+            int n, i = 0, rows = 360, cols = 640;
+            std::vector<uint8_t> host;
+            explicit Synthetic(int count) : n(count), host((size_t)rows * cols * 3) {}
+            bool isOpened() const override { return true; }
+            double get(int) const override { return 10.0 * i; }
+            bool read(lvk::VideoFrame& f) override
+            {
+                if (i >= n) return false;
+                for (int y = 0; y < rows; y++)
+                    for (int x = 0; x < cols; x++)
+                    {
+                        uint8_t* p = &host[((size_t)y * cols + x) * 3];
+                        const int xs = x + (i % 3), ys = y + (i % 2);
+                        p[0] = (uint8_t)((((xs / 12) + (ys / 12)) % 2) ? 210 : 30 + (xs * 5 + ys * 11) % 29); p[1] = 120; p[2] = 140;
+                    }
+                i++;
+                f.upload(host.data(), rows, cols, lvk::VideoFrame::YUV, 0);
+                return true;
+            }
+        };
+        lvk::StabilizationFilterSettings st;
+        st.predictive_samples = 4;
+        lvk::StabilizationFilter filter(st);
+        Synthetic all(20);
+        std::vector<uint64_t> stamps;
+        filter.stream(all, [&](lvk::Frame& out) { stamps.push_back(out.timestamp); return false; });
+        if (stamps.size() != 16) { std::printf("stream: emitted %zu frames, expected 16\n", stamps.size()); return 1; }
+        for (size_t k = 0; k < stamps.size(); k++)
+            if (stamps[k] != (uint64_t)(10.0 * (double)(k + 1) * 1.0e6)) { std::printf("stream: bad timestamp %zu\n", k); return 1; }
+        filter.restart();
+        Synthetic many(200);
+        int seen = 0;
+        filter.stream(many, [&](lvk::Frame&) { return ++seen == 5; });
+        if (seen != 5 || many.i >= 200) { std::printf("stream: early termination failed (%d, %d)\n", seen, many.i); return 1; }
+        std::printf("stream ok: 16 frames in order, stopped after %d of %d read\n", seen, many.i);
+    }
     lvk::VSFilterLike vs;
     vs.configure(false, true, 0.05f, 0.05f, 5, true, false, true);
     const int rows = 360, cols = 640;
