@@ -141,7 +141,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     import livevisionkit_amd as lvk
-    ctx = lvk.Context(local_rank)
+    # the filter works on its own (non-blocking) stream: the process default stream would implicitly serialise with every
+    # blocking stream of the process
+    work_stream = torch.cuda.Stream(device)
+    ctx = lvk.Context(local_rank, stream=work_stream)
     settings = lvk.StabilizationFilterSettings.obs_preset(args.preset)
     # the OBS plugin's flow (VSFilter.cpp:255-293): a default-constructed filter that is then configured with the preset --
     # constructing the "field" preset directly would keep FrameTracker's constructor-time 256x256 mesh constraints (reference quirk)

@@ -16,6 +16,9 @@
 #include "lvk_hip_internal.hpp"
 #include "host_logic.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 
@@ -33,6 +36,32 @@ inline float step_toward(float current, float target, float amount)   // Functio
 {
     return current > target ? std::max(current - amount, target) : std::min(current + amount, target);
 }
+
+// Host-side wall-clock trace of one push (LVK_HIP_HOST_TRACE=1: summary on stderr at destroy) -- development aid
+struct HostTrace
+{
+    enum { ENTER, DOWN_PYR_LAUNCH, FAST_SYNC, GRID, LK_LAUNCH, LK_SYNC, FILTER, RANSAC_LAUNCH, RANSAC_SYNC, POST, SMOOTH, REMAP_LAUNCH, EXIT, N };
+    bool on = std::getenv("LVK_HIP_HOST_TRACE") != nullptr;
+    double acc[N] = {0}; long cnt[N] = {0};
+    std::chrono::steady_clock::time_point last;
+    void begin() { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(int k)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(now - last).count(); cnt[k]++; last = now;
+    }
+    void dump() const
+    {
+        if (!on) return;
+        static const char* names[N] = {"enter", "downscale+pyramid launch", "fast launch+sync", "grid (host)", "lk upload+launch", "lk sync", "filter (host)",
+                                       "ransac upload+launch", "ransac sync", "post (host)", "qa+smoother (host)", "remap launch", "exit"};
+        double total = 0; long frames = cnt[DOWN_PYR_LAUNCH] ? cnt[DOWN_PYR_LAUNCH] : 1;
+        for (int i = 0; i < N; i++) total += acc[i];
+        std::fprintf(stderr, "[lvk host trace] %ld frames, %.1f us/frame inside push\n", frames, total / frames);
+        for (int i = 0; i < N; i++) if (cnt[i]) std::fprintf(stderr, "  %-28s %8.1f us/frame (%ld marks)\n", names[i], acc[i] / frames, cnt[i]);
+    }
+};
 
 struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; int format; };
 
@@ -76,6 +105,8 @@ struct lvk_hip_stab
         return LVK_HIP_OK;
     }
 
+    HostTrace trace;
+
     // ---- host state
     lvkh::FeatureGridH grid;
     lvkh::PathSmootherH smoother;
@@ -98,6 +129,8 @@ struct lvk_hip_stab
     hipEvent_t remap_done[2] = {nullptr, nullptr};
     int remap_slot = 0;
     const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
+    hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame (runs on remap_stream in overlap mode)
+    bool ingest_pending = false;
     int pending_slot = -1;
 
     // ---- optional per-stage GPU timing (HIP events on the launch stream)
@@ -304,6 +337,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     pe = prof_begin(LVK_STAGE_PYRAMID);
     if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
     prof_end(pe);
+    trace.mark(HostTrace::DOWN_PYR_LAUNCH);
     if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return LVK_HIP_OK; }
 
     // ---- FeatureDetector::detect
@@ -320,6 +354,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
                                   d_fast_masks, d_fast_scores, h_fast_out, fast_cap, h_fast_counts)) != LVK_HIP_OK) return rc;
         prof_end(pe);
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        trace.mark(HostTrace::FAST_SYNC);
     }
     for (size_t i = 0; i < plan.size(); i++)
         if (plan[i].active) grid.absorb(i, h_fast_out + i * (size_t)fast_cap, std::min(h_fast_counts[i], fast_cap));
@@ -328,6 +363,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return LVK_HIP_OK; }
     if (tracked.size() > cap_features) return fail(LVK_HIP_ERR_RUNTIME, "feature count exceeds the suppression grid capacity");
 
+    trace.mark(HostTrace::GRID);
     // ---- sparse optical flow prev -> cur
     const int n = (int)tracked.size();
     for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
@@ -335,6 +371,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     pe = prof_begin(LVK_STAGE_PYRLK);
     if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, h_matched, h_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
     prof_end(pe);
+    trace.mark(HostTrace::LK_LAUNCH);
     if (lens)
     {
         // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks)
@@ -342,6 +379,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
                                             d_pts, n, h_matched, n, h_und)) != LVK_HIP_OK) return rc;
     }
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    trace.mark(HostTrace::LK_SYNC);
 
     if (lens)
     {
@@ -366,6 +404,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     last_matched = m;
     if ((size_t)m < (size_t)s.min_motion_samples) { tracked.clear(); return LVK_HIP_OK; }
 
+    trace.mark(HostTrace::FILTER);
     // ---- motion estimate
     motion = WarpMeshF(s.motion_height, s.motion_width);
     const float2* e1 = lens ? h_und : h_pts;
@@ -397,7 +436,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     pe = prof_begin(LVK_STAGE_MOTION);
     if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + m, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
     prof_end(pe);
+    trace.mark(HostTrace::RANSAC_LAUNCH);
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    trace.mark(HostTrace::RANSAC_SYNC);
     std::memcpy(last_H, h_H, sizeof(last_H));
     motion.from_homography(last_H, (float)cur_w, (float)cur_h);
 
@@ -412,6 +453,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     }
     grid.propagate(tracked);
     have_motion = true;
+    trace.mark(HostTrace::POST);
     return LVK_HIP_OK;
 }
 
@@ -448,9 +490,11 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
 {
     if (!st) return;
     (void)hipStreamSynchronize(st->ctx->stream);
+    st->trace.dump();
     st->free_tracker_buffers();
     st->pyr[0].release(); st->pyr[1].release();
     st->free_pool();
+    if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
     if (st->remap_stream)
     {
         (void)hipStreamSynchronize(st->remap_stream);
@@ -475,7 +519,11 @@ int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
     if (st->remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st->remap_stream));
     if (enable && !st->remap_stream)
     {
-        LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&st->remap_stream, hipStreamNonBlocking));
+        // lowest priority: the bulk kernels of this stream (remap, 4:2:0 conversion) fill every CU; the tracker's small,
+        // latency-bound kernels on the main stream should get the wave slots they free first
+        int prio_least = 0, prio_greatest = 0;
+        LVK_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        LVK_HIP_CHECK(ctx, hipStreamCreateWithPriority(&st->remap_stream, hipStreamNonBlocking, prio_least));
         LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[0], hipEventDisableTiming));
         LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[1], hipEventDisableTiming));
         ctx->aux_streams.push_back(st->remap_stream);
@@ -654,6 +702,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         return emit(st->s.crop_to_stable_region ? &st->smoother.scene_crop() : st->lens ? &identity_mesh : nullptr);
     }
 
+    st->trace.mark(HostTrace::ENTER);
     WarpMeshF motion(st->s.motion_height, st->s.motion_width);                            // m_NullMotion
     WarpMeshF est; bool have = false;
     int rc = st->track(in, luma, luma_step, luma_pix, luma_channel, est, have);
@@ -674,7 +723,10 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     if (st->queue.size() != st->queue_capacity) return LVK_HIP_OK;                        // !ready(): output.release()
     if (st->s.crop_to_stable_region) correction += st->smoother.scene_crop();
     st->last_correction = correction;
-    return emit(&correction);
+    st->trace.mark(HostTrace::SMOOTH);
+    const int erc = emit(&correction);
+    st->trace.mark(HostTrace::REMAP_LAUNCH);
+    return erc;
 }
 
 int lvk_hip_stab::ensure_pool(int rows, int cols)
@@ -714,7 +766,10 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
                       void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
 {
     if (!st) return LVK_HIP_ERR_ARG;
-    return push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+    st->trace.begin();
+    const int rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+    st->trace.mark(HostTrace::EXIT);
+    return rc;
 }
 
 // The OBS asynchronous path in one call: I4XXIngest / NV12Ingest::to_ocl -> StabilizationFilter::filter -> ::to_obs
@@ -728,6 +783,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
 {
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_hip_ctx* ctx = st->ctx;
+    st->trace.begin();
     if (produced) *produced = 0;
     int rc = st->ensure_pool(rows, cols);
     if (rc != LVK_HIP_OK) return rc;
@@ -743,13 +799,29 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         LVK_HIP_REQUIRE(ctx, !st->pool_free.empty());
     }
     void* slot = st->pool_free.back(); st->pool_free.pop_back();
-    int pe = st->prof_begin(LVK_STAGE_INGEST);
-    rc = lvk_launch_ingest_yuv420(ctx, ctx->stream, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
-    st->prof_end(pe);
+    // The packed frame is only read by the remap `predictive_samples` pushes later (the tracker reads the luma plane itself), so in
+    // overlap mode the conversion runs on the remap stream, off the tracker's critical path; same-stream order protects the slot.
+    const bool side_ingest = st->overlap && st->s.stabilize_output;
+    hipStream_t is = side_ingest ? st->remap_stream : ctx->stream;
+    int pe = st->prof_begin(LVK_STAGE_INGEST, is);
+    rc = lvk_launch_ingest_yuv420(ctx, is, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
+    st->prof_end(pe, is);
     if (rc != LVK_HIP_OK) { st->pool_free.push_back(slot); return rc; }
+    if (side_ingest)
+    {
+        if (!st->ingest_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->ingest_done, hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventRecord(st->ingest_done, is));
+        st->ingest_pending = true;
+    }
     int prod = 0; const void* released = nullptr;
     rc = push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released);
     if (released) st->pool_free.push_back(const_cast<void*>(released));
+    if (side_ingest)
+    {
+        // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago)
+        LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
+        st->ingest_pending = false;
+    }
     if (rc != LVK_HIP_OK) return rc;
     if (prod)
     {
@@ -762,6 +834,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
     }
+    st->trace.mark(HostTrace::EXIT);
     return LVK_HIP_OK;
 }
 
