@@ -87,7 +87,8 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
 // Pyramidal LK (pyrlk.hip)
 int lvk_pyramid_geometry(int rows, int cols, int max_level, int win_w, int win_h, int* lrows, int* lcols);
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
-                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig);
+                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig,
+                     float2* d_prev_copy = nullptr);     // pts may be device-visible host memory; d_prev_copy receives a device copy
 
 // Image pyramid + Scharr derivative images of one tracking frame, resident in HBM.
 struct DevicePyramid
@@ -103,7 +104,12 @@ struct DevicePyramid
 // Robust global motion (motion.hip)
 size_t lvk_ransac_workspace_bytes(int n);
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
-                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask);
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n = nullptr);
+// fast_filter (Functions/Container.tpp:97-121) of the optical-flow result on the GPU: compacts (prev, matched) by `status` into
+// (d_p1, d_p2) in exactly the order the host's back-to-front swap-erase produces, writes the count to d_count, and mirrors the raw
+// matched points / status flags into device-visible host memory for the host's own bookkeeping.
+int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
+                             float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status);
 
 struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)

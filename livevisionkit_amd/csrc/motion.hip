@@ -177,9 +177,11 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
 // voting loop is not a chain of dependent global-memory round trips.
 template <bool STAGED>
 __global__ __launch_bounds__(NT)
-void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, double t2, int full,
+void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
                          double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
 {
+    if (n_dev) n = min(*n_dev, n);                          // pair count decided on the GPU (k_match_compact); n = capacity
+    if (n < (full ? 4 : 2)) { if (threadIdx.x == 0) hyp_score[blockIdx.x] = -1; return; }
     __shared__ double sA[64], sb[8], sH[9];
     __shared__ int s_ok;
     __shared__ long long s_scratch[NT / 64];
@@ -358,7 +360,7 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 // Single wavefront: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
 template <bool STAGED>
 __global__ __launch_bounds__(NT)
-void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, double t2, int full,
+void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
                        double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
                        uint8_t* __restrict__ gmask_a, uint8_t* __restrict__ gmask_b,
@@ -371,6 +373,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
     __shared__ uint8_t s_mask[2][STAGED ? LDS_POINTS : 1];
     const int lane = threadIdx.x;
+    if (n_dev) n = max(min(*n_dev, n), 0);
     if (STAGED)
     {
         for (int i = lane; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
@@ -432,6 +435,67 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     if (lane == 0) *out_ninl = ninl;
 }
 
+// fast_filter on the GPU (see lvk_launch_match_compact).  The host algorithm walks k = n-1 .. 0 and, for every dropped k, swaps
+// element k with the last element of the still-kept prefix.  Closed form of the result: with r dropped elements, m = n - r, the
+// kept elements below m never move; the hole with descending rank j (1 = highest dropped index) receives what position n - j
+// holds at that moment, which is that position's own element if it was kept, or else whatever was moved into it when IT was a
+// hole (rank i < j, i.e. the content of position n - i) -- a chain that ends at a kept tail element.
+constexpr int CMP_NT = 1024, CMP_CAP = 4096;
+__global__ __launch_bounds__(CMP_NT)
+void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
+                     float2* __restrict__ p1, float2* __restrict__ p2, int* __restrict__ count, int* __restrict__ host_count,
+                     float2* __restrict__ host_matched, uint8_t* __restrict__ host_status)
+{
+    __shared__ unsigned short s_above[CMP_CAP];            // number of dropped elements with a higher index
+    __shared__ uint8_t s_keep[CMP_CAP];
+    __shared__ int s_wave[CMP_NT / 64];
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += CMP_NT)
+    {
+        const uint8_t k = status[i];
+        s_keep[i] = k; host_status[i] = k; host_matched[i] = matched[i];
+    }
+    __syncthreads();
+    // exclusive prefix count of dropped elements over the reversed index j = n - 1 - i; thread t owns j = 4t .. 4t + 3
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const int j = 4 * t + q;
+        loc[q] = sum;
+        sum += (j < n && !s_keep[n - 1 - j]) ? 1 : 0;
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((t & 63) >= o) inc += v; }
+    if ((t & 63) == 63) s_wave[t >> 6] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < CMP_NT / 64; w++) { const int v = s_wave[w]; total += v; if (w < (t >> 6)) base += v; }
+    const int excl = base + inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const int j = 4 * t + q;
+        if (j < n) s_above[n - 1 - j] = (unsigned short)(excl + loc[q]);
+    }
+    __syncthreads();
+    const int m = n - total;
+    if (t == 0) { *count = m; *host_count = m; }
+    for (int i = t; i < m; i += CMP_NT)
+    {
+        int src = i;
+        if (!s_keep[i])
+        {
+            int p = n - ((int)s_above[i] + 1);
+            while (!s_keep[p]) p = n - ((int)s_above[p] + 1);
+            src = p;
+        }
+        p1[i] = prev[src]; p2[i] = matched[src];
+    }
+}
+
 } // namespace
 
 size_t lvk_ransac_workspace_bytes(int n)
@@ -442,9 +506,9 @@ size_t lvk_ransac_workspace_bytes(int n)
 
 // d_p1/d_p2: n pairs; d_ws: lvk_ransac_workspace_bytes(n); outputs d_H (9 doubles), d_ninl, d_mask (n bytes).
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
-                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask)
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n)
 {
-    LVK_HIP_REQUIRE(ctx, d_p1 && d_p2 && d_ws && d_H && d_ninl && d_mask && n >= (full_homography ? 4 : 2));
+    LVK_HIP_REQUIRE(ctx, d_p1 && d_p2 && d_ws && d_H && d_ninl && d_mask && (d_n || n >= (full_homography ? 4 : 2)));
     double* hyp_H = (double*)d_ws;
     long long* hyp_score = (long long*)(hyp_H + K_HYPOTHESES * 9);
     uint8_t* mask_a = (uint8_t*)(hyp_score + K_HYPOTHESES);
@@ -452,16 +516,25 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     const double t2 = threshold * threshold;
     if (n <= LDS_POINTS)
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
-        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     else
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
-        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, t2, full_homography ? 1 : 0,
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
+                             float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status)
+{
+    LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n >= 0 && n <= CMP_CAP);
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(CMP_NT), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

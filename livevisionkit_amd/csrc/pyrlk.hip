@@ -74,7 +74,7 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
 // LDS layout per block (one wave): tile[(win_h+1) * tw] u8 image samples, dtile[... ] short2 derivative samples,
 // then the cached patches I, Ix, Iy (int16 each, win_w * win_h).
 __global__ __launch_bounds__(64)
-void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, int n,
+void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, float2* __restrict__ prev_copy, int n,
              float2* __restrict__ next_pts, uint8_t* __restrict__ status,
              int win_w, int win_h, int max_count, double epsilon_sq, float min_eig_threshold)
 {
@@ -95,7 +95,8 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, in
     const int py0 = lane / win_w, px0 = lane - py0 * win_w, pdy_ = 64 / win_w, pdx_ = 64 - pdy_ * win_w;
     const int lx = lane & 15, ly = lane >> 4;                                 // 16 x 4 lane grid for the staging loops
 
-    const float2 p0 = prev_pts[pt];
+    const float2 p0 = prev_pts[pt];                        // may live in pinned host memory: one 8-byte read per wave
+    if (lane == 0 && prev_copy) prev_copy[pt] = p0;        // device-resident copy for the kernels that follow
     const float halfx = (win_w - 1) * 0.5f, halfy = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     float outx = 0.f, outy = 0.f;
@@ -236,7 +237,7 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, in
 size_t lvk_pyrlk_lds_bytes(int win_w, int win_h) { return lvk_pyrlk_part_offset(win_w, win_h) + 3 * 64 * sizeof(long long); }
 
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
-                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig)
+                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig, float2* d_prev_copy)
 {
     LVK_HIP_REQUIRE(ctx, prev.nlevels >= 1 && prev.nlevels == next.nlevels && prev.nlevels <= LVK_MAX_PYR_LEVELS);
     LVK_HIP_REQUIRE(ctx, win_w >= 3 && win_h >= 3 && win_w <= 31 && win_h <= 31);
@@ -245,7 +246,7 @@ int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next,
     max_count = std::min(std::max(max_count, 0), 100);
     epsilon = std::min(std::max(epsilon, 0.), 10.);
     epsilon *= epsilon;
-    hipLaunchKernelGGL(k_pyrlk, dim3(n), dim3(64), lvk_pyrlk_lds_bytes(win_w, win_h), ctx->stream, prev, next, d_prev_pts, n,
+    hipLaunchKernelGGL(k_pyrlk, dim3(n), dim3(64), lvk_pyrlk_lds_bytes(win_w, win_h), ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
                        d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;

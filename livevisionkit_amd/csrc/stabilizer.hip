@@ -85,10 +85,12 @@ struct lvk_hip_stab
     uint32_t* d_fast_out = nullptr; int* d_fast_counts = nullptr;
     float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr, *d_p2 = nullptr; uint8_t* d_status = nullptr;
     void* d_ransac_ws = nullptr; double* d_H = nullptr; int* d_ninl = nullptr; uint8_t* d_mask = nullptr;
+    int* d_count = nullptr;                    // number of matches after the GPU-side fast_filter
     // pinned host mirrors
     uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
     float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr, *h_p2 = nullptr; uint8_t* h_status = nullptr;
     double* h_H = nullptr; int* h_ninl = nullptr; uint8_t* h_mask = nullptr;
+    int* h_count = nullptr;                    // d_count as the GPU-side fast_filter reported it (checked against the host's own)
     float2* h_und = nullptr;                   // fused lens mode: lens-corrected (previous | matched) point positions
 
     // ---- fused lens pre-warp (lvk_hip_stab_set_lens): model of the current frame size
@@ -200,14 +202,14 @@ int lvk_hip_stab::alloc_pyramids()
 
 void lvk_hip_stab::free_tracker_buffers()
 {
-    void* dev[] = {d_regions, d_fast_masks, d_fast_scores, d_fast_out, d_fast_counts, d_pts, d_matched, d_p1, d_p2, d_status, d_ransac_ws, d_H, d_ninl, d_mask};
+    void* dev[] = {d_regions, d_fast_masks, d_fast_scores, d_fast_out, d_fast_counts, d_pts, d_matched, d_p1, d_p2, d_status, d_ransac_ws, d_H, d_ninl, d_mask, d_count};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_p2, h_status, h_H, h_ninl, h_mask, h_und};
+    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_p2, h_status, h_H, h_ninl, h_mask, h_und, h_count};
     for (void* p : host) if (p) (void)hipHostFree(p);
     d_regions = nullptr; d_fast_masks = d_fast_scores = nullptr; d_fast_out = nullptr; d_fast_counts = nullptr;
-    d_pts = d_matched = d_p1 = d_p2 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_H = nullptr; d_ninl = nullptr; d_mask = nullptr;
+    d_pts = d_matched = d_p1 = d_p2 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_H = nullptr; d_ninl = nullptr; d_mask = nullptr; d_count = nullptr;
     h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = h_p2 = nullptr; h_status = nullptr;
-    h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr;
+    h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr; h_count = nullptr;
 }
 
 int lvk_hip_stab::alloc_tracker_buffers()
@@ -239,6 +241,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_H, 9 * sizeof(double)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_ninl, sizeof(int)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_mask, n));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_count, sizeof(int)));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
@@ -251,6 +254,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_und, 2 * n * sizeof(float2), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_count, sizeof(int), hipHostMallocDefault));
     return LVK_HIP_OK;
 }
 
@@ -367,10 +371,27 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // ---- sparse optical flow prev -> cur
     const int n = (int)tracked.size();
     for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, h_pts, n * sizeof(float2), hipMemcpyHostToDevice, st));
+    const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
+    // Global-motion mode without a lens model: the whole chain optical flow -> fast_filter -> RANSAC runs on the GPU without a
+    // host round trip in between (the flow kernel reads the points from pinned host memory, k_match_compact reproduces the host's
+    // swap-erase order); the host synchronises once and then repeats the cheap bookkeeping on its own copies.
+    const bool chained = !s.track_local_motions && !lens && n <= 4096;
     pe = prof_begin(LVK_STAGE_PYRLK);
-    if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, h_matched, h_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
-    prof_end(pe);
+    if (chained)
+    {
+        if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, h_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG, d_pts)) != LVK_HIP_OK) return rc;
+        if ((rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+        pe = prof_begin(LVK_STAGE_MOTION);
+        if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+    }
+    else
+    {
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, h_pts, n * sizeof(float2), hipMemcpyHostToDevice, st));
+        if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, d_pts, n, h_matched, h_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+    }
     trace.mark(HostTrace::LK_LAUNCH);
     if (lens)
     {
@@ -402,6 +423,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         }
     tracked.resize(m);
     last_matched = m;
+    if (chained && *h_count != m) return fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter disagrees with the host's");
     if ((size_t)m < (size_t)s.min_motion_samples) { tracked.clear(); return LVK_HIP_OK; }
 
     trace.mark(HostTrace::FILTER);
@@ -427,18 +449,20 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         have_motion = true;
         return LVK_HIP_OK;
     }
-    const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
     // both point sets travel in one copy (h_p1 | h_p2 and d_p1 | d_p2 are each one allocation); results come back through
     // the pinned host block the kernel writes directly
-    std::memcpy(h_p1, e1, m * sizeof(float2));
-    std::memcpy(h_p1 + m, e2, m * sizeof(float2));
-    LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, 2 * (size_t)m * sizeof(float2), hipMemcpyHostToDevice, st));
-    pe = prof_begin(LVK_STAGE_MOTION);
-    if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + m, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
-    prof_end(pe);
-    trace.mark(HostTrace::RANSAC_LAUNCH);
-    LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    trace.mark(HostTrace::RANSAC_SYNC);
+    if (!chained)
+    {
+        std::memcpy(h_p1, e1, m * sizeof(float2));
+        std::memcpy(h_p1 + m, e2, m * sizeof(float2));
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, 2 * (size_t)m * sizeof(float2), hipMemcpyHostToDevice, st));
+        pe = prof_begin(LVK_STAGE_MOTION);
+        if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + m, m, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+        trace.mark(HostTrace::RANSAC_LAUNCH);
+        LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        trace.mark(HostTrace::RANSAC_SYNC);
+    }
     std::memcpy(last_H, h_H, sizeof(last_H));
     motion.from_homography(last_H, (float)cur_w, (float)cur_h);
 
