@@ -153,6 +153,11 @@ int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int
 int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const float* pts2, int n, double threshold,
                                    double region_w, double region_h, int full_homography, double H[9], uint8_t* mask);
 
+/* fast_filter (Functions/Container.tpp:97-121; call site Vision/FrameTracker.cpp:149) as the GPU runs it between the optical
+ * flow and the motion estimate: keeps the pairs whose status is non-zero, in the order the reference's back-to-front swap-erase
+ * leaves them.  Host arrays (n x 2 floats, n bytes); returns the number of pairs kept (>= 0) or LVK_HIP_ERR_*. */
+int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matched, const uint8_t* status, int n, float* out_prev, float* out_matched);
+
 /* ---- a1/a2: the stabilization filter ----------------------------------------------------------------------
  * lvk_stab_settings flattens lvk::StabilizationFilterSettings (Filters/StabilizationFilter.hpp:28-39) and its bases
  * FrameTrackerSettings (Vision/FrameTracker.hpp:31-44) : FeatureDetectorSettings (Vision/FeatureDetector.hpp:28-37) and

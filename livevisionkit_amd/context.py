@@ -273,3 +273,15 @@ class Context:
                                                   p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(p), float(scaling[0]), float(scaling[1]), cp,
                                                   int(cross_size), int(thickness)))
         return frame
+
+    def fast_filter(self, prev, matched, status):
+        """GPU-side fast_filter of the flow result: (kept prev, kept matched) in the reference's swap-erase order."""
+        a = np.ascontiguousarray(prev, np.float32).reshape(-1, 2); b = np.ascontiguousarray(matched, np.float32).reshape(-1, 2)
+        st = np.ascontiguousarray(status, np.uint8).reshape(-1)
+        oa = np.zeros_like(a); ob = np.zeros_like(b)
+        fp = ctypes.POINTER(ctypes.c_float)
+        m = self.lib.lvk_hip_fast_filter(self.handle, a.ctypes.data_as(fp), b.ctypes.data_as(fp), st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(a),
+                                         oa.ctypes.data_as(fp), ob.ctypes.data_as(fp))
+        if m < 0:
+            self._check(m)
+        return oa[:m], ob[:m]

@@ -575,4 +575,36 @@ int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const fl
     return ninl >= 0 ? ninl : -10 + ninl;
 }
 
+// Synchronous test entry point of the GPU-side fast_filter: host arrays in, compacted pairs + count out.
+int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matched, const uint8_t* status, int n, float* out_prev, float* out_matched)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, prev && matched && status && out_prev && out_matched && n >= 0 && n <= CMP_CAP);
+    if (n == 0) return 0;
+    float2 *d = nullptr, *h_m = nullptr; uint8_t *d_s = nullptr, *h_s = nullptr; int *d_c = nullptr, *h_c = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d); (void)hipFree(d_s); (void)hipFree(d_c); (void)hipHostFree(h_m); (void)hipHostFree(h_s); (void)hipHostFree(h_c); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d, 4 * (size_t)n * sizeof(float2))) != hipSuccess || (e = hipMalloc((void**)&d_s, n)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_c, sizeof(int))) != hipSuccess || (e = hipHostMalloc((void**)&h_m, n * sizeof(float2), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&h_s, n, hipHostMallocDefault)) != hipSuccess || (e = hipHostMalloc((void**)&h_c, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMemcpyAsync(d, prev, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d + n, matched, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_s, status, n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+    { cleanup(); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
+    int rc = lvk_launch_match_compact(ctx, d, d + n, d_s, n, d + 2 * n, d + 3 * n, d_c, h_c, h_m, h_s);
+    int m = 0;
+    if (rc == LVK_HIP_OK)
+    {
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { cleanup(); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
+        m = *h_c;
+        if ((e = hipMemcpy(out_prev, d + 2 * n, (size_t)m * sizeof(float2), hipMemcpyDeviceToHost)) != hipSuccess ||
+            (e = hipMemcpy(out_matched, d + 3 * n, (size_t)m * sizeof(float2), hipMemcpyDeviceToHost)) != hipSuccess)
+        { cleanup(); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
+        for (int i = 0; i < n; i++) if (h_s[i] != status[i] || h_m[i].x != matched[2 * i] || h_m[i].y != matched[2 * i + 1]) rc = LVK_HIP_ERR_RUNTIME;
+        if (rc != LVK_HIP_OK) ctx->fail(rc, "host mirror of the flow result differs");
+    }
+    cleanup();
+    return rc == LVK_HIP_OK ? m : rc;
+}
+
 } // extern "C"

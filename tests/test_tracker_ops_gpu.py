@@ -145,3 +145,30 @@ def test_luma_area_resize_bgr_rgb(ctx, oracle, src_size, dst_size, channel):
     got = ctx.luma_area_resize(_gpu(frame), *dst_size, channel=channel)
     ctx.sync()
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+def _swap_erase(arrays, keep):
+    """fast_filter (Functions/Container.tpp:97-121): back to front, swap a dropped element with the last kept one."""
+    arrays = [a.copy() for a in arrays]
+    m = len(keep)
+    for k in range(len(keep) - 1, -1, -1):
+        if not keep[k]:
+            m -= 1
+            for a in arrays:
+                a[[k, m]] = a[[m, k]]
+    return [a[:m] for a in arrays]
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 257, 1856, 3728, 4096])
+def test_gpu_fast_filter_matches_swap_erase_order(ctx, n):
+    rng = np.random.default_rng(n)
+    prev = rng.uniform(0, 480, (n, 2)).astype(np.float32); matched = rng.uniform(0, 480, (n, 2)).astype(np.float32)
+    patterns = [np.ones(n, np.uint8), np.zeros(n, np.uint8), (np.arange(n) % 2).astype(np.uint8), ((np.arange(n) + 1) % 2).astype(np.uint8),
+                (rng.random(n) < 0.9).astype(np.uint8), (rng.random(n) < 0.3).astype(np.uint8),
+                (np.arange(n) < n // 3).astype(np.uint8), (np.arange(n) >= n // 3).astype(np.uint8),      # all holes in the tail / in the front
+                (rng.random(n) < 0.5).astype(np.uint8) * 255]
+    for keep in patterns:
+        want_p, want_m = _swap_erase([prev, matched], keep)
+        got_p, got_m = ctx.fast_filter(prev, matched, keep)
+        assert len(got_p) == len(want_p)
+        assert np.array_equal(got_p, want_p) and np.array_equal(got_m, want_m)
