@@ -143,7 +143,7 @@ def main():
     import livevisionkit_amd as lvk
     # the filter works on its own (non-blocking) stream: the process default stream would implicitly serialise with every
     # blocking stream of the process
-    work_stream = torch.cuda.Stream(device)
+    work_stream = torch.cuda.Stream(device, priority=int(os.environ.get("LVK_BENCH_STREAM_PRIO", "0")))
     ctx = lvk.Context(local_rank, stream=work_stream)
     settings = lvk.StabilizationFilterSettings.obs_preset(args.preset)
     # the OBS plugin's flow (VSFilter.cpp:255-293): a default-constructed filter that is then configured with the preset --
@@ -224,6 +224,24 @@ def main():
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t) * 1e3)
 
+    # the same remap kernel alone on the GPU at full occupancy (the timed region runs its occupancy-capped `_co` variant next to the tracker)
+    standalone_us = None
+    if rank == 0 and args.lens != "two-pass":
+        torch.cuda.synchronize()
+        meshes = filt.meshes()[1]
+        src = frames[0]; dst = torch.empty_like(src)
+        bgc = tuple(int(v) for v in settings.background)
+        with torch.cuda.stream(work_stream):
+            for _ in range(3):
+                ctx.warpmesh_apply(src, meshes, bg=bgc, yuv=True, out=dst)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(work_stream)
+            for i in range(20):
+                ctx.warpmesh_apply(frames[i % pool], meshes, bg=bgc, yuv=True, out=dst)
+            e1.record(work_stream)
+        torch.cuda.synchronize()
+        standalone_us = e0.elapsed_time(e1) / 20 * 1e3
+
     elapsed_max, total_frames = lvk.shard.reduce_timing(elapsed, emitted, device=device)
 
     result = None
@@ -263,10 +281,14 @@ def main():
             "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))},
             "stage_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof.items()},
             "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked},
-            "roofline": {"kernel": ("k_remap_homography" if args.preset == "homography" else "k_remap_mesh") + ("_lens<yuv>" if args.lens == "fused" else "<yuv>"),
+            "roofline": {"kernel": ("k_remap_homography" if args.preset == "homography" else "k_remap_mesh") + ("_lens" if args.lens == "fused" else "")
+                                   + ("<yuv>" if args.no_overlap else "_co<yuv>"),
                          "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": remap_ms / remap_n * 1e3 if remap_n else None, "launches": remap_n,
+                         # the full-occupancy kernel alone on the GPU (outside the timed region), same frames and warp
+                         "standalone_us": standalone_us,
+                         "standalone_frac": (alg_bytes / (standalone_us * 1e-6)) / 1e9 / 8000.0 if standalone_us else None,
                          # the kernel is VALU-issue bound: 487 VALU wave-instructions per output pixel (rocprofv3 SQ_INSTS_VALU,
                          # profiles/r01_sq_counters_per_kernel.txt) against 64.6 T lane-instr/s measured with scripts/valu_peak.hip
                          "valu_frac": (487.0 * rows * cols / (remap_ms / remap_n * 1e-3)) / 64.6e12 if remap_n else None},

@@ -115,10 +115,10 @@ struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)
 int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
                                 void* d_dst, int dst_step, int dst_rows, int dst_cols, int off_x, int off_y,
-                                const float H[9], const uint8_t bg[3], int yuv, const LensArgs* lens = nullptr);
+                                const float H[9], const uint8_t bg[3], int yuv, const LensArgs* lens = nullptr, bool co_scheduled = false);
 int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
                           void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv,
-                          const LensArgs* lens = nullptr);
+                          const LensArgs* lens = nullptr, bool co_scheduled = false);
 int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                               void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 
@@ -143,7 +143,7 @@ int lvk_launch_lens_undistort(lvk_hip_ctx* ctx, hipStream_t stream, const LensMo
 // lens != nullptr composes the closed-form lens map into the coordinate (fused mode)
 int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                    void* d_dst, int dst_step, const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv,
-                                   const LensArgs* lens);
+                                   const LensArgs* lens, bool co_scheduled = false);   // co_scheduled: occupancy-capped kernels for overlap mode
 
 // Debug overlays (draw.hip)
 int lvk_launch_draw_grid(lvk_hip_ctx* ctx, hipStream_t stream, void* d_dst, int dst_step, int rows, int cols, int grid_w, int grid_h,

@@ -692,7 +692,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
         if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
-                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr);
+                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr, side);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
