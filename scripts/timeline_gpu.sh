@@ -13,13 +13,15 @@ import csv, glob, sys
 ev = []
 for f in glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:48], "q" + r.get("Queue_Id", "?")))
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ","")[:34], "q" + r.get("Queue_Id", "?")))
 for f in glob.glob("$OUT/t/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", ""), "copy"))
 ev.sort()
-# print ~3 steady-state frames from the tail of the timed region
-tail = ev[-14 * 12:-14 * 8]
+# ~4 steady-state frames from the middle of the free-running timed region (the tail of the run is the per-step synchronised latency pass)
+rem = [i for i, e in enumerate(ev) if "k_remap" in e[2]]
+mid = rem[len(rem) // 2 - 10]
+tail = ev[mid:mid + 50]
 t0 = tail[0][0]
 with open("$OUT/frames.txt", "w") as o:
     for s, e, n, q in tail:
