@@ -23,3 +23,37 @@ def reduce_timing(elapsed_s, units, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), int(u.item())
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(device_index, sysfs="/sys"):
+    """CPUs of the NUMA node the GPU hangs off (the host thread that drives a stream, and the pinned buffers it first touches,
+    belong next to that GPU: SURVEY.md section 8e).  Returns [] when the topology cannot be read."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")).read())
+        if node < 0:
+            return []
+        return _parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read())
+    except Exception:
+        return []
+
+
+def bind_to_gpu_numa(device_index):
+    """Pins the calling process to the CPUs local to its GPU.  Returns the CPU list used ([] = left unbound)."""
+    cpus = gpu_numa_cpus(device_index)
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0))) if cpus else []
+    if allowed:
+        os.sched_setaffinity(0, allowed)
+    return allowed

@@ -42,3 +42,11 @@ def test_timing_reduction_two_ranks_gloo(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_cpulist_parsing_and_unbound_fallback():
+    from livevisionkit_amd import shard
+    assert shard._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert shard._parse_cpulist("") == []
+    # without a visible GPU (or without the sysfs entries) the process is left unbound
+    assert shard.gpu_numa_cpus(0, sysfs="/nonexistent") == []
