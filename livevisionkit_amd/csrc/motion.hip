@@ -10,6 +10,8 @@
 //   up to 3 least-squares refits accepted while the score strictly improves.  All math binary64, no contraction.
 #include "lvk_hip_internal.hpp"
 
+#include <utility>
+
 namespace {
 
 constexpr int K_HYPOTHESES = 128;
@@ -40,44 +42,80 @@ __device__ bool draw_sample(int h, int n, int m, int* idx)
     return got == m;
 }
 
-// Gaussian elimination with partial pivoting on LDS-resident A (n x n, n <= 8) and b, executed by one wavefront:
-// the row operations of each pivot step run one element per lane (each element sees exactly the operations of the
-// sequential algorithm, so the result is bit-identical to it); the short back substitution runs on lane 0.
-// All threads return the same verdict.  Must be called by every thread of the block.
-__device__ bool solve_n(double* A, double* b, int n)
+__device__ __forceinline__ double lane_value(double v, int src_lane)          // wave-uniform copy of one lane's binary64 value
 {
-    const int lane = threadIdx.x;          // only the first (n-1)*(n+1) <= 63 threads carry elements; all threads hit the barriers
-    for (int i = 0; i < n; i++)
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffu), src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Gaussian elimination with partial pivoting of the N x N system (A, b) in LDS, N <= 8, executed by wave 0 of the block entirely
+// in registers: lane q holds column q of A (lane N: the right-hand side), pivots and multipliers travel by v_readlane, so a
+// pivot step needs neither LDS nor a barrier.  Every element sees exactly the operations of the sequential algorithm in the same
+// order (f = A[j][i] * (1 / A[i][i]); A[j][q] -= f * A[i][q]; back substitution s -= A[i][q] * x[q], q ascending), so the result
+// is bit-identical to it.  Must be called by every thread of the block (one block barrier at the end); the solution replaces b,
+// all threads return the same verdict.
+template <int N>
+__device__ bool solve_n(double* A, double* b, int* s_verdict)
+{
+    if (threadIdx.x < 64)
     {
-        int piv = i;
-        for (int j = i + 1; j < n; j++) if (fabs(A[j * n + i]) > fabs(A[piv * n + i])) piv = j;     // uniform: every lane reads the same column
-        if (fabs(A[piv * n + i]) < 1e-10) return false;
-        __syncthreads();
-        if (piv != i)
+        const int q = threadIdx.x;
+        double a[N];
+#pragma unroll
+        for (int r = 0; r < N; r++) a[r] = q < N ? A[r * N + q] : (q == N ? b[r] : 0.0);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; i++)
         {
-            if (lane < n) { const double t = A[i * n + lane]; A[i * n + lane] = A[piv * n + lane]; A[piv * n + lane] = t; }
-            else if (lane == n) { const double t = b[i]; b[i] = b[piv]; b[piv] = t; }
+            if (ok)
+            {
+                int piv = i;
+                double best = fabs(lane_value(a[i], i));
+#pragma unroll
+                for (int j = i + 1; j < N; j++)
+                {
+                    const double v = fabs(lane_value(a[j], i));
+                    if (v > best) { best = v; piv = j; }
+                }
+                if (best < 1e-10) ok = false;
+                else
+                {
+#pragma unroll
+                    for (int r = i + 1; r < N; r++)
+                        if (piv == r) { const double t = a[i]; a[i] = a[r]; a[r] = t; }          // wave-uniform row swap
+                    const double inv = 1.0 / lane_value(a[i], i);
+#pragma unroll
+                    for (int j = i + 1; j < N; j++)
+                    {
+                        const double f = lane_value(a[j], i) * inv;
+                        if (q > i) a[j] = a[j] - f * a[i];
+                    }
+                }
+            }
         }
-        __syncthreads();
-        const double inv = 1.0 / A[i * n + i];
-        const int j = i + 1 + lane / (n + 1), q = i + 1 + lane % (n + 1);     // q == n stands for the right-hand side
-        if (j < n && q <= n)
+        if (ok)
         {
-            const double f = A[j * n + i] * inv;
-            if (q < n) A[j * n + q] = A[j * n + q] - f * A[i * n + q];
-            else b[j] = b[j] - f * b[i];
+            double x[N];
+#pragma unroll
+            for (int i = N - 1; i >= 0; i--)
+            {
+                double sum = lane_value(a[i], N);
+#pragma unroll
+                for (int c = i + 1; c < N; c++) sum = sum - lane_value(a[i], c) * x[c];
+                x[i] = sum / lane_value(a[i], i);
+            }
+            if (q == 0)
+            {
+#pragma unroll
+                for (int i = 0; i < N; i++) b[i] = x[i];
+            }
         }
-        __syncthreads();
+        if (q == 0) *s_verdict = ok ? 1 : 0;
     }
-    if (lane == 0)
-        for (int i = n - 1; i >= 0; i--)
-        {
-            double s = b[i];
-            for (int q = i + 1; q < n; q++) s = s - A[i * n + q] * b[q];
-            b[i] = s / A[i * n + i];
-        }
     __syncthreads();
-    return true;
+    return *s_verdict != 0;
 }
 
 __device__ __forceinline__ double reproj_err2(const double* H, double x, double y, double u, double v)
@@ -139,6 +177,7 @@ __device__ long long score_model(const double* H, const float2* __restrict__ p1,
 __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, const int* idx,
                                   double* A, double* b, double* H)
 {
+    __shared__ int s_solved;
     const int lane = threadIdx.x;
     if (full)
     {
@@ -151,7 +190,7 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
             r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * v; r1[7] = -y * v; b[i + 4] = v;
         }
         __syncthreads();
-        if (!solve_n(A, b, 8)) return false;
+        if (!solve_n<8>(A, b, &s_solved)) return false;
         if (lane < 8) H[lane] = b[lane];
         if (lane == 8) H[8] = 1.0;
         __syncthreads();
@@ -207,79 +246,152 @@ void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict
     }
 }
 
-// Least-squares refit on the masked pairs; sums in wave order (lane = i mod 64, xor butterfly).
-// Block-order sums: part[k * NT + t] holds thread t's partial of sum k (pairs i = t, t + NT, ... in increasing i).  The
-// NT partials of each sum are combined by the tree  v[j] += v[j + o]  for j < o, o = NT/2 ... 1, with all threads spread
-// over the NS sums.  Totals end up in part[k * NT].
-__device__ __forceinline__ void tree_reduce(double* part, int ns)
+// v[j] + v[j + o] for the lanes j < o of one wavefront (other lanes: unspecified), binary64: o = 32, 16 cross the 16-lane DPP
+// rows (ds_bpermute), o = 8 ... 1 are DPP row shifts.
+template <int O>
+__device__ __forceinline__ double lane_plus(double v)
 {
-    __syncthreads();
-    for (int o = NT / 2; o >= 1; o >>= 1)
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    int lo = (int)(unsigned)(u & 0xffffffffu), hi = (int)(unsigned)(u >> 32);
+    if (O >= 16)
     {
-        for (int i = threadIdx.x; i < ns * o; i += NT)
-        {
-            const int k = i / o, l = i - k * o;
-            part[k * NT + l] = part[k * NT + l] + part[k * NT + l + o];
-        }
-        __syncthreads();
+        const int src = (((int)threadIdx.x & 63) + O) << 2;
+        lo = __builtin_amdgcn_ds_bpermute(src, lo); hi = __builtin_amdgcn_ds_bpermute(src, hi);
     }
+    else
+    {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + O, 0xf, 0xf, false);      // row_shl:O -- lane j reads lane j + O of its row
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + O, 0xf, 0xf, false);
+    }
+    return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-__device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
-                      double cx, double cy, double sc, double* A, double* b, double* H, double* part)
+// Least-squares refit on the masked pairs.  Block-order sums (the specification): partial t, t = 0 .. NT-1, is the sum over the
+// pairs i = t, t + NT, ... in increasing i; the NT partials are combined by the tree  v[j] += v[j + o]  for j < o, o = NT/2 ... 1.
+// Execution: wave w owns the sums id = w, w + 4, ... and computes ALL 256 partials of them itself -- lane l carries the four
+// partials l, l + 64, l + 128, l + 192 -- so the two upper tree levels are additions inside a thread, the six lower ones lane
+// shifts inside the wave, and no partial ever crosses a wave: the reduction needs no LDS traffic and no block barrier.
+// Pairing and order of every addition are those of the plain tree, so the totals are bit-identical to it.
+constexpr int tri_row(int id, int n) { int a = 0; while (id >= n - a) { id -= n - a; a++; } return a; }
+constexpr int tri_col(int id, int n) { int a = 0; while (id >= n - a) { id -= n - a; a++; } return a + id; }
+
+__device__ __forceinline__ double tree_total(double p0, double p64, double p128, double p192)
 {
-    const int lane = threadIdx.x;
-    if (full)
-    {
-        double N[36], g[8];
+    double v = (p0 + p128) + (p64 + p192);           // o = 128: (t, t + 128) and (t + 64, t + 192); o = 64: their sum
+    v = lane_plus<32>(v); v = lane_plus<16>(v); v = lane_plus<8>(v);
+    v = lane_plus<4>(v);  v = lane_plus<2>(v);  v = lane_plus<1>(v);
+    return v;                                        // valid on lane 0
+}
+
+// one term of sum ID for one point pair (ID is a compile-time constant so that r0 / r1 stay in registers)
+template <int ID>
+__device__ __forceinline__ double full_term(const double (&r0)[8], const double (&r1)[8], double u, double v)
+{
+    if constexpr (ID < 36) { constexpr int a = tri_row(ID, 8), c = tri_col(ID, 8); return r0[a] * r0[c] + r1[a] * r1[c]; }
+    else return r0[ID - 36] * u + r1[ID - 36] * v;
+}
+template <int ID>
+__device__ __forceinline__ double partial_term(const double (&r0)[4], const double (&r1)[4], double u, double v)
+{
+    if constexpr (ID < 10) { constexpr int a = tri_row(ID, 4), c = tri_col(ID, 4); return r0[a] * r0[c] + r1[a] * r1[c]; }
+    else return r0[ID - 10] * u + r1[ID - 10] * v;
+}
+template <int W, int NS, int... K>
+__device__ __forceinline__ void add_full_terms(double (&acc)[NS], const double (&r0)[8], const double (&r1)[8], double u, double v, std::integer_sequence<int, K...>)
+{
+    ((acc[K] = acc[K] + full_term<W + 4 * K>(r0, r1, u, v)), ...);
+}
+template <int W, int NS, int... K>
+__device__ __forceinline__ void add_partial_terms(double (&acc)[NS], const double (&r0)[4], const double (&r1)[4], double u, double v, std::integer_sequence<int, K...>)
+{
+    ((acc[K] = acc[K] + partial_term<W + 4 * K>(r0, r1, u, v)), ...);
+}
+template <int W, int N, int NS, int... K>
+__device__ __forceinline__ void store_totals(const double (&acc)[4][NS], int n_tri, double* A, double* b, std::integer_sequence<int, K...>)
+{
+    const int lane = threadIdx.x & 63;
+    auto one = [&](auto kc) {
+        constexpr int k = decltype(kc)::value, id = W + 4 * k;
+        const double t = tree_total(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
+        if (lane == 0)
+        {
+            if constexpr (id < N * (N + 1) / 2) { constexpr int a = tri_row(id, N), c = tri_col(id, N); A[a * N + c] = t; A[c * N + a] = t; }
+            else b[id - N * (N + 1) / 2] = t;
+        }
+    };
+    (one(std::integral_constant<int, K>{}), ...);
+}
+
+// Full homography: 36 upper-triangle entries of the 8 x 8 normal matrix (ids 0 .. 35, row major) + 8 right-hand sides (36 .. 43).
+template <int W>
+__device__ __forceinline__ void refit_sums_full(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
+                                                double cx, double cy, double sc, double* A, double* b)
+{
+    constexpr int NS = 11;                           // ids W, W + 4, ..., W + 40
+    const int lane = threadIdx.x & 63;
+    double acc[4][NS];
 #pragma unroll
-        for (int k = 0; k < 36; k++) N[k] = 0.0;
+    for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int k = 0; k < 8; k++) g[k] = 0.0;
-        for (int i = lane; i < n; i += NT)
+        for (int k = 0; k < NS; k++) acc[c][k] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        for (int i = lane + 64 * c; i < n; i += NT)
         {
             if (!mask[i]) continue;
             const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
             const double u = ((double)p2[i].x - cx) * sc, v = ((double)p2[i].y - cy) * sc;
             const double r0[8] = {x, y, 1, 0, 0, 0, -x * u, -y * u};
             const double r1[8] = {0, 0, 0, x, y, 1, -x * v, -y * v};
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 8; a++)
-#pragma unroll
-                for (int c = a; c < 8; c++, k++)
-                    N[k] = N[k] + (r0[a] * r0[c] + r1[a] * r1[c]);
-#pragma unroll
-            for (int a = 0; a < 8; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
+            add_full_terms<W>(acc[c], r0, r1, u, v, std::make_integer_sequence<int, NS>{});
         }
-        // 44 block-order sums, reduced 11 at a time through the 22 KB scratch
+    store_totals<W, 8>(acc, 36, A, b, std::make_integer_sequence<int, NS>{});
+}
+
+// Similarity: 10 upper-triangle entries of the 4 x 4 normal matrix (ids 0 .. 9) + 4 right-hand sides (10 .. 13).
+template <int W>
+__device__ __forceinline__ void refit_sums_partial(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
+                                                   double cx, double cy, double sc, double* A, double* b)
+{
+    constexpr int NS = W < 2 ? 4 : 3;                // ids W, W + 4, W + 8 (, W + 12)
+    const int lane = threadIdx.x & 63;
+    double acc[4][NS];
 #pragma unroll
-        for (int chunk = 0; chunk < 4; chunk++)
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int k = 0; k < NS; k++) acc[c][k] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        for (int i = lane + 64 * c; i < n; i += NT)
         {
-#pragma unroll
-            for (int k = 0; k < 11; k++)
-            {
-                const int id = chunk * 11 + k;
-                part[k * NT + lane] = id < 36 ? N[id < 36 ? id : 0] : g[id >= 36 ? id - 36 : 0];
-            }
-            tree_reduce(part, 11);
-            if (lane < 11)
-            {
-                const int id = chunk * 11 + lane;
-                const double t = part[lane * NT];
-                if (id < 36)
-                {
-                    int a = 0, rem = id;
-                    while (rem >= 8 - a) { rem -= 8 - a; a++; }
-                    const int c = a + rem;
-                    A[a * 8 + c] = t; A[c * 8 + a] = t;
-                }
-                else b[id - 36] = t;
-            }
-            __syncthreads();
+            if (!mask[i]) continue;
+            const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
+            const double u = ((double)p2[i].x - cx) * sc, v = ((double)p2[i].y - cy) * sc;
+            const double r0[4] = {x, -y, 1, 0};
+            const double r1[4] = {y, x, 0, 1};
+            add_partial_terms<W>(acc[c], r0, r1, u, v, std::make_integer_sequence<int, NS>{});
         }
+    store_totals<W, 4>(acc, 10, A, b, std::make_integer_sequence<int, NS>{});
+}
+
+__device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
+                      double cx, double cy, double sc, double* A, double* b, double* H)
+{
+    const int lane = threadIdx.x;
+    if (full)
+    {
+        static_assert(NT == 256, "four waves, four partials per lane");
+        switch (threadIdx.x >> 6)
+        {
+            case 0: refit_sums_full<0>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            case 1: refit_sums_full<1>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            case 2: refit_sums_full<2>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            default: refit_sums_full<3>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+        }
+        __syncthreads();
         __shared__ int s_ok;
-        bool ok = solve_n(A, b, 8);
+        __shared__ int s_solved8;
+        bool ok = solve_n<8>(A, b, &s_solved8);
         if (lane == 0)
         {
             if (ok)
@@ -300,47 +412,16 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
     }
     else
     {
-        double N[10], g[4];
-#pragma unroll
-        for (int k = 0; k < 10; k++) N[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) g[k] = 0.0;
-        for (int i = lane; i < n; i += NT)
+        switch (threadIdx.x >> 6)
         {
-            if (!mask[i]) continue;
-            const double x = ((double)p1[i].x - cx) * sc, y = ((double)p1[i].y - cy) * sc;
-            const double u = ((double)p2[i].x - cx) * sc, v = ((double)p2[i].y - cy) * sc;
-            const double r0[4] = {x, -y, 1, 0};
-            const double r1[4] = {y, x, 0, 1};
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int c = a; c < 4; c++, k++)
-                    N[k] = N[k] + (r0[a] * r0[c] + r1[a] * r1[c]);
-#pragma unroll
-            for (int a = 0; a < 4; a++) g[a] = g[a] + (r0[a] * u + r1[a] * v);
-        }
-#pragma unroll
-        for (int k = 0; k < 10; k++) part[k * NT + lane] = N[k];
-#pragma unroll
-        for (int k = 0; k < 4; k++) part[(10 + k) * NT + lane] = g[k];
-        tree_reduce(part, 14);
-        if (lane < 14)
-        {
-            const double t = part[lane * NT];
-            if (lane < 10)
-            {
-                int a = 0, rem = lane;
-                while (rem >= 4 - a) { rem -= 4 - a; a++; }
-                const int c = a + rem;
-                A[a * 4 + c] = t; A[c * 4 + a] = t;
-            }
-            else b[lane - 10] = t;
+            case 0: refit_sums_partial<0>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            case 1: refit_sums_partial<1>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            case 2: refit_sums_partial<2>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            default: refit_sums_partial<3>(p1, p2, n, mask, cx, cy, sc, A, b); break;
         }
         __syncthreads();
-        __shared__ int s_ok2;
-        const bool ok = solve_n(A, b, 4);
+        __shared__ int s_solved4, s_ok2;
+        const bool ok = solve_n<4>(A, b, &s_solved4);
         if (lane == 0)
         {
             if (ok)
@@ -367,7 +448,6 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
                        double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
 {
     __shared__ double sA[64], sb[8], sH[9], sBest[9];
-    __shared__ double s_part[14 * NT];                                       // block-order reduction scratch (<= 14 sums at a time)
     __shared__ long long s_scratch[NT / 64];
     __shared__ long long s_best[NT / 64]; __shared__ int s_best_h[NT / 64];
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
@@ -420,7 +500,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     for (int round = 0; round < LO_ROUNDS; round++)
     {
         if (ninl < m) break;
-        if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH, s_part)) break;
+        if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH)) break;
         int nt = 0;
         const long long s = score_model(sH, p1, p2, n, t2, trial, &nt, s_scratch);
         __syncthreads();
