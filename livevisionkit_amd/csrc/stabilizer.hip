@@ -137,6 +137,7 @@ struct lvk_hip_stab
 
     // ---- optional per-stage GPU timing (HIP events on the launch stream)
     bool profiling = false;
+    unsigned prof_mask = ~0u;                  // stages that are timed while profiling is on (bit = LVK_STAGE_*)
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
     double prof_ms[LVK_STAGE_COUNT] = {0}; long prof_n[LVK_STAGE_COUNT] = {0};
@@ -164,7 +165,7 @@ struct lvk_hip_stab
 int lvk_hip_stab::prof_begin(int kind, hipStream_t stream)
 {
     if (!stream) stream = ctx->stream;
-    if (!profiling) return -1;
+    if (!profiling || !((prof_mask >> kind) & 1u)) return -1;
     if (ev_used == ev_pool.size())
     {
         EvPair p{nullptr, nullptr, kind};
@@ -564,6 +565,7 @@ int lvk_hip_stab_set_profiling(lvk_hip_stab* st, int enable)
     if (!st) return LVK_HIP_ERR_ARG;
     const int rc = st->prof_collect();
     st->profiling = enable != 0;
+    st->prof_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;          // 1: every stage; otherwise (1 << (stage + 1)) bits
     for (int i = 0; i < LVK_STAGE_COUNT; i++) { st->prof_ms[i] = 0; st->prof_n[i] = 0; }
     return rc;
 }

@@ -244,8 +244,14 @@ class StabilizationFilter:
 
     STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap", "ingest", "egress")
 
-    def set_profiling(self, enable=True):
-        self.ctx._check(self.lib.lvk_hip_stab_set_profiling(self.handle, 1 if enable else 0))
+    def set_profiling(self, enable=True, stages=None):
+        """stages: optional subset of STAGES to time (every timed stage costs two event records per frame on the host)."""
+        flag = 1 if enable else 0
+        if enable and stages is not None:
+            flag = 0
+            for name in stages:
+                flag |= 1 << (self.STAGES.index(name) + 1)
+        self.ctx._check(self.lib.lvk_hip_stab_set_profiling(self.handle, flag))
 
     def profile(self):
         """{stage: (total_ms, launches)} measured with HIP events on the launch stream since set_profiling(True)."""
