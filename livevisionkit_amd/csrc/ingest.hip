@@ -62,7 +62,9 @@ void k_ingest_yuv420(const uint8_t* __restrict__ yp, int y_step, const uint8_t* 
 
 // Exact 2x chroma upsampling (always the case for 4:2:0) without tables and without byte loads: the coefficients have the
 // closed form below (phase .25 / .75, clamped at the borders exactly like the table), and the chroma samples of a thread's
-// 4 output pixels -- columns x0/2 - 1 .. x0/2 + 2 -- come from one aligned 8-byte (I420) / 16-byte (NV12) window per row.
+// 4 output columns -- chroma columns x0/2 - 1 .. x0/2 + 2 -- come from one unaligned 8-byte (I420) / 16-byte (NV12) window per
+// chroma row.  A thread produces the 4 x 2 output pixels of the luma rows 2k - 1 and 2k: both interpolate between the SAME two
+// chroma rows (k - 1, k) with mirrored weights, so the windows are loaded and filtered horizontally once for the two rows.
 // Preconditions (checked by the launcher): Y and dst dword aligned incl. pitch, cols % 4 == 0, cols >= 16.
 template <bool NV12>
 __global__ __launch_bounds__(256)
@@ -70,13 +72,11 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
                         const uint8_t* __restrict__ vp, int v_step, int rows, int cols, uint8_t* __restrict__ dst, int dst_step)
 {
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x0 >= cols || y >= rows) return;
+    const int k = blockIdx.y * 4 + threadIdx.y;                   // luma rows 2k - 1 (odd) and 2k (even); k = 0 .. rows / 2
     const int cc = cols >> 1, cr = rows >> 1;
+    if (x0 >= cols || k > cr) return;
     // vertical taps (rows clipped individually, coefficients unclamped -- resize.cpp resizeGeneric_Invoker)
-    const int sy = (y - 1) >> 1;                                  // floor((y - 1) / 2), -1 for y == 0
-    const int r0 = max(sy, 0), r1 = min(sy + 1, cr - 1);
-    const int b0 = (y & 1) ? 1536 : 512, b1 = 2048 - b0;
+    const int r0 = max(k - 1, 0), r1 = min(k, cr - 1);
     // window of chroma columns [wc, wc + 8)
     const int c0 = x0 >> 1;
     const int wc = min(max(c0 - 1, 0), cc - 8);                   // 8 samples starting at c0 - 1 (unaligned load), clamped inside the row
@@ -104,8 +104,11 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
         wv0 = reinterpret_cast<const P8*>(vp + (long)r0 * v_step + wc)->q;
         wv1 = reinterpret_cast<const P8*>(vp + (long)r1 * v_step + wc)->q;
     }
-    const uint32_t yw = *reinterpret_cast<const uint32_t*>(yp + (long)y * y_step + x0);
-    uint32_t px[4];
+    const int ya = 2 * k - 1, yb = 2 * k;
+    const bool has_a = ya >= 0, has_b = yb < rows;
+    const uint32_t ywa = has_a ? *reinterpret_cast<const uint32_t*>(yp + (long)ya * y_step + x0) : 0u;
+    const uint32_t ywb = has_b ? *reinterpret_cast<const uint32_t*>(yp + (long)yb * y_step + x0) : 0u;
+    uint32_t pa[4], pb[4];
 #pragma unroll
     for (int p = 0; p < 4; p++)
     {
@@ -117,18 +120,28 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
         else { s0 = (x - 1) >> 1; s1 = s0 + 1; a0 = (x & 1) ? 1536 : 512; }
         const int a1 = 2048 - a0;
         const int i0 = 8 * (s0 - wc), i1 = 8 * (s1 - wc);
-        const int hu0 = (int)((wu0 >> i0) & 0xff) * a0 + (int)((wu0 >> i1) & 0xff) * a1;
-        const int hu1 = (int)((wu1 >> i0) & 0xff) * a0 + (int)((wu1 >> i1) & 0xff) * a1;
-        const int hv0 = (int)((wv0 >> i0) & 0xff) * a0 + (int)((wv0 >> i1) & 0xff) * a1;
-        const int hv1 = (int)((wv1 >> i0) & 0xff) * a0 + (int)((wv1 >> i1) & 0xff) * a1;
-        const uint32_t u = (uint32_t)((((b0 * (hu0 >> 4)) >> 16) + ((b1 * (hu1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        const uint32_t v = (uint32_t)((((b0 * (hv0 >> 4)) >> 16) + ((b1 * (hv1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        px[p] = ((yw >> (8 * p)) & 0xffu) | (u << 8) | (v << 16);
+        const int hu0 = ((int)((wu0 >> i0) & 0xff) * a0 + (int)((wu0 >> i1) & 0xff) * a1) >> 4;
+        const int hu1 = ((int)((wu1 >> i0) & 0xff) * a0 + (int)((wu1 >> i1) & 0xff) * a1) >> 4;
+        const int hv0 = ((int)((wv0 >> i0) & 0xff) * a0 + (int)((wv0 >> i1) & 0xff) * a1) >> 4;
+        const int hv1 = ((int)((wv1 >> i0) & 0xff) * a0 + (int)((wv1 >> i1) & 0xff) * a1) >> 4;
+        // odd row 2k - 1: weights (1536, 512) on chroma rows (k - 1, k); even row 2k: (512, 1536)
+        const uint32_t ua = (uint32_t)((((1536 * hu0) >> 16) + ((512 * hu1) >> 16) + 2) >> 2) & 0xffu;
+        const uint32_t va = (uint32_t)((((1536 * hv0) >> 16) + ((512 * hv1) >> 16) + 2) >> 2) & 0xffu;
+        const uint32_t ub = (uint32_t)((((512 * hu0) >> 16) + ((1536 * hu1) >> 16) + 2) >> 2) & 0xffu;
+        const uint32_t vb = (uint32_t)((((512 * hv0) >> 16) + ((1536 * hv1) >> 16) + 2) >> 2) & 0xffu;
+        pa[p] = ((ywa >> (8 * p)) & 0xffu) | (ua << 8) | (va << 16);
+        pb[p] = ((ywb >> (8 * p)) & 0xffu) | (ub << 8) | (vb << 16);
     }
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)y * dst_step + 3 * x0);
-    d[0] = px[0] | (px[1] << 24);
-    d[1] = (px[1] >> 8) | (px[2] << 16);
-    d[2] = (px[2] >> 16) | (px[3] << 8);
+    if (has_a)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)ya * dst_step + 3 * x0);
+        d[0] = pa[0] | (pa[1] << 24); d[1] = (pa[1] >> 8) | (pa[2] << 16); d[2] = (pa[2] >> 16) | (pa[3] << 8);
+    }
+    if (has_b)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)yb * dst_step + 3 * x0);
+        d[0] = pb[0] | (pb[1] << 24); d[1] = (pb[1] >> 8) | (pb[2] << 16); d[2] = (pb[2] >> 16) | (pb[3] << 8);
+    }
 }
 
 // thread = one 2x2 block of packed pixels -> 4 luma bytes + one (U, V) sample
@@ -203,11 +216,12 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
     if ((rc = lvk_get_lin8tab(ctx, cols / 2, cols, false, &xt)) != LVK_HIP_OK) return rc;
     if ((rc = lvk_get_lin8tab(ctx, rows / 2, rows, true, &yt)) != LVK_HIP_OK) return rc;
     const int fast = ((reinterpret_cast<uintptr_t>(d_dst) | (uintptr_t)dst_step) & 3u) == 0 ? 1 : 0;
-    const dim3 block(64, 4), grid((cols / 4 + 63 + (cols % 4 ? 1 : 0)) / 64, (rows + 3) / 4);
+    const dim3 block(64, 4), grid1((cols / 4 + 63 + (cols % 4 ? 1 : 0)) / 64, (rows + 3) / 4);
     const bool x2 = fast && cols % 4 == 0 && cols >= 16 && rows >= 4 &&
                     ((reinterpret_cast<uintptr_t>(d_y) | (uintptr_t)y_step) & 3u) == 0;
     if (x2)
     {
+        const dim3 grid(grid1.x, (rows / 2 + 1 + 3) / 4);                       // one thread row per chroma row pair: k = 0 .. rows / 2
         if (nv12) hipLaunchKernelGGL(k_ingest_yuv420_x2<true>, grid, block, 0, stream, (const uint8_t*)d_y, y_step, (const uint8_t*)d_u, u_step,
                                      (const uint8_t*)d_u, u_step, rows, cols, (uint8_t*)d_dst, dst_step);
         else hipLaunchKernelGGL(k_ingest_yuv420_x2<false>, grid, block, 0, stream, (const uint8_t*)d_y, y_step, (const uint8_t*)d_u, u_step,
@@ -215,6 +229,7 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
         LVK_HIP_CHECK(ctx, hipGetLastError());
         return LVK_HIP_OK;
     }
+    const dim3 grid = grid1;
     if (nv12)
         hipLaunchKernelGGL(k_ingest_yuv420<true>, grid, block, 0, stream, (const uint8_t*)d_y, y_step, (const uint8_t*)d_u, u_step, (const uint8_t*)d_u, u_step,
                            rows, cols, (uint8_t*)d_dst, dst_step, xt, yt, fast);
