@@ -131,6 +131,7 @@ struct lvk_hip_stab
     hipEvent_t remap_done[2] = {nullptr, nullptr};
     int remap_slot = 0;
     const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
+    bool pool_frames = false;                  // the queued frames are pool slots that only stream-ordered kernels of remap_stream touch
     hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame (runs on remap_stream in overlap mode)
     bool ingest_pending = false;
     int pending_slot = -1;
@@ -282,6 +283,9 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     LVK_HIP_REQUIRE(ctx, st.predictive_samples > 0 && st.smoothing_steps > 0 && st.response_rate >= 0 && st.response_rate <= 1);
     LVK_HIP_REQUIRE(ctx, st.detection_width >= 8 && st.detection_height >= 8 && st.detection_width < 4096 && st.detection_height < 4096);
 
+    if (configured && s.stabilize_output != st.stabilize_output && remap_stream)
+        // the 4:2:0 conversions change streams with this flag: drain the bulk stream so that no pool slot is shared across the switch
+        LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
     if (configured && s.stabilize_output && !st.stabilize_output) reset_context();        // StabilizationFilter.cpp:49-52
     const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
     const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
@@ -704,7 +708,13 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
         if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222
-        if (side)
+        if (side && st->pool_frames)
+        {
+            // 4:2:0 path in overlap mode: the slot is next written by an ingest on this same stream, i.e. after the remap that is
+            // reading it now -- stream order is all the protection it needs (no event, no host wait)
+            if (released) *released = f.d_ptr;
+        }
+        else if (side)
         {
             // the frame stays borrowed until its remap has finished: hand back the previous one instead
             const int slot = st->remap_slot; st->remap_slot ^= 1;
@@ -793,6 +803,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
 {
     if (!st) return LVK_HIP_ERR_ARG;
     st->trace.begin();
+    st->pool_frames = false;
     const int rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
     st->trace.mark(HostTrace::EXIT);
     return rc;
@@ -840,6 +851,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         st->ingest_pending = true;
     }
     int prod = 0; const void* released = nullptr;
+    st->pool_frames = side_ingest;
     rc = push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released);
     if (released) st->pool_free.push_back(const_cast<void*>(released));
     if (side_ingest)
