@@ -295,6 +295,40 @@ private:
     bool m_force = false;
 };
 
+// Right-looking Cholesky of a symmetric positive definite band matrix stored column by column (see MeshSolverH::at), with the
+// forward substitution of g carried along.  Every element (i, k) receives its updates  -= L(i, j) * L(k, j)  for j ascending,
+// exactly like the textbook row-oriented loop; only the traversal is by columns so that the inner loop is contiguous and the
+// compiler can vectorise it across i (independent elements: no reassociation, bit-identical to scalar code; the translation unit
+// is built with -ffp-contract=off).  AVX-512 / AVX2 clones are picked at load time.
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+inline bool lvkh_band_cholesky(double* B, double* g, int n, int hb)
+{
+    const size_t ld = (size_t)hb + 1;
+    for (int j = 0; j < n; j++)
+    {
+        double* cj = B + (size_t)j * ld;
+        const double d = std::sqrt(cj[0]);
+        if (!(d > 0.0)) return false;
+        cj[0] = d;
+        const int last = std::min(n - 1, j + hb), len = last - j;
+        for (int t = 1; t <= len; t++) cj[t] = cj[t] / d;
+        g[j] = g[j] / d;
+        const double gj = g[j];
+        for (int t = 1; t <= len; t++) g[j + t] = g[j + t] - cj[t] * gj;
+        for (int t = 1; t <= len; t++)
+        {
+            const double lk = cj[t];
+            double* __restrict ck = B + (size_t)(j + t) * ld;  // column k = j + t: entries (i, k), i = k .. last
+            const double* __restrict cji = cj + t;             // L(i, j), i = k .. last (another column: no overlap)
+            const int m = len - t;
+            for (int u = 0; u <= m; u++) ck[u] = ck[u] - cji[u] * lk;
+        }
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ local motion (vector field)
 // FrameTracker::generate_mesh_constraints + estimate_local_motions (Vision/FrameTracker.cpp:200-321,380-457).
 // The reference hands the sparse least-squares problem to Eigen::LeastSquaresConjugateGradient; this solves the same
@@ -387,7 +421,7 @@ public:
                     for (int b = 0; b < 4; b++)
                     {
                         const int ib = id[b] + comp;
-                        if (ia >= ib) m_Nq[(size_t)ia * (hb + 1) + (ia - ib)] += llrint((double)wgt[a] * (double)wgt[b] * Q);
+                        if (ia >= ib) m_Nq[(size_t)ib * (hb + 1) + (ia - ib)] += llrint((double)wgt[a] * (double)wgt[b] * Q);
                     }
                 }
             }
@@ -395,22 +429,7 @@ public:
         for (size_t k = 0; k < m_N.size(); k++) m_N[k] = m_N[k] + (double)m_Nq[k] / Q;
         for (int i = 0; i < n; i++) { m_g[i] = m_g[i] + (double)m_gq[i] / Q; at(m_N, i, i) = at(m_N, i, i) + 1e-6; }
 
-        for (int j = 0; j < n; j++)                                            // banded Cholesky + forward substitution
-        {
-            const double d = std::sqrt(at(m_N, j, j));
-            if (!(d > 0.0)) return false;
-            at(m_N, j, j) = d;
-            const int last = std::min(n - 1, j + hb);
-            for (int i = j + 1; i <= last; i++) at(m_N, i, j) = at(m_N, i, j) / d;
-            m_g[j] = m_g[j] / d;
-            for (int i = j + 1; i <= last; i++)
-            {
-                const double l = at(m_N, i, j);
-                m_g[i] = m_g[i] - l * m_g[j];
-                double* row_i = &at(m_N, i, i);                                // entries (i, k) live at row_i[i - k]
-                for (int k = j + 1; k <= i; k++) row_i[i - k] = row_i[i - k] - l * at(m_N, k, j);
-            }
-        }
+        if (!lvkh_band_cholesky(m_N.data(), m_g.data(), n, hb)) return false;       // banded Cholesky + forward substitution
         for (int j = n - 1; j >= 0; j--)                                       // back substitution
         {
             m_g[j] = m_g[j] / at(m_N, j, j);
@@ -435,7 +454,9 @@ public:
     }
 
 private:
-    double& at(std::vector<double>& B, int i, int j) { return B[(size_t)i * (m_hb + 1) + (size_t)(i - j)]; }
+    // lower band, column by column: entry (i, j), j <= i <= j + hb, lives at B[j * (hb + 1) + (i - j)] -- the factorisation then walks
+    // contiguous memory in its inner loop
+    double& at(std::vector<double>& B, int i, int j) { return B[(size_t)j * (m_hb + 1) + (size_t)(i - j)]; }
     int m_cols = 0, m_rows = 0, m_n = 0, m_hb = 0, m_static_rows = 0;
     float m_ts = 0.0f;
     std::vector<float> m_mesh, m_fw;
