@@ -261,14 +261,17 @@ def main():
     result = None
     if rank == 0:
         remap_ms, remap_n = prof["remap"]
-        alg_bytes = 6 * rows * cols                      # S_in + S_out of the packed 8UC3 frame the remap kernel reads / writes
+        # S_in + S_out of the frames the dominant kernel reads / writes as stored on the device: the packed 8UC3
+        # frame in; out = packed 8UC3 (6 W H in total) or, on the 4:2:0 path, the planes of the fused remap + egress kernel (4.5 W H)
+        fused_420 = yuv420 and args.lens != "two-pass"
+        alg_bytes = (9 * rows * cols) // 2 if fused_420 else 6 * rows * cols
         achieved = (alg_bytes / (remap_ms / remap_n * 1e-3)) / 1e9 if remap_n else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "remap_pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath))
-                if t.get("rows") == rows and t.get("cols") == cols:
+                if t.get("rows") == rows and t.get("cols") == cols and ("_420" in t.get("kernel", "")) == fused_420:
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -298,13 +301,13 @@ def main():
             "stage_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof_all.items()},
             "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked},
             "roofline": {"kernel": ("k_remap_homography" if args.preset == "homography" else "k_remap_mesh") + ("_lens" if args.lens == "fused" else "")
-                                   + ("<yuv>" if args.no_overlap else "_co<yuv>"),
+                                   + (("_420<nv12>" if args.format == "nv12" else "_420<i420>") if fused_420 else ("<yuv>" if args.no_overlap else "_co<yuv>")),
                          "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": remap_ms / remap_n * 1e3 if remap_n else None, "launches": remap_n,
                          # the full-occupancy kernel alone on the GPU (outside the timed region), same frames and warp
                          "standalone_us": standalone_us,
-                         "standalone_frac": (alg_bytes / (standalone_us * 1e-6)) / 1e9 / 8000.0 if standalone_us else None,
+                         "standalone_frac": (6 * rows * cols / (standalone_us * 1e-6)) / 1e9 / 8000.0 if standalone_us else None,
                          # the kernel is VALU-issue bound: 487 VALU wave-instructions per output pixel (rocprofv3 SQ_INSTS_VALU,
                          # profiles/r01_sq_counters_per_kernel.txt) against 64.6 T lane-instr/s measured with scripts/valu_peak.hip
                          "valu_frac": (487.0 * rows * cols / (remap_ms / remap_n * 1e-3)) / 64.6e12 if remap_n else None},

@@ -93,6 +93,13 @@ int lvk_hip_warpmesh_apply_lens(lvk_hip_ctx* ctx, const void* d_src, int src_ste
 int lvk_hip_lens_undistort_points(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, double sx, double sy,
                                   const float* pts, int n, float* out);
 
+/* WarpMesh::apply followed by the plugin's 4:2:0 egress (I4XXIngest / NV12Ingest::to_obs, Modules/OBS-Plugin/Interop/FrameIngest.cpp:
+ * 540-557,590-602) in one kernel: packed YUV 8UC3 in, I420 (y, u, v) or NV12 (y, uv; o_v ignored) planes out, even dimensions.
+ * Bit-identical to lvk_hip_warpmesh_apply + lvk_hip_egress_yuv420. */
+int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
+                                  void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
+                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3]);
+
 /* WarpMesh::apply(src, dst, background) (Math/WarpMesh.cpp:183-223): a 2x2 mesh goes through
  * cv::getPerspectiveTransform + the homography kernel, anything larger through the mesh kernel. */
 int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,

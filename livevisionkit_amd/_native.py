@@ -41,6 +41,8 @@ _SIG = {
     "lvk_hip_draw_grid": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
     "lvk_hip_draw_crosses": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _c.c_int, _c.c_float, _c.c_float,
                                         _c.POINTER(_c.c_uint8), _c.c_int, _c.c_int]),
+    "lvk_hip_warpmesh_apply_yuv420": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int,
+                                                 _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8)]),
     "lvk_hip_warpmesh_apply": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                           _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
     "lvk_hip_luma_area_resize": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int]),

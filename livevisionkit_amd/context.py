@@ -285,3 +285,20 @@ class Context:
         if m < 0:
             self._check(m)
         return oa[:m], ob[:m]
+
+    def warpmesh_apply_yuv420(self, src, mesh, bg=(255, 0, 255), nv12=False):
+        """WarpMesh::apply + 4:2:0 egress in one kernel: packed YUV [rows, cols, 3] -> (y, u, v) I420 or (y, uv) NV12 planes."""
+        import torch
+        rows, cols = src.shape[0], src.shape[1]
+        y = torch.empty((rows, cols), dtype=torch.uint8, device=src.device)
+        if nv12:
+            u = torch.empty((rows // 2, cols // 2, 2), dtype=torch.uint8, device=src.device); v = u
+        else:
+            u = torch.empty((rows // 2, cols // 2), dtype=torch.uint8, device=src.device); v = torch.empty_like(u)
+        m = np.ascontiguousarray(mesh, dtype=np.float32)
+        ma, mp = _f32(m)
+        bga, bgp = _u8x3(bg)
+        self._check(self.lib.lvk_hip_warpmesh_apply_yuv420(self.handle, src.data_ptr(), src.stride(0), rows, cols, y.data_ptr(), y.stride(0),
+                                                           u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), 1 if nv12 else 0,
+                                                           mp, m.shape[0], m.shape[1], bgp))
+        return (y, u) if nv12 else (y, u, v)

@@ -308,9 +308,66 @@ __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0,
         }
 }
 
-template <bool YUV, class Coord>
+// Where a thread's PXT output pixels go.  PackedSink: the packed 8UC3 frame (three aligned dwords per thread).
+struct PackedSink
+{
+    uint8_t* __restrict__ dst; int dst_step;
+    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active) const
+    {
+        if (!active) return;
+        uint8_t* drow = dst + (long)y * dst_step;
+        store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
+    }
+};
+
+// Planar 4:2:0 sink (I420 or NV12): the remap and the OBS egress (split + cv::resize(0.5, INTER_AREA) = (a + b + c + d + 2) >> 2 on the
+// chroma planes, FrameIngest.cpp:540-557,590-602) in one kernel.  Luma leaves as one dword per thread; the two rows of a chroma
+// sample belong to threads of neighbouring waves of the strip (rows y, y + 1), which meet through 2 KB of LDS and one barrier.
+template <bool NV12>
+struct Sink420
+{
+    uint8_t* __restrict__ yp; int y_step; uint8_t* __restrict__ up; int u_step; uint8_t* __restrict__ vp; int v_step;
+    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active) const
+    {
+        __shared__ uint2 s_uv[256];
+        const int t = (int)threadIdx.x;
+        // (U, V) of the four pixels, two 16-bit sums per word: u0 + u1 | u2 + u3 and v0 + v1 | v2 + v3 (horizontal pairs pre-added)
+        const uint32_t u01 = ((px[0] >> 8) & 0xffu) + ((px[1] >> 8) & 0xffu), u23 = ((px[2] >> 8) & 0xffu) + ((px[3] >> 8) & 0xffu);
+        const uint32_t v01 = ((px[0] >> 16) & 0xffu) + ((px[1] >> 16) & 0xffu), v23 = ((px[2] >> 16) & 0xffu) + ((px[3] >> 16) & 0xffu);
+        s_uv[t] = make_uint2(u01 | (u23 << 16), v01 | (v23 << 16));
+        if (active)
+        {
+            uint8_t* yr = yp + (long)y * y_step + x0;
+            const uint32_t yy = (px[0] & 0xffu) | ((px[1] & 0xffu) << 8) | ((px[2] & 0xffu) << 16) | ((px[3] & 0xffu) << 24);
+            if (npx == PXT && ((reinterpret_cast<uintptr_t>(yr) & 3u) == 0)) *reinterpret_cast<uint32_t*>(yr) = yy;
+            else for (int p = 0; p < npx; p++) yr[p] = (uint8_t)(yy >> (8 * p));
+        }
+        __syncthreads();
+        if (active && ((t >> 6) & 1) == 0)                 // even row of the pair: partner = same lane, next wave
+        {
+            const uint2 a = s_uv[t], b = s_uv[t + 64];
+            const uint32_t u0 = ((a.x & 0xffffu) + (b.x & 0xffffu) + 2u) >> 2, u1 = ((a.x >> 16) + (b.x >> 16) + 2u) >> 2;
+            const uint32_t v0 = ((a.y & 0xffffu) + (b.y & 0xffffu) + 2u) >> 2, v1 = ((a.y >> 16) + (b.y >> 16) + 2u) >> 2;
+            const int cx = x0 >> 1, cy = y >> 1, nc = npx >> 1;
+            if (NV12)
+            {
+                uint8_t* d = up + (long)cy * u_step + 2 * cx;
+                d[0] = (uint8_t)u0; d[1] = (uint8_t)v0;
+                if (nc > 1) { d[2] = (uint8_t)u1; d[3] = (uint8_t)v1; }
+            }
+            else
+            {
+                uint8_t* du = up + (long)cy * u_step + cx; uint8_t* dv = vp + (long)cy * v_step + cx;
+                du[0] = (uint8_t)u0; dv[0] = (uint8_t)v0;
+                if (nc > 1) { du[1] = (uint8_t)u1; dv[1] = (uint8_t)v1; }
+            }
+        }
+    }
+};
+
+template <bool YUV, class Coord, class Sink>
 __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
-                                            uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
+                                            const Sink& sink, int dst_rows, int dst_cols,
                                             const Coord& coord, uint32_t bg)
 {
     const int strips_x = (dst_cols + STRIP_W - 1) / STRIP_W, strips_y = (dst_rows + STRIP_H - 1) / STRIP_H;
@@ -318,12 +375,12 @@ __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int
     const int band = (nstrips + NUM_XCD - 1) / NUM_XCD;
     const int k = (int)(blockIdx.x / NUM_XCD);
     const int strip = (int)(blockIdx.x % NUM_XCD) * band + k;
-    if (k >= band || strip >= nstrips) return;
+    if (k >= band || strip >= nstrips) return;                       // block-uniform
     const int sy_ = strip / strips_x, sx_ = strip - sy_ * strips_x;
     const int x0 = sx_ * STRIP_W + (int)(threadIdx.x & 63) * PXT;
     const int y = sy_ * STRIP_H + (int)(threadIdx.x >> 6);
-    if (x0 >= dst_cols || y >= dst_rows) return;
-    const int npx = min(PXT, dst_cols - x0);
+    const bool active = x0 < dst_cols && y < dst_rows;
+    const int npx = active ? min(PXT, dst_cols - x0) : 0;
     uint32_t px[PXT];
 #pragma unroll
     for (int p = 0; p < PXT; p++)
@@ -350,8 +407,7 @@ __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int
             else px[p] = easu_gather<YUV>(src, src_step, sx, sy, ppx, ppy);
         }
     }
-    uint8_t* drow = dst + (long)y * dst_step;
-    store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
+    sink.store(x0, y, npx, px, active);
 }
 
 template <bool YUV>
@@ -361,7 +417,7 @@ void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_r
                         int off_x, int off_y, HomographyArgs H, uint32_t bg)
 {
     const HomographyCoord coord{H, off_x, off_y};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, dst_rows, dst_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -371,7 +427,7 @@ void k_remap_homography_co(const uint8_t* __restrict__ src, int src_step, int sr
                         int off_x, int off_y, HomographyArgs H, uint32_t bg)
 {
     const HomographyCoord coord{H, off_x, off_y};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, dst_rows, dst_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -382,7 +438,7 @@ void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, i
                   const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
     const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -393,7 +449,7 @@ void k_remap_mesh_co(const uint8_t* __restrict__ src, int src_step, int src_rows
                   const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
     const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -403,7 +459,7 @@ void k_remap_homography_lens(const uint8_t* __restrict__ src, int src_step, int 
                              int off_x, int off_y, HomographyArgs H, LensArgs L, uint32_t bg)
 {
     const LensCoord<HomographyCoord> coord{HomographyCoord{H, off_x, off_y}, L, src_rows, src_cols};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, dst_rows, dst_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -413,7 +469,7 @@ void k_remap_homography_lens_co(const uint8_t* __restrict__ src, int src_step, i
                              int off_x, int off_y, HomographyArgs H, LensArgs L, uint32_t bg)
 {
     const LensCoord<HomographyCoord> coord{HomographyCoord{H, off_x, off_y}, L, src_rows, src_cols};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, dst_rows, dst_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, dst_rows, dst_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -424,7 +480,7 @@ void k_remap_mesh_lens(const uint8_t* __restrict__ src, int src_step, int src_ro
                        const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, LensArgs L, uint32_t bg)
 {
     const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -435,7 +491,7 @@ void k_remap_mesh_lens_co(const uint8_t* __restrict__ src, int src_step, int src
                        const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, LensArgs L, uint32_t bg)
 {
     const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
 }
 
 template <bool YUV>
@@ -444,7 +500,46 @@ void k_remap_map(const uint8_t* __restrict__ src, int src_step, int src_rows, in
                  uint8_t* __restrict__ dst, int dst_step, const uint8_t* __restrict__ map, int map_step, uint32_t bg)
 {
     const MapCoord coord{map, map_step};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, dst, dst_step, src_rows, src_cols, coord, bg);
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
+}
+
+// ---- remap + 4:2:0 egress in one kernel (lvk_hip_stab_push_yuv420): YUV frames only, same size in and out, occupancy-capped like
+//      the other kernels the overlap mode runs next to the tracker
+struct Planes420 { uint8_t* y; int y_step; uint8_t* u; int u_step; uint8_t* v; int v_step; };
+
+template <bool NV12>
+__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+void k_remap_homography_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, uint32_t bg)
+{
+    const HomographyCoord coord{H, 0, 0};
+    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
+}
+
+template <bool NV12>
+__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+void k_remap_homography_lens_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, LensArgs L, uint32_t bg)
+{
+    const LensCoord<HomographyCoord> coord{HomographyCoord{H, 0, 0}, L, rows, cols};
+    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
+}
+
+template <bool NV12>
+__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+void k_remap_mesh_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
+                      const float* __restrict__ mesh, int mesh_cols, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
+{
+    const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows};
+    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
+}
+
+template <bool NV12>
+__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+void k_remap_mesh_lens_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
+                           const float* __restrict__ mesh, int mesh_cols, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab,
+                           LensArgs L, uint32_t bg)
+{
+    const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols};
+    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
 }
 
 inline dim3 remap_grid(int dst_rows, int dst_cols)
@@ -609,6 +704,67 @@ int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream,
     return lvk_launch_remap_mesh(ctx, stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, lens, co);
 }
 
+// WarpMesh::apply + I4XXIngest / NV12Ingest::to_obs in one launch: d_src packed YUV 8UC3, output planar 4:2:0 (I420: y, u, v; NV12: y, uv).
+int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
+                                  void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
+                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens)
+{
+    LVK_HIP_REQUIRE(ctx, d_src && o_y && o_u && (nv12 || o_v) && mesh && bg && mesh_rows >= 2 && mesh_cols >= 2);
+    LVK_HIP_REQUIRE(ctx, rows > 0 && cols > 0 && (rows & 1) == 0 && (cols & 1) == 0 && src_step >= 3 * cols);
+    LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
+    const Planes420 o{(uint8_t*)o_y, oy_step, (uint8_t*)o_u, ou_step, (uint8_t*)(nv12 ? o_u : o_v), nv12 ? ou_step : ov_step};
+    const dim3 block(256), grid = remap_grid(rows, cols);
+    if (mesh_rows == 2 && mesh_cols == 2)
+    {
+        const float w = (float)cols, h = (float)rows;                 // WarpMesh.cpp:194-217, as in lvk_launch_warpmesh_apply_lens
+        const float dstp[8] = { 0, 0, w, 0, 0, h, w, h };
+        float srcp[8];
+        for (int i = 0; i < 4; i++)
+        {
+            srcp[2 * i] = dstp[2 * i] + (float)((double)mesh[2 * i] * (double)cols);
+            srcp[2 * i + 1] = dstp[2 * i + 1] + (float)((double)mesh[2 * i + 1] * (double)rows);
+        }
+        double M[9];
+        if (!perspective_transform(dstp, srcp, M))
+            for (int q = 0; q < 9; q++) M[q] = (q % 4 == 0) ? 1.0 : 0.0;
+        HomographyArgs args;
+        for (int q = 0; q < 9; q++) args.h[q] = (float)M[q];
+        if (lens)
+        {
+            if (nv12) hipLaunchKernelGGL(k_remap_homography_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_homography_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
+        }
+        else
+        {
+            if (nv12) hipLaunchKernelGGL(k_remap_homography_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_homography_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg));
+        }
+    }
+    else
+    {
+        const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
+        LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
+        void* d_mesh = nullptr;
+        int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh);
+        if (rc != LVK_HIP_OK) return rc;
+        const LinTabEntry *xtab = nullptr, *ytab = nullptr;
+        if ((rc = lvk_get_lintab(ctx, mesh_cols, cols, false, &xtab)) != LVK_HIP_OK) return rc;
+        if ((rc = lvk_get_lintab(ctx, mesh_rows, rows, true, &ytab)) != LVK_HIP_OK) return rc;
+        if (lens)
+        {
+            if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_mesh_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
+        }
+        else
+        {
+            if (nv12) hipLaunchKernelGGL(k_remap_mesh_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_mesh_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
+        }
+    }
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
 extern "C" {
 
 int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
@@ -646,6 +802,15 @@ int lvk_hip_warpmesh_apply_lens(lvk_hip_ctx* ctx, const void* d_src, int src_ste
     if (rc != LVK_HIP_OK) return ctx->fail(rc, "invalid camera profile");
     std::memcpy(a.f, m.f, sizeof(a.f));
     return lvk_launch_warpmesh_apply_lens(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, &a, false);
+}
+
+int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
+                                  void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
+                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3])
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_warpmesh_apply_420(ctx, ctx->stream, d_src, src_step, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12,
+                                         mesh, mesh_rows, mesh_cols, bg, nullptr);
 }
 
 int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,

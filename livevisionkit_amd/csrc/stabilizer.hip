@@ -664,9 +664,12 @@ int lvk_hip_stab_frame_delay(const lvk_hip_stab* st) { return st ? st->s.predict
 
 // StabilizationFilter::filter (StabilizationFilter.cpp:69-135).  (luma, luma_step, luma_pix): where the tracker reads the
 // luma of this frame from -- the packed frame itself (pix 3) or, on the YUV420 path, the caller's planar Y (pix 1).
+// planes of a 4:2:0 output: when given, a warped frame leaves through the fused remap + egress kernel instead of d_out
+struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; };
+
 static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
                      const void* luma, int luma_step, int luma_pix,
-                     void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
+                     void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released, OutPlanes420* o420 = nullptr)
 {
     lvk_hip_ctx* ctx = st->ctx;
     if (produced) *produced = 0;
@@ -697,7 +700,13 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         hipStream_t rs = side ? st->remap_stream : ctx->stream;
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
-        if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
+        if (mesh && o420 && o420->y)
+        {
+            rc = lvk_launch_warpmesh_apply_420(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, o420->y, o420->y_step, o420->u, o420->u_step, o420->v, o420->v_step,
+                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, st->lens ? &st->lens_args : nullptr);
+            o420->used = true;
+        }
+        else if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
                                                       f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr, side);
         else
         {
@@ -852,7 +861,9 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     }
     int prod = 0; const void* released = nullptr;
     st->pool_frames = side_ingest;
-    rc = push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released);
+    OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false};
+    if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
+    rc = push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released, &o420);
     if (released) st->pool_free.push_back(const_cast<void*>(released));
     if (side_ingest)
     {
@@ -861,7 +872,8 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         st->ingest_pending = false;
     }
     if (rc != LVK_HIP_OK) return rc;
-    if (prod)
+    if (prod && o420.used) { if (produced) *produced = 1; }                // the fused remap + egress kernel has written the planes
+    else if (prod)
     {
         // the emitted frame has the geometry of the pool (all pooled frames share it)
         LVK_HIP_REQUIRE(ctx, o_y && o_u && (nv12 || o_v));

@@ -16,7 +16,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_0-9]+(?:<[a-z]+>)?)", name)
+    m = re.search(r"(k_[a-z_0-9]+(?:<[a-z0-9, ]+>)?)", name)
     return m.group(1) if m else None
 
 
@@ -64,7 +64,7 @@ if fetch or write:
             fn, fv = fetch.get(k, [0, 0.0]); wn, wv = write.get(k, [0, 0.0])
             fk = fv / fn if fn else 0.0; wk = wv / wn if wn else 0.0
             f.write("%s,%d,%.1f,%.3f,%.1f,%.3f\n" % (k, max(fn, wn), fk, 2 * fk * 1024 / 1e6, wk, wk * 1024 / 1e6))
-    key = next((k for k in fetch if k.startswith("k_remap")), None)
+    key = max((k for k in fetch if k.startswith("k_remap")), key=lambda k: fetch[k][0], default=None)      # the remap the pipeline runs
     if key:
         fk = fetch[key][1] / fetch[key][0]; wk = write.get(key, [1, 0.0]); wk = wk[1] / max(1, wk[0])
         json.dump({"rows": rows, "cols": cols, "kernel": key, "fetch_size_KiB": fk, "write_size_KiB": wk,

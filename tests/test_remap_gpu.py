@@ -155,3 +155,20 @@ def test_remap_strong_distortions_take_the_gather_path(ctx, oracle):
     got = ctx.remap_mesh(dsrc, mesh, yuv=True)
     ctx.sync()
     _assert_same(got, want, "violent mesh")
+
+
+@pytest.mark.parametrize("nv12", [False, True])
+@pytest.mark.parametrize("size", [(72, 96), (66, 130), (270, 480), (8, 8), (6, 10)])
+def test_warpmesh_apply_yuv420_equals_apply_then_egress(ctx, oracle, nv12, size):
+    """remap + 4:2:0 egress in one kernel == the two-kernel chain == the oracle's chain, bit for bit."""
+    rows, cols = size
+    rng = np.random.default_rng(rows + cols)
+    src = synth.textured_frame(rows, cols, seed=rows) if rows >= 32 else rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    dsrc = _to_gpu(src)
+    for mesh in (np.zeros((2, 2, 2), np.float32), rng.uniform(-0.03, 0.03, (2, 2, 2)).astype(np.float32), synth.random_mesh(16, 16, rng, amp=0.02),
+                 synth.random_mesh(3, 5, rng, amp=0.4)):
+        want = oracle.egress_yuv420(oracle.warpmesh_apply(src, mesh, bg=(105, 212, 235), yuv=True), nv12=nv12)
+        got = ctx.warpmesh_apply_yuv420(dsrc, mesh, bg=(105, 212, 235), nv12=nv12)
+        ctx.sync()
+        for a, b in zip(got, want):
+            assert np.array_equal(a.cpu().numpy(), b), (size, nv12, mesh.shape)
