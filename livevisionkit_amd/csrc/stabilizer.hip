@@ -81,14 +81,13 @@ struct lvk_hip_stab
     bool initialized = false;
     size_t cap_features = 0;                   // suppression-grid capacity (max features)
     int fast_cap = 0, fast_max_rw = 0, fast_max_rh = 0, fast_regions = 0;
-    FastRegion* d_regions = nullptr; void* d_fast_masks = nullptr; void* d_fast_scores = nullptr;
-    uint32_t* d_fast_out = nullptr; int* d_fast_counts = nullptr;
-    float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr, *d_p2 = nullptr; uint8_t* d_status = nullptr;
-    void* d_ransac_ws = nullptr; double* d_H = nullptr; int* d_ninl = nullptr; uint8_t* d_mask = nullptr;
+    void* d_fast_masks = nullptr; void* d_fast_scores = nullptr;
+    float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr; uint8_t* d_status = nullptr;      // d_p1: 2 * cap_features pairs (p1 | p2)
+    void* d_ransac_ws = nullptr;
     int* d_count = nullptr;                    // number of matches after the GPU-side fast_filter
     // pinned host mirrors
     uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
-    float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr, *h_p2 = nullptr; uint8_t* h_status = nullptr;
+    float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr; uint8_t* h_status = nullptr;
     double* h_H = nullptr; int* h_ninl = nullptr; uint8_t* h_mask = nullptr;
     int* h_count = nullptr;                    // d_count as the GPU-side fast_filter reported it (checked against the host's own)
     float2* h_und = nullptr;                   // fused lens mode: lens-corrected (previous | matched) point positions
@@ -133,7 +132,6 @@ struct lvk_hip_stab
     const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
     bool pool_frames = false;                  // the queued frames are pool slots that only stream-ordered kernels of remap_stream touch
     hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame (runs on remap_stream in overlap mode)
-    bool ingest_pending = false;
     int pending_slot = -1;
 
     // ---- optional per-stage GPU timing (HIP events on the launch stream)
@@ -204,13 +202,13 @@ int lvk_hip_stab::alloc_pyramids()
 
 void lvk_hip_stab::free_tracker_buffers()
 {
-    void* dev[] = {d_regions, d_fast_masks, d_fast_scores, d_fast_out, d_fast_counts, d_pts, d_matched, d_p1, d_p2, d_status, d_ransac_ws, d_H, d_ninl, d_mask, d_count};
+    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_p2, h_status, h_H, h_ninl, h_mask, h_und, h_count};
+    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count};
     for (void* p : host) if (p) (void)hipHostFree(p);
-    d_regions = nullptr; d_fast_masks = d_fast_scores = nullptr; d_fast_out = nullptr; d_fast_counts = nullptr;
-    d_pts = d_matched = d_p1 = d_p2 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_H = nullptr; d_ninl = nullptr; d_mask = nullptr; d_count = nullptr;
-    h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = h_p2 = nullptr; h_status = nullptr;
+    d_fast_masks = d_fast_scores = nullptr;
+    d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr;
+    h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = nullptr; h_status = nullptr;
     h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr; h_count = nullptr;
 }
 
@@ -229,20 +227,13 @@ int lvk_hip_stab::alloc_tracker_buffers()
     size_t mb, sb;
     lvk_fast_workspace_bytes(fast_regions, fast_max_rw, fast_max_rh, &mb, &sb);
     const size_t n = cap_features;
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_regions, fast_regions * sizeof(FastRegion)));
     LVK_HIP_CHECK(ctx, hipMalloc(&d_fast_masks, mb));
     LVK_HIP_CHECK(ctx, hipMalloc(&d_fast_scores, sb));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_fast_counts, fast_regions * sizeof(int)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_pts, n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_matched, n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p1, 2 * n * sizeof(float2)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p2, n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_status, n));
     LVK_HIP_CHECK(ctx, hipMalloc(&d_ransac_ws, lvk_ransac_workspace_bytes((int)n)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_H, 9 * sizeof(double)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_ninl, sizeof(int)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_mask, n));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_count, sizeof(int)));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
@@ -250,7 +241,6 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_pts, n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_matched, n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, 2 * n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p2, n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_status, n, hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocDefault));
@@ -454,7 +444,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         have_motion = true;
         return LVK_HIP_OK;
     }
-    // both point sets travel in one copy (h_p1 | h_p2 and d_p1 | d_p2 are each one allocation); results come back through
+    // both point sets travel in one copy (h_p1 and d_p1 each hold p1 | p2 in one allocation); results come back through
     // the pinned host block the kernel writes directly
     if (!chained)
     {
@@ -857,7 +847,6 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     {
         if (!st->ingest_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->ingest_done, hipEventDisableTiming));
         LVK_HIP_CHECK(ctx, hipEventRecord(st->ingest_done, is));
-        st->ingest_pending = true;
     }
     int prod = 0; const void* released = nullptr;
     st->pool_frames = side_ingest;
@@ -869,7 +858,6 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     {
         // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago)
         LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
-        st->ingest_pending = false;
     }
     if (rc != LVK_HIP_OK) return rc;
     if (prod && o420.used) { if (produced) *produced = 1; }                // the fused remap + egress kernel has written the planes
