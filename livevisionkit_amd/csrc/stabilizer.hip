@@ -6,12 +6,16 @@
 //   FeatureDetector::{detect,propagate,reset} bookkeeping                                           Vision/FeatureDetector.cpp:114-214
 //
 // Per frame, on the context's stream:
-//   luma + INTER_AREA downscale -> pyramid (pyrDown x3, Scharr x4)                       [imgproc.hip]
+//   luma (Y / BGR / RGB -> gray) + INTER_AREA downscale -> pyramid (pyrDown x3, Scharr x4)   [imgproc.hip]
 //   FAST-9/16 + NMS per due region, ordered compaction                                  [fast.hip]      -> host: suppression grid
-//   pyramidal LK, one wavefront per feature                                             [pyrlk.hip]     -> host: swap-erase filter
-//   RANSAC hypotheses + local optimisation                                              [motion.hip]    -> host: ageing, propagate, QA, path smoothing
-//   EASU remap of the delayed frame (homography or in-kernel mesh)                      [remap.hip]
-// Frames are never copied: the filter borrows the caller's device buffer until that frame has been emitted
+//   pyramidal LK, one wavefront per feature (points read from pinned host memory)       [pyrlk.hip]
+//   fast_filter in the reference's swap-erase order                                     [motion.hip k_match_compact]
+//   RANSAC hypotheses + local optimisation, pair count from the device                  [motion.hip]    -> ONE sync; host: ageing, propagate, QA, smoothing
+//   (vector-field preset / lens modes: sync after LK, point filter + mesh solve on the host)
+// and on the bulk stream (overlap mode; else the same stream):
+//   4:2:0 ingest of the new frame, EASU remap of the delayed frame (homography or in-kernel mesh, optionally with the lens
+//   pre-warp composed in, optionally with the 4:2:0 egress fused)                         [ingest.hip, remap.hip]
+// Packed frames are never copied: the filter borrows the caller's device buffer until that frame has been emitted
 // (the reference moves the input frame into its queue, StabilizationFilter.cpp:118).
 #include "lvk_hip_internal.hpp"
 #include "host_logic.hpp"
