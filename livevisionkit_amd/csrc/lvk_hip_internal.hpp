@@ -109,7 +109,8 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
 // (d_p1, d_p2) in exactly the order the host's back-to-front swap-erase produces, writes the count to d_count, and mirrors the raw
 // matched points / status flags into device-visible host memory for the host's own bookkeeping.
 int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
-                             float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status);
+                             float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
+                             const float2* d_und = nullptr, float region_w = 0.0f, float region_h = 0.0f);   // d_und: lens-corrected (prev | matched), see k_match_compact
 
 struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)

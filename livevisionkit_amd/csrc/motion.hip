@@ -524,15 +524,26 @@ constexpr int CMP_NT = 1024, CMP_CAP = 4096;
 __global__ __launch_bounds__(CMP_NT)
 void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
                      float2* __restrict__ p1, float2* __restrict__ p2, int* __restrict__ count, int* __restrict__ host_count,
-                     float2* __restrict__ host_matched, uint8_t* __restrict__ host_status)
+                     float2* __restrict__ host_matched, uint8_t* __restrict__ host_status,
+                     const float2* __restrict__ und, float region_w, float region_h)
 {
     __shared__ unsigned short s_above[CMP_CAP];            // number of dropped elements with a higher index
     __shared__ uint8_t s_keep[CMP_CAP];
     __shared__ int s_wave[CMP_NT / 64];
     const int t = threadIdx.x;
+    // fused lens mode: `und` holds the lens-corrected positions (previous | matched); they are what the motion is estimated from,
+    // and a match whose corrected positions leave the tracking region is dropped (it is not visible in the corrected frame)
+    const float2* pair_prev = und ? und : prev;
+    const float2* pair_next = und ? und + n : matched;
     for (int i = t; i < n; i += CMP_NT)
     {
-        const uint8_t k = status[i];
+        uint8_t k = status[i];
+        if (und)
+        {
+            const float2 a = und[i], b = und[n + i];
+            const bool inside = a.x >= 0.0f && a.x < region_w && a.y >= 0.0f && a.y < region_h && b.x >= 0.0f && b.x < region_w && b.y >= 0.0f && b.y < region_h;
+            if (!inside) k = 0;
+        }
         s_keep[i] = k; host_status[i] = k; host_matched[i] = matched[i];
     }
     __syncthreads();
@@ -572,7 +583,7 @@ void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__
             while (!s_keep[p]) p = n - ((int)s_above[p] + 1);
             src = p;
         }
-        p1[i] = prev[src]; p2[i] = matched[src];
+        p1[i] = pair_prev[src]; p2[i] = pair_next[src];
     }
 }
 
@@ -611,10 +622,12 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
 }
 
 int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
-                             float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status)
+                             float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
+                             const float2* d_und, float region_w, float region_h)
 {
     LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n >= 0 && n <= CMP_CAP);
-    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(CMP_NT), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status);
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(CMP_NT), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
+                       d_und, region_w, region_h);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
@@ -671,7 +684,7 @@ int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matche
         (e = hipMemcpyAsync(d + n, matched, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(d_s, status, n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
     { cleanup(); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
-    int rc = lvk_launch_match_compact(ctx, d, d + n, d_s, n, d + 2 * n, d + 3 * n, d_c, h_c, h_m, h_s);
+    int rc = lvk_launch_match_compact(ctx, d, d + n, d_s, n, d + 2 * n, d + 3 * n, d_c, h_c, h_m, h_s, nullptr, 0.0f, 0.0f);
     int m = 0;
     if (rc == LVK_HIP_OK)
     {

@@ -89,6 +89,7 @@ struct lvk_hip_stab
     float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr; uint8_t* d_status = nullptr;      // d_p1: 2 * cap_features pairs (p1 | p2)
     void* d_ransac_ws = nullptr;
     int* d_count = nullptr;                    // number of matches after the GPU-side fast_filter
+    float2* d_und = nullptr;                   // fused lens mode, chained path: lens-corrected (previous | matched) positions
     // pinned host mirrors
     uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
     float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr; uint8_t* h_status = nullptr;
@@ -206,12 +207,12 @@ int lvk_hip_stab::alloc_pyramids()
 
 void lvk_hip_stab::free_tracker_buffers()
 {
-    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count};
+    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count};
     for (void* p : host) if (p) (void)hipHostFree(p);
     d_fast_masks = d_fast_scores = nullptr;
-    d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr;
+    d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr; d_und = nullptr;
     h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = nullptr; h_status = nullptr;
     h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr; h_count = nullptr;
 }
@@ -239,6 +240,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_status, n));
     LVK_HIP_CHECK(ctx, hipMalloc(&d_ransac_ws, lvk_ransac_workspace_bytes((int)n)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_count, sizeof(int)));
+    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_und, 2 * n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
@@ -374,12 +376,19 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // Global-motion mode without a lens model: the whole chain optical flow -> fast_filter -> RANSAC runs on the GPU without a
     // host round trip in between (the flow kernel reads the points from pinned host memory, k_match_compact reproduces the host's
     // swap-erase order); the host synchronises once and then repeats the cheap bookkeeping on its own copies.
-    const bool chained = !s.track_local_motions && !lens && n <= 4096;
+    const bool chained = !s.track_local_motions && n <= 4096;
     pe = prof_begin(LVK_STAGE_PYRLK);
     if (chained)
     {
         if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, h_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG, d_pts)) != LVK_HIP_OK) return rc;
-        if ((rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status)) != LVK_HIP_OK) return rc;
+        if (lens)
+        {
+            // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks)
+            if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
+                                                d_pts, n, d_matched, n, d_und)) != LVK_HIP_OK) return rc;
+        }
+        if ((rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
+                                           lens ? d_und : nullptr, (float)cur_w, (float)cur_h)) != LVK_HIP_OK) return rc;
         prof_end(pe);
         pe = prof_begin(LVK_STAGE_MOTION);
         if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count)) != LVK_HIP_OK) return rc;
@@ -392,16 +401,15 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         prof_end(pe);
     }
     trace.mark(HostTrace::LK_LAUNCH);
-    if (lens)
+    if (lens && !chained)
     {
-        // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks)
         if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
                                             d_pts, n, h_matched, n, h_und)) != LVK_HIP_OK) return rc;
     }
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     trace.mark(HostTrace::LK_SYNC);
 
-    if (lens)
+    if (lens && !chained)                     // (the chained path has folded this test into the status flags on the GPU)
     {
         // a match whose corrected positions leave the tracking region is not visible in the lens-corrected frame: drop it
         const float w = (float)cur_w, h = (float)cur_h;
@@ -418,7 +426,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
             std::swap(tracked[k], tracked[m]);
             std::swap(h_pts[k], h_pts[m]);
             std::swap(h_matched[k], h_matched[m]);
-            if (lens) { std::swap(h_und[k], h_und[m]); std::swap(h_und[n + k], h_und[n + m]); }
+            if (lens && !chained) { std::swap(h_und[k], h_und[m]); std::swap(h_und[n + k], h_und[n + m]); }
         }
     tracked.resize(m);
     last_matched = m;
