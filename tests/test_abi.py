@@ -53,3 +53,13 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"lvko_|liblvk_oracle|oracle/|oracle_lib", text):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps each C-ABI symbol to the reference interface it replaces."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "lvk_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set(re.findall(r"\b(lvk_(?:hip|stab)_[a-z0-9_]+)\s*\(", header))
+    assert not [n for n in sorted(names) if n not in doc]
