@@ -136,6 +136,7 @@ struct lvk_hip_stab
     int remap_slot = 0;
     const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
     bool pool_frames = false;                  // the queued frames are pool slots that only stream-ordered kernels of remap_stream touch
+    int queue_kind = 0;                        // who owns the queued frames: 0 = queue empty, 1 = borrowed from the caller, 2 = pool slots
     hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame (runs on remap_stream in overlap mode)
     int pending_slot = -1;
 
@@ -645,8 +646,10 @@ int lvk_hip_stab_set_lens(lvk_hip_stab* st, const lvk_camera_params* params)
 int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::restart (StabilizationFilter.cpp:139-144)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    // the queue's frames go back to their owners: nothing on the bulk stream may still be reading them
+    if (st->remap_stream) LVK_HIP_CHECK(st->ctx, hipStreamSynchronize(st->remap_stream));
     st->scene_quality = 1.0f;
-    st->queue.clear();
+    st->queue.clear(); st->queue_kind = 0;
     st->pending_release = nullptr; st->pending_slot = -1;
     st->reset_context();
     return LVK_HIP_OK;
@@ -814,6 +817,9 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
 {
     if (!st) return LVK_HIP_ERR_ARG;
     st->trace.begin();
+    if (st->queue.empty()) st->queue_kind = 0;
+    if (st->queue_kind == 2) return st->fail(LVK_HIP_ERR_ARG, "frames of lvk_hip_stab_push_yuv420 are still queued: restart() before switching to lvk_hip_stab_push");
+    st->queue_kind = 1;
     st->pool_frames = false;
     const int rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
     st->trace.mark(HostTrace::EXIT);
@@ -833,6 +839,9 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     lvk_hip_ctx* ctx = st->ctx;
     st->trace.begin();
     if (produced) *produced = 0;
+    if (st->queue.empty()) st->queue_kind = 0;
+    if (st->queue_kind == 1) return st->fail(LVK_HIP_ERR_ARG, "borrowed frames of lvk_hip_stab_push are still queued: restart() before switching to lvk_hip_stab_push_yuv420");
+    st->queue_kind = 2;
     int rc = st->ensure_pool(rows, cols);
     if (rc != LVK_HIP_OK) return rc;
     if (st->pool_free.empty())

@@ -331,3 +331,24 @@ def test_stabilizer_bgr_rgb_frames_bit_exact(ctx, oracle, clip, fmt):
     outs_f = [ost3.push(f, ts=i, fmt=fmt)[0] for i, f in enumerate(frames[:5])]
     assert not np.array_equal(outs[4], outs_f[4])
     ost.close(); gst.close(); ost2.close(); ost3.close()
+
+
+def test_mixing_push_flavours_needs_a_restart(ctx):
+    """Borrowed packed frames and pooled 4:2:0 frames cannot share one queue: the switch is refused until restart()."""
+    import torch
+    import livevisionkit_amd as lvk
+    s = _to_settings(oracle_lib.preset("homography", predictive_samples=3))
+    f = lvk.StabilizationFilter(s, context=ctx)
+    packed = torch.zeros((270, 480, 3), dtype=torch.uint8, device="cuda")
+    planes = (torch.zeros((270, 480), dtype=torch.uint8, device="cuda"), torch.zeros((135, 240), dtype=torch.uint8, device="cuda"),
+              torch.zeros((135, 240), dtype=torch.uint8, device="cuda"))
+    f.apply(packed)
+    with pytest.raises(lvk.LvkHipError):
+        f.apply_yuv420(planes)
+    f.restart()
+    f.apply_yuv420(planes)
+    with pytest.raises(lvk.LvkHipError):
+        f.apply(packed)
+    f.restart()
+    f.apply(packed)
+    ctx.sync(); f.close()
