@@ -308,9 +308,11 @@ def main():
                          # the full-occupancy kernel alone on the GPU (outside the timed region), same frames and warp
                          "standalone_us": standalone_us,
                          "standalone_frac": (6 * rows * cols / (standalone_us * 1e-6)) / 1e9 / 8000.0 if standalone_us else None,
-                         # the kernel is VALU-issue bound: 487 VALU wave-instructions per output pixel (rocprofv3 SQ_INSTS_VALU,
-                         # profiles/r01_sq_counters_per_kernel.txt) against 64.6 T lane-instr/s measured with scripts/valu_peak.hip
-                         "valu_frac": (487.0 * rows * cols / (remap_ms / remap_n * 1e-3)) / 64.6e12 if remap_n else None},
+                         # the kernel is VALU-issue bound: 531 (packed output) / 534 (planar 4:2:0 output) VALU wave-instructions per output
+                         # pixel (rocprofv3 SQ_INSTS_VALU, profiles/r01_sq_counters_per_kernel.txt) against 64.6 T lane-instr/s measured
+                         # with scripts/valu_peak.hip
+                         "valu_frac": ((534.0 if fused_420 else 531.0) * rows * cols / (remap_ms / remap_n * 1e-3)) / 64.6e12 if remap_n else None,
+                         "standalone_valu_frac": (531.0 * rows * cols / (standalone_us * 1e-6)) / 64.6e12 if standalone_us else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             ncpu = os.cpu_count() or 1
