@@ -224,10 +224,11 @@ def test_stabilizer_restart(ctx, oracle, clip):
 
 
 def test_1080p_and_4k_streams_match_oracle(ctx, oracle):
-    """BASELINE configs 2 and 3 (1080p / 4K packed YUV): a short clip each, every emitted frame bit-identical."""
+    """BASELINE configs 1-3 (720p -- the non-integer INTER_AREA downscale --, 1080p, 4K packed YUV): a short clip each, every emitted
+    frame bit-identical."""
     import torch
     import livevisionkit_amd as lvk
-    for (rows, cols, n) in [(1080, 1920, 7), (2160, 3840, 5)]:
+    for (rows, cols, n) in [(720, 1280, 8), (1080, 1920, 7), (2160, 3840, 5)]:
         small, _ = synth.make_clip(rows // 4, cols // 4, n, seed=rows, jitter=1.0)
         frames = np.ascontiguousarray(small.repeat(4, axis=1).repeat(4, axis=2))            # cheap full-size frames with corners
         s = oracle_lib.preset("homography", predictive_samples=2)
