@@ -245,17 +245,19 @@ int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int ro
 
 /* The OBS asynchronous path in one call (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-212): YUV 4:2:0 planes in
  * (I420, or NV12 with nv12 != 0 and d_u = interleaved UV), ingest -> filter -> egress, 4:2:0 planes out.  The packed
- * frames the filter queues live in an internal pool.  Input planes are consumed when the call returns (stream order);
- * output planes are complete after lvk_hip_sync(). */
+ * frames the filter queues live in an internal pool; a warped frame leaves through one kernel that remaps and writes the planes.
+ * Input planes are consumed when the call returns; output planes are complete after lvk_hip_sync().  A filter is fed EITHER
+ * through this call OR through lvk_hip_stab_push -- switching needs lvk_hip_stab_restart() (the two own their queued frames
+ * differently). */
 int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
                               int rows, int cols, uint64_t timestamp,
                               void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,
                               int* produced, uint64_t* out_timestamp);
 
-/* Optional: run the output remap on a second HIP stream so that it overlaps the tracking of the next frame
- * (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches, Functions/Image.cpp:76).
- * With overlap enabled d_out is complete only after lvk_hip_sync(), and *released reports a borrowed frame one
- * push later (after its remap has finished). */
+/* Optional: run the bulk kernels (4:2:0 ingest, the output remap) on a second, low-priority HIP stream so that they overlap the
+ * tracking of the next frame (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches,
+ * Functions/Image.cpp:76); the remap then uses its occupancy-capped variants.  With overlap enabled d_out is complete only after
+ * lvk_hip_sync(), and *released reports a borrowed frame one push later (after its remap has finished). */
 int  lvk_hip_stab_set_overlap(lvk_hip_stab* stab, int enable);
 
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
