@@ -171,6 +171,7 @@ int lvk_hip_stab::prof_begin(int kind, hipStream_t stream)
 {
     if (!stream) stream = ctx->stream;
     if (!profiling || !((prof_mask >> kind) & 1u)) return -1;
+    if (ev_used >= 1024 && prof_collect() != LVK_HIP_OK) return -1;      // long sessions: fold the pending pairs in (one stream sync) and reuse them
     if (ev_used == ev_pool.size())
     {
         EvPair p{nullptr, nullptr, kind};
