@@ -80,7 +80,6 @@ void k_area_fast_dw(const uint8_t* __restrict__ src, int src_step, uint8_t* __re
 #pragma unroll
         for (int kx = 0; kx < SX; kx++)
         {
-            constexpr int dummy = 0; (void)dummy;
             const int b = kx * PIX;                       // byte of channel 0 of source pixel kx inside the segment
             const int c0 = (int)((w[ky][b >> 2] >> ((b & 3) * 8)) & 0xffu);
             if (MODE == 0) sum += c0;
