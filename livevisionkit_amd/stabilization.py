@@ -8,7 +8,7 @@ import time
 import numpy as np
 
 from . import _native
-from .context import Context, LvkHipError
+from .context import Context
 
 _c = ctypes
 

@@ -1,7 +1,6 @@
 """Micro-benchmark of the remap kernels (HIP events on the launch stream). Usage: python scripts/bench_remap.py [rows cols]"""
 import os
 import sys
-import time
 
 import numpy as np
 import torch

@@ -3,7 +3,7 @@ warm-up), and two fresh filters over the same clip must emit identical planes.  
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import livevisionkit_amd as lvk
 import bench
 ctx = lvk.Context(0, stream=torch.cuda.Stream())
