@@ -373,7 +373,7 @@ int lvk_launch_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int row
 }
 
 // Levels 1.. and all derivative images of a pyramid whose level 0 is filled: two launches for the usual 4-level pyramid.
-int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args)
+int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args, bool derivs)
 {
     int rc;
     if (args.nlevels == 4)
@@ -385,8 +385,11 @@ int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args)
         for (int i = 1; i < args.nlevels; i++)
             if ((rc = lvk_launch_pyr_down(ctx, args.lv[i - 1].img, args.lv[i - 1].step, args.lv[i - 1].rows, args.lv[i - 1].cols,
                                           const_cast<uint8_t*>(args.lv[i].img), args.lv[i].step)) != LVK_HIP_OK) return rc;
-    const dim3 sgrid((args.lv[0].cols + 63) / 64, (args.lv[0].rows + 3) / 4, args.nlevels);
-    hipLaunchKernelGGL(k_scharr_all, sgrid, dim3(64, 4), 0, ctx->stream, args);
+    if (derivs)                               // (the flow kernel derives them from its staged windows; only the test entry asks for the images)
+    {
+        const dim3 sgrid((args.lv[0].cols + 63) / 64, (args.lv[0].rows + 3) / 4, args.nlevels);
+        hipLaunchKernelGGL(k_scharr_all, sgrid, dim3(64, 4), 0, ctx->stream, args);
+    }
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

@@ -76,7 +76,7 @@ int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_ste
 int lvk_launch_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
 int lvk_launch_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
 struct PyrArgs;
-int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args);
+int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args, bool derivs = false);   // derivs: also fill the Scharr images (test entry only)
 
 // FAST-9/16 + NMS per region (fast.hip)
 int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks_bytes, size_t* scores_bytes);
@@ -97,7 +97,7 @@ struct DevicePyramid
     uint8_t* deriv_base = nullptr;
     PyrArgs args{};
     int allocate(lvk_hip_ctx* ctx, int rows, int cols, int max_level, int win_w, int win_h);
-    int build(lvk_hip_ctx* ctx);      // level 0 image must be filled; enqueues pyrDown + Scharr
+    int build(lvk_hip_ctx* ctx, bool derivs = false);   // level 0 image must be filled; enqueues pyrDown (+ the Scharr images on request)
     void release();
 };
 

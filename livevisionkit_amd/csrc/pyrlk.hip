@@ -26,8 +26,9 @@ constexpr int LK_MARGIN = 3;     // search margin (pixels) of the staged next-fr
 __host__ __device__ inline size_t lvk_pyrlk_part_offset(int win_w, int win_h)
 {
     const size_t tarea = (size_t)(win_w + 1) * (win_h + 1), area = (size_t)win_w * win_h;
+    const size_t earea = (size_t)(win_w + 3) * (win_h + 3);                  // image window + 1-px ring for the in-kernel Scharr
     const size_t jarea = (size_t)(win_w + 1 + 2 * LK_MARGIN) * (win_h + 1 + 2 * LK_MARGIN);
-    return ((tarea * 4 + area * 6 + tarea + jarea) + 15) & ~(size_t)15;
+    return ((tarea * 4 + area * 6 + earea + jarea) + 15) & ~(size_t)15;
 }
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -93,8 +94,9 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
     short* Iw = reinterpret_cast<short*>(smem + (size_t)tarea * 4);           // area * 2 B
     short* Ixw = Iw + area;
     short* Iyw = Ixw + area;
-    uint8_t* tile = reinterpret_cast<uint8_t*>(Iyw + area);                   // tarea B
-    uint8_t* jtile = tile + tarea;                                            // jw * jh B
+    const int ew = tw + 2, eh = th + 2;                                       // image window with a 1-px ring (Scharr support)
+    uint8_t* etile = reinterpret_cast<uint8_t*>(Iyw + area);                  // ew * eh B
+    uint8_t* jtile = etile + ew * eh;                                         // jw * jh B
     long long* part = reinterpret_cast<long long*>(smem + lvk_pyrlk_part_offset(win_w, win_h));   // 3 * 64 int64
     // division-free walk over the window: pixel p = lane + 64 r  ->  (y, x) advances by (64 / win_w, 64 % win_w)
     const int py0 = lane / win_w, px0 = lane - py0 * win_w, pdy_ = 64 / win_w, pdx_ = 64 - pdy_ * win_w;
@@ -138,18 +140,10 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
         const bool j_valid = !(jx0 < -win_w || jx0 >= J.cols || jy0 < -win_h || jy0 >= J.rows);
         jx0 = j_valid ? jx0 - LK_MARGIN : INT_MIN / 2; jy0 = j_valid ? jy0 - LK_MARGIN : INT_MIN / 2;
         __syncthreads();
-        for (int ty = ly; ty < th; ty += 4)
+        for (int ey = ly; ey < eh; ey += 4)
         {
-            const int yy = ipy + ty;
-            const uint8_t* irow = I.img + (long)reflect101(yy, I.rows) * I.step;
-            for (int tx = lx; tx < tw; tx += 16)
-            {
-                const int xx = ipx + tx;
-                tile[ty * tw + tx] = irow[reflect101(xx, I.cols)];
-                short2 d = make_short2(0, 0);
-                if (xx >= 0 && yy >= 0 && xx < I.cols && yy < I.rows) d = I.deriv[(long)yy * I.cols + xx];
-                dtile[ty * tw + tx] = d;
-            }
+            const uint8_t* irow = I.img + (long)reflect101(ipy - 1 + ey, I.rows) * I.step;
+            for (int ex = lx; ex < ew; ex += 16) etile[ey * ew + ex] = irow[reflect101(ipx - 1 + ex, I.cols)];
         }
         if (j_valid)
             for (int ty = ly; ty < jh; ty += 4)
@@ -158,11 +152,30 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
                 for (int tx = lx; tx < jw; tx += 16) jtile[ty * jw + tx] = jrow[reflect101(jx0 + tx, J.cols)];
             }
         __syncthreads();
+        // calcScharrDeriv on the staged window (reflect-101 ring, same integers as k_scharr_all); positions outside the image get
+        // zero derivatives like the zero border the derivative images used to be read with
+        for (int ty = ly; ty < th; ty += 4)
+            for (int tx = lx; tx < tw; tx += 16)
+            {
+                const int xx = ipx + tx, yy = ipy + ty;
+                short2 d = make_short2(0, 0);
+                if (xx >= 0 && yy >= 0 && xx < I.cols && yy < I.rows)
+                {
+                    const uint8_t* r0 = etile + ty * ew + tx; const uint8_t* r1 = r0 + ew; const uint8_t* r2 = r1 + ew;
+                    const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
+                    const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
+                    d = make_short2((short)(t0p - t0m), (short)((t1p + t1m) * 3 + t1c * 10));
+                }
+                dtile[ty * tw + tx] = d;
+            }
+        __syncthreads();
+        const uint8_t* tile = etile + ew + 1;                                     // the (win+1)^2 image window, pitch ew
         long long sA[3] = {0, 0, 0};
         for (int p = lane, y = py0, x = px0; p < area; p += 64)
         {
             const int i00 = y * tw + x, i01 = i00 + 1, i10 = i00 + tw, i11 = i10 + 1;
-            const int ival = descale(tile[i00] * w00 + tile[i01] * w01 + tile[i10] * w10 + tile[i11] * w11, 14 - 5);
+            const int e00 = y * ew + x, e01 = e00 + 1, e10 = e00 + ew, e11 = e10 + 1;
+            const int ival = descale(tile[e00] * w00 + tile[e01] * w01 + tile[e10] * w10 + tile[e11] * w11, 14 - 5);
             const int ixval = descale(dtile[i00].x * w00 + dtile[i01].x * w01 + dtile[i10].x * w10 + dtile[i11].x * w11, 14);
             const int iyval = descale(dtile[i00].y * w00 + dtile[i01].y * w01 + dtile[i10].y * w10 + dtile[i11].y * w11, 14);
             Iw[p] = (short)ival; Ixw[p] = (short)ixval; Iyw[p] = (short)iyval;
@@ -301,7 +314,7 @@ void DevicePyramid::release()
 }
 
 // Level 0 must already hold the tracking-resolution image; builds levels 1.. and all derivative images.
-int DevicePyramid::build(lvk_hip_ctx* ctx) { return lvk_launch_pyramid(ctx, args); }
+int DevicePyramid::build(lvk_hip_ctx* ctx, bool derivs) { return lvk_launch_pyramid(ctx, args, derivs); }
 
 extern "C" {
 
@@ -353,7 +366,7 @@ int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int row
     int rc;
     if ((rc = P.allocate(ctx, rows, cols, max_level, win_w, win_h)) != LVK_HIP_OK) return rc;
     hipError_t e = hipMemcpy2DAsync(const_cast<uint8_t*>(P.args.lv[0].img), P.args.lv[0].step, d_img, step, cols, rows, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess && (rc = P.build(ctx)) == LVK_HIP_OK)
+    if (e == hipSuccess && (rc = P.build(ctx, true)) == LVK_HIP_OK)
     {
         size_t lo = 0, dofs = 0;
         for (int i = 0; i < P.args.nlevels && e == hipSuccess; i++)
