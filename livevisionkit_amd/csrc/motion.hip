@@ -275,14 +275,6 @@ __device__ __forceinline__ double lane_plus(double v)
 constexpr int tri_row(int id, int n) { int a = 0; while (id >= n - a) { id -= n - a; a++; } return a; }
 constexpr int tri_col(int id, int n) { int a = 0; while (id >= n - a) { id -= n - a; a++; } return a + id; }
 
-__device__ __forceinline__ double tree_total(double p0, double p64, double p128, double p192)
-{
-    double v = (p0 + p128) + (p64 + p192);           // o = 128: (t, t + 128) and (t + 64, t + 192); o = 64: their sum
-    v = lane_plus<32>(v); v = lane_plus<16>(v); v = lane_plus<8>(v);
-    v = lane_plus<4>(v);  v = lane_plus<2>(v);  v = lane_plus<1>(v);
-    return v;                                        // valid on lane 0
-}
-
 // one term of sum ID for one point pair (ID is a compile-time constant so that r0 / r1 stay in registers)
 template <int ID>
 __device__ __forceinline__ double full_term(const double (&r0)[8], const double (&r1)[8], double u, double v)
@@ -310,16 +302,25 @@ template <int W, int N, int NS, int... K>
 __device__ __forceinline__ void store_totals(const double (&acc)[4][NS], int n_tri, double* A, double* b, std::integer_sequence<int, K...>)
 {
     const int lane = threadIdx.x & 63;
-    auto one = [&](auto kc) {
-        constexpr int k = decltype(kc)::value, id = W + 4 * k;
-        const double t = tree_total(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
-        if (lane == 0)
-        {
-            if constexpr (id < N * (N + 1) / 2) { constexpr int a = tri_row(id, N), c = tri_col(id, N); A[a * N + c] = t; A[c * N + a] = t; }
-            else b[id - N * (N + 1) / 2] = t;
-        }
-    };
-    (one(std::integral_constant<int, K>{}), ...);
+    // level by level over ALL sums of this wave, so that the NS independent lane shifts of a level are in flight together (a
+    // ds_bpermute round trip is ~100 cycles; sum after sum they would serialise into 6 x NS of them)
+    double t[NS];
+    ((t[K] = (acc[0][K] + acc[2][K]) + (acc[1][K] + acc[3][K])), ...);      // o = 128: (t, t + 128), (t + 64, t + 192); o = 64: their sum
+    ((t[K] = lane_plus<32>(t[K])), ...);
+    ((t[K] = lane_plus<16>(t[K])), ...);
+    ((t[K] = lane_plus<8>(t[K])), ...);
+    ((t[K] = lane_plus<4>(t[K])), ...);
+    ((t[K] = lane_plus<2>(t[K])), ...);
+    ((t[K] = lane_plus<1>(t[K])), ...);
+    if (lane == 0)
+    {
+        auto one = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, id = W + 4 * k;
+            if constexpr (id < N * (N + 1) / 2) { constexpr int a = tri_row(id, N), c = tri_col(id, N); A[a * N + c] = t[k]; A[c * N + a] = t[k]; }
+            else b[id - N * (N + 1) / 2] = t[k];
+        };
+        (one(std::integral_constant<int, K>{}), ...);
+    }
 }
 
 // Full homography: 36 upper-triangle entries of the 8 x 8 normal matrix (ids 0 .. 35, row major) + 8 right-hand sides (36 .. 43).
