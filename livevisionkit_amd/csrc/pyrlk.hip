@@ -175,13 +175,15 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
         {
             const int i00 = y * tw + x, i01 = i00 + 1, i10 = i00 + tw, i11 = i10 + 1;
             const int e00 = y * ew + x, e01 = e00 + 1, e10 = e00 + ew, e11 = e10 + 1;
-            const int ival = descale(tile[e00] * w00 + tile[e01] * w01 + tile[e10] * w10 + tile[e11] * w11, 14 - 5);
-            const int ixval = descale(dtile[i00].x * w00 + dtile[i01].x * w01 + dtile[i10].x * w10 + dtile[i11].x * w11, 14);
-            const int iyval = descale(dtile[i00].y * w00 + dtile[i01].y * w01 + dtile[i10].y * w10 + dtile[i11].y * w11, 14);
+            // every factor fits 24 signed bits (samples <= 255, |derivatives| <= 4080, weights <= 16384): v_mul_i32_i24 / v_mad_i32_i24
+            // run at full rate where the 32-bit v_mul_lo_u32 takes four passes; the products are exact either way
+            const int ival = descale(__mul24(tile[e00], w00) + __mul24(tile[e01], w01) + __mul24(tile[e10], w10) + __mul24(tile[e11], w11), 14 - 5);
+            const int ixval = descale(__mul24(dtile[i00].x, w00) + __mul24(dtile[i01].x, w01) + __mul24(dtile[i10].x, w10) + __mul24(dtile[i11].x, w11), 14);
+            const int iyval = descale(__mul24(dtile[i00].y, w00) + __mul24(dtile[i01].y, w01) + __mul24(dtile[i10].y, w10) + __mul24(dtile[i11].y, w11), 14);
             Iw[p] = (short)ival; Ixw[p] = (short)ixval; Iyw[p] = (short)iyval;
-            sA[0] += (long long)ixval * ixval;
-            sA[1] += (long long)ixval * iyval;
-            sA[2] += (long long)iyval * iyval;
+            sA[0] += (long long)__mul24(ixval, ixval);           // |ixval|, |iyval| <= 4080: the squares fit 32 bits
+            sA[1] += (long long)__mul24(ixval, iyval);
+            sA[2] += (long long)__mul24(iyval, iyval);
             y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
         }
         wave_sums<3>(sA, part);
@@ -223,9 +225,9 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
             for (int p = lane, y = py0, x = px0; p < area; p += 64)
             {
                 const int i00 = y * jw + x, i01 = i00 + 1, i10 = i00 + jw, i11 = i10 + 1;
-                const int diff = descale(jt[i00] * w00 + jt[i01] * w01 + jt[i10] * w10 + jt[i11] * w11, 14 - 5) - Iw[p];
-                sb[0] += (long long)diff * Ixw[p];
-                sb[1] += (long long)diff * Iyw[p];
+                const int diff = descale(__mul24(jt[i00], w00) + __mul24(jt[i01], w01) + __mul24(jt[i10], w10) + __mul24(jt[i11], w11), 14 - 5) - Iw[p];
+                sb[0] += (long long)__mul24(diff, Ixw[p]);              // |diff| <= 8160, |Ix| <= 4080
+                sb[1] += (long long)__mul24(diff, Iyw[p]);
                 y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
             }
             wave_sums<2>(sb, part);
