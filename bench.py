@@ -26,8 +26,8 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=2000)     # 2000 x ~0.14 ms: a 0.3 s timed region (a 40 ms one is at the mercy of clock ramps)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--rows", type=int, default=2160)
     ap.add_argument("--cols", type=int, default=3840)
     ap.add_argument("--preset", default="homography", choices=["homography", "field"])
@@ -223,7 +223,7 @@ def main():
 
     # per-step latency pass (each step synchronised) for p50 / p99 ms per frame
     lat = []
-    for _ in range(min(args.steps, 200)):
+    for _ in range(min(args.steps, 500)):
         torch.cuda.synchronize()
         t = time.perf_counter()
         step()
