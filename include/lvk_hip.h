@@ -259,6 +259,10 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
  * Functions/Image.cpp:76); the remap then uses its occupancy-capped variants.  With overlap enabled d_out is complete only after
  * lvk_hip_sync(), and *released reports a borrowed frame one push later (after its remap has finished). */
 int  lvk_hip_stab_set_overlap(lvk_hip_stab* stab, int enable);
+/* The hipStream_t the outputs of the following pushes are produced on (the bulk stream in overlap mode, else the context's
+ * stream): enqueue stream-ordered consumers of d_out / the output planes (a D2H copy, an encoder) there instead of calling
+ * lvk_hip_sync().  Changes when lvk_hip_stab_set_overlap or stabilize_output change. */
+void* lvk_hip_stab_output_stream(lvk_hip_stab* stab);
 
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
 /* last frame motion (after the trust factor) and last applied correction; each motion_height x motion_width x 2 floats */

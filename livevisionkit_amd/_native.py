@@ -35,6 +35,7 @@ _SIG = {
     "lvk_hip_warpmesh_apply_lens": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int, _P]),
     "lvk_hip_lens_undistort_points": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.POINTER(_c.c_float), _c.c_int, _c.POINTER(_c.c_float)]),
     "lvk_hip_stab_set_lens": (_c.c_int, [_P, _P]),
+    "lvk_hip_stab_output_stream": (_P, [_P]),
     "lvk_hip_fast_filter": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.POINTER(_c.c_uint8), _c.c_int, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)]),
     "lvk_hip_stab_draw_trackers": (_c.c_int, [_P]),
     "lvk_hip_stab_draw_motion_mesh": (_c.c_int, [_P]),

@@ -544,6 +544,14 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
 // next frame (the two are independent: the delayed frame was uploaded at least one push earlier).  The output of a
 // push is then complete only after lvk_hip_sync(), and a borrowed frame is handed back (*released) one push later,
 // after its remap has finished.
+// The stream the output of the next pushes is produced on (the bulk stream in overlap mode, else the context's): a caller that
+// wants to chain its own stream-ordered work behind an output (a D2H copy, an encoder) enqueues it there instead of synchronising.
+void* lvk_hip_stab_output_stream(lvk_hip_stab* st)
+{
+    if (!st) return nullptr;
+    return (void*)((st->overlap && st->s.stabilize_output && st->remap_stream) ? st->remap_stream : st->ctx->stream);
+}
+
 int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
 {
     if (!st) return LVK_HIP_ERR_ARG;

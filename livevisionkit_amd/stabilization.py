@@ -238,6 +238,11 @@ class StabilizationFilter:
         arr = (ctypes.c_double * 9)(*[float(v) for v in params]) if params is not None else None
         self.ctx._check(self.lib.lvk_hip_stab_set_lens(self.handle, arr))
 
+    def output_stream(self):
+        """torch stream the outputs of the following pushes are produced on (chain D2H copies / consumers behind it instead of sync())."""
+        import torch
+        return torch.cuda.ExternalStream(self.lib.lvk_hip_stab_output_stream(self.handle), device=torch.device("cuda", self.ctx.device))
+
     def set_overlap(self, enable=True):
         """Run the output remap on a second stream, overlapping the next frame's tracking (output valid after ctx.sync())."""
         self.ctx._check(self.lib.lvk_hip_stab_set_overlap(self.handle, 1 if enable else 0))
