@@ -50,6 +50,7 @@ void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols
                    const FastRegion* __restrict__ regions, int segs_x,
                    unsigned long long* __restrict__ masks, uint8_t* __restrict__ scores, int max_rh, int max_rw)
 {
+    LVK_TRACKER_PRIORITY();
     const FastRegion rg = regions[blockIdx.z];
     if (!rg.active) return;
     const int lx0 = blockIdx.x * TW, ly0 = blockIdx.y * TH;
@@ -102,6 +103,7 @@ void k_fast_compact(const FastRegion* __restrict__ regions, int segs_x,
                     const unsigned long long* __restrict__ masks, const uint8_t* __restrict__ scores, int max_rh, int max_rw,
                     uint32_t* __restrict__ out, int cap, int* __restrict__ counts)
 {
+    LVK_TRACKER_PRIORITY();
     const int r = blockIdx.x;
     const FastRegion rg = regions[r];
     if (!rg.active) { if (threadIdx.x == 0) counts[r] = 0; return; }

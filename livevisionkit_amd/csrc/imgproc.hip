@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256)
 void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
                  uint8_t* __restrict__ dst, int dst_step, int drows, int dcols, int sx, int sy)
 {
+    LVK_TRACKER_PRIORITY();
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= dcols || y >= drows) return;
@@ -62,6 +63,7 @@ template <int SX, int SY, int PIX, int MODE = 0>          // MODE 0: channel 0; 
 __global__ __launch_bounds__(256)
 void k_area_fast_dw(const uint8_t* __restrict__ src, int src_step, uint8_t* __restrict__ dst, int dst_step, int drows, int dcols)
 {
+    LVK_TRACKER_PRIORITY();
     constexpr int NW = SX * PIX / 4;
     static_assert((SX * PIX) % 4 == 0, "row segment must be whole dwords");
     const int x = blockIdx.x * 64 + threadIdx.x;
@@ -104,6 +106,7 @@ void k_area_general(const uint8_t* __restrict__ src, int src_step, int pix_strid
                     const int2* __restrict__ xrange, const AreaTabEntry* __restrict__ xtab,
                     const int2* __restrict__ yrange, const AreaTabEntry* __restrict__ ytab)
 {
+    LVK_TRACKER_PRIORITY();
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= dcols || y >= drows) return;
@@ -195,6 +198,7 @@ __device__ __forceinline__ int pyr_tap(const uint8_t* t, int pitch, int ox, int 
 __global__ __launch_bounds__(256)
 void k_pyr_fused3(PyrArgs a)
 {
+    LVK_TRACKER_PRIORITY();
     __shared__ uint8_t t0[F0 * F0P], t1[F1 * F1P], t2[F2 * F2P];
     const int tid = threadIdx.x;
     const int x3 = blockIdx.x * T3, y3 = blockIdx.y * T3;

@@ -57,6 +57,13 @@ struct lvk_hip_ctx
             return (ctx)->fail(LVK_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// First statement of the tracker's small, latency-bound kernels: their waves take instruction-issue priority over the waves of the
+// VALU-bound bulk kernels (remap) that share the SIMDs in overlap mode (s_setprio; no effect when they run alone).
+#ifndef LVK_TRACKER_PRIO
+#define LVK_TRACKER_PRIO 3
+#endif
+#define LVK_TRACKER_PRIORITY() __builtin_amdgcn_s_setprio(LVK_TRACKER_PRIO)
+
 #define LVK_HIP_REQUIRE(ctx, cond)                                                                    \
     do { if (!(cond)) return (ctx)->fail(LVK_HIP_ERR_ARG, "pre-condition failed: " #cond); } while (0)
 

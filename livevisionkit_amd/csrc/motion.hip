@@ -219,6 +219,7 @@ __global__ __launch_bounds__(NT)
 void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
                          double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
 {
+    LVK_TRACKER_PRIORITY();
     if (n_dev) n = min(*n_dev, n);                          // pair count decided on the GPU (k_match_compact); n = capacity
     if (n < (full ? 4 : 2)) { if (threadIdx.x == 0) hyp_score[blockIdx.x] = -1; return; }
     __shared__ double sA[64], sb[8], sH[9];
@@ -448,6 +449,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
                        uint8_t* __restrict__ gmask_a, uint8_t* __restrict__ gmask_b,
                        double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
 {
+    LVK_TRACKER_PRIORITY();
     __shared__ double sA[64], sb[8], sH[9], sBest[9];
     __shared__ long long s_scratch[NT / 64];
     __shared__ long long s_best[NT / 64]; __shared__ int s_best_h[NT / 64];
@@ -528,6 +530,7 @@ void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__
                      float2* __restrict__ host_matched, uint8_t* __restrict__ host_status,
                      const float2* __restrict__ und, float region_w, float region_h)
 {
+    LVK_TRACKER_PRIORITY();
     __shared__ unsigned short s_above[CMP_CAP];            // number of dropped elements with a higher index
     __shared__ uint8_t s_keep[CMP_CAP];
     __shared__ int s_wave[CMP_NT / 64];

@@ -285,10 +285,11 @@ struct LensCoord
 // source rows, and with this order those re-reads hit that XCD's L2 instead of going back to HBM.
 constexpr int PXT = 4, STRIP_W = 64 * PXT, STRIP_H = 4;
 // The `_co` kernel variants are for the stabilizer's overlap mode, where the remap shares the GPU with the next frame's tracker:
-// capped at 3 waves per SIMD they leave register space on every SIMD, so the tracker's small latency-bound kernels are placed
-// at once instead of queueing behind 17-us remap workgroups.  Measured at 4K (MI355X): the remap itself 107 -> 114 us, the
-// concurrent downscale + pyramid 62 -> 36 us, whole-pipeline throughput +9 ... +20 %.  (2 waves: 126 us / 29 us; 1 wave: 177 us.)
-#define LVK_CO_SCHEDULED __attribute__((amdgpu_waves_per_eu(3, 3)))
+// capped at 4 waves per SIMD they leave register space on every SIMD, so the tracker's small latency-bound kernels are placed
+// at once instead of queueing behind 17-us remap workgroups -- and those kernels raise their own issue priority (s_setprio,
+// LVK_TRACKER_PRIORITY) so that they are not starved by the VALU-bound remap waves they share a SIMD with.  Measured at 4K
+// (MI355X, whole pipeline): cap 3 / 4 / 5 waves with the priority raise 7.1k / 7.6k / 7.0k frames/s (cap 3 without it: 6.9k).
+#define LVK_CO_SCHEDULED __attribute__((amdgpu_waves_per_eu(4, 4)))
 constexpr int NUM_XCD = 8;
 
 __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
