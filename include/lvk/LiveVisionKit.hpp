@@ -463,6 +463,72 @@ private:
     int m_LastRows = 0, m_LastCols = 0;
 };
 
+// ---------------------------------------------------------------------------------------------- Functions/Image.hpp, Filters/ScalingFilter.hpp
+// lvk::upscale (Image.cpp:155-202): EASU upsampling to `size`; size == src.size() copies.
+inline void upscale(const VideoFrame& src, VideoFrame& dst, const cv::Size& size, const bool yuv = true)
+{
+    LVK_HIP_ASSERT(size.width >= src.cols && size.height >= src.rows);
+    LVK_HIP_ASSERT(!src.empty());
+    const auto& ctx = src.context();
+    VideoFrame out;                                        // dst may be the object src refers to
+    out.create(size, CV_8UC3, ctx);
+    ctx->check(lvk_hip_upscale(ctx->get(), src.device_ptr(), (int)src.step, src.rows, src.cols,
+                               out.device_ptr(), (int)out.step, out.rows, out.cols, yuv ? 1 : 0), "upscale");
+    out.timestamp = src.timestamp; out.format = src.format;
+    dst = std::move(out);
+}
+
+// lvk::sharpen (Image.cpp:206-233): RCAS.  The reference's ScalingFilter passes the same frame as src and dst, where its kernel races
+// neighbour reads against writes; here the result is always that of distinct buffers (src == dst goes through a fresh frame).
+inline void sharpen(const VideoFrame& src, VideoFrame& dst, const float sharpness = 0.7f)
+{
+    LVK_HIP_ASSERT(sharpness >= 0.0f && sharpness <= 1.0f);
+    LVK_HIP_ASSERT(!src.empty());
+    const auto& ctx = src.context();
+    VideoFrame out;
+    out.create(src.size(), CV_8UC3, ctx);
+    ctx->check(lvk_hip_sharpen(ctx->get(), src.device_ptr(), (int)src.step, src.rows, src.cols, out.device_ptr(), (int)out.step, sharpness), "sharpen");
+    out.timestamp = src.timestamp; out.format = src.format;
+    dst = std::move(out);
+}
+
+struct ScalingFilterSettings                         // Filters/ScalingFilter.hpp:27-32
+{
+    cv::Size output_size = {1920, 1080};
+    float sharpness = 0.8f;
+    bool yuv_input = true;
+};
+
+class ScalingFilter final : public VideoFilter, public Configurable<ScalingFilterSettings>   // Filters/ScalingFilter.cpp:27-59
+{
+public:
+    explicit ScalingFilter(const ScalingFilterSettings& settings = {}) : VideoFilter("Scaling Filter") { configure(settings); }
+    explicit ScalingFilter(const cv::Size& output_size, const float sharpness = 0.8f) : VideoFilter("Scaling Filter")
+    {
+        ScalingFilterSettings settings; settings.output_size = output_size; settings.sharpness = sharpness;
+        configure(settings);
+    }
+    void configure(const ScalingFilterSettings& settings) override
+    {
+        LVK_HIP_ASSERT(settings.sharpness >= 0.0f && settings.sharpness <= 1.0f);
+        LVK_HIP_ASSERT(settings.output_size.width > 0);
+        LVK_HIP_ASSERT(settings.output_size.height > 0);
+        m_Settings = settings;
+    }
+private:
+    void filter(VideoFrame&& input, VideoFrame& output) override
+    {
+        LVK_HIP_ASSERT(!input.empty());
+        VideoFrame in = std::move(input), scaled;
+        m_Ctx = in.context();
+        lvk::upscale(in, scaled, m_Settings.output_size, m_Settings.yuv_input);
+        lvk::sharpen(scaled, output, m_Settings.sharpness);
+        output.timestamp = in.timestamp;
+    }
+    void sync_gpu(bool trigger) override { if (trigger && m_Ctx) m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); }
+    std::shared_ptr<hip::Context> m_Ctx;
+};
+
 // north-star aliases (BASELINE.json names from another LVK snapshot; SURVEY.md name mapping)
 using PathStabilizerSettings = PathSmootherSettings;
 using GridDetectorSettings = FeatureDetectorSettings;

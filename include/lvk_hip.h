@@ -78,6 +78,16 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
 int lvk_hip_remap_map(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
                       const void* d_map, int map_step, const uint8_t bg[3], int yuv);
 
+/* lvk::upscale(src, dst, size, yuv) (Functions/Image.cpp:155-202, kernel easu_scale FSR.cl:324-358): EASU upsampling of an
+ * 8UC3 frame to dst_cols x dst_rows >= the source size (equal size = copy).  d_dst must not alias d_src. */
+int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_rows, int src_cols,
+                    void* d_dst, int dst_step, int dst_rows, int dst_cols, int yuv);
+
+/* lvk::sharpen(src, dst, sharpness) (Functions/Image.cpp:206-233, kernel rcas FSR.cl:460-535): RCAS with sharpness in [0, 1].
+ * OUT OF PLACE: the reference's ScalingFilter sharpens in place (Filters/ScalingFilter.cpp:57), where neighbour reads race
+ * with writes; the defined result is that of distinct buffers, and aliasing is rejected.  Border pixels are copied. */
+int lvk_hip_sharpen(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step, float sharpness);
+
 /* Lens correction: the offset map LCFilter::prepare_undistort_maps builds
  * (Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-171) for a camera profile in the plugin's format
  * (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153); LCFilter::filter == lvk_hip_remap_map with it. */

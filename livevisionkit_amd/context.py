@@ -221,6 +221,26 @@ class Context:
                                                offsets.data_ptr(), offsets.stride(0) * 4, bgp, 1 if yuv else 0))
         return out
 
+    def upscale(self, src, size, yuv=True, out=None):
+        """lvk::upscale(src, dst, size, yuv): EASU upsampling to size = (width, height) >= the source size."""
+        import torch
+        rows, cols = src.shape[:2]
+        if out is None:
+            out = torch.empty((int(size[1]), int(size[0]), 3), dtype=torch.uint8, device=src.device)
+        self._check(self.lib.lvk_hip_upscale(self.handle, src.data_ptr(), src.stride(0), rows, cols,
+                                             out.data_ptr(), out.stride(0), out.shape[0], out.shape[1], 1 if yuv else 0))
+        return out
+
+    def sharpen(self, src, sharpness=0.7, out=None):
+        """lvk::sharpen(src, dst, sharpness): RCAS, out of place."""
+        import torch
+        rows, cols = src.shape[:2]
+        if out is None:
+            out = torch.empty_like(src)
+        self._check(self.lib.lvk_hip_sharpen(self.handle, src.data_ptr(), src.stride(0), rows, cols, out.data_ptr(), out.stride(0),
+                                             float(sharpness)))
+        return out
+
     def lens_map(self, params, rows, cols):
         """Device offset map of LCFilter for camera params (fx, fy, cx, cy, k1, k2, p1, p2, k3): (torch view [rows, cols, 2], view_xywh)."""
         import torch

@@ -159,6 +159,12 @@ int lvk_launch_draw_grid(lvk_hip_ctx* ctx, hipStream_t stream, void* d_dst, int 
 int lvk_launch_draw_crosses(lvk_hip_ctx* ctx, hipStream_t stream, void* d_dst, int dst_step, int rows, int cols, const float* pts, int n,
                             float scale_x, float scale_y, const uint8_t colour[3], int cross_size, int thickness);
 
+// ScalingFilter's two kernels: EASU upscale (remap.hip) and RCAS (sharpen.hip)
+int lvk_launch_upscale(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
+                       void* d_dst, int dst_step, int dst_rows, int dst_cols, int yuv);
+int lvk_launch_sharpen(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
+                       void* d_dst, int dst_step, float sharpness);
+
 // remap + 4:2:0 egress in one kernel (remap.hip)
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,

@@ -242,6 +242,16 @@ struct MapCoord             // FSR.cl:376-381: a materialised offset map (pixels
     }
 };
 
+struct ScaleCoord           // easu_scale, FSR.cl:334-338: dst_coord * rscale (rscale = src size / dst size, Image.cpp:192-195)
+{
+    float rsx, rsy;
+    __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
+    {
+        subx = (float)x * rsx;
+        suby = (float)y * rsy;
+    }
+};
+
 // Fused lens pre-warp (BASELINE config 5): the inner functor yields the position (u, v) the
 // stabilizing warp asks for in the LENS-CORRECTED frame; the closed-form Brown-Conrady map (LCFilter.cpp:133-171 reduced by
 // lens.hip to 17 floats) carries it on to the raw frame, so the chain LC -> VS costs one EASU resampling and no map traffic.
@@ -504,6 +514,17 @@ void k_remap_map(const uint8_t* __restrict__ src, int src_step, int src_rows, in
     remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
 }
 
+// lvk::upscale (Image.cpp:155-202): the same strip body; the source coordinate never leaves the image, so the border band is the
+// nearest copy of FSR.cl:342-351 and the background is unreachable.
+template <bool YUV>
+__global__ __launch_bounds__(256)
+void k_easu_scale(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                  uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols, float rsx, float rsy)
+{
+    const ScaleCoord coord{rsx, rsy};
+    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, dst_rows, dst_cols, coord, 0u);
+}
+
 // ---- remap + 4:2:0 egress in one kernel (lvk_hip_stab_push_yuv420): YUV frames only, same size in and out, occupancy-capped like
 //      the other kernels the overlap mode runs next to the tracker
 struct Planes420 { uint8_t* y; int y_step; uint8_t* u; int u_step; uint8_t* v; int v_step; };
@@ -667,6 +688,28 @@ int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src
     return LVK_HIP_OK;
 }
 
+// lvk::upscale(src, dst, size, yuv) (Functions/Image.cpp:155-202)
+int lvk_launch_upscale(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int src_rows, int src_cols,
+                       void* d_dst, int dst_step, int dst_rows, int dst_cols, int yuv)
+{
+    LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && d_src != d_dst);
+    LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0);                                         // Image.cpp:158
+    LVK_HIP_REQUIRE(ctx, dst_cols >= src_cols && dst_rows >= src_rows);                         // Image.cpp:157
+    LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * dst_cols);
+    if (dst_cols == src_cols && dst_rows == src_rows)                                           // Image.cpp:162-166
+    {
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_step, d_src, (size_t)src_step, 3 * (size_t)src_cols, (size_t)src_rows,
+                                            hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    }
+    const float rsx = (float)src_cols / (float)dst_cols, rsy = (float)src_rows / (float)dst_rows;
+    const dim3 block(256), grid = remap_grid(dst_rows, dst_cols);
+    if (yuv) hipLaunchKernelGGL(k_easu_scale<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, rsx, rsy);
+    else hipLaunchKernelGGL(k_easu_scale<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, dst_rows, dst_cols, rsx, rsy);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
 int lvk_launch_warpmesh_apply(lvk_hip_ctx* ctx, hipStream_t stream,
                               const void* d_src, int src_step, int rows, int cols,
                               void* d_dst, int dst_step,
@@ -812,6 +855,13 @@ int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_s
     if (!ctx) return LVK_HIP_ERR_ARG;
     return lvk_launch_warpmesh_apply_420(ctx, ctx->stream, d_src, src_step, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12,
                                          mesh, mesh_rows, mesh_cols, bg, nullptr);
+}
+
+int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_rows, int src_cols,
+                    void* d_dst, int dst_step, int dst_rows, int dst_cols, int yuv)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    return lvk_launch_upscale(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, dst_rows, dst_cols, yuv);
 }
 
 int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,

@@ -493,4 +493,81 @@ int lvko_warpmesh_apply_lens(const uint8_t* src, int src_step, int rows, int col
     return remap_mesh_impl(src, src_step, rows, cols, dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv, nthreads, Lp);
 }
 
+// lvk::upscale -> kernel easu_scale (Functions/Image.cpp:155-202, FSR.cl:324-358).  rscale = (float)src / (float)dst per axis;
+// a destination pixel maps to dst_coord * rscale; where the 12-tap window leaves the image the NEAREST source pixel is copied
+// (there is no background here).  size == src size is a plain copy (Image.cpp:162-166).
+int lvko_upscale(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                 uint8_t* dst, int dst_step, int dst_rows, int dst_cols, int yuv, int nthreads)
+{
+    if (!src || !dst || src_rows <= 0 || src_cols <= 0) return -1;
+    if (dst_cols < src_cols || dst_rows < src_rows) return -1;              // Image.cpp:157
+    if (dst_cols == src_cols && dst_rows == src_rows)
+    {
+        for (int y = 0; y < src_rows; y++) std::memcpy(dst + (size_t)y * dst_step, src + (size_t)y * src_step, 3 * (size_t)src_cols);
+        return 0;
+    }
+    const float rsx = (float)src_cols / (float)dst_cols, rsy = (float)src_rows / (float)dst_rows;   // Image.cpp:192-195
+    const uint8_t bg[3] = {0, 0, 0};                                         // unreachable: the source coordinate is inside
+    parallel_rows(dst_rows, nthreads, [=](int r0, int r1) {
+        for (int y = r0; y < r1; y++)
+        {
+            uint8_t* drow = dst + (size_t)y * dst_step;
+            for (int x = 0; x < dst_cols; x++)
+                remap_pixel(src, src_step, src_rows, src_cols, drow + 3 * x, (float)x * rsx, (float)y * rsy, bg, yuv != 0);   // FSR.cl:334-356
+        }
+    });
+    return 0;
+}
+
+// lvk::sharpen -> kernel rcas (Functions/Image.cpp:206-233, FSR.cl:460-535).  `sharpness` is the user value in [0, 1]; the kernel
+// receives exp2(-2 (1 - sharpness)) (Image.cpp:227).  Arithmetic definition, as for EASU: `x * y + z` is one fmaf, native_recip is
+// the correctly rounded 1.0f / x, min/max are fminf/fmaxf (a NaN operand loses: 0 * inf appears when a ring is all 0 or all 1),
+// convert_uchar3 truncates.  Out of place: the reference's ScalingFilter runs it in place (ScalingFilter.cpp:57), which races
+// reads of neighbours against writes; the defined result is the one of distinct src and dst.  Border pixels are copied; the
+// reference's `coord <= cols || coord <= rows` guard (FSR.cl:478) lets the padding threads of a work-group write past the row
+// end, which is not reproduced.
+namespace {
+inline float APrxMedRcpF1(float a) { const float b = as_float(0x7ef19fffu - as_uint(a)); return b * fmaf(-b, a, 2.0f); }   // FSR.cl:70
+inline float min4f(float a, float b, float c, float d) { return fminf(a, fminf(b, fminf(c, d))); }                     // FSR.cl:85
+inline float max4f(float a, float b, float c, float d) { return fmaxf(a, fmaxf(b, fmaxf(c, d))); }                     // FSR.cl:84
+}
+
+int lvko_sharpen(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step, float sharpness, int nthreads)
+{
+    if (!src || !dst || rows <= 0 || cols <= 0 || !(sharpness >= 0.0f && sharpness <= 1.0f)) return -1;
+    const float sharp = exp2f(-2.0f * (1.0f - sharpness));                  // Image.cpp:227
+    parallel_rows(rows, nthreads, [=](int r0, int r1) {
+        for (int y = r0; y < r1; y++)
+        {
+            const uint8_t* srow = src + (size_t)y * src_step;
+            uint8_t* drow = dst + (size_t)y * dst_step;
+            for (int x = 0; x < cols; x++)
+            {
+                const uint8_t* pe = srow + 3 * x;
+                uint8_t* o = drow + 3 * x;
+                if (x == 0 || x >= cols - 1 || y == 0 || y >= rows - 1) { o[0] = pe[0]; o[1] = pe[1]; o[2] = pe[2]; continue; }   // FSR.cl:475-481
+                const F3 b = load_px(pe - src_step), h = load_px(pe + src_step), d = load_px(pe - 3), e = load_px(pe), f = load_px(pe + 3);
+                const float bc[3] = {b.x, b.y, b.z}, hc[3] = {h.x, h.y, h.z}, dc[3] = {d.x, d.y, d.z}, ec[3] = {e.x, e.y, e.z}, fc[3] = {f.x, f.y, f.z};
+                float lobe_c[3];
+                for (int c = 0; c < 3; c++)                                 // FSR.cl:503-521
+                {
+                    const float mn4 = min4f(bc[c], dc[c], fc[c], hc[c]), mx4 = max4f(bc[c], dc[c], fc[c], hc[c]);
+                    const float hitMin = fminf(mn4, ec[c]) * (1.0f / (4.0f * mx4));
+                    const float hitMax = (1.0f - fmaxf(mx4, ec[c])) * (1.0f / fmaf(4.0f, mn4, -4.0f));
+                    lobe_c[c] = fmaxf(-hitMin, hitMax);
+                }
+                // FSR.cl renames .z -> R, .y -> G, .x -> B and takes max(lobeR, max(lobeG, lobeB))
+                const float lobe = fminf(fmaxf(fmaxf(lobe_c[2], fmaxf(lobe_c[1], lobe_c[0])), -0.1875f), 0.0f) * sharp;   // FSR.cl:525
+                const float rcpL = APrxMedRcpF1(fmaf(4.0f, lobe, 1.0f));    // FSR.cl:528
+                for (int c = 0; c < 3; c++)                                 // FSR.cl:529-531
+                {
+                    const float v = fmaf(((bc[c] + dc[c]) + hc[c]) + fc[c], lobe, ec[c]) * rcpL;
+                    o[c] = (uint8_t)(int)(v * 255.0f);
+                }
+            }
+        }
+    });
+    return 0;
+}
+
 } // extern "C"

@@ -197,6 +197,13 @@ int lvko_warpmesh_apply_lens(const uint8_t* src, int src_step, int rows, int col
                              const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
                              int yuv, int nthreads, const double* model /* NULL = no lens */);
 
+/* SURVEY section 8f row 4, second half: lvk::upscale (kernel easu_scale) and lvk::sharpen (kernel rcas) of ScalingFilter
+ * (Functions/Image.cpp:155-233, Functions/OpenCL/Sources/FSR.cl:324-358,460-535, Filters/ScalingFilter.cpp:52-59).
+ * `sharpness` in [0, 1] as the caller of lvk::sharpen passes it. */
+int lvko_upscale(const uint8_t* src, int src_step, int src_rows, int src_cols,
+                 uint8_t* dst, int dst_step, int dst_rows, int dst_cols, int yuv, int nthreads);
+int lvko_sharpen(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step, float sharpness, int nthreads);
+
 /* Debug overlays (oracle/draw.cpp; reference Functions/Drawing.tpp:53-93,146-196, Functions/OpenCL/Sources/Drawing.cl:22-39,75-105,
  * Filters/StabilizationFilter.cpp:163-188): drawn into the newest queued frame. */
 int lvko_draw_grid(uint8_t* dst, int dst_step, int rows, int cols, int grid_w, int grid_h, const uint8_t colour[3], int thickness);

@@ -132,6 +132,26 @@ int main()
         if (seen != 5 || many.i >= 200) { std::printf("stream: early termination failed (%d, %d)\n", seen, many.i); return 1; }
         std::printf("stream ok: 16 frames in order, stopped after %d of %d read\n", seen, many.i);
     }
+    {
+        // ScalingFilter (Filters/ScalingFilter.cpp:27-59; CLI construction FilterParser.tpp): upscale + sharpen, output aliases the input
+        const int srows = 90, scols = 160;
+        std::vector<uint8_t> small((size_t)srows * scols * 3), big((size_t)180 * 320 * 3);
+        for (size_t k = 0; k < small.size(); k++) small[k] = (uint8_t)((k * 37 + (k / 480) * 11) % 251);
+        lvk::ScalingFilter scaler(cv::Size(320, 180), 0.8f);
+        lvk::Frame frame;
+        frame.upload(small.data(), srows, scols, lvk::VideoFrame::YUV, 77);
+        scaler.apply(std::move(frame), frame, true);
+        if (frame.empty() || frame.cols != 320 || frame.rows != 180 || frame.timestamp != 77) { std::printf("scaling: bad output frame\n"); return 1; }
+        frame.download(big.data());
+        // corners: upscale copies the nearest source pixel on its border band, sharpen copies its border
+        if (big[0] != small[0] || big[1] != small[1] || big[2] != small[2]) { std::printf("scaling: corner pixel changed\n"); return 1; }
+        scaler.reconfigure([](lvk::ScalingFilterSettings& settings) { settings.output_size = cv::Size(160, 90); settings.sharpness = 0.0f; });
+        lvk::Frame same;
+        same.upload(small.data(), srows, scols, lvk::VideoFrame::YUV, 78);
+        scaler.apply(same, same);
+        if (same.cols != 160 || same.rows != 90) { std::printf("scaling: identity size failed\n"); return 1; }
+        std::printf("scaling ok: %s %.3f ms\n", scaler.alias().c_str(), scaler.timings().average().milliseconds());
+    }
     lvk::VSFilterLike vs;
     vs.configure(false, true, 0.05f, 0.05f, 5, true, false, true);
     const int rows = 360, cols = 640;
@@ -167,6 +187,11 @@ int main()
         auto filter = std::make_shared<lvk::StabilizationFilter>();
         std::static_pointer_cast<lvk::Configurable<lvk::StabilizationFilterSettings>>(filter)->configure(lvk::StabilizationFilterSettings{});
         std::printf("%s %f\n", filter->alias().c_str(), filter->timings().average().milliseconds());
+        auto scaler = std::make_shared<lvk::ScalingFilter>();
+        std::static_pointer_cast<lvk::Configurable<lvk::ScalingFilterSettings>>(scaler)->configure(lvk::ScalingFilterSettings{});
+        lvk::Frame a, b;
+        lvk::upscale(a, b, cv::Size(1920, 1080));
+        lvk::sharpen(b, b);
     }
     return 0;
 #endif

@@ -142,3 +142,48 @@ def _remap_tail(src, subx, suby, bg, yuv):
     if ea.any():
         out[ea] = easu_points(src, sx[ea], sy[ea], ppx[ea].astype(f32), ppy[ea].astype(f32), yuv)
     return out
+
+
+def upscale(src, size, yuv):
+    """lvk::upscale / easu_scale (Functions/Image.cpp:155-202, FSR.cl:324-358); size = (width, height)."""
+    rows, cols = src.shape[:2]
+    dw, dh = int(size[0]), int(size[1])
+    if (dw, dh) == (cols, rows):
+        return src.copy()
+    rsx = f32(cols) / f32(dw); rsy = f32(rows) / f32(dh)
+    yy, xx = np.mgrid[0:dh, 0:dw]
+    subx = xx.astype(f32) * rsx; suby = yy.astype(f32) * rsy
+    sx = np.trunc(subx).astype(np.int64); sy = np.trunc(suby).astype(np.int64)
+    ppx = subx - np.floor(subx); ppy = suby - np.floor(suby)
+    out = np.empty((dh, dw, 3), np.uint8)
+    border = (sx == 0) | (sy == 0) | (sx >= cols - 4) | (sy >= rows - 4)
+    out[border] = src[sy[border], sx[border]]
+    ea = ~border
+    if ea.any():
+        out[ea] = easu_points(src, sx[ea], sy[ea], ppx[ea].astype(f32), ppy[ea].astype(f32), yuv)
+    return out
+
+
+def sharpen(src, sharpness):
+    """lvk::sharpen / rcas (Functions/Image.cpp:206-233, FSR.cl:460-535), out of place."""
+    rows, cols = src.shape[:2]
+    sharp = f32(np.exp2(f32(-2.0) * (f32(1.0) - f32(sharpness))))
+    out = src.copy()
+    if rows < 3 or cols < 3:
+        return out
+    norm = f32(0.00392156862)
+    p = src.astype(f32) * norm
+    b = p[:-2, 1:-1]; h = p[2:, 1:-1]; d = p[1:-1, :-2]; e = p[1:-1, 1:-1]; f = p[1:-1, 2:]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        mn4 = np.fmin(b, np.fmin(d, np.fmin(f, h))); mx4 = np.fmax(b, np.fmax(d, np.fmax(f, h)))
+        hit_min = np.fmin(mn4, e) * (f32(1) / (f32(4) * mx4))
+        hit_max = (f32(1) - np.fmax(mx4, e)) * (f32(1) / _fma(mn4, f32(4), f32(-4)))
+        lobe_c = np.fmax(-hit_min, hit_max)
+    lobe = np.fmax(lobe_c[..., 2], np.fmax(lobe_c[..., 1], lobe_c[..., 0]))
+    lobe = np.fmin(np.fmax(lobe, f32(-0.1875)), f32(0)) * sharp
+    a = _fma(lobe, f32(4), f32(1))
+    r = (np.uint32(0x7ef19fff) - a.view(np.uint32)).view(f32)
+    rcp = r * _fma(-r, a, f32(2))
+    v = _fma(((b + d) + h) + f, lobe[..., None], e) * rcp[..., None]
+    out[1:-1, 1:-1] = (v * f32(255)).astype(np.int32).astype(np.uint8)
+    return out

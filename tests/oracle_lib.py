@@ -235,6 +235,27 @@ class Oracle:
                   _p(bg, _u8p), 1 if yuv else 0, nthreads) == 0
         return dst
 
+    def upscale(self, src, size, yuv=True, nthreads=8):
+        """size = (width, height) like cv::Size."""
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((int(size[1]), int(size[0]), 3), np.uint8)
+        fn = self.lib.lvko_upscale
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]
+        rc = fn(_p(src, _u8p), src.strides[0], src.shape[0], src.shape[1], _p(dst, _u8p), dst.strides[0], dst.shape[0], dst.shape[1],
+                1 if yuv else 0, nthreads)
+        assert rc == 0, rc
+        return dst
+
+    def sharpen(self, src, sharpness=0.7, nthreads=8):
+        src = np.ascontiguousarray(src, np.uint8); dst = np.zeros_like(src)
+        fn = self.lib.lvko_sharpen
+        fn.restype = _c.c_int
+        fn.argtypes = [_u8p, _c.c_int, _c.c_int, _c.c_int, _u8p, _c.c_int, _c.c_float, _c.c_int]
+        rc = fn(_p(src, _u8p), src.strides[0], src.shape[0], src.shape[1], _p(dst, _u8p), dst.strides[0], float(sharpness), nthreads)
+        assert rc == 0, rc
+        return dst
+
     def find_homography(self, p1, p2, threshold, region=(480, 270), partial=False):
         p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
         H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8)

@@ -31,3 +31,4 @@ def test_plugin_call_sites_run_on_gpu(tmp_path):
     exe = _build(tmp_path, ["-DRUN_ON_GPU"])
     out = subprocess.check_output([exe], timeout=300).decode()
     assert "emitted 7 frames" in out
+    assert "scaling ok: Scaling Filter" in out
