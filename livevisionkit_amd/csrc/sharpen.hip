@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int RCAS_PXT = 4, RCAS_ROWS = 4, RCAS_STRIP_W = 64 * RCAS_PXT, RCAS_STRIP_H = 4 * RCAS_ROWS;
+constexpr int RCAS_PXT = 4, RCAS_STRIP_W = 64 * RCAS_PXT;
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
@@ -40,43 +40,72 @@ __device__ __forceinline__ Px unpack(uint32_t lo_bytes)
     return r;
 }
 
-// One source row as a thread sees it: the pixel left of its four, its four, and the pixel right of them (raw bytes kept for the
-// border copy).
-struct Row
-{
-    Px p[RCAS_PXT + 2];
-    uint32_t raw[3];
-};
+// One source row as a thread sees it: the pixel left of its four, its four, and the pixel right of them.
+struct RawRow { uint32_t w0, w1, w2, wl, wr; };
+struct Row { Px p[RCAS_PXT + 2]; };
 
-__device__ __forceinline__ void load_row(Row& r, const uint8_t* __restrict__ src, int step, int y, int x0, int cols, bool full)
+// Unconditional loads (no branches, so that all rows of a thread are in flight together): the row index is clamped into the image
+// and the two side loads fall back to in-row addresses at the frame edge -- whatever they return there belongs to border pixels,
+// which are copied.  Requires x0 + 4 <= cols.
+__device__ __forceinline__ RawRow load_row(const uint8_t* __restrict__ src, int step, int y, int rows, int x0, int cols)
 {
-    const uint8_t* rp = src + (long)y * step + 3 * (long)x0;
-    uint32_t w0, w1, w2, wl = 0u, wr = 0u;
-    if (full)
-    {
-        const U12B v = *reinterpret_cast<const U12B*>(rp);
-        w0 = v.w[0]; w1 = v.w[1]; w2 = v.w[2];
-    }
-    else
-    {
-        uint8_t b[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) b[i] = (x0 + i / 3 < cols) ? rp[i] : (uint8_t)0;
-        w0 = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
-        w1 = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
-        w2 = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
-    }
-    if (x0 > 0) wl = reinterpret_cast<const U4B*>(rp - 4)->w >> 8;                       // bytes -3..-1
-    if (x0 + RCAS_PXT < cols) wr = (uint32_t)rp[12] | ((uint32_t)rp[13] << 8) | ((uint32_t)rp[14] << 16);
-    r.raw[0] = w0; r.raw[1] = w1; r.raw[2] = w2;
-    r.p[0] = unpack(wl);
-    r.p[1] = unpack(w0);
-    r.p[2] = unpack((w0 >> 24) | (w1 << 8));
-    r.p[3] = unpack((w1 >> 16) | (w2 << 16));
-    r.p[4] = unpack(w2 >> 8);
-    r.p[5] = unpack(wr);
+    const uint8_t* rp = src + (long)min(max(y, 0), rows - 1) * step + 3 * (long)x0;
+    const U12B v = *reinterpret_cast<const U12B*>(rp);
+    RawRow r;
+    r.w0 = v.w[0]; r.w1 = v.w[1]; r.w2 = v.w[2];
+    r.wl = reinterpret_cast<const U4B*>(x0 > 0 ? rp - 4 : rp)->w >> 8;                        // bytes -3..-1
+    r.wr = reinterpret_cast<const U4B*>(x0 + RCAS_PXT < cols ? rp + 11 : rp + 8)->w >> 8;     // bytes 12..14
+    return r;
 }
 
+__device__ __forceinline__ Row unpack_row(const RawRow& r)
+{
+    Row o;
+    o.p[0] = unpack(r.wl);
+    o.p[1] = unpack(r.w0);
+    o.p[2] = unpack((r.w0 >> 24) | (r.w1 << 8));
+    o.p[3] = unpack((r.w1 >> 16) | (r.w2 << 16));
+    o.p[4] = unpack(r.w2 >> 8);
+    o.p[5] = unpack(r.wr);
+    return o;
+}
+
+// FSR.cl:486-534 for one pixel: b above, h below, d left, f right, e centre.  Returns 0x00ZZYYXX.
+__device__ __forceinline__ uint32_t rcas_pixel(const Px& b, const Px& d, const Px& e, const Px& f, const Px& h, float sharp,
+                                               const float* __restrict__ s_rmin, const float* __restrict__ s_rmax)
+{
+    float lobe_c[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)                              // FSR.cl:503-521
+    {
+        const float mn4 = min_(b.c[c], min_(d.c[c], min_(f.c[c], h.c[c])));
+        const float mx4 = max_(b.c[c], max_(d.c[c], max_(f.c[c], h.c[c])));
+        // Byte offset 4 k of an extremum k * norm_factor in the tables, without a conversion or a left shift (both half-rate VALU
+        // classes on gfx950, scripts/valu_peak.hip): 1020 (k norm) + 2 = 4 k + 2 - 8e-9 k, and adding 2^23 leaves that integer,
+        // rounded to 4 k + 2 for every k in 0..255, in the low mantissa bits.
+        const uint32_t omx = __float_as_uint(fma_(mx4, 1020.0f, 8388610.0f)) & 0x3fcu;
+        const uint32_t omn = __float_as_uint(fma_(mn4, 1020.0f, 8388610.0f)) & 0x3fcu;
+        const float hitMin = min_(mn4, e.c[c]) * *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_rmin) + omx);
+        const float hitMax = (1.0f - max_(mx4, e.c[c])) * *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_rmax) + omn);
+        lobe_c[c] = max_(-hitMin, hitMax);
+    }
+    const float lobe = min_(max_(max_(lobe_c[2], max_(lobe_c[1], lobe_c[0])), -0.1875f), 0.0f) * sharp;   // FSR.cl:525
+    const float a = fma_(4.0f, lobe, 1.0f);                  // FSR.cl:528, APrxMedRcpF1 (FSR.cl:70)
+    const float rb = __uint_as_float(0x7ef19fffu - __float_as_uint(a));
+    const float rcpL = rb * fma_(-rb, a, 2.0f);
+    uint32_t px = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++)                              // FSR.cl:529-531
+    {
+        const float v = fma_(((b.c[c] + d.c[c]) + h.c[c]) + f.c[c], lobe, e.c[c]) * rcpL;
+        px |= ((uint32_t)(int)(v * 255.0f) & 0xffu) << (8 * c);
+    }
+    return px;
+}
+
+__device__ __forceinline__ uint32_t load_px_raw(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+
+template <int ROWS>
 __global__ __launch_bounds__(256)
 void k_rcas(const uint8_t* __restrict__ src, int src_step, int rows, int cols, uint8_t* __restrict__ dst, int dst_step, float sharp)
 {
@@ -90,63 +119,54 @@ void k_rcas(const uint8_t* __restrict__ src, int src_step, int rows, int cols, u
     __syncthreads();
 
     const int x0 = (int)blockIdx.x * RCAS_STRIP_W + (int)(threadIdx.x & 63) * RCAS_PXT;
-    const int y0 = (int)blockIdx.y * RCAS_STRIP_H + (int)(threadIdx.x >> 6) * RCAS_ROWS;
+    const int y0 = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * ROWS;
     if (x0 >= cols || y0 >= rows) return;
-    const int npx = min(RCAS_PXT, cols - x0);
-    const bool full = npx == RCAS_PXT;
 
-    Row win[3] = {};                                                 // rows y - 1, y, y + 1 (rows outside the image stay 0: unused)
-    if (y0 > 0) load_row(win[0], src, src_step, y0 - 1, x0, cols, full);
-    load_row(win[1], src, src_step, y0, x0, cols, full);
+    if (x0 + RCAS_PXT > cols)                                        // ragged right edge (cols % 4 != 0): one pixel at a time
+    {
+        for (int y = y0; y < min(y0 + ROWS, rows); y++)
+            for (int x = x0; x < cols; x++)
+            {
+                const uint8_t* pe = src + (long)y * src_step + 3 * (long)x;
+                uint32_t px = load_px_raw(pe);
+                if (!(x == 0 || x >= cols - 1 || y == 0 || y >= rows - 1))
+                    px = rcas_pixel(unpack(load_px_raw(pe - src_step)), unpack(load_px_raw(pe - 3)), unpack(px), unpack(load_px_raw(pe + 3)),
+                                    unpack(load_px_raw(pe + src_step)), sharp, s_rmin, s_rmax);
+                uint8_t* o = dst + (long)y * dst_step + 3 * (long)x;
+                o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
+            }
+        return;
+    }
+
+    RawRow raw[ROWS + 2];                                            // rows y0 - 1 .. y0 + ROWS, all in flight together
 #pragma unroll
-    for (int r = 0; r < RCAS_ROWS; r++)
+    for (int r = 0; r < ROWS + 2; r++) raw[r] = load_row(src, src_step, y0 - 1 + r, rows, x0, cols);
+    Row win[3];
+    win[0] = unpack_row(raw[0]);
+    win[1] = unpack_row(raw[1]);
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
     {
         const int y = y0 + r;
         if (y >= rows) break;
-        Row& up = win[r % 3];
-        Row& mid = win[(r + 1) % 3];
+        const Row& up = win[r % 3];
+        const Row& mid = win[(r + 1) % 3];
         Row& down = win[(r + 2) % 3];
-        if (y + 1 < rows) load_row(down, src, src_step, y + 1, x0, cols, full);
-        uint32_t out[RCAS_PXT];
+        down = unpack_row(raw[r + 2]);
+        const RawRow& m = raw[r + 1];
+        const uint32_t centre[RCAS_PXT] = { m.w0 & 0xffffffu, (m.w0 >> 24) | ((m.w1 & 0xffffu) << 8), (m.w1 >> 16) | ((m.w2 & 0xffu) << 16), m.w2 >> 8 };
         const bool border_row = y == 0 || y >= rows - 1;
+        uint32_t out[RCAS_PXT];
 #pragma unroll
         for (int p = 0; p < RCAS_PXT; p++)
         {
             const int x = x0 + p;
-            // raw bytes of pixel p of the middle row
-            const uint32_t raw = p == 0 ? (mid.raw[0] & 0xffffffu)
-                               : p == 1 ? ((mid.raw[0] >> 24) | ((mid.raw[1] & 0xffffu) << 8))
-                               : p == 2 ? ((mid.raw[1] >> 16) | ((mid.raw[2] & 0xffu) << 16))
-                               : (mid.raw[2] >> 8);
-            const bool border = border_row || x == 0 || x >= cols - 1;              // FSR.cl:475-481: copied (selected below)
-            const Px &b = up.p[p + 1], &h = down.p[p + 1], &d = mid.p[p], &e = mid.p[p + 1], &f = mid.p[p + 2];
-            float lobe_c[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++)                              // FSR.cl:503-521
-            {
-                const float mn4 = min_(b.c[c], min_(d.c[c], min_(f.c[c], h.c[c])));
-                const float mx4 = max_(b.c[c], max_(d.c[c], max_(f.c[c], h.c[c])));
-                // k of an extremum k * norm_factor: k * norm * 255 = k (1 - 2e-9), + 0.5 truncates to k for every k in 0..255
-                const int kmx = (int)fma_(mx4, 255.0f, 0.5f), kmn = (int)fma_(mn4, 255.0f, 0.5f);
-                const float hitMin = min_(mn4, e.c[c]) * s_rmin[kmx];
-                const float hitMax = (1.0f - max_(mx4, e.c[c])) * s_rmax[kmn];
-                lobe_c[c] = max_(-hitMin, hitMax);
-            }
-            const float lobe = min_(max_(max_(lobe_c[2], max_(lobe_c[1], lobe_c[0])), -0.1875f), 0.0f) * sharp;   // FSR.cl:525
-            const float a = fma_(4.0f, lobe, 1.0f);                  // FSR.cl:528, APrxMedRcpF1 (FSR.cl:70)
-            const float rb = __uint_as_float(0x7ef19fffu - __float_as_uint(a));
-            const float rcpL = rb * fma_(-rb, a, 2.0f);
-            uint32_t px = 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++)                              // FSR.cl:529-531
-            {
-                const float v = fma_(((b.c[c] + d.c[c]) + h.c[c]) + f.c[c], lobe, e.c[c]) * rcpL;
-                px |= ((uint32_t)(int)(v * 255.0f) & 0xffu) << (8 * c);
-            }
-            out[p] = border ? raw : px;
+            const bool border = border_row || x == 0 || x >= cols - 1;              // FSR.cl:475-481: copied
+            const uint32_t px = rcas_pixel(up.p[p + 1], mid.p[p], mid.p[p + 1], mid.p[p + 2], down.p[p + 1], sharp, s_rmin, s_rmax);
+            out[p] = border ? centre[p] : px;
         }
         uint8_t* drow = dst + (long)y * dst_step + 3 * (long)x0;
-        if (full && ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0))
+        if ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0)
         {
             uint32_t* o = reinterpret_cast<uint32_t*>(drow);
             o[0] = out[0] | (out[1] << 24);
@@ -154,7 +174,7 @@ void k_rcas(const uint8_t* __restrict__ src, int src_step, int rows, int cols, u
             o[2] = (out[2] >> 16) | (out[3] << 8);
         }
         else
-            for (int p = 0; p < npx; p++) { drow[3 * p] = (uint8_t)out[p]; drow[3 * p + 1] = (uint8_t)(out[p] >> 8); drow[3 * p + 2] = (uint8_t)(out[p] >> 16); }
+            for (int p = 0; p < RCAS_PXT; p++) { drow[3 * p] = (uint8_t)out[p]; drow[3 * p + 1] = (uint8_t)(out[p] >> 8); drow[3 * p + 2] = (uint8_t)(out[p] >> 16); }
     }
 }
 
@@ -169,8 +189,9 @@ int lvk_launch_sharpen(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, 
     LVK_HIP_REQUIRE(ctx, sharpness >= 0.0f && sharpness <= 1.0f);                // LVK_ASSERT_01, Image.cpp:210
     LVK_HIP_REQUIRE(ctx, src_step >= 3 * cols && dst_step >= 3 * cols);
     const float sharp = exp2f(-2.0f * (1.0f - sharpness));                       // Image.cpp:227
-    const dim3 block(256), grid((unsigned)((cols + RCAS_STRIP_W - 1) / RCAS_STRIP_W), (unsigned)((rows + RCAS_STRIP_H - 1) / RCAS_STRIP_H));
-    hipLaunchKernelGGL(k_rcas, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, sharp);
+    constexpr int ROWS = 4;                                                      // rows per thread: 1 / 2 / 4 / 8 measure 24.3 / 23.0 / 23.3 / 25.7 us at 4K
+    const dim3 block(256), grid((unsigned)((cols + RCAS_STRIP_W - 1) / RCAS_STRIP_W), (unsigned)((rows + 4 * ROWS - 1) / (4 * ROWS)));
+    hipLaunchKernelGGL(k_rcas<ROWS>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, sharp);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

@@ -98,6 +98,12 @@ def main():
     dpts = np.c_[rng.uniform(-5, 60, 30), rng.uniform(-5, 45, 30)].astype(np.float32)
     out["draw"] = dict(src=dsrc, pts=dpts, grid=o.draw_grid(dsrc, (5, 3), (29, 255, 107), 1), crosses=o.draw_crosses(dsrc, dpts, (76, 84, 255), 7, 4, scaling=(1.0, 1.0)))
 
+    # ---- 8f-4 second half: ScalingFilter's EASU upscale + RCAS
+    ssrc = synth.textured_frame(40, 56, seed=9)
+    ssrc[4:8, 4:20] = 0; ssrc[20:24, 30:50] = 255
+    up = o.upscale(ssrc, (100, 61), yuv=True)
+    out["scaling"] = dict(src=ssrc, up_yuv=up, up_rgb=o.upscale(ssrc, (112, 80), yuv=False), sharp=o.sharpen(up, 0.8), sharp_src=o.sharpen(ssrc, 0.35))
+
     # ---- a2 end to end: a short clip through both presets (outputs as digests, meshes and statistics in full)
     clip, _ = synth.make_clip(180, 320, 10, seed=8)
     e2e = dict(clip=clip)
@@ -117,7 +123,10 @@ def main():
     out["stabilizer"] = e2e
 
     total = 0
+    only = set(sys.argv[1:])                 # python make_golden.py scaling  -> rewrite just that fixture
     for k, d in out.items():
+        if only and k not in only:
+            continue
         path = os.path.join(HERE, k + ".npz")
         np.savez_compressed(path, **d)
         total += os.path.getsize(path)

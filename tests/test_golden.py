@@ -74,6 +74,13 @@ def test_oracle_yuv420_lens_draw_golden(oracle):
     assert np.array_equal(oracle.draw_crosses(w["src"], w["pts"], (76, 84, 255), 7, 4), w["crosses"])
 
 
+def test_oracle_scaling_golden(oracle):
+    d = load("scaling")
+    assert np.array_equal(oracle.upscale(d["src"], (100, 61), yuv=True), d["up_yuv"])
+    assert np.array_equal(oracle.upscale(d["src"], (112, 80), yuv=False), d["up_rgb"])
+    assert np.array_equal(oracle.sharpen(d["up_yuv"], 0.8), d["sharp"]) and np.array_equal(oracle.sharpen(d["src"], 0.35), d["sharp_src"])
+
+
 @pytest.mark.parametrize("name", ["homography", "field"])
 def test_oracle_stabilizer_golden(oracle, name):
     d = load("stabilizer")
@@ -132,6 +139,11 @@ def test_hip_stage_golden(ctx):
     w = load("draw")
     assert np.array_equal(ctx.draw_grid(_gpu(w["src"]), (5, 3), (29, 255, 107), 1).cpu().numpy(), w["grid"])
     assert np.array_equal(ctx.draw_crosses(_gpu(w["src"]), w["pts"], (76, 84, 255), 7, 4).cpu().numpy(), w["crosses"])
+    z = load("scaling")
+    assert np.array_equal(ctx.upscale(_gpu(z["src"]), (100, 61), yuv=True).cpu().numpy(), z["up_yuv"])
+    assert np.array_equal(ctx.upscale(_gpu(z["src"]), (112, 80), yuv=False).cpu().numpy(), z["up_rgb"])
+    assert np.array_equal(ctx.sharpen(_gpu(z["up_yuv"]), 0.8).cpu().numpy(), z["sharp"])
+    assert np.array_equal(ctx.sharpen(_gpu(z["src"]), 0.35).cpu().numpy(), z["sharp_src"])
 
 
 @pytest.mark.gpu
