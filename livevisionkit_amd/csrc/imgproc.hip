@@ -205,11 +205,27 @@ void k_pyr_fused3(PyrArgs a)
     const int o2x = 2 * x3 - 2, o2y = 2 * y3 - 2, o1x = 2 * o2x - 2, o1y = 2 * o2y - 2, o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
     const PyrLevel L0 = a.lv[0], L1 = a.lv[1], L2 = a.lv[2], L3 = a.lv[3];
 
-    for (int i = tid; i < F0 * F0; i += 256)
+    // All of a thread's level-0 loads are issued before the first is consumed (clamped addresses, no branches): one global round
+    // trip for the window instead of one per 256 bytes -- the loop form spent 11 dependent round trips here, 7 of the kernel's 10 us.
     {
-        const int ty = i / F0, tx = i - ty * F0;
-        const int gx = o0x + tx, gy = o0y + ty;
-        if (gx >= 0 && gy >= 0 && gx < L0.cols && gy < L0.rows) t0[ty * F0P + tx] = L0.img[(long)gy * L0.step + gx];
+        constexpr int N0 = (F0 * F0 + 255) / 256;
+        uint8_t v[N0];
+#pragma unroll
+        for (int k = 0; k < N0; k++)
+        {
+            const int i = min(tid + 256 * k, F0 * F0 - 1);
+            const int ty = i / F0, tx = i - ty * F0;
+            const int gx = min(max(o0x + tx, 0), L0.cols - 1), gy = min(max(o0y + ty, 0), L0.rows - 1);
+            v[k] = L0.img[(long)gy * L0.step + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < N0; k++)
+        {
+            const int i = tid + 256 * k;
+            const int ty = i / F0, tx = i - ty * F0;
+            const int gx = o0x + tx, gy = o0y + ty;
+            if (i < F0 * F0 && gx >= 0 && gy >= 0 && gx < L0.cols && gy < L0.rows) t0[ty * F0P + tx] = v[k];
+        }
     }
     __syncthreads();
     for (int i = tid; i < F1 * F1; i += 256)

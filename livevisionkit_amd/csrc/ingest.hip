@@ -60,11 +60,15 @@ void k_ingest_yuv420(const uint8_t* __restrict__ yp, int y_step, const uint8_t* 
         for (int p = 0; p < npx; p++) { uint8_t* d = drow + 3 * (x0 + p); d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16); }
 }
 
-// Exact 2x chroma upsampling (always the case for 4:2:0) without tables and without byte loads: the coefficients have the
-// closed form below (phase .25 / .75, clamped at the borders exactly like the table), and the chroma samples of a thread's
-// 4 output columns -- chroma columns x0/2 - 1 .. x0/2 + 2 -- come from one unaligned 8-byte (I420) / 16-byte (NV12) window per
-// chroma row.  A thread produces the 4 x 2 output pixels of the luma rows 2k - 1 and 2k: both interpolate between the SAME two
-// chroma rows (k - 1, k) with mirrored weights, so the windows are loaded and filtered horizontally once for the two rows.
+// Exact 2x chroma upsampling (always the case for 4:2:0) without tables, byte loads, multiplications or left shifts.  For the 2x
+// case the fixed-point INTER_LINEAR of the general kernel collapses: the horizontal pass (c_a a0 + c_b a1) >> 4 with (a0, a1) =
+// (512, 1536) / (1536, 512) / (2048, 0 at the frame edge) is exactly 32 t with t = c_a + 3 c_b / 3 c_a + c_b / 4 c_a, the edge case
+// being the general one with the edge sample replicated; and the vertical pass ((1536 h0 >> 16) + (512 h1 >> 16) + 2) >> 2 is
+// ((3 t0 >> 2) + (t1 >> 2) + 2) >> 2.  Only additions, right shifts and ANDs remain -- the opcodes gfx950 issues at full rate
+// (scripts/valu_peak.hip); the multiply / 64-bit-shift form this replaces was VALU-bound at 11.4 us for a 4K frame.
+// A thread produces the 4 x 2 output pixels of the luma rows 2k - 1 and 2k: both interpolate between the SAME two chroma rows
+// (k - 1, k) with mirrored weights.  Its chroma columns c0 - 1 .. c0 + 2 (c0 = x0 / 2) are one unaligned dword per plane and row
+// (NV12: one 8-byte load, de-interleaved with v_perm_b32); the first / last thread of a row replicates the edge sample.
 // Preconditions (checked by the launcher): Y and dst dword aligned incl. pitch, cols % 4 == 0, cols >= 16.
 template <bool NV12>
 __global__ __launch_bounds__(256)
@@ -77,33 +81,37 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
     if (x0 >= cols || k > cr) return;
     // vertical taps (rows clipped individually, coefficients unclamped -- resize.cpp resizeGeneric_Invoker)
     const int r0 = max(k - 1, 0), r1 = min(k, cr - 1);
-    // window of chroma columns [wc, wc + 8)
     const int c0 = x0 >> 1;
-    const int wc = min(max(c0 - 1, 0), cc - 8);                   // 8 samples starting at c0 - 1 (unaligned load), clamped inside the row
-    unsigned long long wu0, wu1, wv0, wv1;
+    const bool left = x0 == 0, right = x0 == cols - 4;
+    const int lc = left ? 0 : (right ? cc - 4 : c0 - 1);          // first chroma column of the dword that is loaded
+    struct __attribute__((packed, aligned(1))) P4 { uint32_t w; };
+    struct __attribute__((packed, aligned(1))) P8 { uint32_t w[2]; };
+    uint32_t su0, su1, sv0, sv1;                                   // samples c0 - 1 .. c0 + 2 of (U, V) x (row r0, row r1), one per byte
     if (NV12)
     {
-        struct __attribute__((packed, aligned(1))) P16 { uint32_t w[4]; };
-        const P16 pa = *reinterpret_cast<const P16*>(up + (long)r0 * u_step + 2 * wc);
-        const P16 pb = *reinterpret_cast<const P16*>(up + (long)r1 * u_step + 2 * wc);
-        const uint4 a = make_uint4(pa.w[0], pa.w[1], pa.w[2], pa.w[3]), b = make_uint4(pb.w[0], pb.w[1], pb.w[2], pb.w[3]);
-        // de-interleave UVUV... into one 8-sample word per channel
-        auto even = [](uint4 q) { unsigned long long r = 0; const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) r |= ((unsigned long long)((w[i] & 0xffu) | ((w[i] >> 8) & 0xff00u))) << (16 * i); return r; };
-        auto odd = [](uint4 q) { unsigned long long r = 0; const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) r |= ((unsigned long long)(((w[i] >> 8) & 0xffu) | ((w[i] >> 16) & 0xff00u))) << (16 * i); return r; };
-        wu0 = even(a); wv0 = odd(a); wu1 = even(b); wv1 = odd(b);
+        const P8 a = *reinterpret_cast<const P8*>(up + (long)r0 * u_step + 2 * lc);
+        const P8 b = *reinterpret_cast<const P8*>(up + (long)r1 * u_step + 2 * lc);
+        su0 = __builtin_amdgcn_perm(a.w[1], a.w[0], 0x06040200u); sv0 = __builtin_amdgcn_perm(a.w[1], a.w[0], 0x07050301u);
+        su1 = __builtin_amdgcn_perm(b.w[1], b.w[0], 0x06040200u); sv1 = __builtin_amdgcn_perm(b.w[1], b.w[0], 0x07050301u);
     }
     else
     {
-        struct __attribute__((packed, aligned(1))) P8 { unsigned long long q; };
-        wu0 = reinterpret_cast<const P8*>(up + (long)r0 * u_step + wc)->q;
-        wu1 = reinterpret_cast<const P8*>(up + (long)r1 * u_step + wc)->q;
-        wv0 = reinterpret_cast<const P8*>(vp + (long)r0 * v_step + wc)->q;
-        wv1 = reinterpret_cast<const P8*>(vp + (long)r1 * v_step + wc)->q;
+        su0 = reinterpret_cast<const P4*>(up + (long)r0 * u_step + lc)->w;
+        su1 = reinterpret_cast<const P4*>(up + (long)r1 * u_step + lc)->w;
+        sv0 = reinterpret_cast<const P4*>(vp + (long)r0 * v_step + lc)->w;
+        sv1 = reinterpret_cast<const P4*>(vp + (long)r1 * v_step + lc)->w;
     }
+    if (left)  { su0 = (su0 << 8) | (su0 & 0xffu); su1 = (su1 << 8) | (su1 & 0xffu); sv0 = (sv0 << 8) | (sv0 & 0xffu); sv1 = (sv1 << 8) | (sv1 & 0xffu); }
+    if (right) { su0 = (su0 >> 8) | (su0 & 0xff000000u); su1 = (su1 >> 8) | (su1 & 0xff000000u);
+                 sv0 = (sv0 >> 8) | (sv0 & 0xff000000u); sv1 = (sv1 >> 8) | (sv1 & 0xff000000u); }
+    // horizontal pass: t[p] for the 4 output columns of one window
+    auto horizontal = [](uint32_t w, uint32_t (&t)[4]) {
+        const uint32_t s0 = w & 0xffu, s1 = (w >> 8) & 0xffu, s2 = (w >> 16) & 0xffu, s3 = w >> 24;
+        const uint32_t m1 = s1 + s1 + s1, m2 = s2 + s2 + s2;
+        t[0] = s0 + m1; t[1] = m1 + s2; t[2] = s1 + m2; t[3] = m2 + s3;
+    };
+    uint32_t tu0[4], tu1[4], tv0[4], tv1[4];
+    horizontal(su0, tu0); horizontal(su1, tu1); horizontal(sv0, tv0); horizontal(sv1, tv1);
     const int ya = 2 * k - 1, yb = 2 * k;
     const bool has_a = ya >= 0, has_b = yb < rows;
     const uint32_t ywa = has_a ? *reinterpret_cast<const uint32_t*>(yp + (long)ya * y_step + x0) : 0u;
@@ -112,23 +120,10 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
 #pragma unroll
     for (int p = 0; p < 4; p++)
     {
-        const int x = x0 + p;
-        // horizontal taps: (sx, fx) clamped at the left edge, single tap beyond xmax at the right edge
-        int s0, s1, a0;
-        if (x == 0) { s0 = 0; s1 = 1; a0 = 2048; }
-        else if (x == cols - 1) { s0 = s1 = cc - 1; a0 = 2048; }
-        else { s0 = (x - 1) >> 1; s1 = s0 + 1; a0 = (x & 1) ? 1536 : 512; }
-        const int a1 = 2048 - a0;
-        const int i0 = 8 * (s0 - wc), i1 = 8 * (s1 - wc);
-        const int hu0 = ((int)((wu0 >> i0) & 0xff) * a0 + (int)((wu0 >> i1) & 0xff) * a1) >> 4;
-        const int hu1 = ((int)((wu1 >> i0) & 0xff) * a0 + (int)((wu1 >> i1) & 0xff) * a1) >> 4;
-        const int hv0 = ((int)((wv0 >> i0) & 0xff) * a0 + (int)((wv0 >> i1) & 0xff) * a1) >> 4;
-        const int hv1 = ((int)((wv1 >> i0) & 0xff) * a0 + (int)((wv1 >> i1) & 0xff) * a1) >> 4;
-        // odd row 2k - 1: weights (1536, 512) on chroma rows (k - 1, k); even row 2k: (512, 1536)
-        const uint32_t ua = (uint32_t)((((1536 * hu0) >> 16) + ((512 * hu1) >> 16) + 2) >> 2) & 0xffu;
-        const uint32_t va = (uint32_t)((((1536 * hv0) >> 16) + ((512 * hv1) >> 16) + 2) >> 2) & 0xffu;
-        const uint32_t ub = (uint32_t)((((512 * hu0) >> 16) + ((1536 * hu1) >> 16) + 2) >> 2) & 0xffu;
-        const uint32_t vb = (uint32_t)((((512 * hv0) >> 16) + ((1536 * hv1) >> 16) + 2) >> 2) & 0xffu;
+        // odd row 2k - 1: weights (3/4, 1/4) on chroma rows (k - 1, k); even row 2k: (1/4, 3/4)
+        const uint32_t u0 = tu0[p], u1 = tu1[p], v0 = tv0[p], v1 = tv1[p];
+        const uint32_t ua = ((((u0 + u0 + u0) >> 2) + (u1 >> 2) + 2u) >> 2), ub = (((u0 >> 2) + ((u1 + u1 + u1) >> 2) + 2u) >> 2);
+        const uint32_t va = ((((v0 + v0 + v0) >> 2) + (v1 >> 2) + 2u) >> 2), vb = (((v0 >> 2) + ((v1 + v1 + v1) >> 2) + 2u) >> 2);
         pa[p] = ((ywa >> (8 * p)) & 0xffu) | (ua << 8) | (va << 16);
         pb[p] = ((ywb >> (8 * p)) & 0xffu) | (ub << 8) | (vb << 16);
     }

@@ -1,6 +1,6 @@
-// Pyramidal Lucas-Kanade sparse optical flow for gfx950: one 64-lane wavefront per feature, all pyramid levels
-// inside one launch, patch windows staged in LDS, integer fixed-point bilinear sampling and exact integer
-// wave reductions for the 2x2 system.
+// Pyramidal Lucas-Kanade sparse optical flow for gfx950: one block per feature and one 64-lane wavefront per pyramid
+// level inside one launch (the levels' windows, derivatives and 2x2 systems are prepared concurrently, the iterations
+// then run coarse to fine out of LDS), integer fixed-point bilinear sampling and exact integer wave reductions.
 //
 // Replaces cv::SparsePyrLKOpticalFlow::calc as the reference configures it (reference call:
 // LiveVisionKit/Vision/FrameTracker.cpp:33-35,42-48,140-146; arithmetic: OpenCV 4.8.0 video/lkpyramid.cpp
@@ -20,9 +20,9 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-constexpr int LK_MARGIN = 3;     // search margin (pixels) of the staged next-frame window
+constexpr int LK_MARGIN = 8;     // search margin (pixels) of the staged next-frame window around the zero-flow prediction
 
-// byte offset of the reduction scratch inside the dynamic LDS block (after the tiles and cached patches), 16-byte aligned
+// bytes of one pyramid level's windows and patches in the dynamic LDS block, rounded to 16
 __host__ __device__ inline size_t lvk_pyrlk_part_offset(int win_w, int win_h)
 {
     const size_t tarea = (size_t)(win_w + 1) * (win_h + 1), area = (size_t)win_w * win_h;
@@ -57,9 +57,9 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 // partial is split into a signed high part and an unsigned 16-bit low part whose 64-lane sums both fit in 32 bits (per-lane
 // partials are < 2^46 here: <= 16 window pixels x 2^25), and each part is one DPP reduction -- about 5x cheaper than the
 // LDS column sums with their three barriers that this replaces, and 10x cheaper than 64-bit ds_bpermute butterflies.
-// Every lane returns all K totals in v[].  (`part` is unused and kept for the LDS layout.)
+// Every lane returns all K totals in v[].
 template <int K>
-__device__ __forceinline__ void wave_sums(long long (&v)[K], long long* /*part*/)
+__device__ __forceinline__ void wave_sums(long long (&v)[K])
 {
 #pragma unroll
     for (int k = 0; k < K; k++)
@@ -77,126 +77,309 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
     w11 = 16384 - w00 - w01 - w10;
 }
 
-// LDS layout per block (one wave): tile[(win_h+1) * tw] u8 image samples, dtile[... ] short2 derivative samples,
-// then the cached patches I, Ix, Iy (int16 each, win_w * win_h).
-__global__ __launch_bounds__(64)
+// What phase A leaves behind for one pyramid level (in LDS, next to the level's windows and patches).
+struct LevelState
+{
+    float A11, A12, A22, Dinv;     // covariance matrix of the patch gradients (scaled) and 1 / det
+    int jx0, jy0;                  // origin of the staged next-frame window (INT_MIN / 2: nothing staged)
+    int skip;                      // the level contributes nothing: window outside the image, or a singular system
+    int pad;
+};
+
+// LDS writes of a wave followed by LDS reads of other lanes of the SAME wave: the LDS unit serves one wave's instructions in order, so
+// only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The loop form is the specification's; the first two reflections are peeled so that the common cases need no loop.
+__device__ __forceinline__ int reflect101_fast(int p, int len)
+{
+    if (len == 1) return 0;
+    p = p < 0 ? -p : p;
+    p = p >= len ? 2 * (len - 1) - p : p;
+    while (p < 0 || p >= len) { p = (p < 0) ? -p : 2 * (len - 1) - p; }
+    return p;
+}
+
+// Copies the w x h window of an image whose top-left corner is (x0, y0) (reflect-101 outside the image) into LDS, row-major with
+// pitch w.  A lane's loads are issued CHUNK at a time before any of them is consumed: a window costs ceil(w h / (64 CHUNK)) global
+// round trips instead of one per row group.
+struct WindowSrc { const uint8_t* img; int rows, cols, step, x0, y0, w, h; };
+
+template <int CHUNK>
+__device__ __forceinline__ void window_loads(uint8_t (&v)[CHUNK], const WindowSrc& s, int base, int lane)
+{
+    const int total = s.w * s.h;
+    const float rw = 1.0f / (float)s.w;
+#pragma unroll
+    for (int k = 0; k < CHUNK; k++)
+    {
+        const int idx = min(base + k * 64 + lane, total - 1);            // lanes past the end repeat the last pixel (not stored)
+        int ty = (int)(((float)idx + 0.5f) * rw), tx = idx - ty * s.w;     // idx / w, idx % w (fixed up below: the quotient may be off by one)
+        if (tx < 0) { ty--; tx += s.w; }
+        if (tx >= s.w) { ty++; tx -= s.w; }
+        v[k] = s.img[(long)reflect101_fast(s.y0 + ty, s.rows) * s.step + reflect101_fast(s.x0 + tx, s.cols)];
+    }
+}
+
+template <int CHUNK>
+__device__ __forceinline__ void window_stores(uint8_t* __restrict__ tile, const uint8_t (&v)[CHUNK], int total, int base, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < CHUNK; k++)
+    {
+        const int idx = base + k * 64 + lane;
+        if (idx < total) tile[idx] = v[k];
+    }
+}
+
+template <int CHUNK>
+__device__ __forceinline__ void stage_window(uint8_t* __restrict__ tile, const WindowSrc& s, int lane)
+{
+    const int total = s.w * s.h;
+    for (int base = 0; base < total; base += 64 * CHUNK)
+    {
+        uint8_t v[CHUNK];
+        window_loads<CHUNK>(v, s, base, lane);
+        window_stores<CHUNK>(tile, v, total, base, lane);
+    }
+}
+
+// Interior windows (no reflection anywhere, and the last dword of a row stays inside the image row): rows are fetched as unaligned
+// dwords with plain address arithmetic -- 4 instead of 17 loads per lane for the default windows and none of the ~90 instructions of
+// reflect / divide bookkeeping per byte that made the byte path instruction-bound (5.4 us of a level's 7.4 us preparation).
+struct __attribute__((packed, aligned(1))) LkU4B { uint32_t w; };
+
+__device__ __forceinline__ bool window_is_interior(const WindowSrc& s)
+{
+    const int dpr = (s.w + 3) >> 2;
+    return s.x0 >= 0 && s.y0 >= 0 && s.x0 + 4 * dpr <= s.cols && s.y0 + s.h <= s.rows;
+}
+
+template <int CHUNK>
+__device__ __forceinline__ void interior_loads(uint32_t (&v)[CHUNK], const WindowSrc& s, int lane)
+{
+    const int dpr = (s.w + 3) >> 2, total = s.h * dpr;
+    const float rd = 1.0f / (float)dpr;
+    const uint8_t* origin = s.img + (long)s.y0 * s.step + s.x0;
+#pragma unroll
+    for (int k = 0; k < CHUNK; k++)
+    {
+        const int q = min(k * 64 + lane, total - 1);
+        int ty = (int)(((float)q + 0.5f) * rd), tq = q - ty * dpr;
+        if (tq < 0) { ty--; tq += dpr; }
+        if (tq >= dpr) { ty++; tq -= dpr; }
+        v[k] = reinterpret_cast<const LkU4B*>(origin + ty * s.step + 4 * tq)->w;
+    }
+}
+
+template <int CHUNK>
+__device__ __forceinline__ void interior_stores(uint8_t* __restrict__ tile, const uint32_t (&v)[CHUNK], const WindowSrc& s, int lane)
+{
+    const int dpr = (s.w + 3) >> 2, total = s.h * dpr;
+    const float rd = 1.0f / (float)dpr;
+#pragma unroll
+    for (int k = 0; k < CHUNK; k++)
+    {
+        const int q = k * 64 + lane;
+        int ty = (int)(((float)q + 0.5f) * rd), tq = q - ty * dpr;
+        if (tq < 0) { ty--; tq += dpr; }
+        if (tq >= dpr) { ty++; tq -= dpr; }
+        if (q < total)
+        {
+            uint8_t* d = tile + ty * s.w + 4 * tq;
+            const int nb = min(4, s.w - 4 * tq);
+            d[0] = (uint8_t)v[k];
+            if (nb > 1) d[1] = (uint8_t)(v[k] >> 8);
+            if (nb > 2) d[2] = (uint8_t)(v[k] >> 16);
+            if (nb > 3) d[3] = (uint8_t)(v[k] >> 24);
+        }
+    }
+}
+
+// Two windows in the same round trip(s): the loads of both are in flight before either is stored.  CA / CB = loads per lane that
+// cover the default windows in one chunk; larger windows take the generic chunk loop.
+template <int CA, int CB, int FA, int FB>
+__device__ __forceinline__ void stage_two_windows(uint8_t* __restrict__ ta, const WindowSrc& a, uint8_t* __restrict__ tb, const WindowSrc& b, bool b_valid, int lane)
+{
+    const bool fa = window_is_interior(a) && a.h * ((a.w + 3) >> 2) <= 64 * FA;
+    const bool fb = b_valid && window_is_interior(b) && b.h * ((b.w + 3) >> 2) <= 64 * FB;
+    if (fa && fb)                                                           // wave-uniform: the common case
+    {
+        uint32_t va[FA], vb[FB];
+        interior_loads<FA>(va, a, lane);
+        interior_loads<FB>(vb, b, lane);
+        interior_stores<FA>(ta, va, a, lane);
+        interior_stores<FB>(tb, vb, b, lane);
+        return;
+    }
+    const int na = a.w * a.h, nb = b_valid ? b.w * b.h : 0;
+    for (int t = 0; t * 64 * CA < na || t * 64 * CB < nb; t++)
+    {
+        const bool do_a = t * 64 * CA < na, do_b = t * 64 * CB < nb;       // wave-uniform
+        uint8_t va[CA], vb[CB];
+        if (do_a) window_loads<CA>(va, a, t * 64 * CA, lane);
+        if (do_b) window_loads<CB>(vb, b, t * 64 * CB, lane);
+        if (do_a) window_stores<CA>(ta, va, na, t * 64 * CA, lane);
+        if (do_b) window_stores<CB>(tb, vb, nb, t * 64 * CB, lane);
+    }
+}
+
+template <int CB, int FB>
+__device__ __forceinline__ void stage_one_window(uint8_t* __restrict__ tb, const WindowSrc& b, int lane)
+{
+    if (window_is_interior(b) && b.h * ((b.w + 3) >> 2) <= 64 * FB)
+    {
+        uint32_t vb[FB];
+        interior_loads<FB>(vb, b, lane);
+        interior_stores<FB>(tb, vb, b, lane);
+        return;
+    }
+    stage_window<CB>(tb, b, lane);
+}
+
+// One block per feature, one wave per pyramid level.
+//
+// Phase A (all levels at once, wave w = level w): everything that depends only on the feature's previous position -- the (win + 3)^2
+// window of the previous image, its Scharr derivatives, the bilinearly sampled patches I / Ix / Iy, the 2x2 covariance matrix and its
+// eigenvalue test -- plus the next-frame window around the ZERO-FLOW prediction of where the search will start, with a LK_MARGIN
+// search margin.  The four global round trips of the levels overlap instead of following each other.
+// Phase B (wave 0 alone, coarse to fine): the Newton iterations, out of LDS; a level whose start (twice the coarser level's result)
+// or whose track leaves the staged window re-centres it with one more round trip.  Same integers and float operations in the same
+// order as the one-wave-per-feature kernel this replaces (38 us -> see DESIGN.md), which did the levels' staging one after the other.
+//
+// LDS per level: dtile[(win_h+1) * tw] short2 derivative samples, the cached patches I, Ix, Iy (int16 each, win_w * win_h), etile =
+// image window with a 1-px ring, jtile = next-frame window; then one LevelState per level.
+__global__ __launch_bounds__(64 * LVK_MAX_PYR_LEVELS)
 void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, float2* __restrict__ prev_copy, int n,
              float2* __restrict__ next_pts, uint8_t* __restrict__ status,
-             int win_w, int win_h, int max_count, double epsilon_sq, float min_eig_threshold)
+             int win_w, int win_h, int max_count, double epsilon_sq, float min_eig_threshold, int level_bytes)
 {
     LVK_TRACKER_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int pt = blockIdx.x;
-    if (pt >= n) return;
-    const int lane = threadIdx.x;
+    const int pt = blockIdx.x;                                                // grid = n
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = win_w + 1, th = win_h + 1, area = win_w * win_h, tarea = tw * th;
     const int jw = tw + 2 * LK_MARGIN, jh = th + 2 * LK_MARGIN;               // next-frame window incl. search margin
-    short2* dtile = reinterpret_cast<short2*>(smem);                          // tarea * 4 B
-    short* Iw = reinterpret_cast<short*>(smem + (size_t)tarea * 4);           // area * 2 B
-    short* Ixw = Iw + area;
-    short* Iyw = Ixw + area;
     const int ew = tw + 2, eh = th + 2;                                       // image window with a 1-px ring (Scharr support)
-    uint8_t* etile = reinterpret_cast<uint8_t*>(Iyw + area);                  // ew * eh B
-    uint8_t* jtile = etile + ew * eh;                                         // jw * jh B
-    long long* part = reinterpret_cast<long long*>(smem + lvk_pyrlk_part_offset(win_w, win_h));   // 3 * 64 int64
+    LevelState* states = reinterpret_cast<LevelState*>(smem + (size_t)prev.nlevels * level_bytes);
     // division-free walk over the window: pixel p = lane + 64 r  ->  (y, x) advances by (64 / win_w, 64 % win_w)
     const int py0 = lane / win_w, px0 = lane - py0 * win_w, pdy_ = 64 / win_w, pdx_ = 64 - pdy_ * win_w;
     const int lx = lane & 15, ly = lane >> 4;                                 // 16 x 4 lane grid for the staging loops
 
     const float2 p0 = prev_pts[pt];                        // may live in pinned host memory: one 8-byte read per wave
-    if (lane == 0 && prev_copy) prev_copy[pt] = p0;        // device-resident copy for the kernels that follow
+    if (threadIdx.x == 0 && prev_copy) prev_copy[pt] = p0; // device-resident copy for the kernels that follow
     const float halfx = (win_w - 1) * 0.5f, halfy = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
-    float outx = 0.f, outy = 0.f;
-    bool ok = true;                                                           // status (initialised to 1 by calc())
     const int top = prev.nlevels - 1;
 
-    for (int level = top; level >= 0; level--)
+    // ---- phase A: this wave's level
     {
+        const int level = wave;
+        uint8_t* base = smem + (size_t)level * level_bytes;
+        short2* dtile = reinterpret_cast<short2*>(base);                          // tarea * 4 B
+        short* Iw = reinterpret_cast<short*>(base + (size_t)tarea * 4);           // area * 2 B
+        short* Ixw = Iw + area;
+        short* Iyw = Ixw + area;
+        uint8_t* etile = reinterpret_cast<uint8_t*>(Iyw + area);                  // ew * eh B
+        uint8_t* jtile = etile + ew * eh;                                         // jw * jh B
         const PyrLevel I = prev.lv[level];
         const PyrLevel J = next.lv[level];
         float px = p0.x * (float)(1. / (1 << level));
         float py = p0.y * (float)(1. / (1 << level));
-        float nx, ny;
-        if (level == top) { nx = px; ny = py; }
-        else { nx = outx * 2.f; ny = outy * 2.f; }
-        outx = nx; outy = ny;
-
+        const float nx = px, ny = py;                                             // zero-flow prediction of the level's starting point
+        LevelState st;
+        st.A11 = st.A12 = st.A22 = st.Dinv = 0.f; st.jx0 = st.jy0 = INT_MIN / 2; st.skip = 0; st.pad = 0;
         px -= halfx; py -= halfy;
         const int ipx = (int)__builtin_floorf(px), ipy = (int)__builtin_floorf(py);
-        if (ipx < -win_w || ipx >= I.cols || ipy < -win_h || ipy >= I.rows)
+        if (ipx < -win_w || ipx >= I.cols || ipy < -win_h || ipy >= I.rows) st.skip = 1;
+        else
         {
-            if (level == 0) ok = false;
-            continue;
-        }
-        float a = px - ipx, b = py - ipy;
-        int w00, w01, w10, w11;
-        bilinear_weights(a, b, w00, w01, w10, w11);
-
-        // stage the (win+1)^2 window of the previous image (reflect-101 border) and its derivatives (zero border), and --
-        // in the same round trip -- the next-frame window around the starting point plus a LK_MARGIN search margin, so
-        // that the iterations below normally run out of LDS without touching global memory again
-        int jx0 = (int)__builtin_floorf(nx - halfx), jy0 = (int)__builtin_floorf(ny - halfy);
-        // only positions that pass the tracker's own bounds test are staged (anything else never samples the image)
-        const bool j_valid = !(jx0 < -win_w || jx0 >= J.cols || jy0 < -win_h || jy0 >= J.rows);
-        jx0 = j_valid ? jx0 - LK_MARGIN : INT_MIN / 2; jy0 = j_valid ? jy0 - LK_MARGIN : INT_MIN / 2;
-        __syncthreads();
-        for (int ey = ly; ey < eh; ey += 4)
-        {
-            const uint8_t* irow = I.img + (long)reflect101(ipy - 1 + ey, I.rows) * I.step;
-            for (int ex = lx; ex < ew; ex += 16) etile[ey * ew + ex] = irow[reflect101(ipx - 1 + ex, I.cols)];
-        }
-        if (j_valid)
-            for (int ty = ly; ty < jh; ty += 4)
-            {
-                const uint8_t* jrow = J.img + (long)reflect101(jy0 + ty, J.rows) * J.step;
-                for (int tx = lx; tx < jw; tx += 16) jtile[ty * jw + tx] = jrow[reflect101(jx0 + tx, J.cols)];
-            }
-        __syncthreads();
-        // calcScharrDeriv on the staged window (reflect-101 ring, same integers as k_scharr_all); positions outside the image get
-        // zero derivatives like the zero border the derivative images used to be read with
-        for (int ty = ly; ty < th; ty += 4)
-            for (int tx = lx; tx < tw; tx += 16)
-            {
-                const int xx = ipx + tx, yy = ipy + ty;
-                short2 d = make_short2(0, 0);
-                if (xx >= 0 && yy >= 0 && xx < I.cols && yy < I.rows)
+            const float a = px - ipx, b = py - ipy;
+            int w00, w01, w10, w11;
+            bilinear_weights(a, b, w00, w01, w10, w11);
+            // stage the window of the previous image (reflect-101 border) and -- in the same round trip -- the next-frame window
+            int jx0 = (int)__builtin_floorf(nx - halfx), jy0 = (int)__builtin_floorf(ny - halfy);
+            // only positions that pass the tracker's own bounds test are staged (anything else never samples the image)
+            const bool j_valid = !(jx0 < -win_w || jx0 >= J.cols || jy0 < -win_h || jy0 >= J.rows);
+            jx0 = j_valid ? jx0 - LK_MARGIN : INT_MIN / 2; jy0 = j_valid ? jy0 - LK_MARGIN : INT_MIN / 2;
+            // (defaults: 14 x 14 and 28 x 28 bytes = 1 + 4 dword loads per lane for interior windows, 4 + 13 byte loads at the border; one round trip)
+            stage_two_windows<4, 13, 1, 4>(etile, WindowSrc{I.img, I.rows, I.cols, I.step, ipx - 1, ipy - 1, ew, eh},
+                                     jtile, WindowSrc{J.img, J.rows, J.cols, J.step, jx0, jy0, jw, jh}, j_valid, lane);
+            wave_lds_sync();
+            // calcScharrDeriv on the staged window (reflect-101 ring, same integers as k_scharr_all); positions outside the image get
+            // zero derivatives like the zero border the derivative images used to be read with
+            for (int ty = ly; ty < th; ty += 4)
+                for (int tx = lx; tx < tw; tx += 16)
                 {
-                    const uint8_t* r0 = etile + ty * ew + tx; const uint8_t* r1 = r0 + ew; const uint8_t* r2 = r1 + ew;
-                    const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
-                    const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
-                    d = make_short2((short)(t0p - t0m), (short)((t1p + t1m) * 3 + t1c * 10));
+                    const int xx = ipx + tx, yy = ipy + ty;
+                    short2 d = make_short2(0, 0);
+                    if (xx >= 0 && yy >= 0 && xx < I.cols && yy < I.rows)
+                    {
+                        const uint8_t* r0 = etile + ty * ew + tx; const uint8_t* r1 = r0 + ew; const uint8_t* r2 = r1 + ew;
+                        const int t0m = (r0[0] + r2[0]) * 3 + r1[0] * 10, t0p = (r0[2] + r2[2]) * 3 + r1[2] * 10;
+                        const int t1m = r2[0] - r0[0], t1c = r2[1] - r0[1], t1p = r2[2] - r0[2];
+                        d = make_short2((short)(t0p - t0m), (short)((t1p + t1m) * 3 + t1c * 10));
+                    }
+                    dtile[ty * tw + tx] = d;
                 }
-                dtile[ty * tw + tx] = d;
+            wave_lds_sync();
+            const uint8_t* tile = etile + ew + 1;                                     // the (win+1)^2 image window, pitch ew
+            long long sA[3] = {0, 0, 0};
+            for (int p = lane, y = py0, x = px0; p < area; p += 64)
+            {
+                const int i00 = y * tw + x, i01 = i00 + 1, i10 = i00 + tw, i11 = i10 + 1;
+                const int e00 = y * ew + x, e01 = e00 + 1, e10 = e00 + ew, e11 = e10 + 1;
+                // every factor fits 24 signed bits (samples <= 255, |derivatives| <= 4080, weights <= 16384): v_mul_i32_i24 / v_mad_i32_i24
+                // instead of the multi-pass 32-bit v_mul_lo_u32; the products are exact either way
+                const int ival = descale(__mul24(tile[e00], w00) + __mul24(tile[e01], w01) + __mul24(tile[e10], w10) + __mul24(tile[e11], w11), 14 - 5);
+                const int ixval = descale(__mul24(dtile[i00].x, w00) + __mul24(dtile[i01].x, w01) + __mul24(dtile[i10].x, w10) + __mul24(dtile[i11].x, w11), 14);
+                const int iyval = descale(__mul24(dtile[i00].y, w00) + __mul24(dtile[i01].y, w01) + __mul24(dtile[i10].y, w10) + __mul24(dtile[i11].y, w11), 14);
+                Iw[p] = (short)ival; Ixw[p] = (short)ixval; Iyw[p] = (short)iyval;
+                sA[0] += (long long)__mul24(ixval, ixval);           // |ixval|, |iyval| <= 4080: the squares fit 32 bits
+                sA[1] += (long long)__mul24(ixval, iyval);
+                sA[2] += (long long)__mul24(iyval, iyval);
+                y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
             }
-        __syncthreads();
-        const uint8_t* tile = etile + ew + 1;                                     // the (win+1)^2 image window, pitch ew
-        long long sA[3] = {0, 0, 0};
-        for (int p = lane, y = py0, x = px0; p < area; p += 64)
-        {
-            const int i00 = y * tw + x, i01 = i00 + 1, i10 = i00 + tw, i11 = i10 + 1;
-            const int e00 = y * ew + x, e01 = e00 + 1, e10 = e00 + ew, e11 = e10 + 1;
-            // every factor fits 24 signed bits (samples <= 255, |derivatives| <= 4080, weights <= 16384): v_mul_i32_i24 / v_mad_i32_i24
-            // run at full rate where the 32-bit v_mul_lo_u32 takes four passes; the products are exact either way
-            const int ival = descale(__mul24(tile[e00], w00) + __mul24(tile[e01], w01) + __mul24(tile[e10], w10) + __mul24(tile[e11], w11), 14 - 5);
-            const int ixval = descale(__mul24(dtile[i00].x, w00) + __mul24(dtile[i01].x, w01) + __mul24(dtile[i10].x, w10) + __mul24(dtile[i11].x, w11), 14);
-            const int iyval = descale(__mul24(dtile[i00].y, w00) + __mul24(dtile[i01].y, w01) + __mul24(dtile[i10].y, w10) + __mul24(dtile[i11].y, w11), 14);
-            Iw[p] = (short)ival; Ixw[p] = (short)ixval; Iyw[p] = (short)iyval;
-            sA[0] += (long long)__mul24(ixval, ixval);           // |ixval|, |iyval| <= 4080: the squares fit 32 bits
-            sA[1] += (long long)__mul24(ixval, iyval);
-            sA[2] += (long long)__mul24(iyval, iyval);
-            y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
+            wave_sums<3>(sA);
+            const float A11 = (float)(double)sA[0] * FLT_SCALE, A12 = (float)(double)sA[1] * FLT_SCALE, A22 = (float)(double)sA[2] * FLT_SCALE;
+            const float D = A11 * A22 - A12 * A12;
+            const float minEig = (A22 + A11 - __builtin_sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win_w * win_h);
+            if (minEig < min_eig_threshold || D < 1.1920928955078125e-07f) st.skip = 1;
+            else { st.A11 = A11; st.A12 = A12; st.A22 = A22; st.Dinv = 1.f / D; st.jx0 = jx0; st.jy0 = jy0; }
         }
-        wave_sums<3>(sA, part);
-        const float A11 = (float)(double)sA[0] * FLT_SCALE, A12 = (float)(double)sA[1] * FLT_SCALE, A22 = (float)(double)sA[2] * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - __builtin_sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win_w * win_h);
-        if (minEig < min_eig_threshold || D < 1.1920928955078125e-07f)
+        if (lane == 0) states[level] = st;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    // ---- phase B: coarse to fine
+    float outx = 0.f, outy = 0.f;
+    bool ok = true;                                                           // status (initialised to 1 by calc())
+    for (int level = top; level >= 0; level--)
+    {
+        const PyrLevel J = next.lv[level];
+        const LevelState st = states[level];
+        uint8_t* base = smem + (size_t)level * level_bytes;
+        const short* Iw = reinterpret_cast<const short*>(base + (size_t)tarea * 4);
+        const short* Ixw = Iw + area;
+        const short* Iyw = Ixw + area;
+        uint8_t* jtile = base + (size_t)tarea * 4 + (size_t)area * 6 + ew * eh;
+        float nx, ny;
+        if (level == top) { nx = p0.x * (float)(1. / (1 << level)); ny = p0.y * (float)(1. / (1 << level)); }
+        else { nx = outx * 2.f; ny = outy * 2.f; }
+        outx = nx; outy = ny;
+        if (st.skip)
         {
             if (level == 0) ok = false;
             continue;
         }
-        D = 1.f / D;
+        const float A11 = st.A11, A12 = st.A12, A22 = st.A22, D = st.Dinv;
+        int jx0 = st.jx0, jy0 = st.jy0;
         nx -= halfx; ny -= halfy;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < max_count; j++)
@@ -207,19 +390,16 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
                 if (level == 0) ok = false;
                 break;
             }
-            a = nx - inx; b = ny - iny;
+            const float a = nx - inx, b = ny - iny;
+            int w00, w01, w10, w11;
             bilinear_weights(a, b, w00, w01, w10, w11);
             if (inx < jx0 || iny < jy0 || inx + tw > jx0 + jw || iny + th > jy0 + jh)
             {
-                // the track left the staged window: re-centre it on the current position
+                // the start or the track is outside the staged window: re-centre it on the current position
                 jx0 = inx - LK_MARGIN; jy0 = iny - LK_MARGIN;
-                __syncthreads();
-                for (int ty = ly; ty < jh; ty += 4)
-                {
-                    const uint8_t* jrow = J.img + (long)reflect101(jy0 + ty, J.rows) * J.step;
-                    for (int tx = lx; tx < jw; tx += 16) jtile[ty * jw + tx] = jrow[reflect101(jx0 + tx, J.cols)];
-                }
-                __syncthreads();
+                wave_lds_sync();
+                stage_one_window<13, 4>(jtile, WindowSrc{J.img, J.rows, J.cols, J.step, jx0, jy0, jw, jh}, lane);
+                wave_lds_sync();
             }
             const uint8_t* jt = jtile + (iny - jy0) * jw + (inx - jx0);
             long long sb[2] = {0, 0};
@@ -231,7 +411,7 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
                 sb[1] += (long long)__mul24(diff, Iyw[p]);
                 y += pdy_; x += pdx_; if (x >= win_w) { x -= win_w; y++; }
             }
-            wave_sums<2>(sb, part);
+            wave_sums<2>(sb);
             const float b1 = (float)(double)sb[0] * FLT_SCALE, b2 = (float)(double)sb[1] * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
@@ -255,7 +435,11 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
 
 } // namespace
 
-size_t lvk_pyrlk_lds_bytes(int win_w, int win_h) { return lvk_pyrlk_part_offset(win_w, win_h) + 3 * 64 * sizeof(long long); }
+// dynamic LDS of k_pyrlk: the windows and patches of every level, then the per-level state
+size_t lvk_pyrlk_lds_bytes(int win_w, int win_h, int nlevels)
+{
+    return (size_t)nlevels * lvk_pyrlk_part_offset(win_w, win_h) + (size_t)nlevels * sizeof(LevelState);
+}
 
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
                      float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig, float2* d_prev_copy)
@@ -267,8 +451,11 @@ int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next,
     max_count = std::min(std::max(max_count, 0), 100);
     epsilon = std::min(std::max(epsilon, 0.), 10.);
     epsilon *= epsilon;
-    hipLaunchKernelGGL(k_pyrlk, dim3(n), dim3(64), lvk_pyrlk_lds_bytes(win_w, win_h), ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
-                       d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig);
+    const size_t lds = lvk_pyrlk_lds_bytes(win_w, win_h, prev.nlevels);
+    if (lds > 48 * 1024)
+        LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyrlk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_pyrlk, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
+                       d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h));
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

@@ -299,7 +299,10 @@ constexpr int PXT = 4, STRIP_W = 64 * PXT, STRIP_H = 4;
 // at once instead of queueing behind 17-us remap workgroups -- and those kernels raise their own issue priority (s_setprio,
 // LVK_TRACKER_PRIORITY) so that they are not starved by the VALU-bound remap waves they share a SIMD with.  Measured at 4K
 // (MI355X, whole pipeline): cap 3 / 4 / 5 waves with the priority raise 7.1k / 7.6k / 7.0k frames/s (cap 3 without it: 6.9k).
-#define LVK_CO_SCHEDULED __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef LVK_CO_WAVES
+#define LVK_CO_WAVES 4
+#endif
+#define LVK_CO_SCHEDULED __attribute__((amdgpu_waves_per_eu(LVK_CO_WAVES, LVK_CO_WAVES)))
 constexpr int NUM_XCD = 8;
 
 __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
