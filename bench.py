@@ -198,7 +198,9 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
-    filt.set_profiling(True, stages=("remap",))      # live HIP-event timing of the dominant kernel only inside the timed region
+    # live HIP-event timing of the dominant kernel inside the timed region: that stage only, and one launch in eight (an event pair per
+    # frame is two host API calls in the per-frame turnaround -- the measurement would slow what it measures by ~4 %)
+    filt.set_profiling(True, stages=("remap",), every=8)
 
     def barrier():
         torch.cuda.synchronize()

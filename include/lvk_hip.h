@@ -292,7 +292,8 @@ int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int
 #define LVK_STAGE_EGRESS    7   /* packed 444 -> YUV420 */
 #define LVK_STAGE_COUNT     8
 /* enable: 0 = off, 1 = every stage, otherwise a set of (1 << (LVK_STAGE_x + 1)) bits -- each timed stage costs two event records
- * per frame on the host, so a measurement that needs one kernel should ask for that stage only */
+ * per frame on the host, so a measurement that needs one kernel should ask for that stage only; bits 16..23 = N: time the stages
+ * of one push in N only (0 / 1 = every push), which keeps a live measurement from slowing the stream it measures */
 int  lvk_hip_stab_set_profiling(lvk_hip_stab* stab, int enable);
 int  lvk_hip_stab_get_profile(lvk_hip_stab* stab, double total_ms[LVK_STAGE_COUNT], long long launches[LVK_STAGE_COUNT]);
 

@@ -143,6 +143,7 @@ struct lvk_hip_stab
     // ---- optional per-stage GPU timing (HIP events on the launch stream)
     bool profiling = false;
     unsigned prof_mask = ~0u;                  // stages that are timed while profiling is on (bit = LVK_STAGE_*)
+    unsigned prof_every = 1, prof_tick = 0;    // time the stages of one push in `prof_every` (the event records cost host time per frame)
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
     double prof_ms[LVK_STAGE_COUNT] = {0}; long prof_n[LVK_STAGE_COUNT] = {0};
@@ -170,7 +171,7 @@ struct lvk_hip_stab
 int lvk_hip_stab::prof_begin(int kind, hipStream_t stream)
 {
     if (!stream) stream = ctx->stream;
-    if (!profiling || !((prof_mask >> kind) & 1u)) return -1;
+    if (!profiling || !((prof_mask >> kind) & 1u) || (prof_tick % prof_every) != 0) return -1;
     if (ev_used >= 1024 && prof_collect() != LVK_HIP_OK) return -1;      // long sessions: fold the pending pairs in (one stream sync) and reuse them
     if (ev_used == ev_pool.size())
     {
@@ -527,7 +528,6 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     st->free_tracker_buffers();
     st->pyr[0].release(); st->pyr[1].release();
     st->free_pool();
-    if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
     if (st->remap_stream)
     {
         (void)hipStreamSynchronize(st->remap_stream);
@@ -536,6 +536,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
         (void)hipStreamDestroy(st->remap_stream);
         (void)hipEventDestroy(st->remap_done[0]); (void)hipEventDestroy(st->remap_done[1]);
     }
+    if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
     for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete st;
 }
@@ -581,7 +582,9 @@ int lvk_hip_stab_set_profiling(lvk_hip_stab* st, int enable)
     if (!st) return LVK_HIP_ERR_ARG;
     const int rc = st->prof_collect();
     st->profiling = enable != 0;
-    st->prof_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;          // 1: every stage; otherwise (1 << (stage + 1)) bits
+    st->prof_mask = enable == 1 ? ~0u : ((unsigned)enable & 0xffffu) >> 1;   // 1: every stage; otherwise (1 << (stage + 1)) bits
+    st->prof_every = std::max(1u, ((unsigned)enable >> 16) & 0xffu);        // bits 16..23: sample one push in N (0 / 1 = every push)
+    st->prof_tick = 0;
     for (int i = 0; i < LVK_STAGE_COUNT; i++) { st->prof_ms[i] = 0; st->prof_n[i] = 0; }
     return rc;
 }
@@ -826,6 +829,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
 {
     if (!st) return LVK_HIP_ERR_ARG;
     st->trace.begin();
+    st->prof_tick++;
     if (st->queue.empty()) st->queue_kind = 0;
     if (st->queue_kind == 2) return st->fail(LVK_HIP_ERR_ARG, "frames of lvk_hip_stab_push_yuv420 are still queued: restart() before switching to lvk_hip_stab_push");
     st->queue_kind = 1;
@@ -847,6 +851,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_hip_ctx* ctx = st->ctx;
     st->trace.begin();
+    st->prof_tick++;
     if (produced) *produced = 0;
     if (st->queue.empty()) st->queue_kind = 0;
     if (st->queue_kind == 1) return st->fail(LVK_HIP_ERR_ARG, "borrowed frames of lvk_hip_stab_push are still queued: restart() before switching to lvk_hip_stab_push_yuv420");
@@ -886,7 +891,8 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     if (released) st->pool_free.push_back(const_cast<void*>(released));
     if (side_ingest)
     {
-        // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago)
+        // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago).  An event, not
+        // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
         LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
     }
     if (rc != LVK_HIP_OK) return rc;

@@ -249,13 +249,20 @@ class StabilizationFilter:
 
     STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap", "ingest", "egress")
 
-    def set_profiling(self, enable=True, stages=None):
-        """stages: optional subset of STAGES to time (every timed stage costs two event records per frame on the host)."""
+    def set_profiling(self, enable=True, stages=None, every=1):
+        """stages: optional subset of STAGES to time (every timed stage costs two event records per frame on the host);
+        every = N: time one push in N."""
         flag = 1 if enable else 0
         if enable and stages is not None:
             flag = 0
             for name in stages:
                 flag |= 1 << (self.STAGES.index(name) + 1)
+        if enable and every > 1:
+            if flag == 1:
+                flag = 0
+                for i in range(len(self.STAGES)):
+                    flag |= 1 << (i + 1)
+            flag |= (min(int(every), 255) & 0xff) << 16
         self.ctx._check(self.lib.lvk_hip_stab_set_profiling(self.handle, flag))
 
     def profile(self):
