@@ -63,6 +63,7 @@ template <int SX, int SY, int PIX, int MODE = 0>          // MODE 0: channel 0; 
 __global__ __launch_bounds__(256)
 void k_area_fast_dw(const uint8_t* __restrict__ src, int src_step, uint8_t* __restrict__ dst, int dst_step, int drows, int dcols)
 {
+    LVK_TL(0);
     LVK_TRACKER_PRIORITY();
     constexpr int NW = SX * PIX / 4;
     static_assert((SX * PIX) % 4 == 0, "row segment must be whole dwords");
@@ -198,6 +199,7 @@ __device__ __forceinline__ int pyr_tap(const uint8_t* t, int pitch, int ox, int 
 __global__ __launch_bounds__(256)
 void k_pyr_fused3(PyrArgs a)
 {
+    LVK_TL(1);
     LVK_TRACKER_PRIORITY();
     __shared__ uint8_t t0[F0 * F0P], t1[F1 * F1P], t2[F2 * F2P];
     const int tid = threadIdx.x;
@@ -436,3 +438,5 @@ int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, 
 }
 
 } // extern "C"
+
+LVK_TL_EXPORT(imgproc)

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256)
 void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_t* __restrict__ up, int u_step,
                         const uint8_t* __restrict__ vp, int v_step, int rows, int cols, uint8_t* __restrict__ dst, int dst_step)
 {
+    LVK_TL(0);
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int k = blockIdx.y * 4 + threadIdx.y;                   // luma rows 2k - 1 (odd) and 2k (even); k = 0 .. rows / 2
     const int cc = cols >> 1, cr = rows >> 1;
@@ -267,3 +268,5 @@ int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int
 }
 
 } // extern "C"
+
+LVK_TL_EXPORT(ingest)

@@ -64,6 +64,53 @@ struct lvk_hip_ctx
 #endif
 #define LVK_TRACKER_PRIORITY() __builtin_amdgcn_s_setprio(LVK_TRACKER_PRIO)
 
+// Debug builds with -DLVK_TIMELINE (scripts/timeline_build.sh): every instrumented kernel logs the wall clock (100 MHz) at which its
+// first block started and its last block finished into a per-translation-unit ring, read back by lvk_tl_read_<unit>().  rocprofv3's
+// kernel trace slows the host enough to change how the two streams overlap; this does not.  Expands to nothing in product builds.
+#ifdef LVK_TIMELINE
+#define LVK_TL_SLOTS 4
+#define LVK_TL_RING 8192
+static __device__ unsigned lvk_tl_head[LVK_TL_SLOTS];
+static __device__ unsigned long long lvk_tl_log[LVK_TL_SLOTS][LVK_TL_RING][2];
+struct LvkTimelineScope
+{
+    int slot; bool sampled; unsigned long long t0;
+    __device__ explicit LvkTimelineScope(int s) : slot(s), sampled(false), t0(0)
+    {
+        // one workgroup in 64 (plus the first and the last) appends its own (start, end) record; the reader groups records into launches
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        sampled = threadIdx.x == 0 && threadIdx.y == 0 && ((b & 63u) == 63u || b == 0 || b == total - 1);
+        if (sampled) t0 = (unsigned long long)wall_clock64();
+    }
+    __device__ ~LvkTimelineScope()
+    {
+        if (sampled)
+        {
+            const unsigned i = atomicAdd(&lvk_tl_head[slot], 1u) % LVK_TL_RING;
+            lvk_tl_log[slot][i][0] = t0; lvk_tl_log[slot][i][1] = (unsigned long long)wall_clock64();
+        }
+    }
+};
+#define LVK_TL(slot) LvkTimelineScope lvk_tl_scope_(slot)
+// out: LVK_TL_SLOTS x (count, then LVK_TL_RING x (start, end)) int64
+#define LVK_TL_EXPORT(unit)                                                                                     \
+    extern "C" int lvk_tl_read_##unit(long long* out)                                                           \
+    {                                                                                                           \
+        unsigned idx[LVK_TL_SLOTS];                                                                             \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                    \
+        if (hipMemcpyFromSymbol(idx, HIP_SYMBOL(lvk_tl_head), sizeof(idx)) != hipSuccess) return -1;           \
+        for (int s = 0; s < LVK_TL_SLOTS; s++) out[(size_t)s * (1 + 2 * LVK_TL_RING)] = idx[s];                 \
+        for (int s = 0; s < LVK_TL_SLOTS; s++)                                                                  \
+            if (hipMemcpyFromSymbol(out + (size_t)s * (1 + 2 * LVK_TL_RING) + 1, HIP_SYMBOL(lvk_tl_log), sizeof(long long) * 2 * LVK_TL_RING, \
+                                    sizeof(long long) * 2 * LVK_TL_RING * s) != hipSuccess) return -1;         \
+        return 0;                                                                                               \
+    }
+#else
+#define LVK_TL(slot) do { } while (0)
+#define LVK_TL_EXPORT(unit)
+#endif
+
 #define LVK_HIP_REQUIRE(ctx, cond)                                                                    \
     do { if (!(cond)) return (ctx)->fail(LVK_HIP_ERR_ARG, "pre-condition failed: " #cond); } while (0)
 
@@ -168,4 +215,5 @@ int lvk_launch_sharpen(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, 
 // remap + 4:2:0 egress in one kernel (remap.hip)
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
-                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens);
+                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens,
+                                  bool co_scheduled);          // co_scheduled: the persistent grid of the overlap mode

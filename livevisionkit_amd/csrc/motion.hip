@@ -219,6 +219,7 @@ __global__ __launch_bounds__(NT)
 void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
                          double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
 {
+    LVK_TL(0);
     LVK_TRACKER_PRIORITY();
     if (n_dev) n = min(*n_dev, n);                          // pair count decided on the GPU (k_match_compact); n = capacity
     if (n < (full ? 4 : 2)) { if (threadIdx.x == 0) hyp_score[blockIdx.x] = -1; return; }
@@ -441,14 +442,17 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
 }
 
 // Single wavefront: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
+// At most 168 VGPRs (3 waves per SIMD's worth): the block has to fit NEXT TO the co-scheduled remap of the overlap mode (4 waves x 80
+// VGPRs per SIMD leave 192); the unconstrained allocation of 250 made it wait for remap workgroups to retire.
 template <bool STAGED>
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3)))
 void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
                        double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
                        uint8_t* __restrict__ gmask_a, uint8_t* __restrict__ gmask_b,
                        double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
 {
+    LVK_TL(1);
     LVK_TRACKER_PRIORITY();
     __shared__ double sA[64], sb[8], sH[9], sBest[9];
     __shared__ long long s_scratch[NT / 64];
@@ -530,6 +534,7 @@ void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__
                      float2* __restrict__ host_matched, uint8_t* __restrict__ host_status,
                      const float2* __restrict__ und, float region_w, float region_h)
 {
+    LVK_TL(2);
     LVK_TRACKER_PRIORITY();
     __shared__ unsigned short s_above[CMP_CAP];            // number of dropped elements with a higher index
     __shared__ uint8_t s_keep[CMP_CAP];
@@ -705,3 +710,5 @@ int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matche
 }
 
 } // extern "C"
+
+LVK_TL_EXPORT(motion)

@@ -259,6 +259,7 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
              float2* __restrict__ next_pts, uint8_t* __restrict__ status,
              int win_w, int win_h, int max_count, double epsilon_sq, float min_eig_threshold, int level_bytes)
 {
+    LVK_TL(0);
     LVK_TRACKER_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int pt = blockIdx.x;                                                // grid = n
@@ -576,3 +577,5 @@ int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int row
 }
 
 } // extern "C"
+
+LVK_TL_EXPORT(pyrlk)

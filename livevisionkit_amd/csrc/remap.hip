@@ -14,6 +14,7 @@
 #include "lvk_hip_internal.hpp"
 
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 
@@ -294,15 +295,18 @@ struct LensCoord
 // (block b -> XCD b mod 8) form a contiguous band of the frame: vertically adjacent strips re-read 3 of their 7
 // source rows, and with this order those re-reads hit that XCD's L2 instead of going back to HBM.
 constexpr int PXT = 4, STRIP_W = 64 * PXT, STRIP_H = 4;
-// The `_co` kernel variants are for the stabilizer's overlap mode, where the remap shares the GPU with the next frame's tracker:
-// capped at 4 waves per SIMD they leave register space on every SIMD, so the tracker's small latency-bound kernels are placed
-// at once instead of queueing behind 17-us remap workgroups -- and those kernels raise their own issue priority (s_setprio,
-// LVK_TRACKER_PRIORITY) so that they are not starved by the VALU-bound remap waves they share a SIMD with.  Measured at 4K
-// (MI355X, whole pipeline): cap 3 / 4 / 5 waves with the priority raise 7.1k / 7.6k / 7.0k frames/s (cap 3 without it: 6.9k).
+// Overlap mode: the remap shares the GPU with the next frame's tracker, whose small latency-bound kernels must be PLACED at once when
+// they are launched.  The `_co` launches therefore run a persistent grid of LVK_CO_WAVES blocks per CU (one wave per SIMD each, every
+// block walking several strips), which holds the remap at 4 waves per SIMD WITHOUT inflating its register allocation: the first
+// version capped the occupancy with amdgpu_waves_per_eu(4, 4), which the compiler implements by padding the kernel to 104 VGPRs --
+// 416 of a SIMD's 512 registers, so that the tracker's 1024-thread compaction block and its 250-VGPR RANSAC finalize block did not fit
+// next to it and waited ~11 us each for remap workgroups to retire (in-kernel timeline, scripts/timeline_free.py).  With 72 VGPRs per
+// remap wave 224 stay free on every SIMD.  The tracker kernels also raise their issue priority (s_setprio, LVK_TRACKER_PRIORITY)
+// so that they are not starved by the VALU-bound remap waves they share a SIMD with.
 #ifndef LVK_CO_WAVES
 #define LVK_CO_WAVES 4
 #endif
-#define LVK_CO_SCHEDULED __attribute__((amdgpu_waves_per_eu(LVK_CO_WAVES, LVK_CO_WAVES)))
+#define LVK_CO_SCHEDULED
 constexpr int NUM_XCD = 8;
 
 __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
@@ -326,7 +330,7 @@ __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0,
 struct PackedSink
 {
     uint8_t* __restrict__ dst; int dst_step;
-    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active) const
+    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active, int /*parity*/) const
     {
         if (!active) return;
         uint8_t* drow = dst + (long)y * dst_step;
@@ -341,9 +345,12 @@ template <bool NV12>
 struct Sink420
 {
     uint8_t* __restrict__ yp; int y_step; uint8_t* __restrict__ up; int u_step; uint8_t* __restrict__ vp; int v_step;
-    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active) const
+    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active, int parity) const
     {
-        __shared__ uint2 s_uv[256];
+        // two buffers, alternating per strip of a block: a wave that is already writing the next strip's sums cannot overwrite what a
+        // slower wave of the block still has to read for this one (the one barrier per strip orders everything else)
+        __shared__ uint2 s_uv2[2][256];
+        uint2* s_uv = s_uv2[parity & 1];
         const int t = (int)threadIdx.x;
         // (U, V) of the four pixels, two 16-bit sums per word: u0 + u1 | u2 + u3 and v0 + v1 | v2 + v3 (horizontal pairs pre-added)
         const uint32_t u01 = ((px[0] >> 8) & 0xffu) + ((px[1] >> 8) & 0xffu), u23 = ((px[2] >> 8) & 0xffu) + ((px[3] >> 8) & 0xffu);
@@ -380,20 +387,14 @@ struct Sink420
 };
 
 template <bool YUV, class Coord, class Sink>
-__device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
-                                            const Sink& sink, int dst_rows, int dst_cols,
-                                            const Coord& coord, uint32_t bg)
+__device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                                                const Sink& sink, int dst_rows, int dst_cols, const Coord& coord, uint32_t bg,
+                                                int strip, int nstrips, int strips_x, int parity)
 {
-    const int strips_x = (dst_cols + STRIP_W - 1) / STRIP_W, strips_y = (dst_rows + STRIP_H - 1) / STRIP_H;
-    const int nstrips = strips_x * strips_y;
-    const int band = (nstrips + NUM_XCD - 1) / NUM_XCD;
-    const int k = (int)(blockIdx.x / NUM_XCD);
-    const int strip = (int)(blockIdx.x % NUM_XCD) * band + k;
-    if (k >= band || strip >= nstrips) return;                       // block-uniform
     const int sy_ = strip / strips_x, sx_ = strip - sy_ * strips_x;
     const int x0 = sx_ * STRIP_W + (int)(threadIdx.x & 63) * PXT;
     const int y = sy_ * STRIP_H + (int)(threadIdx.x >> 6);
-    const bool active = x0 < dst_cols && y < dst_rows;
+    const bool active = strip < nstrips && x0 < dst_cols && y < dst_rows;
     const int npx = active ? min(PXT, dst_cols - x0) : 0;
     uint32_t px[PXT];
 #pragma unroll
@@ -421,7 +422,30 @@ __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int
             else px[p] = easu_gather<YUV>(src, src_step, sx, sy, ppx, ppy);
         }
     }
-    sink.store(x0, y, npx, px, active);
+    sink.store(x0, y, npx, px, active, parity);
+}
+
+template <bool YUV, class Coord, class Sink>
+__device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
+                                            const Sink& sink, int dst_rows, int dst_cols,
+                                            const Coord& coord, uint32_t bg)
+{
+    const int strips_x = (dst_cols + STRIP_W - 1) / STRIP_W, strips_y = (dst_rows + STRIP_H - 1) / STRIP_H;
+    const int nstrips = strips_x * strips_y;
+    const int band = (nstrips + NUM_XCD - 1) / NUM_XCD;
+    // A block walks the band of its XCD with the stride of the launch: one strip per block for a full grid, several for the persistent
+    // grid of the overlap mode (lvk_co_grid).  Everything up to the sink is block-uniform.  (Drawing the strips dynamically from a
+    // per-XCD counter instead -- L2-local atomics keyed by HW_REG_XCC_ID, one draw kept in flight -- was built and measured: bit-exact,
+    // but 143 us instead of 103: the returning atomic sits in the same in-order vmcnt queue as the strip's first tap loads.)
+    const int xcd = (int)(blockIdx.x % NUM_XCD);
+    const int kstride = (int)(gridDim.x / NUM_XCD);
+    int parity = 0;
+    for (int k = (int)(blockIdx.x / NUM_XCD); k < band; k += kstride, parity ^= 1)
+    {
+        const int strip = xcd * band + k;
+        if (strip >= nstrips) break;                                    // block-uniform (only the last band is short)
+        remap_one_strip<YUV>(src, src_step, src_rows, src_cols, sink, dst_rows, dst_cols, coord, bg, strip, nstrips, strips_x, parity);
+    }
 }
 
 template <bool YUV>
@@ -536,6 +560,7 @@ template <bool NV12>
 __global__ __launch_bounds__(256) LVK_CO_SCHEDULED
 void k_remap_homography_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, uint32_t bg)
 {
+    LVK_TL(0);
     const HomographyCoord coord{H, 0, 0};
     remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
 }
@@ -571,6 +596,17 @@ inline dim3 remap_grid(int dst_rows, int dst_cols)
 {
     const int nstrips = ((dst_cols + STRIP_W - 1) / STRIP_W) * ((dst_rows + STRIP_H - 1) / STRIP_H);
     return dim3((unsigned)(((nstrips + NUM_XCD - 1) / NUM_XCD) * NUM_XCD));
+}
+
+// Persistent grid of the overlap mode: LVK_CO_WAVES blocks (of 4 waves, one per SIMD) per CU, a multiple of the XCD count.
+inline dim3 lvk_co_grid(lvk_hip_ctx* ctx, int dst_rows, int dst_cols)
+{
+    static int cus[64] = {0};
+    int& n = cus[ctx->device & 63];
+    if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) n = 256;
+    const unsigned full = remap_grid(dst_rows, dst_cols).x;
+    const unsigned persistent = (unsigned)(((n * LVK_CO_WAVES) / NUM_XCD) * NUM_XCD);
+    return dim3(full < persistent ? full : persistent);
 }
 
 inline uint32_t pack_bg(const uint8_t bg[3]) { return (uint32_t)bg[0] | ((uint32_t)bg[1] << 8) | ((uint32_t)bg[2] << 16); }
@@ -626,12 +662,12 @@ int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream,
     LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * dst_cols);
     HomographyArgs args;
     std::memcpy(args.h, H, sizeof(args.h));
-    const dim3 block(256), grid = remap_grid(dst_rows, dst_cols);
+    const dim3 block(256), grid = remap_grid(dst_rows, dst_cols), cogrid = lvk_co_grid(ctx, dst_rows, dst_cols);
 #define LVK_LAUNCH_REMAP(K, ...)                                                                                          \
     do {                                                                                                                  \
-        if (yuv) { if (co) hipLaunchKernelGGL(K##_co<true>, grid, block, 0, stream, __VA_ARGS__);                         \
+        if (yuv) { if (co) hipLaunchKernelGGL(K##_co<true>, cogrid, block, 0, stream, __VA_ARGS__);                       \
                    else hipLaunchKernelGGL(K<true>, grid, block, 0, stream, __VA_ARGS__); }                               \
-        else { if (co) hipLaunchKernelGGL(K##_co<false>, grid, block, 0, stream, __VA_ARGS__);                            \
+        else { if (co) hipLaunchKernelGGL(K##_co<false>, cogrid, block, 0, stream, __VA_ARGS__);                          \
                else hipLaunchKernelGGL(K<false>, grid, block, 0, stream, __VA_ARGS__); }                                  \
     } while (0)
     if (lens)
@@ -664,7 +700,7 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
     if ((rc = lvk_get_lintab(ctx, mesh_cols, src_cols, false, &xtab)) != LVK_HIP_OK) return rc;
     if ((rc = lvk_get_lintab(ctx, mesh_rows, src_rows, true, &ytab)) != LVK_HIP_OK) return rc;
 
-    const dim3 block(256), grid = remap_grid(src_rows, src_cols);
+    const dim3 block(256), grid = remap_grid(src_rows, src_cols), cogrid = lvk_co_grid(ctx, src_rows, src_cols);
     if (lens)
         LVK_LAUNCH_REMAP(k_remap_mesh_lens, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols,
                          xtab, ytab, *lens, pack_bg(bg));
@@ -754,13 +790,13 @@ int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream,
 // WarpMesh::apply + I4XXIngest / NV12Ingest::to_obs in one launch: d_src packed YUV 8UC3, output planar 4:2:0 (I420: y, u, v; NV12: y, uv).
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
-                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens)
+                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens, bool co)
 {
     LVK_HIP_REQUIRE(ctx, d_src && o_y && o_u && (nv12 || o_v) && mesh && bg && mesh_rows >= 2 && mesh_cols >= 2);
     LVK_HIP_REQUIRE(ctx, rows > 0 && cols > 0 && (rows & 1) == 0 && (cols & 1) == 0 && src_step >= 3 * cols);
     LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
     const Planes420 o{(uint8_t*)o_y, oy_step, (uint8_t*)o_u, ou_step, (uint8_t*)(nv12 ? o_u : o_v), nv12 ? ou_step : ov_step};
-    const dim3 block(256), grid = remap_grid(rows, cols);
+    const dim3 block(256), grid = co ? lvk_co_grid(ctx, rows, cols) : remap_grid(rows, cols);
     if (mesh_rows == 2 && mesh_cols == 2)
     {
         const float w = (float)cols, h = (float)rows;                 // WarpMesh.cpp:194-217, as in lvk_launch_warpmesh_apply_lens
@@ -857,7 +893,7 @@ int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_s
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     return lvk_launch_warpmesh_apply_420(ctx, ctx->stream, d_src, src_step, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12,
-                                         mesh, mesh_rows, mesh_cols, bg, nullptr);
+                                         mesh, mesh_rows, mesh_cols, bg, nullptr, false);
 }
 
 int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_rows, int src_cols,
@@ -877,3 +913,5 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
 }
 
 } // extern "C"
+
+LVK_TL_EXPORT(remap)

@@ -720,7 +720,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         if (mesh && o420 && o420->y)
         {
             rc = lvk_launch_warpmesh_apply_420(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, o420->y, o420->y_step, o420->u, o420->u_step, o420->v, o420->v_step,
-                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, st->lens ? &st->lens_args : nullptr);
+                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, st->lens ? &st->lens_args : nullptr, side);
             o420->used = true;
         }
         else if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
