@@ -161,6 +161,12 @@ struct lvk_hip_stab
     int configure(const lvk_stab_settings& st);
     void tracker_restart();
     void reset_context() { tracker_restart(); smoother.restart(); }
+    // Chained path: the host's own fast_filter pass, the ageing of the features and the re-seeding of the suppression grid are not
+    // needed to launch the remap (the motion estimate, the match count and the inlier mask come from the GPU): they run after the
+    // launch, before the push returns.  post_n >= 0: pending for a frame with post_n tracked points / post_m matches.
+    int post_n = -1, post_m = 0;
+    bool post_error = false;
+    void finish_post();
     int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion);
 
     // ---- YUV420 front/back end: pool of packed frames the planes are converted into
@@ -269,6 +275,32 @@ void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameT
     grid.reset();
     initialized = false;
     solver.reset();
+    post_n = -1;
+}
+
+void lvk_hip_stab::finish_post()
+{
+    if (post_n < 0) return;
+    const int n = post_n, m_gpu = post_m;
+    post_n = -1;
+    // fast_filter(features, tracked points, matched points; keep = status): back-to-front swap-erase (Container.tpp:97-121)
+    int m = n;
+    for (int k = n - 1; k >= 0; k--)
+        if (!h_status[k])
+        {
+            m--;
+            std::swap(tracked[k], tracked[m]);
+            std::swap(h_pts[k], h_pts[m]);
+            std::swap(h_matched[k], h_matched[m]);
+        }
+    tracked.resize(m);
+    if (m != m_gpu) { post_error = true; tracked.clear(); return; }                       // reported by the next push
+    for (int i = m - 1; i >= 0; i--)                                                     // FrameTracker.cpp:183-192
+    {
+        if (h_mask[i]) { tracked[i].age++; tracked[i].x = h_matched[i].x; tracked[i].y = h_matched[i].y; }
+        else { std::swap(tracked[i], tracked.back()); tracked.pop_back(); }
+    }
+    grid.propagate(tracked);
 }
 
 int lvk_hip_stab::configure(const lvk_stab_settings& st)
@@ -415,6 +447,25 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     }
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     trace.mark(HostTrace::LK_SYNC);
+
+    if (chained)
+    {
+        // everything the remap launch needs is in the pinned result block; the list bookkeeping follows in finish_post()
+        const int m = *h_count;
+        last_matched = m;
+        if (m < 0 || m > n) return fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter returned an impossible count");
+        if ((size_t)m < (size_t)s.min_motion_samples) { tracked.clear(); return LVK_HIP_OK; }
+        motion = WarpMeshF(s.motion_height, s.motion_width);
+        std::memcpy(last_H, h_H, sizeof(last_H));
+        motion.from_homography(last_H, (float)cur_w, (float)cur_h);
+        size_t inliers = 0;
+        for (int i = 0; i < m; i++) inliers += h_mask[i] ? 1 : 0;
+        tracking_stability = (float)inliers / (float)m;                                  // ratio_of(inlier_status, 1)
+        have_motion = true;
+        post_n = n; post_m = m;
+        trace.mark(HostTrace::POST);
+        return LVK_HIP_OK;
+    }
 
     if (lens && !chained)                     // (the chained path has folded this test into the status flags on the GPU)
     {
@@ -771,8 +822,9 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     st->trace.mark(HostTrace::ENTER);
     WarpMeshF motion(st->s.motion_height, st->s.motion_width);                            // m_NullMotion
     WarpMeshF est; bool have = false;
+    if (st->post_error) { st->post_error = false; return st->fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter disagrees with the host's"); }
     int rc = st->track(in, luma, luma_step, luma_pix, luma_channel, est, have);
-    if (rc != LVK_HIP_OK) return rc;
+    if (rc != LVK_HIP_OK) { st->finish_post(); return rc; }
     if (have) motion = est;
 
     // quality assurance (StabilizationFilter.cpp:101-115)
@@ -786,12 +838,13 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
 
     enqueue();
     WarpMeshF correction = st->smoother.next(motion);
-    if (st->queue.size() != st->queue_capacity) return LVK_HIP_OK;                        // !ready(): output.release()
+    if (st->queue.size() != st->queue_capacity) { st->finish_post(); return LVK_HIP_OK; }   // !ready(): output.release()
     if (st->s.crop_to_stable_region) correction += st->smoother.scene_crop();
     st->last_correction = correction;
     st->trace.mark(HostTrace::SMOOTH);
     const int erc = emit(&correction);
     st->trace.mark(HostTrace::REMAP_LAUNCH);
+    st->finish_post();
     return erc;
 }
 
