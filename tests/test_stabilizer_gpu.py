@@ -304,6 +304,37 @@ def test_stabilizer_yuv420_in_out_bit_exact(ctx, oracle, clip, nv12, overlap):
     ost.close(); gst.close()
 
 
+@pytest.mark.parametrize("size,nv12", [((1080, 1920), False), ((2160, 3840), False), ((1080, 1920), True)])
+def test_overlap_yuv420_full_size_persistent_grid_bit_exact(ctx, oracle, size, nv12):
+    """Overlap mode at 1080p / 4K: the fused remap + 4:2:0 egress runs on the persistent grid (several strips per block, double-buffered
+    chroma exchange), free-running next to the tracker; every emitted plane bit-identical to the oracle chain."""
+    import torch
+    import livevisionkit_amd as lvk
+    rows, cols = size
+    n = 7
+    small, _ = synth.make_clip(rows // 4, cols // 4, n, seed=rows + 1, jitter=1.0)
+    frames = np.ascontiguousarray(small.repeat(4, axis=1).repeat(4, axis=2))
+    s = oracle_lib.preset("homography", predictive_samples=2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    gst.set_overlap(True)
+    wants, gots = [], []
+    outs = []
+    for i, f in enumerate(frames):
+        planes = oracle.egress_yuv420(f, nv12=nv12)
+        want, _ = ost.push(oracle.ingest_yuv420(*planes), ts=i, nthreads=32)
+        got, _ = gst.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)   # no sync between pushes
+        assert (want is None) == (got is None), i
+        if want is not None:
+            wants.append(oracle.egress_yuv420(want, nv12=nv12)); gots.append(got)
+    ctx.sync()
+    assert len(wants) == n - 2
+    for i, (w, g) in enumerate(zip(wants, gots)):
+        for a, b in zip(g, w):
+            assert np.array_equal(a.cpu().numpy(), b), (size, i)
+    ost.close(); gst.close()
+
+
 @pytest.mark.parametrize("fmt", [0, 2])
 def test_stabilizer_bgr_rgb_frames_bit_exact(ctx, oracle, clip, fmt):
     """VideoFrame formats BGR (0) / RGB (2): tracking luma = cvtColor(..2GRAY), remap = the RGB EASU program."""

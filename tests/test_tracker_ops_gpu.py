@@ -134,6 +134,21 @@ def test_pyrlk_other_geometry(ctx, oracle):
         assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)), (rows, cols, win)
 
 
+def test_pyrlk_large_windows_and_large_flow(ctx, oracle):
+    """Windows up to the 31 x 31 limit (the per-level LDS of a block then exceeds the default dynamic-LDS cap and the window staging
+    takes its generic chunk loops), deep pyramids, and flows beyond the staged search margin (the next-frame window is re-centred)."""
+    for (rows, cols, win, lv, shift) in [(540, 960, (31, 31), 4, (1.3, -0.7)), (270, 480, (21, 25), 3, (0.4, 0.9)),
+                                          (270, 480, (11, 11), 3, (14.0, -11.0)), (400, 400, (31, 17), 5, (-9.5, 6.25))]:
+        prev = _smooth_scene(rows, cols, 0, 0)
+        nxt = _smooth_scene(rows, cols, shift[0], shift[1])
+        rng = np.random.default_rng(rows + win[0])
+        pts = np.c_[rng.uniform(-3, cols + 3, 200), rng.uniform(-3, rows + 3, 200)].astype(np.float32)
+        want_p, want_s = oracle.pyrlk(prev, nxt, pts, win=win, max_level=lv)
+        got_p, got_s = ctx.pyrlk(_gpu(prev), _gpu(nxt), pts, win=win, max_level=lv)
+        assert np.array_equal(got_s, want_s), (rows, cols, win)
+        assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)), (rows, cols, win)
+
+
 @pytest.mark.parametrize("channel", [-1, -2])
 @pytest.mark.parametrize("src_size,dst_size", [((2160, 3840), (270, 480)), ((1080, 1920), (270, 480)), ((720, 1280), (270, 480)),
                                                  ((270, 480), (270, 480)), ((90, 130), (45, 65)), ((61, 97), (20, 31))])
