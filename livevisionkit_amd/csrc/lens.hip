@@ -107,6 +107,7 @@ struct LensModelD { double d[17]; };
 __global__ void k_lens_undistort(LensModelD M, double sx, double sy, const float2* __restrict__ a, int na,
                                  const float2* __restrict__ b, int nb, float2* __restrict__ out)
 {
+    LVK_TRACKER_PRIORITY();                        // part of the tracker chain in the fused lens mode
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= na + nb) return;
     const float2 p = i < na ? a[i] : b[i - na];
