@@ -23,6 +23,7 @@
 #include <iostream>
 #include <mutex>
 #include <thread>
+#include <initializer_list>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -131,6 +132,15 @@ struct VideoFrame
     }
     const std::shared_ptr<hip::Context>& context() const { return m_ctx; }
     std::shared_ptr<void> buffer() const { return m_buf; }
+    VideoFrame clone() const                               // cv::UMat::clone: a device copy with the same metadata
+    {
+        VideoFrame c;
+        if (empty()) return c;
+        c.create(size(), CV_8UC3, m_ctx);
+        m_ctx->check(lvk_hip_upscale(m_ctx->get(), m_buf.get(), (int)step, rows, cols, c.m_buf.get(), (int)c.step, rows, cols, 1), "VideoFrame::clone");
+        c.timestamp = timestamp; c.format = format;
+        return c;
+    }
 
 private:
     std::shared_ptr<void> m_buf;
@@ -527,6 +537,59 @@ private:
     }
     void sync_gpu(bool trigger) override { if (trigger && m_Ctx) m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); }
     std::shared_ptr<hip::Context> m_Ctx;
+};
+
+// ---------------------------------------------------------------------------------------------- Filters/CompositeFilter.hpp
+struct CompositeFilterSettings                       // Filters/CompositeFilter.hpp:28-34
+{
+    std::vector<std::shared_ptr<lvk::VideoFilter>> filter_chain;
+    bool save_outputs = false;
+};
+
+// A chain of filters run back to back on one frame (CompositeFilter.cpp:28-190): a disabled filter is skipped, an empty intermediate
+// frame (a filter that is still filling its delay) ends the pass with an empty output, `save_outputs` keeps every stage's result.
+class CompositeFilter final : public VideoFilter, public Configurable<CompositeFilterSettings>
+{
+public:
+    explicit CompositeFilter(const CompositeFilterSettings& settings = {}) : VideoFilter("Composite Filter") { configure(settings); }
+    CompositeFilter(const std::initializer_list<std::shared_ptr<lvk::VideoFilter>>& filter_chain, const CompositeFilterSettings& settings = {})
+        : VideoFilter("Composite Filter")
+    {
+        CompositeFilterSettings chained; chained.filter_chain = filter_chain; chained.save_outputs = settings.save_outputs;
+        configure(chained);
+    }
+    void configure(const CompositeFilterSettings& settings) override
+    {
+        m_Settings = settings;
+        m_FilterOutputs.resize(settings.filter_chain.size());
+        m_FilterRunState.assign(settings.filter_chain.size(), true);
+    }
+    const std::vector<std::shared_ptr<lvk::VideoFilter>>& filters() const { return m_Settings.filter_chain; }
+    std::shared_ptr<lvk::VideoFilter> filters(const size_t index) { LVK_HIP_ASSERT(index < m_Settings.filter_chain.size()); return m_Settings.filter_chain[index]; }
+    const std::vector<Frame>& outputs() const { return m_FilterOutputs; }
+    const VideoFrame& outputs(const size_t index) { LVK_HIP_ASSERT(index < m_FilterOutputs.size()); return m_FilterOutputs[index]; }
+    bool is_filter_enabled(const size_t index) { LVK_HIP_ASSERT(index < m_FilterRunState.size()); return m_FilterRunState[index]; }
+    void disable_filter(const size_t index) { LVK_HIP_ASSERT(index < m_FilterRunState.size()); m_FilterRunState[index] = false; }
+    void enable_filter(const size_t index) { LVK_HIP_ASSERT(index < m_FilterRunState.size()); m_FilterRunState[index] = true; }
+    void enable_all_filters() { m_FilterRunState.assign(m_FilterRunState.size(), true); }
+    size_t filter_count() const { return m_Settings.filter_chain.size(); }
+
+private:
+    void filter(VideoFrame&& input, VideoFrame& output) override
+    {
+        LVK_HIP_ASSERT(!input.empty());
+        VideoFrame current = std::move(input);
+        for (size_t i = 0; i < m_Settings.filter_chain.size(); i++)
+        {
+            if (!m_FilterRunState[i]) continue;
+            if (current.empty()) break;                                    // a stage upstream has nothing to hand on yet
+            m_Settings.filter_chain[i]->apply(std::move(current), m_FilterOutputs[i]);
+            current = m_Settings.save_outputs ? m_FilterOutputs[i].clone() : std::move(m_FilterOutputs[i]);
+        }
+        output = std::move(current);
+    }
+    std::vector<bool> m_FilterRunState;
+    std::vector<Frame> m_FilterOutputs;
 };
 
 // north-star aliases (BASELINE.json names from another LVK snapshot; SURVEY.md name mapping)

@@ -152,6 +152,42 @@ int main()
         if (same.cols != 160 || same.rows != 90) { std::printf("scaling: identity size failed\n"); return 1; }
         std::printf("scaling ok: %s %.3f ms\n", scaler.alias().c_str(), scaler.timings().average().milliseconds());
     }
+    {
+        // CompositeFilter (Filters/CompositeFilter.cpp:28-190; the CLI builds one from its filter list, VideoProcessor.cpp): stabilizer
+        // (delay 2) followed by a 2x ScalingFilter; outputs appear once the stabilizer's delay is filled, carry the delayed timestamps and
+        // the scaled size; a disabled stage is skipped; save_outputs keeps the intermediate frames
+        lvk::StabilizationFilterSettings st;
+        st.predictive_samples = 2;
+        auto stab = std::make_shared<lvk::StabilizationFilter>(st);
+        auto scale = std::make_shared<lvk::ScalingFilter>(cv::Size(1280, 720), 0.5f);
+        lvk::CompositeFilterSettings cs; cs.save_outputs = true;
+        lvk::CompositeFilter chain({stab, scale}, cs);
+        if (chain.filter_count() != 2 || chain.filters(1) != scale) { std::printf("composite: bad chain\n"); return 1; }
+        std::vector<uint8_t> img((size_t)360 * 640 * 3);
+        int got = 0;
+        for (int i = 0; i < 8; i++)
+        {
+            for (int y = 0; y < 360; y++)
+                for (int x = 0; x < 640; x++)
+                {
+                    uint8_t* p = &img[((size_t)y * 640 + x) * 3];
+                    const int xs = x + (i % 3), ys = y + (i % 2);
+                    p[0] = (uint8_t)((((xs / 16) + (ys / 16)) % 2) ? 200 : 40 + (xs * 7 + ys * 13) % 23); p[1] = 128; p[2] = 128;
+                }
+            if (i == 6) chain.disable_filter(1);
+            lvk::Frame frame;
+            frame.upload(img.data(), 360, 640, lvk::VideoFrame::YUV, 500 + i);
+            chain.apply(std::move(frame), frame);
+            if (i < 2) { if (!frame.empty()) { std::printf("composite: output before the delay is filled\n"); return 1; } continue; }
+            const int want_cols = i >= 6 ? 640 : 1280;
+            if (frame.empty() || frame.cols != want_cols || frame.timestamp != (uint64_t)(500 + i - 2)) { std::printf("composite: bad frame %d\n", i); return 1; }
+            if (i < 6 && (chain.outputs(0).cols != 640 || chain.outputs(1).cols != 1280)) { std::printf("composite: outputs not saved\n"); return 1; }
+            got++;
+        }
+        chain.enable_all_filters();
+        if (!chain.is_filter_enabled(1)) { std::printf("composite: enable_all_filters\n"); return 1; }
+        std::printf("composite ok: %d frames\n", got);
+    }
     lvk::VSFilterLike vs;
     vs.configure(false, true, 0.05f, 0.05f, 5, true, false, true);
     const int rows = 360, cols = 640;

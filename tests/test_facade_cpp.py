@@ -32,3 +32,4 @@ def test_plugin_call_sites_run_on_gpu(tmp_path):
     out = subprocess.check_output([exe], timeout=300).decode()
     assert "emitted 7 frames" in out
     assert "scaling ok: Scaling Filter" in out
+    assert "composite ok: 6 frames" in out
