@@ -305,8 +305,27 @@ def main():
             torch.cuda.synchronize()
             dtp = time.perf_counter() - tp
             mb = sum(p.numel() for p in planes[0]) / 1e6
+            # per-frame latency with the transfers inside (BASELINE's p99 ms/frame for host-resident frames): upload the planes, push,
+            # download the emitted planes, synchronise -- one frame at a time, nothing prefetched
+            lat_pcie = []
+            for i in range(step_no[0], step_no[0] + 200):
+                tl = time.perf_counter()
+                upload(i)
+                work_stream.wait_event(ev_up[i % K]); out_stream.wait_event(ev_up[i % K])
+                res, _ = filt.apply_yuv420_prepared(dev_in_args[i % K], i, outs_args[i & 3])
+                if res is not None:
+                    ev_out[i & 3].record(out_stream)
+                    down.wait_event(ev_out[i & 3])
+                    with torch.cuda.stream(down):
+                        for h, d in zip(host_out[i & 3], outs[i & 3]):
+                            h.copy_(d, non_blocking=True)
+                torch.cuda.synchronize()
+                lat_pcie.append((time.perf_counter() - tl) * 1e3)
+            step_no[0] += 200
             pcie = {"value": nsteps / dtp, "unit": "frames/s", "host_to_device_MB_per_frame": mb, "device_to_host_MB_per_frame": mb,
                     "GBps_each_way": nsteps / dtp * mb / 1e3,
+                    "latency_ms": {"p50": float(np.percentile(lat_pcie, 50)), "p99": float(np.percentile(lat_pcie, 99)),
+                                   "note": "upload + push + download + synchronise, one frame at a time"},
                     "note": "same stream, I420 planes in pinned host memory; uploads prefetched one frame ahead on their own stream, downloads on a third "
                             "stream behind an event on the filter's output stream; not the headline value (inputs of `value` are resident in HBM)"}
         except Exception as e:          # the extra pass must never break the contract line
