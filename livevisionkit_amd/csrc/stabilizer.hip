@@ -8,7 +8,7 @@
 // Per frame, on the context's stream:
 //   luma (Y / BGR / RGB -> gray) + INTER_AREA downscale -> pyramid (pyrDown x3, Scharr x4)   [imgproc.hip]
 //   FAST-9/16 + NMS per due region, ordered compaction                                  [fast.hip]      -> host: suppression grid
-//   pyramidal LK, one wavefront per feature (points read from pinned host memory)       [pyrlk.hip]
+//   pyramidal LK, one block per feature, one wave per level (points read from pinned host memory) [pyrlk.hip]
 //   fast_filter in the reference's swap-erase order                                     [motion.hip k_match_compact]
 //   RANSAC hypotheses + local optimisation, pair count from the device                  [motion.hip]    -> ONE sync; host: ageing, propagate, QA, smoothing
 //   (vector-field preset / lens modes: sync after LK, point filter + mesh solve on the host)
