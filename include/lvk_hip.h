@@ -88,6 +88,11 @@ int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_r
  * with writes; the defined result is that of distinct buffers, and aliasing is rejected.  Border pixels are copied. */
 int lvk_hip_sharpen(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step, float sharpness);
 
+/* native_recip(x) of FSR.cl as the EASU / RCAS kernels of this library evaluate it (v_rcp_f32, what the reference's OpenCL source
+ * compiles to for gfx950), elementwise over n binary32 values on the device.  OpenCL leaves native_recip implementation-defined:
+ * this entry point lets a host (and the parity tests' CPU model of the kernels) read the device's definition. */
+int lvk_hip_native_rcp(lvk_hip_ctx* ctx, const float* d_in, float* d_out, size_t n);
+
 /* Lens correction: the offset map LCFilter::prepare_undistort_maps builds
  * (Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-171) for a camera profile in the plugin's format
  * (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153); LCFilter::filter == lvk_hip_remap_map with it. */

@@ -241,6 +241,14 @@ class Context:
                                              float(sharpness)))
         return out
 
+    def native_rcp(self, x):
+        """native_recip of FSR.cl as this device defines it (v_rcp_f32), elementwise; x: torch float32 on the GPU."""
+        import torch
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        self._check(self.lib.lvk_hip_native_rcp(self.handle, x.data_ptr(), out.data_ptr(), x.numel()))
+        return out
+
     def lens_map(self, params, rows, cols):
         """Device offset map of LCFilter for camera params (fx, fy, cx, cy, k1, k2, p1, p2, k3): (torch view [rows, cols, 2], view_xywh)."""
         import torch

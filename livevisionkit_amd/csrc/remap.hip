@@ -5,9 +5,10 @@
 // easu_remap / easu_remap_homography (LiveVisionKit/Functions/OpenCL/Sources/FSR.cl:362-452) including
 // WarpMesh::apply's map construction (LiveVisionKit/Math/WarpMesh.cpp:183-223).
 //
-// Arithmetic contract (must stay in lock-step with the specification the tests check against):
-// binary32 IEEE ops, no implicit contraction (the file is compiled with -ffp-contract=off), fused
-// multiply-adds exactly where written as fma(), correctly rounded division.
+// Arithmetic contract (must stay in lock-step with the specification the tests check against): the binary32 operation
+// sequence the reference's OpenCL source compiles to for this device (the GPU tests check bit-identical
+// output): no implicit contraction (the file is compiled with -ffp-contract=off), fused multiply-adds exactly where clang's
+// FP_CONTRACT ON forms them (written as fma()), and native_recip / `1.0f / x` = the device reciprocal v_rcp_f32.
 //
 // Work decomposition: see remap_strip() -- 256 x 4 output strips, 4 pixels per thread, taps gathered with unaligned
 // dwordx2/x4 loads, XCD-aware strip order.
@@ -29,6 +30,14 @@ __device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ float rcp_lo(float a) { return __uint_as_float(0x7ef07ebbu - __float_as_uint(a)); }   // FSR.cl:65
 __device__ __forceinline__ float rsq_lo(float a) { return __uint_as_float(0x5f347d74u - (__float_as_uint(a) >> 1)); } // FSR.cl:60
 __device__ __forceinline__ float sat_(float x) { return max_(0.0f, min_(1.0f, x)); }                             // FSR.cl:79
+// native_recip(x) and OpenCL's `1.0f / x` as the reference's kernels compute them on gfx950: v_frexp_mant, v_rcp_f32, v_frexp_exp,
+// v_ldexp (denormal-safe).  For a normal argument with a normal result the plain instruction gives the same bits (all 2^32 inputs
+// checked, scripts/rcp_probe.hip): rcp_native() is used where the argument's range is known, rcp_cl() where the caller controls it.
+__device__ __forceinline__ float rcp_native(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rcp_cl(float x)
+{
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(x)), -__builtin_amdgcn_frexp_expf(x));
+}
 
 struct F3 { float x, y, z; };
 
@@ -121,7 +130,7 @@ __device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, flo
     accumulate(dirx, diry, len, ppx * ppy, t[TG].w, t[TJ].w, t[TK].w, t[TL].w, t[TO].w);
 
     // FSR.cl:252-258
-    float dirR = fma_(dirx, dirx, diry * diry);
+    float dirR = dirx * dirx + diry * diry;          // two statements in FSR.cl (dir2 = dir * dir; dir2.x + dir2.y): not contracted
     const bool zro = dirR < (1.0f / 32768.0f);
     dirR = rsq_lo(dirR);
     dirR = zro ? 1.0f : dirR;
@@ -162,7 +171,8 @@ __device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, flo
 #undef LVK_TAP
 
     // FSR.cl:316-317
-    const float rW = 1.0f / aW;
+    // aW: the centre taps alone contribute > 0.5 and no tap reaches 2, so 1/aW and aW are normal numbers
+    const float rW = rcp_native(aW);
     const float px = min_(ma4.x, max_(mi4.x, aC.x * rW));
     const float py = min_(ma4.y, max_(mi4.y, aC.y * rW));
     const float pz = min_(ma4.z, max_(mi4.z, aC.z * rW));
@@ -201,9 +211,10 @@ struct HomographyCoord      // FSR.cl:422-430
     __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
     {
         const float fx = (float)x, fy = (float)y;
-        const float dz = 1.0f / fma_(H.h[6], fx, fma_(H.h[7], fy, H.h[8]));
-        const float ox = fma_(H.h[0], fx, fma_(H.h[1], fy, H.h[2])) * dz - fx;
-        const float oy = fma_(H.h[3], fx, fma_(H.h[4], fy, H.h[5])) * dz - fy;
+        // `r.x * fx + r.y * fy + r.z` = ((r.x * fx) + (r.y * fy)) + r.z: clang fuses the first product only
+        const float dz = rcp_cl(fma_(H.h[6], fx, H.h[7] * fy) + H.h[8]);
+        const float ox = (fma_(H.h[0], fx, H.h[1] * fy) + H.h[2]) * dz - fx;
+        const float oy = (fma_(H.h[3], fx, H.h[4] * fy) + H.h[5]) * dz - fy;
         subx = (float)(x + off_x) + ox;
         suby = (float)(y + off_y) + oy;
     }

@@ -5,7 +5,7 @@
 // (LiveVisionKit/Filters/ScalingFilter.cpp:52-59).
 //
 // Arithmetic contract (must stay in lock-step with the specification the tests check against): binary32 IEEE ops, no implicit contraction, fused
-// multiply-adds exactly where written as fma(), native_recip = the correctly rounded 1.0f / x, min/max with fmin/fmax semantics
+// multiply-adds exactly where written as fma(), native_recip = v_rcp_f32 as in the reference's compiled kernel (see k_rcas), min/max with fmin/fmax semantics
 // (a NaN operand loses), truncating byte conversion.  Out of place; border pixels are copied.
 //
 // Shape: 6 B of traffic and ~90 VALU instructions per pixel put this kernel near the point where the HBM and VALU rooflines
@@ -113,8 +113,10 @@ void k_rcas(const uint8_t* __restrict__ src, int src_step, int rows, int cols, u
     __shared__ float s_rmin[256], s_rmax[256];
     {
         const float v = (float)threadIdx.x * 0.00392156862f;
-        s_rmin[threadIdx.x] = 1.0f / (4.0f * v);                    // native_recip(4 * mx4)
-        s_rmax[threadIdx.x] = 1.0f / fma_(4.0f, v, -4.0f);           // native_recip(4 * mn4 + peakC.y)
+        // What the reference's kernel computes when it is compiled for this device: LLVM folds `-hitMin` into
+        // min * (-1.0f / (4 mx4)), a correctly rounded divide; the hitMax reciprocal stays the device's v_rcp_f32.
+        s_rmin[threadIdx.x] = 1.0f / (4.0f * v);                                   // native_recip(4 * mx4), negation folded in
+        s_rmax[threadIdx.x] = __builtin_amdgcn_rcpf(fma_(4.0f, v, -4.0f));         // native_recip(4 * mn4 + peakC.y)
     }
     __syncthreads();
 
@@ -200,4 +202,24 @@ extern "C" int lvk_hip_sharpen(lvk_hip_ctx* ctx, const void* d_src, int src_step
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     return lvk_launch_sharpen(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, sharpness);
+}
+
+// native_recip of FSR.cl on this device (lvk_hip.h): what rcp_native() / the table of k_rcas evaluate.
+namespace {
+__global__ __launch_bounds__(256) void k_native_rcp(const float* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = __builtin_amdgcn_rcpf(in[i]);
+}
+}
+
+extern "C" int lvk_hip_native_rcp(lvk_hip_ctx* ctx, const float* d_in, float* d_out, size_t n)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, d_in != nullptr && d_out != nullptr);
+    if (n == 0) return LVK_HIP_OK;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_native_rcp, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ctx->stream, d_in, d_out, n);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
 }

@@ -3,12 +3,17 @@
 // easu_remap / easu_remap_homography and helpers), launched by Functions/Image.cpp:28-151 from
 // Math/WarpMesh.cpp:183-223.  Scalar, one output pixel at a time, in the reference's own order.
 //
-// Arithmetic definition (the reference is OpenCL C, where a*b+c may or may not be contracted and
-// native_recip is implementation defined, so the oracle fixes both):
-//   * every multiply-add that FSR.cl writes as `x * y + z` / `z + x * y` / `acc += x * y` is ONE fused
-//     fmaf (what an OpenCL compiler with FP_CONTRACT ON emits for a GPU); a sum of two products
-//     `a*b + c*d` is fmaf(a, b, c*d).  Everything else is a separately rounded binary32 op.
-//   * native_recip(x) and `1.0f / x` are the correctly rounded 1.0f / x.
+// Arithmetic definition.  The reference is OpenCL C, compiled at run time for the device it runs on; the oracle follows what the
+// reference's own source compiles to for gfx950 with the image's ROCm clang (oracle/_ref/fsr_*.hsaco, `make -C oracle ref`; the
+// GPU tests check oracle == that code object == the HIP kernels bit for bit, tests/test_ref_pin_gpu.py):
+//   * contraction is clang's FP_CONTRACT ON: a multiply feeding an add INSIDE ONE EXPRESSION is one fused fmaf (`x * y + z`,
+//     `z + x * y`, `acc += x * y`); a sum of two products `a*b + c*d` is fmaf(a, b, c*d); `a*b + c*d + e` is fmaf(a, b, c*d) + e.
+//     Everything else is a separately rounded binary32 op.
+//   * native_recip(x) and `1.0f / x` (OpenCL's 2.5 ulp divide) both compile to v_frexp_mant / v_rcp_f32 / v_ldexp: the device's
+//     reciprocal, within 1 ulp of 1/x (exact for 89 % of the mantissas, scripts/rcp_probe.hip), sign-symmetric and exponent
+//     independent.  native_rcp() below models it with the table of v_rcp_f32 over the 2^23 mantissas, which the GPU tests read from
+//     the device and install with lvko_set_device_rcp_table.  WITHOUT a table (the CPU-only tests, fixtures under tests/golden/)
+//     it is the correctly rounded 1.0f / x: at most 1 LSB away in about 2 of 10^5 output bytes.
 //   * convert_int2_rtz saturates (NaN -> 0); convert_uchar3 truncates (values are within [0,255]).
 //   * min/max are fminf/fmaxf.
 #include "lvk_oracle.h"
@@ -23,6 +28,17 @@ namespace {
 
 inline float as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline uint32_t as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// The device reciprocal (see the header comment): g_rcp_tab[m] = v_rcp_f32(1.m) in (0.5, 1] for the 23 mantissa bits m.
+std::vector<float> g_rcp_tab;
+inline float native_rcp(float x)
+{
+    if (g_rcp_tab.empty() || x == 0.0f || std::isinf(x) || std::isnan(x)) return 1.0f / x;
+    int e;
+    const float m = frexpf(x, &e);                                   // |m| in [0.5, 1), x = m * 2^e  (v_frexp_mant / v_frexp_exp)
+    const float r = g_rcp_tab[as_uint(m) & 0x7fffffu];               // rcp(1.mant); rcp(|m|) = 2 * r
+    return copysignf(ldexpf(r, 1 - e), x);                           // v_ldexp_f32
+}
 
 // FSR.cl:60,65
 inline float APrxLoRsqF1(float a) { return as_float(0x5f347d74u - (as_uint(a) >> 1)); }
@@ -114,7 +130,8 @@ inline void easu(const uint8_t* src, int step, int sx, int sy, float ppx, float 
     easu_accumulate(dirx, diry, len, ppx * ppy, gL, jL, kL, lL, oL);   // v
 
     // FSR.cl:252-258
-    float dirR = fmaf(dirx, dirx, diry * diry);
+    // FSR.cl:252-253 are TWO statements (dir2 = dir * dir; dirR = dir2.x + dir2.y): clang contracts within an expression only
+    float dirR = dirx * dirx + diry * diry;
     const bool zro = dirR < (1.0f / 32768.0f);
     dirR = APrxLoRsqF1(dirR);
     dirR = zro ? 1.0f : dirR;
@@ -152,7 +169,7 @@ inline void easu(const uint8_t* src, int step, int sx, int sy, float ppx, float 
     easu_tap(aC, aW,  1.0f - ppx,  2.0f - ppy, dirx, diry, len2x, len2y, lob, clp, o);
 
     // FSR.cl:316-317
-    const float rW = 1.0f / aW;
+    const float rW = native_rcp(aW);
     const float px = fminf(ma4.x, fmaxf(mi4.x, aC.x * rW));
     const float py = fminf(ma4.y, fmaxf(mi4.y, aC.y * rW));
     const float pz = fminf(ma4.z, fmaxf(mi4.z, aC.z * rW));
@@ -291,9 +308,10 @@ static int remap_homography_impl(const uint8_t* src, int src_step, int src_rows,
             {
                 // FSR.cl:422-427
                 const float fx = (float)x, fy = (float)y;
-                const float dz = 1.0f / fmaf(H[6], fx, fmaf(H[7], fy, H[8]));
-                const float ox = fmaf(H[0], fx, fmaf(H[1], fy, H[2])) * dz - fx;
-                const float oy = fmaf(H[3], fx, fmaf(H[4], fy, H[5])) * dz - fy;
+                // `r.x * fx + r.y * fy + r.z` parses as ((r.x * fx) + (r.y * fy)) + r.z: one fused multiply-add, then a plain add
+                const float dz = native_rcp(fmaf(H[6], fx, H[7] * fy) + H[8]);
+                const float ox = (fmaf(H[0], fx, H[1] * fy) + H[2]) * dz - fx;
+                const float oy = (fmaf(H[3], fx, H[4] * fy) + H[5]) * dz - fy;
                 // FSR.cl:430
                 const float subx = (float)(x + off_x) + ox;
                 const float suby = (float)(y + off_y) + oy;
@@ -520,8 +538,11 @@ int lvko_upscale(const uint8_t* src, int src_step, int src_rows, int src_cols,
 }
 
 // lvk::sharpen -> kernel rcas (Functions/Image.cpp:206-233, FSR.cl:460-535).  `sharpness` is the user value in [0, 1]; the kernel
-// receives exp2(-2 (1 - sharpness)) (Image.cpp:227).  Arithmetic definition, as for EASU: `x * y + z` is one fmaf, native_recip is
-// the correctly rounded 1.0f / x, min/max are fminf/fmaxf (a NaN operand loses: 0 * inf appears when a ring is all 0 or all 1),
+// receives exp2(-2 (1 - sharpness)) (Image.cpp:227).  Arithmetic definition, as for EASU: `x * y + z` is one fmaf, min/max are
+// fminf/fmaxf (a NaN operand loses: 0 * inf appears when a ring is all 0 or all 1).  The two limiter reciprocals differ in the
+// compiled reference: LLVM folds the negation of `-hitMin` into the reciprocal, `min * (-1.0f / (4 mx))`, and that division has lost
+// its 2.5 ulp licence -> a correctly rounded IEEE divide (v_div_scale / v_div_fmas / v_div_fixup in oracle/_ref); the hitMax
+// reciprocal stays the device reciprocal native_rcp().
 // convert_uchar3 truncates.  Out of place: the reference's ScalingFilter runs it in place (ScalingFilter.cpp:57), which races
 // reads of neighbours against writes; the defined result is the one of distinct src and dst.  Border pixels are copied; the
 // reference's `coord <= cols || coord <= rows` guard (FSR.cl:478) lets the padding threads of a work-group write past the row
@@ -553,7 +574,7 @@ int lvko_sharpen(const uint8_t* src, int src_step, int rows, int cols, uint8_t* 
                 {
                     const float mn4 = min4f(bc[c], dc[c], fc[c], hc[c]), mx4 = max4f(bc[c], dc[c], fc[c], hc[c]);
                     const float hitMin = fminf(mn4, ec[c]) * (1.0f / (4.0f * mx4));
-                    const float hitMax = (1.0f - fmaxf(mx4, ec[c])) * (1.0f / fmaf(4.0f, mn4, -4.0f));
+                    const float hitMax = (1.0f - fmaxf(mx4, ec[c])) * native_rcp(fmaf(4.0f, mn4, -4.0f));
                     lobe_c[c] = fmaxf(-hitMin, hitMax);
                 }
                 // FSR.cl renames .z -> R, .y -> G, .x -> B and takes max(lobeR, max(lobeG, lobeB))
@@ -567,6 +588,15 @@ int lvko_sharpen(const uint8_t* src, int src_step, int rows, int cols, uint8_t* 
             }
         }
     });
+    return 0;
+}
+
+// Installs (n == 1 << 23) or removes (tab == nullptr) the device reciprocal table: tab[m] = v_rcp_f32(as_float(0x3f800000 | m)).
+int lvko_set_device_rcp_table(const float* tab, int n)
+{
+    if (tab == nullptr) { g_rcp_tab.clear(); return 0; }
+    if (n != (1 << 23)) return -1;
+    g_rcp_tab.assign(tab, tab + n);
     return 0;
 }
 

@@ -204,6 +204,10 @@ int lvko_upscale(const uint8_t* src, int src_step, int src_rows, int src_cols,
                  uint8_t* dst, int dst_step, int dst_rows, int dst_cols, int yuv, int nthreads);
 int lvko_sharpen(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step, float sharpness, int nthreads);
 
+/* native_recip / `1.0f / x` of FSR.cl = the DEVICE's reciprocal (v_rcp_f32 in oracle/_ref).  tab[m] = v_rcp_f32(as_float(0x3f800000 | m))
+ * for the 2^23 mantissas m, read from the GPU by the tests; nullptr restores the default (the correctly rounded 1.0f / x).  See easu.cpp. */
+int lvko_set_device_rcp_table(const float* tab, int n);
+
 /* Debug overlays (oracle/draw.cpp; reference Functions/Drawing.tpp:53-93,146-196, Functions/OpenCL/Sources/Drawing.cl:22-39,75-105,
  * Filters/StabilizationFilter.cpp:163-188): drawn into the newest queued frame. */
 int lvko_draw_grid(uint8_t* dst, int dst_step, int rows, int cols, int grid_w, int grid_h, const uint8_t colour[3], int thickness);

@@ -68,7 +68,7 @@ def easu_points(src, sx, sy, ppx, ppy, yuv):
     acc(omx * ppy, L['f'], L['i'], L['j'], L['k'], L['n'])
     acc(ppx * ppy, L['g'], L['j'], L['k'], L['l'], L['o'])
 
-    dirR = _fma(dirx, dirx, diry * diry)
+    dirR = dirx * dirx + diry * diry          # two statements in FSR.cl:252-253: not contracted
     zro = dirR < f32(1.0 / 32768.0)
     dirR = _rsq_lo(dirR)
     dirR = np.where(zro, one, dirR)
@@ -113,9 +113,10 @@ def remap_homography(src, H, bg, yuv):
     H = np.asarray(H, f32).reshape(9)
     yy, xx = np.mgrid[0:rows, 0:cols]
     fx = xx.astype(f32); fy = yy.astype(f32)
-    dz = f32(1) / _fma(H[6], fx, _fma(H[7], fy, H[8]))
-    ox = _fma(H[0], fx, _fma(H[1], fy, H[2])) * dz - fx
-    oy = _fma(H[3], fx, _fma(H[4], fy, H[5])) * dz - fy
+    # FSR.cl:423-427 as clang contracts it: ((r.x * fx) + (r.y * fy)) + r.z = fma(r.x, fx, r.y * fy) + r.z
+    dz = f32(1) / (_fma(H[6], fx, H[7] * fy) + H[8])
+    ox = (_fma(H[0], fx, H[1] * fy) + H[2]) * dz - fx
+    oy = (_fma(H[3], fx, H[4] * fy) + H[5]) * dz - fy
     subx = fx + ox; suby = fy + oy
     return _remap_tail(src, subx, suby, bg, yuv)
 

@@ -57,6 +57,17 @@ class Oracle:
         L.lvko_pyramid_levels.restype = _i
         L.lvko_pyramid_levels.argtypes = [_i, _i, _i, _i, _i, _i32p, _i32p]
 
+    def set_device_rcp(self, on=True):
+        """native_recip of FSR.cl: the gfx950 table (default) or the correctly rounded reciprocal."""
+        fn = self.lib.lvko_set_device_rcp_table
+        fn.restype = _c.c_int
+        fn.argtypes = [_f32p, _c.c_int]
+        if on:
+            tab = np.ascontiguousarray(device_rcp_table())
+            assert fn(_p(tab, _f32p), len(tab)) == 0
+        else:
+            assert fn(None, 0) == 0
+
     # ---- remap -----------------------------------------------------------------------------------
     def remap_homography(self, src, H, bg=(255, 0, 255), yuv=True, dst_size=None, offset=(0, 0), nthreads=8):
         src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -458,11 +469,30 @@ class OracleStabilizer:
 _inst = None
 
 
-def load():
+RCP_FIXTURE = os.path.join(ROOT, "tests", "golden", "gfx950_rcp.npz")
+
+
+def device_rcp_table(path=RCP_FIXTURE):
+    """v_rcp_f32 of gfx950 over the 2^23 mantissas of [1, 2) (float32 array), decoded from the committed device dump
+    (scripts/dump_rcp_table.py: 2-bit deltas to the correctly rounded reciprocal; tests/test_ref_pin_gpu.py checks it against the GPU)."""
+    packed = np.load(path)["packed"]
+    code = np.empty(1 << 23, np.uint8)
+    for k in range(4):
+        code[k::4] = (packed >> (2 * k)) & 3
+    delta = np.where(code == 3, -1, code.astype(np.int64))
+    x = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+    cr = (1.0 / x.astype(np.float64)).astype(np.float32)
+    return (cr.view(np.uint32).astype(np.int64) + delta).astype(np.uint32).view(np.float32)
+
+
+def load(device_rcp=True):
+    """The oracle with native_recip = gfx950's v_rcp_f32 (what the reference's OpenCL kernels compile to for this device, oracle/_ref);
+    device_rcp=False on the returned object's set_device_rcp() gives the correctly rounded 1/x instead."""
     global _inst
     if _inst is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
         if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
             build()
         _inst = Oracle(ctypes.CDLL(LIB))
+        _inst.set_device_rcp(device_rcp)
     return _inst
