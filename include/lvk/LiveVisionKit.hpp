@@ -56,7 +56,15 @@ public:
         if (lvk_hip_ctx_create(device, &m_ctx) != LVK_HIP_OK)
             lvk::context::assert_handler("LiveVisionKit.hpp", "Context", std::string("lvk_hip_ctx_create: ") + lvk_hip_last_error(nullptr));
     }
+    // a context that enqueues on an existing hipStream_t (e.g. the stream a filter produces its outputs on)
+    Context(int device, void* hip_stream)
+    {
+        if (lvk_hip_ctx_create_on_stream(device, hip_stream, &m_ctx) != LVK_HIP_OK)
+            lvk::context::assert_handler("LiveVisionKit.hpp", "Context", std::string("lvk_hip_ctx_create_on_stream: ") + lvk_hip_last_error(nullptr));
+    }
     ~Context() { lvk_hip_ctx_destroy(m_ctx); }
+    // everything enqueued so far on `producer` happens before what this context enqueues from now on (GPU-side, no host wait)
+    void wait_for(const Context& producer) const { if (producer.m_ctx != m_ctx) check(lvk_hip_ctx_wait(m_ctx, producer.m_ctx), "Context::wait_for"); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     lvk_hip_ctx* get() const { return m_ctx; }
@@ -106,7 +114,9 @@ struct VideoFrame
     void release() { m_buf.reset(); cols = rows = 0; step = 0; }
     void create(const cv::Size& sz, int /*type = CV_8UC3*/, const std::shared_ptr<hip::Context>& ctx = nullptr)
     {
-        if (m_buf && m_buf.use_count() == 1 && cols == sz.width && rows == sz.height) return;
+        if (m_buf && m_buf.use_count() == 1 && cols == sz.width && rows == sz.height && (!ctx || ctx == m_ctx)) return;
+        // lvk_hip_malloc / lvk_hip_free pool by size (like cv::UMat's OpenCL buffer pool): no hipMalloc / hipFree in steady state.
+        // A frame's buffer is written on its context's stream; a filter that reads it on another stream fences it back before dropping it.
         m_ctx = ctx ? ctx : (m_ctx ? m_ctx : hip::shared_context());
         void* p = nullptr;
         step = (size_t)sz.width * 3;
@@ -147,6 +157,51 @@ private:
     std::shared_ptr<hip::Context> m_ctx;
 };
 typedef VideoFrame Frame;
+
+// The plugin's wire format on the device: I420 (y, u, v planes) or NV12 (y + interleaved uv), what I4XXIngest / NV12Ingest move between
+// OBS and the filter chain (Modules/OBS-Plugin/Interop/FrameIngest.cpp:494-602).  StabilizationFilter::apply takes it directly: the
+// 4:2:0 -> 4:4:4 conversion, the filter and the 4:4:4 -> 4:2:0 conversion run as one push (lvk_hip_stab_push_yuv420).
+struct VideoFrame420
+{
+    uint64_t timestamp = 0;
+    bool nv12 = false;
+    int cols = 0, rows = 0;
+
+    bool empty() const { return !m_buf || cols == 0 || rows == 0; }
+    void release() { m_buf.reset(); cols = rows = 0; }
+    void create(const cv::Size& sz, bool nv12_, const std::shared_ptr<hip::Context>& ctx = nullptr)
+    {
+        LVK_HIP_ASSERT(sz.width > 0 && sz.height > 0 && sz.width % 2 == 0 && sz.height % 2 == 0);
+        if (m_buf && m_buf.use_count() == 1 && cols == sz.width && rows == sz.height && nv12 == nv12_ && (!ctx || ctx == m_ctx)) return;
+        m_ctx = ctx ? ctx : (m_ctx ? m_ctx : hip::shared_context());
+        void* p = nullptr;
+        m_ctx->check(lvk_hip_malloc(m_ctx->get(), (size_t)sz.width * sz.height * 3 / 2, &p), "VideoFrame420::create");
+        auto c = m_ctx;
+        m_buf = std::shared_ptr<void>(p, [c](void* q) { lvk_hip_free(c->get(), q); });
+        cols = sz.width; rows = sz.height; nv12 = nv12_;
+    }
+    // one allocation: Y, then U and V (I420) or the interleaved UV plane (NV12)
+    uint8_t* y() const { return static_cast<uint8_t*>(m_buf.get()); }
+    uint8_t* u() const { return y() + (size_t)cols * rows; }
+    uint8_t* v() const { return nv12 ? u() : u() + (size_t)(cols / 2) * (rows / 2); }
+    int y_step() const { return cols; }
+    int uv_step() const { return nv12 ? cols : cols / 2; }
+    void upload(const uint8_t* host, int rows_, int cols_, bool nv12_, uint64_t ts, const std::shared_ptr<hip::Context>& ctx = nullptr)
+    {
+        create({cols_, rows_}, nv12_, ctx);
+        m_ctx->check(lvk_hip_upload(m_ctx->get(), m_buf.get(), host, (size_t)cols * rows * 3 / 2), "VideoFrame420::upload");
+        timestamp = ts;
+    }
+    void download(uint8_t* host) const
+    {
+        m_ctx->check(lvk_hip_download(m_ctx->get(), host, m_buf.get(), (size_t)cols * rows * 3 / 2), "VideoFrame420::download");
+        m_ctx->check(lvk_hip_sync(m_ctx->get()), "VideoFrame420::download");
+    }
+    const std::shared_ptr<hip::Context>& context() const { return m_ctx; }
+private:
+    std::shared_ptr<void> m_buf;
+    std::shared_ptr<hip::Context> m_ctx;
+};
 
 // ---------------------------------------------------------------------------------------------- Timing
 class Time
@@ -391,11 +446,20 @@ private:
 typedef VideoFilter IdentityFilter;
 
 // ---------------------------------------------------------------------------------------------- Filters/StabilizationFilter.hpp
+// Camera profile of the plugin's lens-correction filter (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153)
+struct CameraParameters { double fx = 0, fy = 0, cx = 0, cy = 0, k1 = 0, k2 = 0, p1 = 0, p2 = 0, k3 = 0; };
+
 class StabilizationFilter final : public VideoFilter, public Configurable<StabilizationFilterSettings>
 {
 public:
     explicit StabilizationFilter(const StabilizationFilterSettings& settings = {}, int device = 0)
-        : VideoFilter("Stabilization Filter"), m_Ctx(std::make_shared<hip::Context>(device))
+        : VideoFilter("Stabilization Filter"), m_Device(device), m_Ctx(std::make_shared<hip::Context>(device))
+    {
+        configure(settings);
+    }
+    // On the caller's context: the filter then shares the stream its input frames are produced on (no cross-stream fences needed).
+    StabilizationFilter(const StabilizationFilterSettings& settings, const std::shared_ptr<hip::Context>& context, int device = 0)
+        : VideoFilter("Stabilization Filter"), m_Device(device), m_Ctx(context)
     {
         configure(settings);
     }
@@ -411,6 +475,7 @@ public:
         m_Settings = settings;
         static_cast<PathSmootherSettings&>(m_Settings).motion_resolution = settings.motion_resolution;
         static_cast<FrameTrackerSettings&>(m_Settings).motion_resolution = settings.motion_resolution;
+        refresh_output_context();
     }
 
     void restart() { m_Ctx->check(lvk_hip_stab_restart(m_Stab), "restart"); m_Held.clear(); }
@@ -427,6 +492,50 @@ public:
     }
     const std::shared_ptr<hip::Context>& context() const { return m_Ctx; }
 
+    // ---- MI355X additions (no reference counterpart; the reference API above is unchanged) ----------------------------------
+    // Overlap mode: the bulk kernels (4:2:0 conversion, output remap) run on a second stream next to the next frame's tracking
+    // (lvk_hip_stab_set_overlap).  Output frames then belong to a context on that stream: whatever consumes them through
+    // frame.context() (ScalingFilter, download, clone) is ordered behind the remap that writes them.
+    void set_overlap(const bool enable)
+    {
+        // the bulk stream belongs to a context of the facade, so that output frames stay valid after the filter is gone
+        if (enable && !m_BulkCtx) m_BulkCtx = std::make_shared<hip::Context>(m_Device);
+        m_Ctx->check(lvk_hip_stab_set_bulk_context(m_Stab, enable ? m_BulkCtx->get() : nullptr), "set_overlap");
+        m_Overlap = enable;
+        refresh_output_context();
+    }
+    // Fused lens pre-warp (BASELINE config 5): frames are pushed RAW, the lens correction of the plugin's LCFilter
+    // (Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-192) is composed into the stabilizing remap.  Restarts the filter.
+    void set_lens(const CameraParameters& p)
+    {
+        const lvk_camera_params c{p.fx, p.fy, p.cx, p.cy, p.k1, p.k2, p.p1, p.p2, p.k3};
+        m_Ctx->check(lvk_hip_stab_set_lens(m_Stab, &c), "set_lens"); m_Held.clear();
+    }
+    void clear_lens() { m_Ctx->check(lvk_hip_stab_set_lens(m_Stab, nullptr), "clear_lens"); m_Held.clear(); }
+
+    // The OBS asynchronous path in one call (VisionFilter.cpp:151-212 = to_ocl -> filter -> to_obs): 4:2:0 planes in, 4:2:0 planes out.
+    // `output` is released while the delay builds, exactly like the packed overload.
+    using VideoFilter::apply;
+    void apply(const VideoFrame420& input, VideoFrame420& output, const bool profile = false)
+    {
+        LVK_HIP_ASSERT(!input.empty());
+        sync_gpu(profile);
+        m_LastRows = input.rows; m_LastCols = input.cols;
+        if (input.context() != m_Ctx) m_Ctx->wait_for(*input.context());
+        VideoFrame420 result;
+        result.create({input.cols, input.rows}, input.nv12, m_OutCtx);
+        int produced = 0; uint64_t ts = 0;
+        m_Ctx->check(lvk_hip_stab_push_yuv420(m_Stab, input.y(), input.y_step(), input.u(), input.uv_step(), input.v(), input.uv_step(), input.nv12 ? 1 : 0,
+                                              input.rows, input.cols, input.timestamp,
+                                              result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), &produced, &ts),
+                     "StabilizationFilter::apply(4:2:0)");
+        // the planes are consumed when the push returns only in overlap mode; otherwise their conversion is merely enqueued on our stream
+        if (!m_Overlap && input.context() != m_Ctx) input.context()->wait_for(*m_Ctx);
+        if (produced) { result.timestamp = ts; output = std::move(result); }
+        else output.release();
+        sync_gpu(profile);
+    }
+
 private:
     void filter(VideoFrame&& input, VideoFrame& output) override                    // StabilizationFilter.cpp:69-135
     {
@@ -434,20 +543,33 @@ private:
         LVK_HIP_ASSERT(!input.empty());
         m_LastRows = input.rows; m_LastCols = input.cols;
         VideoFrame in = std::move(input);                  // input and output may alias the same object (VSFilter.cpp:358,363)
+        // the frame was written on its own context's stream (an upload, an upstream filter): order our stream behind it
+        if (in.context() && in.context() != m_Ctx) m_Ctx->wait_for(*in.context());
         VideoFrame result;
-        result.create(in.size(), CV_8UC3, m_Ctx);
+        result.create(in.size(), CV_8UC3, m_OutCtx);       // pooled: the reference's dst.create is a no-op in steady state (Image.cpp:116)
         int produced = 0; uint64_t ts = 0; const void* released = nullptr;
-        m_Held.push_back(in.buffer());                     // keep the borrowed device buffer alive while it is queued
+        m_Held.push_back({in.buffer(), in.context()});     // keep the borrowed device buffer alive while it is queued
         m_Ctx->check(lvk_hip_stab_push(m_Stab, in.device_ptr(), (int)in.step, in.rows, in.cols, in.timestamp, (int)in.format,
                                        result.device_ptr(), (int)result.step, &produced, &ts, &released), "StabilizationFilter::filter");
         if (released)
             for (auto it = m_Held.begin(); it != m_Held.end(); ++it)
-                if (it->get() == released) { m_Retired.push_back(*it); m_Held.erase(it); break; }
-        while (m_Retired.size() > 2) m_Retired.pop_front();    // the remap reading it has been followed by later stream work
+                if (it->buffer.get() == released)
+                {
+                    // hand the buffer back to its owner: its context's stream must not reuse it before our last read (the remap just
+                    // enqueued) has run.  In overlap mode the library reports a frame only after that remap has finished.
+                    if (!m_Overlap && it->ctx && it->ctx != m_Ctx) it->ctx->wait_for(*m_Ctx);
+                    m_Held.erase(it);
+                    break;
+                }
         if (produced) { result.timestamp = ts; result.format = in.format; output = std::move(result); }
         else output.release();
     }
     void sync_gpu(bool trigger) override { if (trigger) m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); }
+    void refresh_output_context()
+    {
+        // outputs are produced on the bulk stream while overlap is on and the output is being stabilized (lvk_hip_stab_output_stream)
+        m_OutCtx = (m_BulkCtx && lvk_hip_stab_output_stream(m_Stab) == lvk_hip_stream(m_BulkCtx->get())) ? m_BulkCtx : m_Ctx;
+    }
 
     static lvk_stab_settings to_pod(const StabilizationFilterSettings& s)
     {
@@ -467,9 +589,12 @@ private:
         return p;
     }
 
-    std::shared_ptr<hip::Context> m_Ctx;
+    struct HeldFrame { std::shared_ptr<void> buffer; std::shared_ptr<hip::Context> ctx; };
+    int m_Device = 0;
+    std::shared_ptr<hip::Context> m_Ctx, m_BulkCtx, m_OutCtx;      // m_OutCtx: the context (stream) output frames are produced on
     lvk_hip_stab* m_Stab = nullptr;
-    std::deque<std::shared_ptr<void>> m_Held, m_Retired;
+    bool m_Overlap = false;
+    std::deque<HeldFrame> m_Held;
     int m_LastRows = 0, m_LastCols = 0;
 };
 

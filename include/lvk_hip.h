@@ -47,10 +47,19 @@ void* lvk_hip_stream(lvk_hip_ctx* ctx);              /* the hipStream_t work is 
 const char* lvk_hip_last_error(lvk_hip_ctx* ctx);    /* NULL ctx: last error of a failed ctx_create */
 const char* lvk_hip_version(void);
 
+/* Ordering between contexts: everything enqueued so far on `producer` (its stream and the streams of its stabilizers) happens
+ * before whatever is enqueued on `ctx` from now on.  GPU-side (an event per stream), no host wait.  What the reference gets from
+ * OpenCV's single in-order OpenCL queue; needed here when a frame written on one context's stream is consumed on another's. */
+int  lvk_hip_ctx_wait(lvk_hip_ctx* ctx, lvk_hip_ctx* producer);
+
 /* ---- device memory helpers (for hosts without their own allocator) ------------------------------
- * Replace cv::UMat(USAGE_ALLOCATE_DEVICE_MEMORY) allocation / upload / download (Data/VideoFrame.cpp:27-29). */
+ * Replace cv::UMat(USAGE_ALLOCATE_DEVICE_MEMORY) allocation / upload / download (Data/VideoFrame.cpp:27-29).
+ * Like OpenCV's OpenCL buffer pool, lvk_hip_free keeps the block for the next lvk_hip_malloc of the same size (no device
+ * synchronisation, no allocation in steady state; at most 4 GiB are kept, lvk_hip_trim gives them back).  A freed block may be
+ * handed out again at once: work that still uses it must be on this context's stream, or have been fenced with lvk_hip_ctx_wait. */
 int lvk_hip_malloc(lvk_hip_ctx* ctx, size_t bytes, void** d_ptr);
 int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr);
+int lvk_hip_trim(lvk_hip_ctx* ctx);
 int lvk_hip_upload(lvk_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* async on the stream */
 int lvk_hip_download(lvk_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* async on the stream */
 
@@ -272,8 +281,16 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
 /* Optional: run the bulk kernels (4:2:0 ingest, the output remap) on a second, low-priority HIP stream so that they overlap the
  * tracking of the next frame (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches,
  * Functions/Image.cpp:76); the remap then uses its occupancy-capped variants.  With overlap enabled d_out is complete only after
- * lvk_hip_sync(), and *released reports a borrowed frame one push later (after its remap has finished). */
+ * lvk_hip_sync(), and *released reports a borrowed frame one push later (after its remap has finished).
+ * Ordering: INPUTS need nothing from the caller -- whatever was enqueued on the context's stream before a push (the decode / copy that
+ * fills the frame or the planes) is made visible to the bulk stream by an event the push records.  OUTPUTS are produced on the
+ * bulk stream: consume them there (lvk_hip_stab_output_stream) or after lvk_hip_sync(); reusing the same output buffer for the
+ * next push is safe (same stream).  Frames dropped outside a push (queue shrunk by configure, mode toggled) come back through
+ * *released of the following pushes. */
 int  lvk_hip_stab_set_overlap(lvk_hip_stab* stab, int enable);
+/* The same mode on a stream the caller owns: the bulk kernels run on the stream of `bulk` (a second context on the same device; NULL
+ * switches overlap off).  For hosts whose output frames outlive the stabilizer or feed stream-ordered consumers: outputs belong to `bulk`. */
+int  lvk_hip_stab_set_bulk_context(lvk_hip_stab* stab, lvk_hip_ctx* bulk);
 /* The hipStream_t the outputs of the following pushes are produced on (the bulk stream in overlap mode, else the context's
  * stream): enqueue stream-ordered consumers of d_out / the output planes (a D2H copy, an encoder) there instead of calling
  * lvk_hip_sync().  Changes when lvk_hip_stab_set_overlap or stabilize_output change. */

@@ -23,6 +23,8 @@ _SIG = {
     "lvk_hip_version": (_c.c_char_p, []),
     "lvk_hip_malloc": (_c.c_int, [_P, _c.c_size_t, _c.POINTER(_P)]),
     "lvk_hip_free": (_c.c_int, [_P, _P]),
+    "lvk_hip_trim": (_c.c_int, [_P]),
+    "lvk_hip_ctx_wait": (_c.c_int, [_P, _P]),
     "lvk_hip_upload": (_c.c_int, [_P, _P, _P, _c.c_size_t]),
     "lvk_hip_download": (_c.c_int, [_P, _P, _P, _c.c_size_t]),
     "lvk_hip_remap_homography": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int,
@@ -80,6 +82,7 @@ _SIG = {
     "lvk_hip_stab_get_meshes": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int]),
     "lvk_hip_stab_get_features": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.c_int]),
     "lvk_hip_stab_set_overlap": (_c.c_int, [_P, _c.c_int]),
+    "lvk_hip_stab_set_bulk_context": (_c.c_int, [_P, _P]),
     "lvk_hip_stab_set_profiling": (_c.c_int, [_P, _c.c_int]),
     "lvk_hip_stab_get_profile": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),
 }

@@ -69,6 +69,8 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
     for (auto& kv : ctx->lin8tabs) (void)hipFree(kv.second);
     for (auto& kv : ctx->areatabs) { (void)hipFree(kv.second.range); (void)hipFree(kv.second.tab); }
     for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+    for (hipEvent_t e : ctx->wait_events) (void)hipEventDestroy(e);
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -90,16 +92,77 @@ const char* lvk_hip_last_error(lvk_hip_ctx* ctx) { return ctx ? ctx->last_error.
 int lvk_hip_malloc(lvk_hip_ctx* ctx, size_t bytes, void** d_ptr)
 {
     if (!ctx || !d_ptr) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, bytes > 0);
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        auto it = ctx->pool_free.find(bytes);
+        if (it != ctx->pool_free.end())
+        {
+            *d_ptr = it->second;
+            ctx->pool_cached_bytes -= bytes;
+            ctx->pool_free.erase(it);
+            return LVK_HIP_OK;
+        }
+    }
     LVK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     LVK_HIP_CHECK(ctx, hipMalloc(d_ptr, bytes));
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    ctx->pool_sizes[*d_ptr] = bytes;
     return LVK_HIP_OK;
 }
 
 int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
+    if (!d_ptr) return LVK_HIP_OK;
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        auto it = ctx->pool_sizes.find(d_ptr);
+        if (it != ctx->pool_sizes.end() && ctx->pool_cached_bytes + it->second <= lvk_hip_ctx::kPoolMaxCachedBytes)
+        {
+            ctx->pool_free.emplace(it->second, d_ptr);
+            ctx->pool_cached_bytes += it->second;
+            return LVK_HIP_OK;
+        }
+        if (it != ctx->pool_sizes.end()) ctx->pool_sizes.erase(it);
+    }
     LVK_HIP_CHECK(ctx, hipFree(d_ptr));
     return LVK_HIP_OK;
+}
+
+int lvk_hip_trim(lvk_hip_ctx* ctx)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    for (auto& kv : ctx->pool_free) { ctx->pool_sizes.erase(kv.second); (void)hipFree(kv.second); }
+    ctx->pool_free.clear();
+    ctx->pool_cached_bytes = 0;
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_ctx_wait(lvk_hip_ctx* ctx, lvk_hip_ctx* producer)
+{
+    if (!ctx || !producer) return LVK_HIP_ERR_ARG;
+    if (ctx == producer) return LVK_HIP_OK;
+    LVK_HIP_REQUIRE(ctx, ctx->device == producer->device);
+    const size_t need = 1 + producer->aux_streams.size();
+    while (ctx->wait_events.size() < need)
+    {
+        hipEvent_t e = nullptr;
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->wait_events.push_back(e);
+    }
+    size_t k = 0;
+    auto carry = [&](hipStream_t from) -> int {
+        if (from == ctx->stream) return LVK_HIP_OK;
+        LVK_HIP_CHECK(ctx, hipEventRecord(ctx->wait_events[k], from));
+        LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->wait_events[k], 0));
+        k++;
+        return LVK_HIP_OK;
+    };
+    int rc = carry(producer->stream);
+    for (hipStream_t a : producer->aux_streams) if (rc == LVK_HIP_OK) rc = carry(a);
+    return rc;
 }
 
 int lvk_hip_upload(lvk_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
@@ -118,7 +181,13 @@ int lvk_hip_download(lvk_hip_ctx* ctx, void* h_dst, const void* d_src, size_t by
 
 } // extern "C"
 
-int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, size_t bytes, void** d_out)
+int lvk_stage_consumed(lvk_hip_ctx* ctx, int slot, hipStream_t stream)
+{
+    LVK_HIP_CHECK(ctx, hipEventRecord(ctx->stage_done[slot], stream));
+    return LVK_HIP_OK;
+}
+
+int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, size_t bytes, void** d_out, int* slot_out)
 {
     LVK_HIP_REQUIRE(ctx, bytes <= lvk_hip_ctx::kStageBytes);
     const int slot = ctx->stage_next;
@@ -129,7 +198,8 @@ int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, siz
     uint8_t* d = ctx->stage_dev + (size_t)slot * lvk_hip_ctx::kStageBytes;
     std::memcpy(h, host, bytes);
     LVK_HIP_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
-    LVK_HIP_CHECK(ctx, hipEventRecord(ctx->stage_done[slot], stream));
+    if (slot_out) *slot_out = slot;
+    else LVK_HIP_CHECK(ctx, hipEventRecord(ctx->stage_done[slot], stream));
     *d_out = d;
     return LVK_HIP_OK;
 }

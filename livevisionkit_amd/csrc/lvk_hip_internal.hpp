@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include <utility>
 
 #include "lvk_hip.h"
@@ -37,6 +38,17 @@ struct lvk_hip_ctx
 
     // extra streams owned by objects of this context (synchronised by lvk_hip_sync as well)
     std::vector<hipStream_t> aux_streams;
+
+    // lvk_hip_malloc / lvk_hip_free: freed blocks are kept by size and handed out again (cv::UMat's OpenCL buffer pool plays this role
+    // in the reference: Image.cpp:53,116 `dst.create` allocates nothing in steady state).  Guarded: frames may be dropped on any thread.
+    std::mutex pool_mutex;
+    std::multimap<size_t, void*> pool_free;
+    std::map<void*, size_t> pool_sizes;            // every live block of this context -> its size
+    size_t pool_cached_bytes = 0;
+    static constexpr size_t kPoolMaxCachedBytes = (size_t)4 << 30;
+
+    // lvk_hip_ctx_wait: events that carry "everything enqueued on the other context so far" onto this context's stream
+    std::vector<hipEvent_t> wait_events;
 
     // Cached INTER_LINEAR tables: key = (mesh extent, frame extent, vertical?)
     std::map<std::tuple<int, int, int>, LinTabEntry*> lintabs;
@@ -116,7 +128,10 @@ struct LvkTimelineScope
 
 // Copies `bytes` (<= kStageBytes) of host data into a device staging slot, asynchronously on the
 // context's stream, and returns the device address.  The slot is recycled after kStageSlots uses.
-int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, size_t bytes, void** d_out);
+// With `slot` != nullptr the slot is NOT marked consumed by the copy: the caller launches the kernel that reads it and then calls
+// lvk_stage_consumed(ctx, *slot, stream), so that a reuse of the slot (from either stream of a stabilizer) waits for that kernel.
+int lvk_stage_params(lvk_hip_ctx* ctx, hipStream_t stream, const void* host, size_t bytes, void** d_out, int* slot = nullptr);
+int lvk_stage_consumed(lvk_hip_ctx* ctx, int slot, hipStream_t stream);
 
 // Device-resident INTER_LINEAR table for resizing a mesh axis of `msize` vertices to `fsize` pixels.
 int lvk_get_lintab(lvk_hip_ctx* ctx, int msize, int fsize, bool vertical, const LinTabEntry** d_out);

@@ -704,8 +704,8 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
     const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
     LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
 
-    void* d_mesh = nullptr;
-    int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh);
+    void* d_mesh = nullptr; int stage_slot = 0;
+    int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot);
     if (rc != LVK_HIP_OK) return rc;
     const LinTabEntry *xtab = nullptr, *ytab = nullptr;
     if ((rc = lvk_get_lintab(ctx, mesh_cols, src_cols, false, &xtab)) != LVK_HIP_OK) return rc;
@@ -720,7 +720,7 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
                          xtab, ytab, pack_bg(bg));
 #undef LVK_LAUNCH_REMAP
     LVK_HIP_CHECK(ctx, hipGetLastError());
-    return LVK_HIP_OK;
+    return lvk_stage_consumed(ctx, stage_slot, stream);             // the slot is free again once this kernel has read the mesh
 }
 
 // lvk::remap(src, dst, offset_map, background) with the map resident in HBM (Functions/Image.cpp:28-81): dst and map have
@@ -808,6 +808,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
     LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
     const Planes420 o{(uint8_t*)o_y, oy_step, (uint8_t*)o_u, ou_step, (uint8_t*)(nv12 ? o_u : o_v), nv12 ? ou_step : ov_step};
     const dim3 block(256), grid = co ? lvk_co_grid(ctx, rows, cols) : remap_grid(rows, cols);
+    int stage_slot = -1;
     if (mesh_rows == 2 && mesh_cols == 2)
     {
         const float w = (float)cols, h = (float)rows;                 // WarpMesh.cpp:194-217, as in lvk_launch_warpmesh_apply_lens
@@ -839,7 +840,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
         const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
         LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
         void* d_mesh = nullptr;
-        int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh);
+        int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot);
         if (rc != LVK_HIP_OK) return rc;
         const LinTabEntry *xtab = nullptr, *ytab = nullptr;
         if ((rc = lvk_get_lintab(ctx, mesh_cols, cols, false, &xtab)) != LVK_HIP_OK) return rc;
@@ -856,7 +857,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
         }
     }
     LVK_HIP_CHECK(ctx, hipGetLastError());
-    return LVK_HIP_OK;
+    return stage_slot >= 0 ? lvk_stage_consumed(ctx, stage_slot, stream) : LVK_HIP_OK;
 }
 
 extern "C" {

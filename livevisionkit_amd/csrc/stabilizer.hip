@@ -133,6 +133,7 @@ struct lvk_hip_stab
     // ---- optional overlap of the output remap with the next frame's tracking (second stream)
     bool overlap = false;
     hipStream_t remap_stream = nullptr;
+    bool remap_stream_owned = false;             // created by lvk_hip_stab_set_overlap (else: the caller's, lvk_hip_stab_set_bulk_context)
     hipEvent_t remap_done[2] = {nullptr, nullptr};
     int remap_slot = 0;
     const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
@@ -142,6 +143,29 @@ struct lvk_hip_stab
     int run_deferred_ingest() { auto f = std::move(deferred_ingest); deferred_ingest = nullptr; return f ? f() : LVK_HIP_OK; }
     hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame (runs on remap_stream in overlap mode)
     int pending_slot = -1;
+    // Overlap mode: what the caller enqueued on the context's stream before a push (a decode / copy that fills the frame or the planes)
+    // must be visible to the kernels of the bulk stream that read it.  The event is recorded when the push starts -- before the tracker's
+    // own kernels, so that the bulk stream never waits for those -- and the bulk stream waits for it ahead of its first launch of the push.
+    hipEvent_t caller_ready = nullptr;
+    bool caller_wait_pending = false;
+    int mark_caller_work()
+    {
+        if (!(overlap && s.stabilize_output && remap_stream)) return LVK_HIP_OK;
+        if (!caller_ready) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&caller_ready, hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventRecord(caller_ready, ctx->stream));
+        caller_wait_pending = true;
+        return LVK_HIP_OK;
+    }
+    int bulk_stream_sees_caller_work()
+    {
+        if (!caller_wait_pending) return LVK_HIP_OK;
+        caller_wait_pending = false;
+        LVK_HIP_CHECK(ctx, hipStreamWaitEvent(remap_stream, caller_ready, 0));
+        return LVK_HIP_OK;
+    }
+    // Borrowed frames that left the queue outside a push (queue shrunk by configure(), overlap / stabilize_output toggled while a remap
+    // was pending): handed back through *released by the following pushes, one per push.
+    std::deque<const void*> orphaned;
 
     // ---- optional per-stage GPU timing (HIP events on the launch stream)
     bool profiling = false;
@@ -316,10 +340,15 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     LVK_HIP_REQUIRE(ctx, st.corrective_limit_x >= 0 && st.corrective_limit_x <= 1 && st.corrective_limit_y >= 0 && st.corrective_limit_y <= 1);
     LVK_HIP_REQUIRE(ctx, st.predictive_samples > 0 && st.smoothing_steps > 0 && st.response_rate >= 0 && st.response_rate <= 1);
     LVK_HIP_REQUIRE(ctx, st.detection_width >= 8 && st.detection_height >= 8 && st.detection_width < 4096 && st.detection_height < 4096);
+    // the remap kernels take the mesh through a staging slot
+    LVK_HIP_REQUIRE(ctx, (size_t)st.motion_width * (size_t)st.motion_height * 2 * sizeof(float) <= lvk_hip_ctx::kStageBytes);
 
     if (configured && s.stabilize_output != st.stabilize_output && remap_stream)
+    {
         // the 4:2:0 conversions change streams with this flag: drain the bulk stream so that no pool slot is shared across the switch
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
+        if (pending_release) { if (queue_kind == 1) orphaned.push_back(pending_release); pending_release = nullptr; pending_slot = -1; }
+    }
     if (configured && s.stabilize_output && !st.stabilize_output) reset_context();        // StabilizationFilter.cpp:49-52
     const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
     const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
@@ -340,7 +369,11 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     tracker_s = st;
     smoother.configure(st);
     queue_capacity = (size_t)st.predictive_samples + 1;
-    while (queue.size() > queue_capacity) queue.pop_front();
+    while (queue.size() > queue_capacity)
+    {
+        if (queue_kind == 1) orphaned.push_back(queue.front().d_ptr);      // a borrowed frame nobody will emit: give it back
+        queue.pop_front();
+    }
     grid.configure(st);
     if (configured && res_changed && initialized) grid.reset();                          // FrameTracker.cpp:86-91
     s = st;
@@ -501,7 +534,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the feature matches
         if (!solver.solve(&e1[0].x, &e2[0].x, m, (float)cur_w, (float)cur_h, s.temporal_smoothing, s.acceptance_threshold,
                           h_mask, motion.off.data()))
+        {
+            tracked.clear();                                                          // like the other no-motion exits
             return LVK_HIP_OK;                                                        // no estimate this frame (identity motion)
+        }
         size_t inl = 0;
         for (int i = 0; i < m; i++) inl += h_mask[i] ? 1 : 0;
         tracking_stability = (float)inl / (float)m;
@@ -588,10 +624,11 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
         (void)hipStreamSynchronize(st->remap_stream);
         auto& aux = st->ctx->aux_streams;
         aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
-        (void)hipStreamDestroy(st->remap_stream);
-        (void)hipEventDestroy(st->remap_done[0]); (void)hipEventDestroy(st->remap_done[1]);
+        if (st->remap_stream_owned) (void)hipStreamDestroy(st->remap_stream);
     }
+    for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventDestroy(st->remap_done[i]);
     if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
+    if (st->caller_ready) (void)hipEventDestroy(st->caller_ready);
     for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete st;
 }
@@ -608,25 +645,64 @@ void* lvk_hip_stab_output_stream(lvk_hip_stab* st)
     return (void*)((st->overlap && st->s.stabilize_output && st->remap_stream) ? st->remap_stream : st->ctx->stream);
 }
 
-int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
+static int stab_detach_bulk_stream(lvk_hip_stab* st)
 {
-    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    if (!st->remap_stream) return LVK_HIP_OK;
+    auto& aux = ctx->aux_streams;
+    aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
+    if (st->remap_stream_owned) LVK_HIP_CHECK(ctx, hipStreamDestroy(st->remap_stream));
+    st->remap_stream = nullptr; st->remap_stream_owned = false;
+    return LVK_HIP_OK;
+}
+
+static int stab_set_overlap(lvk_hip_stab* st, bool enable, lvk_hip_ctx* bulk)
+{
     lvk_hip_ctx* ctx = st->ctx;
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (st->remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st->remap_stream));
-    if (enable && !st->remap_stream)
+    // both streams are idle: a frame whose remap was pending is free again
+    if (st->pending_release) { if (st->queue_kind == 1) st->orphaned.push_back(st->pending_release); st->pending_release = nullptr; st->pending_slot = -1; }
+    st->caller_wait_pending = false;
+    if (enable)
     {
-        // lowest priority: the bulk kernels of this stream (remap, 4:2:0 conversion) fill every CU; the tracker's small,
-        // latency-bound kernels on the main stream should get the wave slots they free first
-        int prio_least = 0, prio_greatest = 0;
-        LVK_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        LVK_HIP_CHECK(ctx, hipStreamCreateWithPriority(&st->remap_stream, hipStreamNonBlocking, prio_least));
-        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[0], hipEventDisableTiming));
-        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[1], hipEventDisableTiming));
-        ctx->aux_streams.push_back(st->remap_stream);
+        hipStream_t want = bulk ? bulk->stream : nullptr;
+        if (bulk) LVK_HIP_REQUIRE(ctx, bulk != ctx && bulk->device == ctx->device && bulk->stream != ctx->stream);
+        if (st->remap_stream && (bulk ? st->remap_stream != want : !st->remap_stream_owned))
+        { const int rc = stab_detach_bulk_stream(st); if (rc != LVK_HIP_OK) return rc; }
+        if (!st->remap_stream)
+        {
+            if (bulk) { st->remap_stream = want; st->remap_stream_owned = false; }
+            else
+            {
+                // lowest priority: the bulk kernels of this stream (remap, 4:2:0 conversion) fill every CU; the tracker's small,
+                // latency-bound kernels on the main stream should get the wave slots they free first
+                int prio_least = 0, prio_greatest = 0;
+                LVK_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+                LVK_HIP_CHECK(ctx, hipStreamCreateWithPriority(&st->remap_stream, hipStreamNonBlocking, prio_least));
+                st->remap_stream_owned = true;
+            }
+            ctx->aux_streams.push_back(st->remap_stream);
+        }
+        for (int i = 0; i < 2; i++)
+            if (!st->remap_done[i]) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[i], hipEventDisableTiming));
     }
-    st->overlap = enable != 0;
+    st->overlap = enable;
     return LVK_HIP_OK;
+}
+
+int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    return stab_set_overlap(st, enable != 0, nullptr);
+}
+
+// Overlap mode on a stream the CALLER owns: the bulk kernels run on `bulk`'s stream (NULL: overlap off).  For hosts whose output frames
+// outlive the stabilizer or are consumed by stream-ordered work of their own: the frames then belong to `bulk` (the C++ facade does this).
+int lvk_hip_stab_set_bulk_context(lvk_hip_stab* st, lvk_hip_ctx* bulk)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    return stab_set_overlap(st, bulk != nullptr, bulk);
 }
 
 // Per-stage GPU time measured with HIP events on the launch stream.  enable != 0 starts (and resets) the
@@ -718,6 +794,7 @@ int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::rest
     st->scene_quality = 1.0f;
     st->queue.clear(); st->queue_kind = 0;
     st->pending_release = nullptr; st->pending_slot = -1;
+    st->orphaned.clear();                          // restart(): every borrowed frame is the caller's again
     st->reset_context();
     return LVK_HIP_OK;
 }
@@ -770,6 +847,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         // so the remap may run on its own stream concurrently with the next frame's tracking
         const bool side = st->overlap && mesh && st->s.stabilize_output;
         hipStream_t rs = side ? st->remap_stream : ctx->stream;
+        if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
         if (mesh && o420 && o420->y)
@@ -891,7 +969,10 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     if (st->queue_kind == 2) return st->fail(LVK_HIP_ERR_ARG, "frames of lvk_hip_stab_push_yuv420 are still queued: restart() before switching to lvk_hip_stab_push");
     st->queue_kind = 1;
     st->pool_frames = false;
-    const int rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+    int rc = st->mark_caller_work();
+    if (rc != LVK_HIP_OK) return rc;
+    rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+    if (released && !*released && !st->orphaned.empty()) { *released = st->orphaned.front(); st->orphaned.pop_front(); }
     st->trace.mark(HostTrace::EXIT);
     return rc;
 }
@@ -915,6 +996,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     st->queue_kind = 2;
     int rc = st->ensure_pool(rows, cols);
     if (rc != LVK_HIP_OK) return rc;
+    if ((rc = st->mark_caller_work()) != LVK_HIP_OK) return rc;
     if (st->pool_free.empty())
     {
         // frames dropped by restart() / a shrinking queue never came back through *released: reclaim them
@@ -933,6 +1015,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     hipStream_t is = side_ingest ? st->remap_stream : ctx->stream;
     int pe = 0;
     auto do_ingest = [=]() -> int {
+        if (side_ingest) { const int w = st->bulk_stream_sees_caller_work(); if (w != LVK_HIP_OK) return w; }
         const int pi = st->prof_begin(LVK_STAGE_INGEST, is);
         const int r = lvk_launch_ingest_yuv420(ctx, is, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
         st->prof_end(pi, is);

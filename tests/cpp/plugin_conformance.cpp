@@ -7,9 +7,11 @@
 //   .../VSFilter.cpp:368-383                                         timings().average()/deviation().milliseconds(), stable_region()
 //   Modules/VideoEditor/FilterParser.tpp:51-64                       make_shared<StabilizationFilter>() + Configurable<>::configure
 // With -DRUN_ON_GPU it also runs a short synthetic stream (needs a GPU).
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "lvk/LiveVisionKit.hpp"
@@ -88,9 +90,176 @@ private:
 
 } // namespace lvk
 
-int main()
+#ifdef RUN_ON_GPU
+namespace {
+
+// The settings tests/test_golden.py runs the golden clip with: library defaults, then the OBS preset `name` with
+// predictive_samples 3, tracking at 320 x 180 and the relaxed QA thresholds (oracle_lib.preset(name, **STAB_OVER)).
+lvk::StabilizationFilterSettings golden_settings(const std::string& name)
+{
+    lvk::StabilizationFilterSettings s;
+    s.detection_resolution = {320, 180};
+    s.max_feature_density = 0.12f; s.accumulation_rate = 3.0f;
+    s.min_scene_quality = 0.4f; s.min_tracking_quality = 0.2f;
+    s.corrective_limits = {0.05f, 0.05f};
+    s.crop_to_stable_region = true;
+    s.background_colour = {105, 212, 235};
+    s.predictive_samples = 3;
+    if (name == "field")
+    {
+        s.acceptance_threshold = 10.0f; s.track_local_motions = true; s.motion_resolution = {16, 16};
+        s.detection_regions = {2, 2}; s.min_feature_density = 0.06f;
+    }
+    else
+    {
+        s.acceptance_threshold = 3.0f; s.track_local_motions = false; s.motion_resolution = {2, 2};
+        s.detection_regions = {2, 1}; s.min_feature_density = 0.04f;
+    }
+    return s;
+}
+
+// --golden <clip.raw> <n> <rows> <cols> <out.raw>: every frame of the packed YUV clip through lvk::StabilizationFilter::apply (both
+// presets, then the 4:2:0 overload with overlap on); emitted frames are appended to out.raw for the Python side to compare with
+// tests/golden/stabilizer.npz / the oracle.
+int run_golden(const char* clip_path, int n, int rows, int cols, const char* out_path)
+{
+    std::vector<uint8_t> clip((size_t)n * rows * cols * 3);
+    FILE* f = std::fopen(clip_path, "rb");
+    if (!f || std::fread(clip.data(), 1, clip.size(), f) != clip.size()) { std::printf("golden: cannot read the clip\n"); return 1; }
+    std::fclose(f);
+    FILE* out = std::fopen(out_path, "wb");
+    if (!out) return 1;
+    std::vector<uint8_t> host((size_t)rows * cols * 3);
+    for (const char* name : {"homography", "field"})
+    {
+        lvk::StabilizationFilter filter;                        // library defaults first, then configure: the order the golden run uses
+        filter.configure(golden_settings(name));
+        int emitted = 0;
+        for (int i = 0; i < n; i++)
+        {
+            lvk::Frame frame;
+            frame.upload(clip.data() + (size_t)i * rows * cols * 3, rows, cols, lvk::VideoFrame::YUV, 1000 + i);
+            filter.apply(std::move(frame), frame);
+            if (frame.empty()) continue;
+            if (frame.timestamp != (uint64_t)(1000 + i - 3)) { std::printf("golden: bad timestamp\n"); return 1; }
+            frame.download(host.data());
+            std::fwrite(host.data(), 1, host.size(), out);
+            emitted++;
+        }
+        std::printf("golden %s: %d frames\n", name, emitted);
+    }
+    std::fclose(out);
+    return 0;
+}
+
+// A chain whose stages run on DIFFERENT streams with nothing but the facade's fences between them: asynchronous upload on the
+// thread's context -> ScalingFilter (same context) -> StabilizationFilter (its own context; overlap: a third stream) -> ScalingFilter
+// on the output frame's context -> download.  Compared with the same chain run with a full synchronisation after every stage.
+int run_chain_race_check()
+{
+    const int rows = 270, cols = 480, n = 14;
+    std::vector<std::vector<uint8_t>> frames(n, std::vector<uint8_t>((size_t)rows * cols * 3));
+    for (int i = 0; i < n; i++)
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++)
+            {
+                uint8_t* p = &frames[i][((size_t)y * cols + x) * 3];
+                const int xs = x + 2 * (i % 3), ys = y + (i % 2);
+                p[0] = (uint8_t)((((xs / 14) + (ys / 14)) % 2) ? 205 : 35 + (xs * 5 + ys * 9) % 31); p[1] = (uint8_t)(100 + (x >> 3)); p[2] = (uint8_t)(90 + (y >> 2));
+            }
+    auto run = [&](bool synchronous, bool overlap, std::vector<std::vector<uint8_t>>& outs) {
+        lvk::StabilizationFilterSettings st; st.predictive_samples = 3; st.detection_resolution = {480, 270}; st.track_local_motions = false;
+        auto pre = std::make_shared<lvk::ScalingFilter>(cv::Size(960, 540), 0.6f);
+        auto stab = std::make_shared<lvk::StabilizationFilter>(st);
+        stab->set_overlap(overlap);
+        auto post = std::make_shared<lvk::ScalingFilter>(cv::Size(1280, 720), 0.3f);
+        lvk::CompositeFilter chain({pre, stab, post});
+        for (int i = 0; i < n; i++)
+        {
+            lvk::Frame frame;
+            frame.upload(frames[i].data(), rows, cols, lvk::VideoFrame::YUV, i);
+            if (synchronous)
+            {
+                // every stage completed (device idle) before the next one starts
+                frame.context()->check(lvk_hip_sync(frame.context()->get()), "chain");
+                pre->apply(std::move(frame), frame, true);
+                stab->apply(std::move(frame), frame, true);
+                if (!frame.empty()) post->apply(std::move(frame), frame, true);
+            }
+            else chain.apply(std::move(frame), frame);
+            if (frame.empty()) continue;
+            outs.emplace_back((size_t)frame.rows * frame.cols * 3);
+            frame.download(outs.back().data());
+        }
+    };
+    for (bool overlap : {false, true})
+    {
+        std::vector<std::vector<uint8_t>> a, b;
+        run(true, overlap, a); run(false, overlap, b);
+        if (a.size() != (size_t)n - 3 || a.size() != b.size()) { std::printf("chain: %zu / %zu frames\n", a.size(), b.size()); return 1; }
+        for (size_t k = 0; k < a.size(); k++) if (a[k] != b[k]) { std::printf("chain: frame %zu differs between the synchronous and the free-running chain (overlap %d)\n", k, (int)overlap); return 1; }
+    }
+    std::printf("chain ok: free-running == synchronous, with and without overlap\n");
+    return 0;
+}
+
+// --bench <rows> <cols> <frames>: steady-state frames/s through lvk::StabilizationFilter::apply with the frames resident in HBM
+// (packed overload, then the 4:2:0 overload with overlap on): what bench.py measures over the C-ABI, here through the facade.
+int run_bench(int rows, int cols, int count)
+{
+    const int distinct = 12;
+    std::vector<uint8_t> host((size_t)rows * cols * 3);
+    std::vector<lvk::Frame> packed(distinct);
+    std::vector<lvk::VideoFrame420> planar(distinct);
+    for (int i = 0; i < distinct; i++)
+    {
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++)
+            {
+                uint8_t* p = &host[((size_t)y * cols + x) * 3];
+                const int xs = x + 3 * (i % 4), ys = y + 2 * (i % 3);
+                p[0] = (uint8_t)((((xs / 48) + (ys / 48)) % 2) ? 200 : 40 + (xs * 7 + ys * 13) % 23); p[1] = 128; p[2] = 128;
+            }
+        packed[i].upload(host.data(), rows, cols, lvk::VideoFrame::YUV, i);
+        std::vector<uint8_t> p420((size_t)rows * cols * 3 / 2, 128);
+        for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) p420[(size_t)y * cols + x] = host[((size_t)y * cols + x) * 3];
+        planar[i].upload(p420.data(), rows, cols, false, i);
+    }
+    lvk::hip::shared_context()->check(lvk_hip_sync(lvk::hip::shared_context()->get()), "bench");
+    lvk::StabilizationFilterSettings st;
+    st.detection_resolution = {480, 270}; st.acceptance_threshold = 3.0f; st.track_local_motions = false; st.detection_regions = {2, 1};
+    st.max_feature_density = 0.12f; st.min_feature_density = 0.04f; st.accumulation_rate = 3.0f; st.corrective_limits = {0.05f, 0.05f};
+    st.crop_to_stable_region = true;
+    for (int mode = 0; mode < 3; mode++)
+    {
+        lvk::StabilizationFilter filter(st);
+        filter.set_overlap(mode >= 1);
+        lvk::Frame out; lvk::VideoFrame420 out420;
+        auto step = [&](int i) {
+            if (mode == 2) filter.apply(planar[i % distinct], out420);
+            else filter.apply(packed[i % distinct], out);              // const-ref overload: the resident frame is shared, not consumed
+        };
+        for (int i = 0; i < 40; i++) step(i);
+        filter.context()->check(lvk_hip_sync(filter.context()->get()), "bench");
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < count; i++) step(40 + i);
+        filter.context()->check(lvk_hip_sync(filter.context()->get()), "bench");
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("facade bench %dx%d %s: %.0f frames/s (%.3f ms/frame)\n", cols, rows,
+                    mode == 0 ? "packed" : (mode == 1 ? "packed+overlap" : "i420+overlap"), count / sec, 1e3 * sec / count);
+    }
+    return 0;
+}
+
+} // namespace
+#endif
+
+int main(int argc, char** argv)
 {
 #ifdef RUN_ON_GPU
+    if (argc >= 7 && std::string(argv[1]) == "--golden") return run_golden(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
+    if (argc >= 5 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
+    if (run_chain_race_check() != 0) return 1;
     {
         // VideoFilter::stream (Filters/VideoFilter.cpp:62-209; CLI use Modules/VideoEditor/VideoProcessor.cpp:148-230): reader thread ->
         // filter thread -> callback, frames the filter holds back are skipped, callback returning true stops early
@@ -216,6 +385,7 @@ int main()
     std::printf("emitted %d frames\n", emitted);
     return emitted == 7 ? 0 : 1;
 #else
+    (void)argc; (void)argv;
     // CLI-style construction (FilterParser.tpp:51-64)
     std::printf("conformance TU compiled; sizeof(StabilizationFilterSettings) = %zu\n", sizeof(lvk::StabilizationFilterSettings));
     if (false)
