@@ -151,6 +151,9 @@ struct lvk_hip_stab
     int mark_caller_work()
     {
         if (!(overlap && s.stabilize_output && remap_stream)) return LVK_HIP_OK;
+        // nothing pending on the context's stream (the steady state of a caller whose frames are already resident): nothing to order
+        if (hipStreamQuery(ctx->stream) == hipSuccess) { caller_wait_pending = false; return LVK_HIP_OK; }
+        (void)hipGetLastError();
         if (!caller_ready) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&caller_ready, hipEventDisableTiming));
         LVK_HIP_CHECK(ctx, hipEventRecord(caller_ready, ctx->stream));
         caller_wait_pending = true;

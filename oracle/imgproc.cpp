@@ -7,6 +7,7 @@
 //   cv::FastFeatureDetector(TYPE_9_16, nms=true)  Vision/FeatureDetector.cpp:38-41,130-134
 // Everything here is integer arithmetic except the non-integer INTER_AREA path (binary32, no contraction).
 #include "lvk_oracle.h"
+#include "parallel.h"
 
 #include <cmath>
 #include <cstring>
@@ -89,7 +90,8 @@ int lvko_luma_area_resize(const uint8_t* src, int src_step, int pix_stride, int 
         // the 2x2 case uses the dedicated (a + b + c + d + 2) >> 2 vector kernel.
         const int area = iscale_x * iscale_y;
         const float scale = 1.f / (float)area;
-        for (int y = 0; y < drows; y++)
+        lvko_parallel_for(drows, 8, [&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
             for (int x = 0; x < dcols; x++)
             {
                 int sum = 0;
@@ -98,6 +100,7 @@ int lvko_luma_area_resize(const uint8_t* src, int src_step, int pix_stride, int 
                         sum += S(y * iscale_y + ky, x * iscale_x + kx);
                 dst[(size_t)y * dst_step + x] = (iscale_x == 2 && iscale_y == 2) ? (uint8_t)((sum + 2) >> 2) : sat_u8_round((float)sum * scale);
             }
+        });
         return 0;
     }
     // resizeArea_: separable "decimate alpha" tables, float accumulation in table order.
@@ -236,4 +239,9 @@ int lvko_fast9_16(const uint8_t* img, int step, int roi_x, int roi_y, int roi_w,
     return n;
 }
 
+static int g_lvko_threads = 1;
+int lvko_set_num_threads(int n) { const int prev = g_lvko_threads; g_lvko_threads = n < 1 ? 1 : n; return prev; }
+
 } // extern "C"
+
+int lvko_num_threads() { return g_lvko_threads; }

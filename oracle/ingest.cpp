@@ -10,6 +10,7 @@
 //     source rows clipped individually;
 //   INTER_AREA with scale exactly 2: (a + b + c + d + 2) >> 2.
 #include "lvk_oracle.h"
+#include "parallel.h"
 
 #include <cmath>
 #include <vector>
@@ -67,7 +68,8 @@ int lvko_ingest_yuv420(const uint8_t* y, int y_step, const uint8_t* u, int u_ste
     if (!y || !u || (!nv12 && !v) || !dst || rows <= 0 || cols <= 0 || (rows & 1) || (cols & 1)) return -1;
     const int cr = rows / 2, cc = cols / 2;
     const LinTab8 tx = make_tab(cc, cols, false), ty = make_tab(cr, rows, true);
-    for (int yy = 0; yy < rows; yy++)
+    lvko_parallel_for(rows, 16, [&](int r0, int r1) {
+    for (int yy = r0; yy < r1; yy++)
         for (int xx = 0; xx < cols; xx++)
         {
             uint8_t* d = dst + (size_t)yy * dst_step + 3 * (size_t)xx;
@@ -75,6 +77,7 @@ int lvko_ingest_yuv420(const uint8_t* y, int y_step, const uint8_t* u, int u_ste
             if (nv12) { d[1] = lin8(u, u_step, 2, 0, tx, ty, xx, yy); d[2] = lin8(u, u_step, 2, 1, tx, ty, xx, yy); }
             else { d[1] = lin8(u, u_step, 1, 0, tx, ty, xx, yy); d[2] = lin8(v, v_step, 1, 0, tx, ty, xx, yy); }
         }
+    });
     return 0;
 }
 
@@ -83,9 +86,10 @@ int lvko_egress_yuv420(const uint8_t* src, int src_step, int rows, int cols,
                        uint8_t* y, int y_step, uint8_t* u, int u_step, uint8_t* v, int v_step, int nv12)
 {
     if (!src || !y || !u || (!nv12 && !v) || rows <= 0 || cols <= 0 || (rows & 1) || (cols & 1)) return -1;
-    for (int yy = 0; yy < rows; yy++)
+    lvko_parallel_for(rows / 2, 8, [&](int c0, int c1) {
+    for (int yy = 2 * c0; yy < 2 * c1; yy++)
         for (int xx = 0; xx < cols; xx++) y[(size_t)yy * y_step + xx] = src[(size_t)yy * src_step + 3 * (size_t)xx];
-    for (int cy = 0; cy < rows / 2; cy++)
+    for (int cy = c0; cy < c1; cy++)
         for (int cx = 0; cx < cols / 2; cx++)
             for (int ch = 1; ch <= 2; ch++)
             {
@@ -95,6 +99,7 @@ int lvko_egress_yuv420(const uint8_t* src, int src_step, int rows, int cols,
                 if (nv12) u[(size_t)cy * u_step + 2 * cx + (ch - 1)] = o;
                 else (ch == 1 ? u : v)[(size_t)cy * (ch == 1 ? u_step : v_step) + cx] = o;
             }
+    });
     return 0;
 }
 

@@ -204,6 +204,10 @@ int lvko_upscale(const uint8_t* src, int src_step, int src_rows, int src_cols,
                  uint8_t* dst, int dst_step, int dst_rows, int dst_cols, int yuv, int nthreads);
 int lvko_sharpen(const uint8_t* src, int src_step, int rows, int cols, uint8_t* dst, int dst_step, float sharpness, int nthreads);
 
+/* Thread count of the row / point-parallel stages that take no `nthreads` argument (tracking-frame downscale, optical flow, 4:2:0
+ * conversion); results do not depend on it.  Returns the previous value.  lvko_stab_push* set it from their own argument. */
+int lvko_set_num_threads(int n);
+
 /* native_recip / `1.0f / x` of FSR.cl = the DEVICE's reciprocal (v_rcp_f32 in oracle/_ref).  tab[m] = v_rcp_f32(as_float(0x3f800000 | m))
  * for the 2^23 mantissas m, read from the GPU by the tests; nullptr restores the default (the correctly rounded 1.0f / x).  See easu.cpp. */
 int lvko_set_device_rcp_table(const float* tab, int n);

@@ -9,6 +9,7 @@
 // accumulates in float in a SIMD-width dependent order); all other float ops are the ones written in
 // lkpyramid.cpp, separately rounded (no contraction).
 #include "lvk_oracle.h"
+#include "parallel.h"
 
 #include <cmath>
 #include <cstring>
@@ -90,13 +91,15 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
     const float halfx = (win_w - 1) * 0.5f, halfy = (win_h - 1) * 0.5f;
     const int W_BITS = 14;
     const float FLT_SCALE = 1.f / (1 << 20);
-    std::vector<int> Iw((size_t)win_w * win_h), Ixw((size_t)win_w * win_h), Iyw((size_t)win_w * win_h);
 
     for (int level = top; level >= 0; level--)
     {
         const Level& I = P[level];
         const Level& J = N[level];
-        for (int pt = 0; pt < n; pt++)
+        // the points are independent of each other (OpenCV runs this loop under parallel_for_ as well)
+        lvko_parallel_for(n, 16, [&](int pt0, int pt1) {
+        std::vector<int> Iw((size_t)win_w * win_h), Ixw((size_t)win_w * win_h), Iyw((size_t)win_w * win_h);
+        for (int pt = pt0; pt < pt1; pt++)
         {
             float px = prev_pts[2 * pt] * (float)(1. / (1 << level));
             float py = prev_pts[2 * pt + 1] * (float)(1. / (1 << level));
@@ -181,6 +184,7 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
                 pdx = dx; pdy = dy;
             }
         }
+        });
     }
     return top;
 }

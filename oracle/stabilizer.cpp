@@ -8,6 +8,7 @@
 //   StreamBuffer / SpatialMap / VirtualGrid semantics                Data/StreamBuffer.tpp, Data/SpatialMap.tpp, Math/VirtualGrid.cpp
 // Float elementwise ops follow OpenCV's scalar definitions (separately rounded, no contraction).
 #include "lvk_oracle.h"
+#include "parallel.h"
 
 #include <cmath>
 #include <cstring>
@@ -578,6 +579,8 @@ int lvko_stab_push_fmt(lvko_stab* st, const uint8_t* frame, int step, int rows, 
                        uint8_t* out, int out_step, uint64_t* out_ts, int nthreads)
 {
     if (!st || !frame || rows <= 0 || cols <= 0 || !(format == 0 || format == 2 || format == 4)) return -1;
+    // the tracker's row / point-parallel stages follow the push's thread count (restored on every exit)
+    struct ThreadScope { int prev; explicit ThreadScope(int n) : prev(lvko_set_num_threads(n)) {} ~ThreadScope() { lvko_set_num_threads(prev); } } thread_scope(nthreads);
     const int luma_channel = format == 4 ? 0 : (format == 0 ? -1 : -2);
     lvko_stab::QFrame qf; qf.rows = rows; qf.cols = cols; qf.ts = ts; qf.format = format; qf.px.resize((size_t)rows * cols * 3);
     for (int y = 0; y < rows; y++) std::memcpy(&qf.px[(size_t)y * cols * 3], frame + (size_t)y * step, (size_t)cols * 3);

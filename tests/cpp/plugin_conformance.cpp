@@ -203,28 +203,33 @@ int run_chain_race_check()
     return 0;
 }
 
-// --bench <rows> <cols> <frames>: steady-state frames/s through lvk::StabilizationFilter::apply with the frames resident in HBM
+// --bench <rows> <cols> <frames> <clip.i420> <distinct>: steady-state frames/s through lvk::StabilizationFilter::apply with the frames resident in HBM
 // (packed overload, then the 4:2:0 overload with overlap on): what bench.py measures over the C-ABI, here through the facade.
-int run_bench(int rows, int cols, int count)
+int run_bench(int rows, int cols, int count, const char* clip_path, int distinct)
 {
-    const int distinct = 12;
-    std::vector<uint8_t> host((size_t)rows * cols * 3);
+    // clip_path: `distinct` I420 frames (Y, U, V planes back to back) written by the Python side from the bench's own clip generator, so
+    // that this loop and the C-ABI loop of tests/test_facade_cpp.py see the same pictures
+    std::vector<uint8_t> host((size_t)rows * cols * 3), p420((size_t)rows * cols * 3 / 2);
     std::vector<lvk::Frame> packed(distinct);
     std::vector<lvk::VideoFrame420> planar(distinct);
+    FILE* cf = std::fopen(clip_path, "rb");
+    if (!cf) { std::printf("bench: cannot open %s\n", clip_path); return 1; }
     for (int i = 0; i < distinct; i++)
     {
+        if (std::fread(p420.data(), 1, p420.size(), cf) != p420.size()) { std::printf("bench: short clip file\n"); return 1; }
+        planar[i].upload(p420.data(), rows, cols, false, i);
+        // the packed overload gets the same luma with nearest-neighbour chroma (only its throughput is looked at)
+        const uint8_t* up = p420.data() + (size_t)rows * cols; const uint8_t* vp = up + (size_t)(rows / 2) * (cols / 2);
         for (int y = 0; y < rows; y++)
             for (int x = 0; x < cols; x++)
             {
                 uint8_t* p = &host[((size_t)y * cols + x) * 3];
-                const int xs = x + 3 * (i % 4), ys = y + 2 * (i % 3);
-                p[0] = (uint8_t)((((xs / 48) + (ys / 48)) % 2) ? 200 : 40 + (xs * 7 + ys * 13) % 23); p[1] = 128; p[2] = 128;
+                p[0] = p420[(size_t)y * cols + x]; p[1] = up[(size_t)(y / 2) * (cols / 2) + x / 2]; p[2] = vp[(size_t)(y / 2) * (cols / 2) + x / 2];
             }
         packed[i].upload(host.data(), rows, cols, lvk::VideoFrame::YUV, i);
-        std::vector<uint8_t> p420((size_t)rows * cols * 3 / 2, 128);
-        for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) p420[(size_t)y * cols + x] = host[((size_t)y * cols + x) * 3];
-        planar[i].upload(p420.data(), rows, cols, false, i);
+        lvk::hip::shared_context()->check(lvk_hip_sync(lvk::hip::shared_context()->get()), "bench");
     }
+    std::fclose(cf);
     lvk::hip::shared_context()->check(lvk_hip_sync(lvk::hip::shared_context()->get()), "bench");
     lvk::StabilizationFilterSettings st;
     st.detection_resolution = {480, 270}; st.acceptance_threshold = 3.0f; st.track_local_motions = false; st.detection_regions = {2, 1};
@@ -236,8 +241,9 @@ int run_bench(int rows, int cols, int count)
         filter.set_overlap(mode >= 1);
         lvk::Frame out; lvk::VideoFrame420 out420;
         auto step = [&](int i) {
-            if (mode == 2) filter.apply(planar[i % distinct], out420);
-            else filter.apply(packed[i % distinct], out);              // const-ref overload: the resident frame is shared, not consumed
+            const int period = 2 * distinct - 2, k = i % period, idx = k < distinct ? k : period - k;     // forward, then backward: continuous motion
+            if (mode == 2) filter.apply(planar[idx], out420);
+            else filter.apply(packed[idx], out);                       // const-ref overload: the resident frame is shared, not consumed
         };
         for (int i = 0; i < 40; i++) step(i);
         filter.context()->check(lvk_hip_sync(filter.context()->get()), "bench");
@@ -258,7 +264,7 @@ int main(int argc, char** argv)
 {
 #ifdef RUN_ON_GPU
     if (argc >= 7 && std::string(argv[1]) == "--golden") return run_golden(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
-    if (argc >= 5 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
+    if (argc >= 7 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5], std::atoi(argv[6]));
     if (run_chain_race_check() != 0) return 1;
     {
         // VideoFilter::stream (Filters/VideoFilter.cpp:62-209; CLI use Modules/VideoEditor/VideoProcessor.cpp:148-230): reader thread ->

@@ -57,6 +57,11 @@ class Oracle:
         L.lvko_pyramid_levels.restype = _i
         L.lvko_pyramid_levels.argtypes = [_i, _i, _i, _i, _i, _i32p, _i32p]
 
+    def set_num_threads(self, n):
+        """Thread count of the oracle's row / point-parallel stages outside the stabilizer (results do not depend on it)."""
+        self.lib.lvko_set_num_threads.restype = _c.c_int; self.lib.lvko_set_num_threads.argtypes = [_c.c_int]
+        return self.lib.lvko_set_num_threads(int(n))
+
     def set_device_rcp(self, on=True):
         """native_recip of FSR.cl: the gfx950 table (default) or the correctly rounded reciprocal."""
         fn = self.lib.lvko_set_device_rcp_table

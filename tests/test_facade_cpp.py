@@ -59,12 +59,50 @@ def test_facade_emits_the_golden_frames(tmp_path):
 
 @pytest.mark.gpu
 def test_facade_throughput_at_4k(tmp_path):
-    """Frames/s through lvk::StabilizationFilter::apply at 3840x2160 with resident frames: no per-frame hipMalloc / hipFree (pooled
-    frames), so the facade must run at the C-ABI's rate -- the floor here is generous, the figure is printed for DESIGN.md."""
+    """Frames/s through lvk::StabilizationFilter::apply at 3840x2160 with resident frames against the same loop over the C-ABI
+    (lvk_hip_stab_push_yuv420, what bench.py times) on the same clip, in the same test on the same box: no per-frame hipMalloc / hipFree
+    (pooled frames) and no fences on idle streams, so the facade must stay within 5 % of the C-ABI rate."""
     import re
+    import time
+    import numpy as np
+    import torch
+    import livevisionkit_amd as lvk
+    from tests import clipgen
+    rows, cols, distinct, steps = 2160, 3840, 32, 1500
+    clip = clipgen.Clip(rows, cols, 600, device="cuda")
+    planes = [clip.render_i420(i) for i in range(distinct)]
+    with open(tmp_path / "clip.i420", "wb") as f:
+        for p in planes:
+            for q in p:
+                f.write(q.cpu().numpy().tobytes())
     exe = _build(tmp_path, ["-DRUN_ON_GPU", "-O2"])
-    out = subprocess.check_output([exe, "--bench", "2160", "3840", "600"], timeout=600).decode()
+    out = subprocess.check_output([exe, "--bench", str(rows), str(cols), str(steps), str(tmp_path / "clip.i420"), str(distinct)], timeout=600).decode()
     print(out)
     rates = {m.group(1): float(m.group(2)) for m in re.finditer(r"facade bench 3840x2160 (\S+): (\d+) frames/s", out)}
     assert set(rates) == {"packed", "packed+overlap", "i420+overlap"}
-    assert rates["packed"] > 2000 and rates["i420+overlap"] > 3000, rates
+    # the same loop over the C-ABI from Python (prepared argument blocks, like bench.py)
+    stream = torch.cuda.Stream()
+    ctx = lvk.Context(0, stream=stream)
+    filt = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
+    filt.configure(lvk.StabilizationFilterSettings.obs_preset("homography"))
+    filt.set_overlap(True)
+    args = [filt.prepare_yuv420(p) for p in planes]
+    outs = [filt.prepare_yuv420(tuple(torch.empty_like(q) for q in planes[0])) for _ in range(4)]
+    period = 2 * distinct - 2
+
+    def step(i):
+        k = i % period
+        filt.apply_yuv420_prepared(args[k if k < distinct else period - k], i, outs[i & 3])
+    for i in range(40):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(40 + i)
+    torch.cuda.synchronize()
+    cabi = steps / (time.perf_counter() - t0)
+    filt.close(); ctx.close()
+    print(f"C-ABI loop (Python, prepared arguments): {cabi:.0f} frames/s; facade i420+overlap {rates['i420+overlap']:.0f} frames/s "
+          f"= {100 * rates['i420+overlap'] / cabi:.1f} %")
+    assert rates["i420+overlap"] >= 0.95 * cabi, (rates, cabi)
+    assert rates["packed"] > 2000, rates
