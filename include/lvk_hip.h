@@ -131,6 +131,23 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
                            void* d_dst, int dst_step,
                            const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 
+/* ---- a10: local motion estimate (vector-field preset) ---------------------------------------------------------------
+ * FrameTracker::estimate_local_motions with the constraint system of generate_mesh_constraints (Vision/FrameTracker.cpp:200-321,
+ * 380-457) for a mesh of cols x rows vertices: the least-squares positions of the mesh vertices from the tracked -> matched point pairs
+ * (host arrays of n x 2 floats, tracking-frame coordinates), the temporal rows pulling towards the previous solution, which the
+ * solver object keeps (the reference's m_OptimizedMesh; _reset zeroes it like FrameTracker::restart).  gen_region / the smoothing
+ * weights are those in force when the reference (re)generates the constraints (:74-82); region / temporal_now those of the call.
+ * Outputs: inlier flag per pair (L1 reprojection error < threshold) and the cols x rows x 2 normalised backward offsets of the motion
+ * mesh.  Returns 0, or 2 / 3 when no estimate is possible (a point in the mesh's last cell row / column, singular system).
+ * Solved on the device (normal equations, band L D L^T in binary64); meshes up to 16 columns x 96 rows. */
+typedef struct lvk_hip_mesh_solver lvk_hip_mesh_solver;
+int  lvk_hip_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_region_w, float gen_region_h,
+                                float temporal_smoothing, float local_smoothing, int max_points, lvk_hip_mesh_solver** out);
+void lvk_hip_mesh_solver_destroy(lvk_hip_mesh_solver* solver);
+int  lvk_hip_mesh_solver_reset(lvk_hip_mesh_solver* solver);
+int  lvk_hip_mesh_solver_solve(lvk_hip_mesh_solver* solver, const float* tracked, const float* matched, int n, float region_w, float region_h,
+                               float temporal_now, float threshold, uint8_t* inliers, float* offsets);
+
 /* ---- a3/a4: luma + INTER_AREA downscale ---------------------------------------------------------------
  * VideoFrame::viewAsFormat(GRAY) for YUV frames (= channel 0, Data/VideoFrame.cpp:260) fused with
  * cv::resize(gray, detection_resolution, INTER_AREA) (Vision/FrameTracker.cpp:117).

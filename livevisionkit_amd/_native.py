@@ -35,6 +35,11 @@ _SIG = {
     "lvk_hip_upscale": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "lvk_hip_sharpen": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_float]),
     "lvk_hip_native_rcp": (_c.c_int, [_P, _P, _P, _c.c_size_t]),
+    "lvk_hip_mesh_solver_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_int, _c.POINTER(_P)]),
+    "lvk_hip_mesh_solver_destroy": (None, [_P]),
+    "lvk_hip_mesh_solver_reset": (_c.c_int, [_P]),
+    "lvk_hip_mesh_solver_solve": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_float,
+                                             _c.POINTER(_c.c_uint8), _c.POINTER(_c.c_float)]),
     "lvk_hip_lens_map_create": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.POINTER(_P), _c.POINTER(_c.c_int)]),
     "lvk_hip_lens_map_destroy": (_c.c_int, [_P, _P]),
     "lvk_hip_warpmesh_apply_lens": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int, _P]),

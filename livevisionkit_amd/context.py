@@ -241,6 +241,10 @@ class Context:
                                              float(sharpness)))
         return out
 
+    def mesh_solver(self, cols, rows, gen_region=(480, 270), temporal=1.0, local=20.0, max_points=4096):
+        """FrameTracker's local-motion solver (stage a10) as an object with .solve(tracked, matched, ...), .reset(), .close()."""
+        return MeshSolver(self, cols, rows, gen_region, temporal, local, max_points)
+
     def native_rcp(self, x):
         """native_recip of FSR.cl as this device defines it (v_rcp_f32), elementwise; x: torch float32 on the GPU."""
         import torch
@@ -330,3 +334,33 @@ class Context:
                                                            u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), 1 if nv12 else 0,
                                                            mp, m.shape[0], m.shape[1], bgp))
         return (y, u) if nv12 else (y, u, v)
+
+
+class MeshSolver:
+    """lvk_hip_mesh_solver_*: FrameTracker::estimate_local_motions on the device; keeps the previous solution between calls."""
+
+    def __init__(self, ctx, cols, rows, gen_region, temporal, local, max_points):
+        self.ctx, self.cols, self.rows = ctx, cols, rows
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.lvk_hip_mesh_solver_create(ctx.handle, cols, rows, float(gen_region[0]), float(gen_region[1]), float(temporal), float(local),
+                                                      int(max_points), ctypes.byref(h)))
+        self.handle = h
+
+    def solve(self, tracked, matched, region=(480, 270), temporal=1.0, threshold=10.0):
+        """Returns (status, inliers uint8 [n], offsets float32 [rows, cols, 2]); status 0 = estimate, 2 / 3 = none."""
+        t = np.ascontiguousarray(tracked, np.float32).reshape(-1, 2); m = np.ascontiguousarray(matched, np.float32).reshape(-1, 2)
+        inl = np.zeros(len(t), np.uint8); off = np.zeros((self.rows, self.cols, 2), np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        rc = self.ctx.lib.lvk_hip_mesh_solver_solve(self.handle, t.ctypes.data_as(fp), m.ctypes.data_as(fp), len(t), float(region[0]), float(region[1]),
+                                                    float(temporal), float(threshold), inl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), off.ctypes.data_as(fp))
+        if rc < 0:
+            self.ctx._check(rc)
+        return rc, inl, off
+
+    def reset(self):
+        self.ctx._check(self.ctx.lib.lvk_hip_mesh_solver_reset(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.lvk_hip_mesh_solver_destroy(self.handle)
+            self.handle = None

@@ -295,47 +295,11 @@ private:
     bool m_force = false;
 };
 
-// Right-looking Cholesky of a symmetric positive definite band matrix stored column by column (see MeshSolverH::at), with the
-// forward substitution of g carried along.  Every element (i, k) receives its updates  -= L(i, j) * L(k, j)  for j ascending,
-// exactly like the textbook row-oriented loop; only the traversal is by columns so that the inner loop is contiguous and the
-// compiler can vectorise it across i (independent elements: no reassociation, bit-identical to scalar code; the translation unit
-// is built with -ffp-contract=off).  AVX-512 / AVX2 clones are picked at load time.
-#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
-__attribute__((target_clones("avx512f", "avx2", "default")))
-#endif
-inline bool lvkh_band_cholesky(double* B, double* g, int n, int hb)
-{
-    const size_t ld = (size_t)hb + 1;
-    for (int j = 0; j < n; j++)
-    {
-        double* cj = B + (size_t)j * ld;
-        const double d = std::sqrt(cj[0]);
-        if (!(d > 0.0)) return false;
-        cj[0] = d;
-        const int last = std::min(n - 1, j + hb), len = last - j;
-        for (int t = 1; t <= len; t++) cj[t] = cj[t] / d;
-        g[j] = g[j] / d;
-        const double gj = g[j];
-        for (int t = 1; t <= len; t++) g[j + t] = g[j + t] - cj[t] * gj;
-        for (int t = 1; t <= len; t++)
-        {
-            const double lk = cj[t];
-            double* __restrict ck = B + (size_t)(j + t) * ld;  // column k = j + t: entries (i, k), i = k .. last
-            const double* __restrict cji = cj + t;             // L(i, j), i = k .. last (another column: no overlap)
-            const int m = len - t;
-            for (int u = 0; u <= m; u++) ck[u] = ck[u] - cji[u] * lk;
-        }
-    }
-    return true;
-}
-
 // ------------------------------------------------------------------------------------------------ local motion (vector field)
 // FrameTracker::generate_mesh_constraints + estimate_local_motions (Vision/FrameTracker.cpp:200-321,380-457).
-// The reference hands the sparse least-squares problem to Eigen::LeastSquaresConjugateGradient; this solves the same
-// problem exactly through its normal equations: static rows -> constant band matrix (binary64),
-// feature rows -> Q32 fixed-point sums (exact, order independent), 1e-6 ridge, right-looking banded Cholesky with the
-// forward substitution carried along, column-oriented back substitution; the solution is kept as float.
-// r01 runs it on the host (n = 512 unknowns, half bandwidth 103 for the 16x16 preset).
+// The reference hands the sparse least-squares problem to Eigen::LeastSquaresConjugateGradient; this library solves the same
+// problem exactly through its normal equations ON THE DEVICE (mesh.hip).  What stays on the host is the
+// constant part: the static rows (temporal + similarity constraints) summed into a band matrix once per configuration.
 class MeshSolverH
 {
 public:
@@ -382,76 +346,10 @@ public:
     int rows() const { return m_rows; }
     void reset() { std::fill(m_mesh.begin(), m_mesh.end(), 0.0f); }
 
-    // tracked/matched: interleaved (x, y).  Returns false when a feature falls outside the mesh or the factorisation breaks down.
-    bool solve(const float* tracked, const float* matched, int count, float region_w, float region_h,
-               float temporal_now, float threshold, uint8_t* inlier, float* offsets)
-    {
-        const int n = m_n, hb = m_hb, W = m_cols;
-        const float kw = (((float)m_cols / (float)(m_cols - 1)) * region_w) / (float)m_cols;
-        const float kh = (((float)m_rows / (float)(m_rows - 1)) * region_h) / (float)m_rows;
-        const double Q = 4294967296.0;
-        m_N = m_static;
-        m_g.assign((size_t)n, 0.0);
-        m_Nq.assign((size_t)n * (hb + 1), 0);
-        m_gq.assign((size_t)n, 0);
-        m_fidx.resize((size_t)count * 4); m_fw.resize((size_t)count * 4);
-        for (int i = 0; i < n; i++) m_g[i] = (double)m_ts * (double)(temporal_now * m_mesh[i]);
-
-        for (int f = 0; f < count; f++)
-        {
-            const float px = tracked[2 * f], py = tracked[2 * f + 1];
-            int kx = (int)(size_t)(px / kw), ky = (int)(size_t)(py / kh);
-            kx = std::min(std::max(kx, 0), m_cols - 1); ky = std::min(std::max(ky, 0), m_rows - 1);
-            const int i00 = 2 * (ky * W + kx), i11 = 2 * ((ky + 1) * W + kx + 1);
-            if (i11 + 1 >= n) return false;
-            const int id[4] = {i00, i11 - 2, i11, i00 + 2};                     // TL, BL, BR, TR
-            const float x1 = (float)kx * kw, y1 = (float)ky * kh;
-            const float cw = (float)(kx + 1) * kw - x1, chh = (float)(ky + 1) * kh - y1;
-            const float inv = 1.0f / (cw * chh);
-            const float rx1 = (x1 + cw) - px, ry1 = (y1 + chh) - py, rx2 = px - x1, ry2 = py - y1;
-            const float wgt[4] = {rx1 * ry1 * inv, rx1 * ry2 * inv, rx2 * ry2 * inv, rx2 * ry1 * inv};
-            for (int a = 0; a < 4; a++) { m_fidx[4 * f + a] = id[a]; m_fw[4 * f + a] = wgt[a]; }
-            for (int comp = 0; comp < 2; comp++)
-            {
-                const float target = matched[2 * f + comp];
-                for (int a = 0; a < 4; a++)
-                {
-                    const int ia = id[a] + comp;
-                    m_gq[ia] += llrint((double)wgt[a] * (double)target * Q);
-                    for (int b = 0; b < 4; b++)
-                    {
-                        const int ib = id[b] + comp;
-                        if (ia >= ib) m_Nq[(size_t)ib * (hb + 1) + (ia - ib)] += llrint((double)wgt[a] * (double)wgt[b] * Q);
-                    }
-                }
-            }
-        }
-        for (size_t k = 0; k < m_N.size(); k++) m_N[k] = m_N[k] + (double)m_Nq[k] / Q;
-        for (int i = 0; i < n; i++) { m_g[i] = m_g[i] + (double)m_gq[i] / Q; at(m_N, i, i) = at(m_N, i, i) + 1e-6; }
-
-        if (!lvkh_band_cholesky(m_N.data(), m_g.data(), n, hb)) return false;       // banded Cholesky + forward substitution
-        for (int j = n - 1; j >= 0; j--)                                       // back substitution
-        {
-            m_g[j] = m_g[j] / at(m_N, j, j);
-            for (int k = std::max(0, j - hb); k < j; k++) m_g[k] = m_g[k] - at(m_N, j, k) * m_g[j];
-        }
-        for (int i = 0; i < n; i++) m_mesh[i] = (float)m_g[i];
-
-        for (int f = 0; f < count; f++)
-        {
-            const int* id = &m_fidx[4 * f]; const float* w = &m_fw[4 * f];
-            const float x = w[0] * m_mesh[id[0]] + w[1] * m_mesh[id[1]] + w[2] * m_mesh[id[2]] + w[3] * m_mesh[id[3]];
-            const float y = w[0] * m_mesh[id[0] + 1] + w[1] * m_mesh[id[1] + 1] + w[2] * m_mesh[id[2] + 1] + w[3] * m_mesh[id[3] + 1];
-            inlier[f] = (std::fabs(x - matched[2 * f]) + std::fabs(y - matched[2 * f + 1])) < threshold ? 1 : 0;
-        }
-        for (int r = 0, index = 0; r < m_rows; r++)
-            for (int c = 0; c < m_cols; c++, index++)
-            {
-                offsets[2 * index] = ((float)c * kw - m_mesh[2 * index]) / region_w;
-                offsets[2 * index + 1] = ((float)r * kh - m_mesh[2 * index + 1]) / region_h;
-            }
-        return true;
-    }
+    int n() const { return m_n; }
+    int hb() const { return m_hb; }
+    int static_rows() const { return m_static_rows; }
+    const std::vector<double>& static_band() const { return m_static; }     // lower band, column by column (see at())
 
 private:
     // lower band, column by column: entry (i, j), j <= i <= j + hb, lives at B[j * (hb + 1) + (i - j)] -- the factorisation then walks
@@ -459,10 +357,8 @@ private:
     double& at(std::vector<double>& B, int i, int j) { return B[(size_t)j * (m_hb + 1) + (size_t)(i - j)]; }
     int m_cols = 0, m_rows = 0, m_n = 0, m_hb = 0, m_static_rows = 0;
     float m_ts = 0.0f;
-    std::vector<float> m_mesh, m_fw;
-    std::vector<double> m_static, m_N, m_g;
-    std::vector<long long> m_Nq, m_gq;
-    std::vector<int> m_fidx;
+    std::vector<float> m_mesh;
+    std::vector<double> m_static;
 };
 
 } // namespace lvkh

@@ -227,6 +227,17 @@ int lvk_launch_upscale(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, 
 int lvk_launch_sharpen(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                        void* d_dst, int dst_step, float sharpness);
 
+// Local motion estimate on the device (mesh.hip): the least-squares mesh of FrameTracker::estimate_local_motions
+struct lvk_mesh_solver_dev;
+int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, float gen_h, float temporal, float local, lvk_mesh_solver_dev** out);
+void lvk_mesh_solver_free(lvk_mesh_solver_dev* s);
+int lvk_mesh_solver_reset(lvk_mesh_solver_dev* s, hipStream_t stream);
+int lvk_mesh_solver_cols(const lvk_mesh_solver_dev* s);
+int lvk_mesh_solver_rows(const lvk_mesh_solver_dev* s);
+int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_scratch /* 32 bytes per pair */, const float2* d_p1, const float2* d_p2, const int* d_count, int n_pts,
+                          int min_samples, float region_w, float region_h, float temporal_now, float threshold,
+                          float* h_offsets, uint8_t* h_mask, int* h_status);
+
 // remap + 4:2:0 egress in one kernel (remap.hip)
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,

@@ -117,9 +117,12 @@ struct lvk_hip_stab
     // ---- host state
     lvkh::FeatureGridH grid;
     lvkh::PathSmootherH smoother;
-    lvkh::MeshSolverH solver;                  // FrameTracker's m_MeshConstraints + m_OptimizedMesh
+    // FrameTracker's m_MeshConstraints + m_OptimizedMesh live on the device (mesh.hip); the parameters the constraints were generated with:
+    struct MeshGen { int cols = 0, rows = 0; float w = 0, h = 0, temporal = 0, local = 0; } mesh_gen;
+    lvk_mesh_solver_dev* mesh_dev = nullptr;
+    void* d_mesh_scratch = nullptr; float* h_offsets = nullptr; int* h_mesh_status = nullptr; size_t h_offsets_floats = 0;
+    int ensure_mesh_solver();
     lvk_stab_settings tracker_s{};             // FrameTracker::m_Settings (what the tracker was last configured with)
-    std::vector<float> solver_offsets;
     std::vector<Feature> tracked;
     std::vector<FastRegion> plan;
     std::deque<QueuedFrame> queue;
@@ -246,12 +249,12 @@ int lvk_hip_stab::alloc_pyramids()
 
 void lvk_hip_stab::free_tracker_buffers()
 {
-    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und};
+    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und, d_mesh_scratch};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count};
     for (void* p : host) if (p) (void)hipHostFree(p);
     d_fast_masks = d_fast_scores = nullptr;
-    d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr; d_und = nullptr;
+    d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr; d_und = nullptr; d_mesh_scratch = nullptr;
     h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = nullptr; h_status = nullptr;
     h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr; h_count = nullptr;
 }
@@ -280,6 +283,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipMalloc(&d_ransac_ws, lvk_ransac_workspace_bytes((int)n)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_count, sizeof(int)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_und, 2 * n * sizeof(float2)));
+    LVK_HIP_CHECK(ctx, hipMalloc(&d_mesh_scratch, 32 * n));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
@@ -301,7 +305,7 @@ void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameT
     tracked.clear();
     grid.reset();
     initialized = false;
-    solver.reset();
+    if (mesh_dev) (void)lvk_mesh_solver_reset(mesh_dev, ctx->stream);
     post_n = -1;
 }
 
@@ -356,19 +360,21 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
     const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
                                 || st.max_feature_density != s.max_feature_density;
-    if (!solver.generated())
+    if (mesh_gen.cols == 0)
     {
         // The reference's FrameTracker member is default-constructed first: FrameTracker(FrameTrackerSettings{}) generates the
         // mesh constraints for a 16x16 mesh over its default 256x256 region with weights 1.0 / 20.0 (FrameTracker.cpp:41-53,
         // FrameTracker.hpp:31-44).  configure() below then only regenerates them when the motion resolution changes.
         lvk_stab_default_settings(&tracker_s);
         tracker_s.motion_width = 16; tracker_s.motion_height = 16;
-        solver.generate(16, 16, 256.0f, 256.0f, tracker_s.temporal_smoothing, tracker_s.local_smoothing);
+        mesh_gen = MeshGen{16, 16, 256.0f, 256.0f, tracker_s.temporal_smoothing, tracker_s.local_smoothing};
     }
     if (st.motion_width != tracker_s.motion_width || st.motion_height != tracker_s.motion_height)
-        // FrameTracker.cpp:74-82: new region, but the PREVIOUS settings' smoothing weights
-        solver.generate(st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height,
-                        tracker_s.temporal_smoothing, tracker_s.local_smoothing);
+    {
+        // FrameTracker.cpp:74-82: new region, but the PREVIOUS settings' smoothing weights; m_OptimizedMesh starts from zero again
+        mesh_gen = MeshGen{st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height, tracker_s.temporal_smoothing, tracker_s.local_smoothing};
+        if (mesh_dev) { LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); lvk_mesh_solver_free(mesh_dev); mesh_dev = nullptr; }
+    }
     tracker_s = st;
     smoother.configure(st);
     queue_capacity = (size_t)st.predictive_samples + 1;
@@ -381,6 +387,7 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     if (configured && res_changed && initialized) grid.reset();                          // FrameTracker.cpp:86-91
     s = st;
     configured = true;
+    if (st.track_local_motions) { const int mrc = ensure_mesh_solver(); if (mrc != LVK_HIP_OK) return mrc; }
     if (layout_changed)
     {
         // New tracking geometry: the cached frame no longer matches, which costs one nullopt frame exactly as the
@@ -394,6 +401,25 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
         }
     }
     return LVK_HIP_OK;
+}
+
+// The device-side least-squares solver of the vector-field preset, for the constraints as the reference would have generated them
+int lvk_hip_stab::ensure_mesh_solver()
+{
+    const size_t want = (size_t)s.motion_width * s.motion_height * 2;
+    if (h_offsets_floats < want)
+    {
+        if (h_offsets) (void)hipHostFree(h_offsets);
+        h_offsets = nullptr; h_offsets_floats = 0;
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_offsets, want * sizeof(float), hipHostMallocDefault));
+        h_offsets_floats = want;
+    }
+    if (!h_mesh_status) LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mesh_status, sizeof(int), hipHostMallocDefault));
+    if (mesh_dev) return LVK_HIP_OK;
+    // the mesh the tracker solves for has the motion resolution; a configuration whose constraints were generated for another one
+    // (cannot happen through configure(): a resolution change regenerates them) would index past the mesh
+    LVK_HIP_REQUIRE(ctx, mesh_gen.cols == s.motion_width && mesh_gen.rows == s.motion_height);
+    return lvk_mesh_solver_create(ctx, mesh_gen.cols, mesh_gen.rows, mesh_gen.w, mesh_gen.h, mesh_gen.temporal, mesh_gen.local, &mesh_dev);
 }
 
 // FrameTracker::track (FrameTracker.cpp:108-196)
@@ -450,7 +476,8 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // Global-motion mode without a lens model: the whole chain optical flow -> fast_filter -> RANSAC runs on the GPU without a
     // host round trip in between (the flow kernel reads the points from pinned host memory, k_match_compact reproduces the host's
     // swap-erase order); the host synchronises once and then repeats the cheap bookkeeping on its own copies.
-    const bool chained = !s.track_local_motions && n <= 4096;
+    const bool chained = n <= 4096;
+    const bool field = s.track_local_motions != 0;
     pe = prof_begin(LVK_STAGE_PYRLK);
     if (chained)
     {
@@ -465,7 +492,13 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
                                            lens ? d_und : nullptr, (float)cur_w, (float)cur_h)) != LVK_HIP_OK) return rc;
         prof_end(pe);
         pe = prof_begin(LVK_STAGE_MOTION);
-        if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count)) != LVK_HIP_OK) return rc;
+        if (field)
+        {
+            // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the matches, solved on the device
+            if ((rc = lvk_launch_mesh_solve(mesh_dev, st, d_mesh_scratch, d_p1, d_p1 + cap_features, d_count, n, s.min_motion_samples, (float)cur_w, (float)cur_h,
+                                            s.temporal_smoothing, s.acceptance_threshold, h_offsets, h_mask, h_mesh_status)) != LVK_HIP_OK) return rc;
+        }
+        else if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count)) != LVK_HIP_OK) return rc;
         prof_end(pe);
     }
     else
@@ -492,8 +525,16 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         if (m < 0 || m > n) return fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter returned an impossible count");
         if ((size_t)m < (size_t)s.min_motion_samples) { tracked.clear(); return LVK_HIP_OK; }
         motion = WarpMeshF(s.motion_height, s.motion_width);
-        std::memcpy(last_H, h_H, sizeof(last_H));
-        motion.from_homography(last_H, (float)cur_w, (float)cur_h);
+        if (field)
+        {
+            if (*h_mesh_status != 0) { tracked.clear(); return LVK_HIP_OK; }             // no estimate this frame (identity motion)
+            std::memcpy(motion.off.data(), h_offsets, motion.off.size() * sizeof(float));
+        }
+        else
+        {
+            std::memcpy(last_H, h_H, sizeof(last_H));
+            motion.from_homography(last_H, (float)cur_w, (float)cur_h);
+        }
         size_t inliers = 0;
         for (int i = 0; i < m; i++) inliers += h_mask[i] ? 1 : 0;
         tracking_stability = (float)inliers / (float)m;                                  // ratio_of(inlier_status, 1)
@@ -534,13 +575,20 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     const float2* e2 = lens ? h_und + n : h_matched;
     if (s.track_local_motions)
     {
-        // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the feature matches
-        if (!solver.solve(&e1[0].x, &e2[0].x, m, (float)cur_w, (float)cur_h, s.temporal_smoothing, s.acceptance_threshold,
-                          h_mask, motion.off.data()))
+        // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the feature matches (more matches than the GPU-side
+        // fast_filter handles: the pairs go up in one copy, as for the RANSAC below)
+        std::memcpy(h_p1, e1, m * sizeof(float2));
+        std::memcpy(h_p1 + m, e2, m * sizeof(float2));
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_p1, h_p1, 2 * (size_t)m * sizeof(float2), hipMemcpyHostToDevice, st));
+        if ((rc = lvk_launch_mesh_solve(mesh_dev, st, d_mesh_scratch, d_p1, d_p1 + m, nullptr, m, 0, (float)cur_w, (float)cur_h,
+                                        s.temporal_smoothing, s.acceptance_threshold, h_offsets, h_mask, h_mesh_status)) != LVK_HIP_OK) return rc;
+        LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (*h_mesh_status != 0)
         {
             tracked.clear();                                                          // like the other no-motion exits
             return LVK_HIP_OK;                                                        // no estimate this frame (identity motion)
         }
+        std::memcpy(motion.off.data(), h_offsets, motion.off.size() * sizeof(float));
         size_t inl = 0;
         for (int i = 0; i < m; i++) inl += h_mask[i] ? 1 : 0;
         tracking_stability = (float)inl / (float)m;
@@ -609,7 +657,13 @@ int lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lvk
     auto* st = new lvk_hip_stab();
     st->ctx = ctx;
     const int rc = st->configure(*settings);
-    if (rc != LVK_HIP_OK) { st->free_tracker_buffers(); st->pyr[0].release(); st->pyr[1].release(); delete st; return rc; }
+    if (rc != LVK_HIP_OK)
+    {
+        st->free_tracker_buffers(); lvk_mesh_solver_free(st->mesh_dev); st->pyr[0].release(); st->pyr[1].release();
+        if (st->h_offsets) (void)hipHostFree(st->h_offsets);
+        if (st->h_mesh_status) (void)hipHostFree(st->h_mesh_status);
+        delete st; return rc;
+    }
     *out = st;
     return LVK_HIP_OK;
 }
@@ -620,6 +674,9 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     (void)hipStreamSynchronize(st->ctx->stream);
     st->trace.dump();
     st->free_tracker_buffers();
+    lvk_mesh_solver_free(st->mesh_dev);
+    if (st->h_offsets) (void)hipHostFree(st->h_offsets);
+    if (st->h_mesh_status) (void)hipHostFree(st->h_mesh_status);
     st->pyr[0].release(); st->pyr[1].release();
     st->free_pool();
     if (st->remap_stream)

@@ -12,8 +12,11 @@
 //   S3  feature rows contribute w_a * w_b (exact binary64 product of two floats) quantised to Q32 fixed point
 //       (llrint(p * 2^32)) and summed as exact integers -- order independent; same for g += w * dst;
 //   S4  N = Ns + Q32 sums * 2^-32, plus a 1e-6 ridge on the diagonal; g = ts_rows * (ts_now * previous) + Q32 sums;
-//   S5  banded Cholesky (half bandwidth 2*(3*cols+3)+1), right-looking, then column-oriented forward and backward
-//       substitution, each entry updated in pivot order -- all binary64, no contraction;
+//   S5  banded root-free factorisation N = L D L^T (half bandwidth 2*(3*cols+3)+1), right-looking, pivots as reciprocals (one
+//       division per column, everything else multiplications: the dependent chain per column is one division, one product and one
+//       multiply-subtract -- half of Cholesky's sqrt + division, which is what bounds a GPU implementation), forward substitution
+//       carried along, then D and the column-oriented backward substitution; each entry updated in pivot order -- all binary64,
+//       no contraction;
 //   S6  the solution is stored as float (Eigen::VectorXf m_OptimizedMesh); inlier test and offsets as the reference.
 #include "lvk_oracle.h"
 
@@ -159,27 +162,30 @@ int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const floa
     for (size_t k = 0; k < N.size(); k++) N[k] = N[k] + (double)Nq[k] / Q;
     for (int i = 0; i < n; i++) { g[i] = g[i] + (double)gq[i] / Q; N[(size_t)i * (hb + 1)] = N[(size_t)i * (hb + 1)] + 1e-6; }
 
-    // S5: right-looking banded Cholesky with the forward substitution carried along
+    // S5: root-free banded factorisation N = L D L^T (L unit lower triangular), right-looking, pivots taken as reciprocals, with the
+    // forward substitution carried along.  Column j:  r_j = 1 / N(j, j);  L(i, j) = N(i, j) * r_j;  N(i, k) -= L(i, j) * N(k, j) for
+    // j < k <= i in the band (N(k, j): the UNSCALED entry);  g(i) -= L(i, j) * g(j).  Every entry receives its updates in pivot order.
     auto B = [&](int i, int j) -> double& { return N[(size_t)i * (hb + 1) + (i - j)]; };
+    std::vector<double> rcp((size_t)n), colraw((size_t)hb + 1);
     for (int j = 0; j < n; j++)
     {
-        const double d = std::sqrt(B(j, j));
+        const double d = B(j, j);
         if (!(d > 0.0)) return -2;
-        B(j, j) = d;
+        const double r = 1.0 / d;
+        rcp[j] = r;
         const int last = std::min(n - 1, j + hb);
-        for (int i = j + 1; i <= last; i++) B(i, j) = B(i, j) / d;
-        g[j] = g[j] / d;
+        for (int i = j + 1; i <= last; i++) { colraw[i - j] = B(i, j); B(i, j) = B(i, j) * r; }      // keep the unscaled column for the updates
         for (int i = j + 1; i <= last; i++)
         {
             const double lij = B(i, j);
             g[i] = g[i] - lij * g[j];
-            for (int k = j + 1; k <= i; k++) B(i, k) = B(i, k) - lij * B(k, j);
+            for (int k = j + 1; k <= i; k++) B(i, k) = B(i, k) - lij * colraw[k - j];
         }
     }
-    // backward substitution, column oriented: x[j] = y[j] / L[j][j]; y[k] -= L[j][k] * x[j] for k in the band
+    // D w = z, then L^T x = w column by column: x(j) = w(j), w(k) -= L(j, k) * x(j) for the rows k of the band above j
+    for (int j = 0; j < n; j++) g[j] = g[j] * rcp[j];
     for (int j = n - 1; j >= 0; j--)
     {
-        g[j] = g[j] / B(j, j);
         const int first = std::max(0, j - hb);
         for (int k = first; k < j; k++) g[k] = g[k] - B(j, k) * g[j];
     }

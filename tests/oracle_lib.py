@@ -383,6 +383,9 @@ class OracleMeshSolver:
                                            _p(inl, _u8p), _p(off, _f32p))
         return rc, inl, off
 
+    def reset(self):
+        self.L.lvko_mesh_solver_reset(self.h)
+
     def mesh(self):
         ptr = self.L.lvko_mesh_solver_mesh(self.h)
         return np.ctypeslib.as_array(ptr, shape=(self.rows, self.cols, 2)).copy()
