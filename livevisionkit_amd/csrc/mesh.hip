@@ -25,20 +25,31 @@
 
 namespace {
 
-constexpr int MS_NT = 256;                  // threads of k_mesh_solve
-constexpr int MS_CA = 4, MS_TB = 13;        // register tile: columns x band offsets
+#ifndef LVK_MESH_NT
+#define LVK_MESH_NT 320
+#endif
+#ifndef LVK_MESH_PER_BAND
+#define LVK_MESH_PER_BAND 1
+#endif
+constexpr int MS_NT = LVK_MESH_NT;          // threads of k_mesh_solve: wavefront 0 walks the pivot chain, the others update the window
+constexpr int MS_BULK = MS_NT - 64;
+#ifndef LVK_MESH_TB
+#define LVK_MESH_TB 7
+#endif
+constexpr int MS_CA = 4, MS_TB = LVK_MESH_TB;   // register tile of a window thread: columns x band offsets
 constexpr int MS_HB_MAX = 103;              // widest band phase 1 holds in registers (meshes up to 16 columns)
 constexpr int MS_WP_MAX = 108;              // window columns: hb + 1 + (MS_CA - 1), rounded up to a multiple of MS_CA
 constexpr int MS_PAD = 8;                   // zeros in front of the LDS columns (negative relative indices of the pivot's own group)
 constexpr int MS_LCOL = MS_PAD + 2 * MS_WP_MAX + 2 * MS_TB + 8;
 constexpr double MS_Q = 4294967296.0;       // Q32
-constexpr int MS_N_MAX = 3072;              // unknowns whose right-hand side fits the workgroup's LDS (16 x 96 vertices)
+constexpr int MS_N_MAX = 2048;              // unknowns whose right-hand side fits the workgroup's LDS (16 x 64 vertices)
 constexpr int MS_CHUNK = 16;                // rows of L staged per round of the backward substitution
-constexpr int MS_PF = (MS_CA * (MS_HB_MAX + 1) + MS_NT - 1) / MS_NT;      // prefetched entries per thread and column group
+constexpr int MS_BANDS = (MS_HB_MAX + MS_TB) / MS_TB;                      // bands of MS_TB band offsets
+constexpr int MS_PF = (MS_BANDS * MS_CA * MS_TB + MS_BULK - 1) / MS_BULK;  // prefetched entries per window thread and column group
 
 struct MeshArgs
 {
-    int cols, rows, n, hb, wp;              // wp: window size in columns (multiple of MS_CA, >= hb + MS_CA)
+    int cols, rows, n, hb, nbands;          // nbands: bands of MS_TB band offsets covering 0 .. hb
     const double* stat;                     // static band, column layout: entry (i, k), k <= i <= k + hb, at [k * (hb + 1) + (i - k)]
     long long* Nq; long long* gq;           // Q32 sums of the feature rows (same layout as stat / one per unknown)
     double* N; double* g0;                  // the assembled system (k_mesh_prepare)
@@ -139,46 +150,96 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-struct FactorShared
-{
-    double raw[2][MS_LCOL];                 // pivot column, unscaled: raw[.][MS_PAD + x] = N(p + x, p); zeros elsewhere (two buffers, by step parity)
-    double w[MS_N_MAX];                     // right-hand side: g, then z = L^-1 g, D^-1 z and finally the solution, in place
-    double next[MS_CA][MS_HB_MAX + 1];      // phase 1: the columns that enter the window when the current group is done
-    double lt[2][MS_CHUNK][MS_HB_MAX + 1];  // phase 2: rows of L, staged chunk by chunk
-};
-
 #if defined(LVK_MESH_TIMING) && LVK_MESH_TIMING > 1
 __device__ long long g_mesh_phase[8];
-#define MESH_T(k) do { const long long t_now = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) g_mesh_phase[k] += t_now - t_last; t_last = t_now; } while (0)
-#else
-#define MESH_T(k) do { } while (0)
 #endif
 
-// One elimination step with the pivot at position CK of its column group.  ONE workgroup barrier per step: the pivot column goes through
-// LDS unscaled, and every thread forms the reciprocal pivot and the scaled entries it needs itself (a division and 16 products per
-// thread cost less than a second barrier plus another LDS round trip on the critical path: the steps are latency bound).  The global
-// traffic of a step is one coalesced store per thread (column p of L) and, once per group, two coalesced loads per thread (the columns
-// that enter the window next), both unconditional: the compiler's vmcnt bookkeeping stays exact and nothing ever waits for a store.
-template <int CK>
-__device__ __forceinline__ bool factor_step(const MeshArgs& a, FactorShared& s, double (&A)[MS_CA][MS_TB], double (&pf)[MS_PF],
-                                            double& r_prev, int p, int cg, int tg, bool valid)
+struct FactorShared
 {
-#if defined(LVK_MESH_TIMING) && LVK_MESH_TIMING > 1
-    long long t_last = (long long)__builtin_readcyclecounter();
-#endif
-    const int wp = a.wp, hb = a.hb, ld = hb + 1;
-    const int kp = p % wp, pg = kp / MS_CA;
-    const int t0 = tg * MS_TB;
-    const int tid = (int)threadIdx.x;
-    const double* raw = s.raw[p & 1];
-    // the columns p0 + wp .. p0 + wp + 3 take this group's slots when its last pivot is done: fetched now, parked in LDS two steps on
+    // pivot column p, by step parity: raw[MS_PAD + x] = N(p + x, p) after all earlier pivots, lcol = the same times the reciprocal pivot
+    // (column p of L); zeros outside 0 .. hb (the updates rely on the padding instead of masks)
+    double raw[2][MS_LCOL], lcol[2][MS_LCOL];
+    double col[2][128];                     // column p + 2 as the window threads leave it after pivot p (read by the chain one step later)
+    double w[MS_N_MAX + 128];               // right-hand side: g, then z = L^-1 g, D^-1 z and finally the solution, in place (+ slack: rows beyond n)
+    double next[MS_BANDS][MS_CA][MS_TB];    // phase 1: per band, the columns that enter its window when the current group is done
+    double lt[2][MS_CHUNK][MS_HB_MAX + 1];  // phase 2: rows of L, staged chunk by chunk
+    int fail;
+};
+
+// ---- phase 1, look-ahead organisation -----------------------------------------------------------------------------------------------
+// The steps of the elimination are latency bound (a division, two trips through LDS and a workgroup barrier per pivot), and the work
+// that can run in parallel -- the rank-1 update of the window -- does not depend on that chain once the pivot column is known.  So the
+// two run side by side, one step apart, with ONE barrier per step:
+//   * wavefront 0 (the chain) owns the NEXT pivot column.  During step p it takes column p + 1 as the window threads left it after
+//     pivot p - 1 (col[]), applies pivot p to it, forms the reciprocal pivot and the column of L, and publishes both (raw / lcol of
+//     parity p + 1); it also carries the forward substitution and stores the column of L.
+//   * wavefronts 1 .. 8 (the window) apply pivot p (raw / lcol of parity p, published during step p - 1) to their 4 x 7 register tiles;
+//     the column p + 2 goes first and is handed to the chain through col[].
+// Every entry still receives its updates in pivot order with the same operands: bit-identical to the plain loop.
+__device__ __forceinline__ double readlane64(double v, int src);
+
+// (Both parts are written without per-entry conditions: the LDS arrays are padded with zeros, entries outside the band are zeros that
+//  stay zeros, and every store is unconditional.  The workgroup's nine wavefronts share ONE scalar unit: exec-mask bookkeeping for
+//  per-entry branches made the first version of this loop scalar-issue bound -- 125 scalar instructions per step and wavefront.)
+
+// the chain's part of step p: finishes column p + 1 and turns it into pivot data of parity (p + 1)
+__device__ __forceinline__ void chain_step(const MeshArgs& a, FactorShared& s, int p, double& r_prev)
+{
+    const int lane = (int)threadIdx.x, hb = a.hb, ld = hb + 1, q = p + 1;
+    if (q >= a.n) return;
+    const double* raw = s.raw[p & 1]; const double* lcol = s.lcol[p & 1];
+    const double r1 = raw[MS_PAD + 1];                                  // N(p + 1, p)
+    const double wq = s.w[q];
+    double c[2], wrow[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        const int t = lane + 64 * h;                                    // band offset inside column q; beyond hb everything is zero
+        c[h] = s.col[p & 1][t] - lcol[MS_PAD + 1 + t] * r1;
+        wrow[h] = s.w[q + t];
+    }
+    const double d = readlane64(c[0], 0);
+    if (!(d > 0.0)) { if (lane == 0) s.fail = 1; return; }
+    const double r = 1.0 / d;
+    double* raw_n = s.raw[q & 1]; double* lcol_n = s.lcol[q & 1];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        const int t = lane + 64 * h;
+        const double l = t == 0 ? 0.0 : c[h] * r;
+        raw_n[MS_PAD + t] = c[h]; lcol_n[MS_PAD + t] = l;
+        a.Lc[(size_t)q * ld + min(t, hb + 1 + lane)] = l;               // offsets beyond hb spill into the next columns' slots, which are
+                                                                        // written later (ascending q), or into the dump area at the end
+        s.w[q + t] = wrow[h] - l * wq;                                  // t = 0 and the rows beyond the matrix keep their value (l = 0)
+    }
+    if (lane == 0) s.w[q - 1] = s.w[q - 1] * r_prev;
+    r_prev = r;
+}
+
+// The window.  An entry (column k, band offset t) is touched by pivot p iff (k - p) + t <= hb: a column at distance s from the pivot
+// needs only its offsets t <= hb - s.  The offsets are therefore split into bands of MS_TB, and every band keeps its OWN window of
+// columns: band b (offsets from T = MS_TB b) holds nb(b) = (hb - T + 3) / 4 + 1 column groups -- 27 for the first band, 2 for the last,
+// 221 tiles of 4 x 7 in all instead of the 405 of one common window (of which half would hold entries no pivot reaches yet).  A tile's
+// thread follows the rotation of its band: m = distance (in groups) of its column group from the pivot's, counting down; when its
+// group has been pivoted it takes over the group that enters the band's window, nb(b) groups on.
+__host__ __device__ __forceinline__ int band_groups(int hb, int b) { return (hb - (LVK_MESH_PER_BAND ? MS_TB * b : 0) + 3) / MS_CA + 1; }
+
+// the window's part of step p, pivot at position CK of its column group
+template <int CK>
+__device__ __forceinline__ void window_step(const MeshArgs& a, FactorShared& s, double (&A)[MS_CA][MS_TB], double (&pf)[MS_PF],
+                                            int p, int& m, int nb, int band, bool valid, int btid)
+{
+    const int hb = a.hb, ld = hb + 1, t0 = band * MS_TB;
+    const double* raw = s.raw[p & 1]; const double* lcol = s.lcol[p & 1];
+    // the columns that take over the slots of the pivot's group in each band's window: fetched now, parked in LDS two steps on
     if (CK == 0)
     {
 #pragma unroll
         for (int q = 0; q < MS_PF; q++)
         {
-            const int idx = tid + MS_NT * q, c = idx / (MS_HB_MAX + 1), t = idx - c * (MS_HB_MAX + 1), k = p + wp + c;
-            const bool in = c < MS_CA && k < a.n && t <= hb && k + t < a.n;
+            const int idx = btid + MS_BULK * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
+            const int k = p + MS_CA * band_groups(hb, pb) + c, t = MS_TB * pb + ti;
+            const bool in = pb < a.nbands && t <= hb && k + t < a.n;
             pf[q] = a.N[in ? (size_t)k * ld + t : 0];
             if (!in) pf[q] = 0.0;
         }
@@ -188,69 +249,40 @@ __device__ __forceinline__ bool factor_step(const MeshArgs& a, FactorShared& s, 
 #pragma unroll
         for (int q = 0; q < MS_PF; q++)
         {
-            const int idx = tid + MS_NT * q, c = idx / (MS_HB_MAX + 1), t = idx - c * (MS_HB_MAX + 1);
-            if (c < MS_CA) s.next[c][t] = pf[q];
+            const int idx = btid + MS_BULK * q;
+            if (idx < MS_BANDS * MS_CA * MS_TB) (&s.next[0][0][0])[idx] = pf[q];
         }
     }
-    MESH_T(0);
-    lds_barrier();                                                      // the pivot column (published at the end of the previous step) is visible
-    MESH_T(1);
-    // everything this step reads from LDS, issued together
-    const int ngroups = wp / MS_CA;
-    const int s0 = cg == pg ? -CK : (MS_CA * ((cg - pg + ngroups) % ngroups) - CK);
-    const int t = min(tid, hb + 1);                                     // threads beyond the band see the zero at offset hb + 1
-    const double d = raw[MS_PAD];
-    const double own = raw[MS_PAD + t];
-    const double wp_row = s.w[p], wt_row = s.w[min(p + t, a.n - 1)];
-    double rc[MS_CA], lw[MS_CA + MS_TB - 1];
-#pragma unroll
-    for (int ck = 0; ck < MS_CA; ck++) rc[ck] = raw[MS_PAD + s0 + ck];
-#pragma unroll
-    for (int j = 0; j < MS_CA + MS_TB - 1; j++) lw[j] = raw[MS_PAD + s0 + t0 + j];
-    if (!(d > 0.0)) return false;                                       // uniform: every thread reads the same pivot
-    const double r = 1.0 / d;
-    // column p of L, forward substitution, D^-1 applied to the previous row's z on the way
-    {
-        const double l = (t >= 1 && t <= hb) ? own * r : 0.0;
-        a.Lc[tid <= hb ? (size_t)p * ld + t : (size_t)a.n * ld + tid] = l;   // offset 0 unused; the other threads hit a dump area
-        if (tid == 0) { if (p > 0) s.w[p - 1] = s.w[p - 1] * r_prev; r_prev = r; }
-        else if (tid <= hb && p + t < a.n) s.w[p + t] = wt_row - l * wp_row;
-    }
-    MESH_T(2);
-    // every entry the pivot touches: N(k + t, k) -= L(k + t, p) * N(k, p), k = p + sc.  The column of the next pivot goes first and
-    // is published at once (the other buffer), so that its way through LDS overlaps the rest of the update.
     if (valid)
     {
+        const int s0 = m == 0 ? -CK : MS_CA * m - CK;                   // column distance of the tile's first column from the pivot
+        double rc[MS_CA], lw[MS_CA + MS_TB - 1];
 #pragma unroll
-        for (int ck = 0; ck < MS_CA; ck++) if (cg == pg && ck <= CK) rc[ck] = 0.0;
+        for (int ck = 0; ck < MS_CA; ck++) { const double v = raw[MS_PAD + s0 + ck]; rc[ck] = (s0 + ck <= 1) ? 0.0 : v; }   // spent columns, the pivot, column p + 1 (the chain's)
 #pragma unroll
-        for (int j = 0; j < MS_CA + MS_TB - 1; j++) lw[j] = lw[j] * r;
-        double* raw_next = s.raw[(p + 1) & 1];
-        constexpr int NK = (CK + 1) % MS_CA;                            // position of the next pivot in ITS group
-        const int npg = ((p + 1) % wp) / MS_CA;
+        for (int j = 0; j < MS_CA + MS_TB - 1; j++) lw[j] = lcol[MS_PAD + s0 + t0 + j];
+        // column p + 2 first: it is the chain's input of the next step
+        constexpr int NK = (CK + 2) % MS_CA;
 #pragma unroll
         for (int ti = 0; ti < MS_TB; ti++) A[NK][ti] = A[NK][ti] - lw[NK + ti] * rc[NK];
-        if (CK == MS_CA - 1 && cg == pg)
-        {
-            // this group's slots are taken over by the columns p0 + wp ..: none of them is the next pivot (that one is in group npg)
-        }
-        if (cg == npg)
+        if (s0 + NK == 2)
 #pragma unroll
-            for (int ti = 0; ti < MS_TB; ti++)
-                if (t0 + ti <= hb) raw_next[MS_PAD + t0 + ti] = A[NK][ti];
+            for (int ti = 0; ti < MS_TB; ti++) s.col[(p + 1) & 1][t0 + ti] = A[NK][ti];
 #pragma unroll
         for (int ck = 0; ck < MS_CA; ck++)
             if (ck != NK)
 #pragma unroll
                 for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = A[ck][ti] - lw[ck + ti] * rc[ck];
-        if (CK == MS_CA - 1 && cg == pg)
+        if (CK == MS_CA - 1)
+        {
+            if (m == 0)
 #pragma unroll
-            for (int ck = 0; ck < MS_CA; ck++)
+                for (int ck = 0; ck < MS_CA; ck++)
 #pragma unroll
-                for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = (t0 + ti <= hb) ? s.next[ck][t0 + ti] : 0.0;
+                    for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = s.next[band][ck][ti];
+            m = m == 0 ? nb - 1 : m - 1;
+        }
     }
-    MESH_T(3);
-    return true;
 }
 
 // wave-uniform value of lane `src` of a binary64 register
@@ -267,7 +299,7 @@ void k_mesh_solve(MeshArgs a)
     LVK_TRACKER_PRIORITY();
     __shared__ FactorShared s;
     const int tid = (int)threadIdx.x;
-    const int n = a.n, hb = a.hb, ld = hb + 1, wp = a.wp;
+    const int n = a.n, hb = a.hb, ld = hb + 1;
     const int m = pair_count(a);
     const int flags = *a.flags;
     __syncthreads();
@@ -279,37 +311,92 @@ void k_mesh_solve(MeshArgs a)
 #endif
 
     // ---- phase 1: N = L D L^T and w = D^-1 L^-1 g
-    const int TG = (hb + MS_TB) / MS_TB;                                // band offsets 0 .. hb in groups of MS_TB
-    const int CG = wp / MS_CA;
-    const int cg = tid / TG, tg = tid % TG;
-    const bool valid = cg < CG;
+    const bool chain = tid < 64;
+    const int btid = tid - 64;                                          // window threads
+    // window thread -> (band, slot), slot-major: neighbouring lanes hold neighbouring BANDS of one column group.  Their operand reads are
+    // then 7 doubles apart (2-way bank conflicts at worst); neighbouring groups of one band are 4 doubles apart -- every fourth lane on
+    // the same LDS banks, a 16-way conflict that made the loop twice as slow.
+    int band = a.nbands, slot = 0, nb = 1;
+    if (!chain)
+    {
+        int rem = btid;
+        for (int j = 0; j < band_groups(hb, 0); j++)
+        {
+            // bands that have a slot j: band_groups(hb, b) > j
+            const int cnt = LVK_MESH_PER_BAND ? min(a.nbands, (hb + 3 - MS_CA * j) / MS_TB + 1) : a.nbands;
+            if (rem < cnt) { band = rem; slot = j; break; }
+            rem -= cnt;
+        }
+        nb = band_groups(hb, min(band, a.nbands - 1));
+    }
+    const bool valid = !chain && band < a.nbands;
+    int gdist = slot;                                                   // distance (in column groups) of this tile's group from the pivot's
+    if (chain) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);      // the chain is the critical path
     double A[MS_CA][MS_TB], pf[MS_PF];
 #pragma unroll
     for (int ck = 0; ck < MS_CA; ck++)
 #pragma unroll
-        for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = valid ? load_entry(a, MS_CA * cg + ck, tg * MS_TB + ti) : 0.0;
+        for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = valid ? load_entry(a, MS_CA * slot + ck, band * MS_TB + ti) : 0.0;
 #pragma unroll
     for (int q = 0; q < MS_PF; q++) pf[q] = 0.0;
-    for (int i = tid; i < 2 * MS_LCOL; i += MS_NT) (&s.raw[0][0])[i] = 0.0;
-    for (int i = tid; i < n; i += MS_NT) s.w[i] = a.g0[i];
+    for (int i = tid; i < 2 * MS_LCOL; i += MS_NT) { (&s.raw[0][0])[i] = 0.0; (&s.lcol[0][0])[i] = 0.0; }
+    for (int i = tid; i < 2 * 128; i += MS_NT) (&s.col[0][0])[i] = 0.0;
+    for (int i = tid; i < MS_BANDS * MS_CA * MS_TB; i += MS_NT) (&s.next[0][0][0])[i] = 0.0;
+    for (int i = tid; i < n + 128; i += MS_NT) s.w[i] = i < n ? a.g0[i] : 0.0;
+    if (tid == 0) s.fail = 0;
     __syncthreads();
-    // the first pivot column
-    if (valid && cg == 0)
+    // start-up: pivot 0 straight from N (parity 0), column 1 as the chain's first input
+    double r_prev = 0.0;
+    if (chain)
+    {
+        const double d0 = a.N[0];
+        if (!(d0 > 0.0)) { if (tid == 0) s.fail = 1; }
+        else
+        {
+            const double r = 1.0 / d0, w0 = s.w[0];
 #pragma unroll
-        for (int ti = 0; ti < MS_TB; ti++)
-            if (tg * MS_TB + ti <= hb) s.raw[0][MS_PAD + tg * MS_TB + ti] = A[0][ti];
+            for (int h = 0; h < 2; h++)
+            {
+                const int t = tid + 64 * h;
+                const double c = load_entry(a, 0, min(t, hb + 1)), l = (t >= 1 && t <= hb) ? c * r : 0.0;
+                if (t <= hb) { s.raw[0][MS_PAD + t] = c; s.lcol[0][MS_PAD + t] = l; s.col[0][t] = load_entry(a, 1, t); }
+                a.Lc[t <= hb ? (size_t)t : (size_t)n * ld + tid] = l;
+                if (t >= 1 && t <= hb && t < n) s.w[t] = s.w[t] - l * w0;
+            }
+            r_prev = r;
+        }
+    }
     __syncthreads();
 #ifdef LVK_MESH_TIMING
     const long long tm1 = wall_clock64();
 #endif
-    bool ok = true;
-    double r_prev = 0.0;
+    bool ok = s.fail == 0;
+#if defined(LVK_MESH_TIMING) && LVK_MESH_TIMING > 1
+    long long pt0 = 0, pt1 = 0;
+    const int pslot = tid == 0 ? 0 : (tid == 64 ? 2 : (tid == 64 + 3 * 64 ? 4 : -1));
+#define MESH_PROBE_BEGIN() pt0 = (long long)__builtin_readcyclecounter()
+#define MESH_PROBE_MID() do { pt1 = (long long)__builtin_readcyclecounter(); if (pslot >= 0) g_mesh_phase[pslot] += pt1 - pt0; } while (0)
+#define MESH_PROBE_END() do { pt0 = (long long)__builtin_readcyclecounter(); if (pslot >= 0) g_mesh_phase[pslot + 1] += pt0 - pt1; } while (0)
+#else
+#define MESH_PROBE_BEGIN() do { } while (0)
+#define MESH_PROBE_MID() do { } while (0)
+#define MESH_PROBE_END() do { } while (0)
+#endif
     for (int p0 = 0; p0 < n && ok; p0 += MS_CA)
     {
-        ok = factor_step<0>(a, s, A, pf, r_prev, p0, cg, tg, valid);
-        if (ok && p0 + 1 < n) ok = factor_step<1>(a, s, A, pf, r_prev, p0 + 1, cg, tg, valid);
-        if (ok && p0 + 2 < n) ok = factor_step<2>(a, s, A, pf, r_prev, p0 + 2, cg, tg, valid);
-        if (ok && p0 + 3 < n) ok = factor_step<3>(a, s, A, pf, r_prev, p0 + 3, cg, tg, valid);
+#define LVK_MESH_STEP(CKV)                                                                      \
+        if (ok && p0 + CKV < n)                                                                  \
+        {                                                                                        \
+            MESH_PROBE_BEGIN();                                                                  \
+            if (chain) chain_step(a, s, p0 + CKV, r_prev);                                       \
+            else window_step<CKV>(a, s, A, pf, p0 + CKV, gdist, nb, band, valid, btid);          \
+            MESH_PROBE_MID();                                                                    \
+            lds_barrier();                                                                       \
+            MESH_PROBE_END();                                                                    \
+            ok = s.fail == 0;                                                                    \
+        }
+        LVK_MESH_STEP(0) LVK_MESH_STEP(1) LVK_MESH_STEP(2) LVK_MESH_STEP(3)
+#undef LVK_MESH_STEP
     }
     if (!ok) { if (tid == 0) *a.out_status = 3; return; }
     if (tid == 0) s.w[n - 1] = s.w[n - 1] * r_prev;
@@ -324,8 +411,8 @@ void k_mesh_solve(MeshArgs a)
     // short contiguous column segments.
     const int nchunks = (n + MS_CHUNK - 1) / MS_CHUNK;
     constexpr int PER = ((MS_HB_MAX + MS_CHUNK) * MS_CHUNK + MS_NT - 1) / MS_NT;
-    double stage[PER];
-    auto fetch = [&](int c) {
+    double stage_a[PER], stage_b[PER];
+    auto fetch = [&](int c, double (&stage)[PER]) {
         const int ilo = n - (c + 1) * MS_CHUNK;                          // rows ilo .. ilo + MS_CHUNK - 1 (the top chunk may start below 0)
 #pragma unroll
         for (int q = 0; q < PER; q++)
@@ -336,7 +423,7 @@ void k_mesh_solve(MeshArgs a)
             if (!in) stage[q] = 0.0;
         }
     };
-    auto commit = [&](int c) {
+    auto commit = [&](int c, const double (&stage)[PER]) {
         const int ilo = n - (c + 1) * MS_CHUNK;
 #pragma unroll
         for (int q = 0; q < PER; q++)
@@ -345,7 +432,10 @@ void k_mesh_solve(MeshArgs a)
             if (kk < hb + MS_CHUNK && t >= 1 && t <= hb) s.lt[c & 1][MS_CHUNK - 1 - rr][t] = stage[q];      // row index counted from the chunk's top row
         }
     };
-    fetch(0); commit(0);
+    // chunk c is consumed from LDS while chunk c + 1 waits in registers and chunk c + 2 is in flight (an L2 round trip is several chain chunks long)
+    for (int i = tid; i < 2 * MS_CHUNK; i += MS_NT) (&s.lt[0][0][0])[(size_t)i * (MS_HB_MAX + 1)] = 0.0;     // entry 0 of every staged row: the zero the chain reads for offsets outside the band
+    fetch(0, stage_a); commit(0, stage_a);
+    if (nchunks > 1) fetch(1, stage_a);
     __syncthreads();
     // rows of the 64-row blocks B, B - 1, B - 2 (B = the block of row n - 1), one per lane of wavefront 0
     const int nblocks = (n + 63) / 64;
@@ -353,21 +443,32 @@ void k_mesh_solve(MeshArgs a)
     double cur = 0.0, p1 = 0.0, p2 = 0.0;
     if (tid < 64) { cur = block_rows(nblocks - 1); p1 = block_rows(nblocks - 2); p2 = block_rows(nblocks - 3); }
     int B = nblocks - 1;
-    for (int c = 0; c < nchunks; c++)
-    {
-        if (c + 1 < nchunks) fetch(c + 1);
+    auto chain_chunk = [&](int c) {
         if (tid < 64)
         {
             const int top = n - 1 - c * MS_CHUNK;
-            for (int r = 0; r < MS_CHUNK && top - r >= 0; r++)
+            const int rows_here = min(MS_CHUNK, top + 1);
+            // The three entries of L this lane needs for a row do not depend on the chain: they are read one row ahead.  An offset
+            // outside 1 .. hb reads the row's entry 0, which is zero: the updates below need no masks (the single wavefront of the
+            // chain issues one instruction every ~5 cycles: the row time is its instruction count).
+            auto entries = [&](int r, double& l0, double& l1, double& l2) {
+                const int tc = ((top - r) & 63) - tid;
+                const double* row = s.lt[c & 1][r];
+                l0 = row[(unsigned)(tc - 1) < (unsigned)hb ? tc : 0];
+                l1 = row[tc + 64 <= hb ? tc + 64 : 0];
+                l2 = row[tc + 128 <= hb ? tc + 128 : 0];
+            };
+            double n0, n1, n2;
+            entries(0, n0, n1, n2);
+            for (int r = 0; r < rows_here; r++)
             {
-                const int j = top - r, lj = j & 63;
+                const int lj = (top - r) & 63;
+                const double l0 = n0, l1 = n1, l2 = n2;
+                if (r + 1 < rows_here) entries(r + 1, n0, n1, n2);
                 const double xj = readlane64(cur, lj);
-                const int tc = lj - tid, t1 = tc + 64, t2 = tc + 128;   // band offsets of this lane's rows in cur / p1 / p2
-                const double l0 = s.lt[c & 1][r][min(max(tc, 0), hb)], l1 = s.lt[c & 1][r][min(t1, hb)], l2 = s.lt[c & 1][r][min(t2, hb)];
-                if (tc >= 1 && tc <= hb) cur = cur - l0 * xj;
-                if (t1 <= hb) p1 = p1 - l1 * xj;
-                if (t2 <= hb) p2 = p2 - l2 * xj;
+                cur = cur - l0 * xj;
+                p1 = p1 - l1 * xj;
+                p2 = p2 - l2 * xj;
                 if (lj == 0)
                 {
                     // block B is final: x of its rows; the registers move up one block
@@ -377,7 +478,18 @@ void k_mesh_solve(MeshArgs a)
                 }
             }
         }
-        if (c + 1 < nchunks) commit(c + 1);
+    };
+    for (int c = 0; c < nchunks; c += 2)
+    {
+        // even chunk: chunk c + 1 sits in stage_a, chunk c + 2 goes to stage_b
+        if (c + 2 < nchunks) fetch(c + 2, stage_b);
+        chain_chunk(c);
+        if (c + 1 < nchunks) commit(c + 1, stage_a);
+        __syncthreads();
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) fetch(c + 3, stage_a);
+        chain_chunk(c + 1);
+        if (c + 2 < nchunks) commit(c + 2, stage_b);
         __syncthreads();
     }
 #ifdef LVK_MESH_TIMING
@@ -386,8 +498,8 @@ void k_mesh_solve(MeshArgs a)
     {
         printf("mesh solve: init %lld, factor %lld, backsolve %lld (100 MHz ticks), n %d hb %d\n", tm1 - tm0, tm2 - tm1, tm3 - tm2, n, hb);
 #if LVK_MESH_TIMING > 1
-        printf("  per step (shader cycles, thread 0): prefetch %lld, barrier %lld, reads + pivot + column %lld, update %lld\n",
-               g_mesh_phase[0] / n, g_mesh_phase[1] / n, g_mesh_phase[2] / n, g_mesh_phase[3] / n);
+        printf("  per step (shader cycles): chain work %lld wait %lld | window wave 1 work %lld wait %lld | window wave 4 work %lld wait %lld\n",
+               g_mesh_phase[0] / n, g_mesh_phase[1] / n, g_mesh_phase[2] / n, g_mesh_phase[3] / n, g_mesh_phase[4] / n, g_mesh_phase[5] / n);
         for (int k = 0; k < 8; k++) g_mesh_phase[k] = 0;
 #endif
     }
@@ -421,7 +533,7 @@ void k_mesh_solve(MeshArgs a)
 struct lvk_mesh_solver_dev
 {
     lvk_hip_ctx* ctx = nullptr;
-    int cols = 0, rows = 0, n = 0, hb = 0, wp = 0;
+    int cols = 0, rows = 0, n = 0, hb = 0;
     float ts_gen = 0.0f;
     double* d_stat = nullptr; long long* d_acc = nullptr;   // d_acc: Nq (n * ld) then gq (n), one allocation, one memset per solve
     float* d_mesh = nullptr; double* d_Lc = nullptr; double* d_N = nullptr;      // d_N: band then right-hand side
@@ -443,10 +555,9 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
     *out = nullptr;
     lvkh::MeshSolverH host;
     host.generate(cols, rows, gen_w, gen_h, temporal, local);
-    LVK_HIP_REQUIRE(ctx, host.hb() <= MS_HB_MAX && host.n() <= MS_N_MAX);      // meshes wider than 16 columns / beyond 16 x 96: not supported by the device solver
+    LVK_HIP_REQUIRE(ctx, host.hb() <= MS_HB_MAX && host.n() <= MS_N_MAX);      // meshes wider than 16 columns / beyond 16 x 64: not supported by the device solver
     auto* s = new lvk_mesh_solver_dev();
     s->ctx = ctx; s->cols = cols; s->rows = rows; s->n = host.n(); s->hb = host.hb(); s->ts_gen = temporal;
-    s->wp = ((s->hb + MS_CA + MS_CA - 1) / MS_CA) * MS_CA;
     const size_t band = (size_t)s->n * (s->hb + 1);
     auto fail = [&](hipError_t e) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); };
     hipError_t e;
@@ -485,7 +596,7 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
     LVK_HIP_REQUIRE(ctx, n_pts >= 0 && d_scratch != nullptr);
     const size_t band = (size_t)s->n * (s->hb + 1);
     MeshArgs a;
-    a.cols = s->cols; a.rows = s->rows; a.n = s->n; a.hb = s->hb; a.wp = s->wp;
+    a.cols = s->cols; a.rows = s->rows; a.n = s->n; a.hb = s->hb; a.nbands = (s->hb + MS_TB) / MS_TB;
     a.stat = s->d_stat; a.Nq = s->d_acc; a.gq = s->d_acc + band; a.N = s->d_N; a.g0 = s->d_N + band; a.mesh = s->d_mesh; a.Lc = s->d_Lc;
     a.fidx = (int*)d_scratch; a.fw = (float*)d_scratch + 4 * (size_t)std::max(n_pts, 1); a.p1 = d_p1; a.p2 = d_p2; a.count = d_count; a.n_pts = n_pts; a.min_samples = min_samples;
     a.region_w = region_w; a.region_h = region_h; a.ts_gen = s->ts_gen; a.ts_now = temporal_now; a.threshold = threshold;

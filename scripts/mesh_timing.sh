@@ -9,7 +9,7 @@ if [ "$1" = "build" ]; then
   mkdir -p $T/livevisionkit_amd $T/include $R/livevisionkit_amd/variants
   cp -r $R/livevisionkit_amd/csrc $T/livevisionkit_amd/; cp -r $R/include/* $T/include/
   rm -f $T/livevisionkit_amd/csrc/*.o
-  sed -i "s/^HIPFLAGS *=/HIPFLAGS = -DLVK_MESH_TIMING=${LVK_MESH_TIMING_LEVEL:-1} /" $T/livevisionkit_amd/csrc/Makefile
+  sed -i "s/^HIPFLAGS *=/HIPFLAGS = -DLVK_MESH_TIMING=${LVK_MESH_TIMING_LEVEL:-1} ${LVK_MESH_EXTRA} /" $T/livevisionkit_amd/csrc/Makefile
   make -j8 -C $T/livevisionkit_amd/csrc > /dev/null
   cp $T/livevisionkit_amd/liblvk_hip.so $V
   rm -rf $T
