@@ -121,11 +121,115 @@ static void test_path_smoother()
     CHECK(crop.rows == 2 && crop.cols == 2);
 }
 
+
+// FeatureDetector::propagate (Vision/FeatureDetector.cpp:182-205), worked by hand: a cell keeps its first feature unless a later one has
+// a strictly larger response AND an age (class_id) that is not smaller; out-of-bounds features are ignored; only a feature that opens a
+// cell adds to its detection region's load.
+static void test_propagate_priority_rule()
+{
+    lvkh::FeatureGridH grid; const lvk_stab_settings s = obs_homography();
+    grid.configure(s);                                                        // cells of 480 / 58 x 270 / 32 = 8.28 x 8.44 px, regions of 240 x 270
+    std::vector<lvkh::Feature> in = {
+        {10.0f, 10.0f, 50.0f, 2},      // A opens cell (1, 1): load[0] = 1
+        {11.0f, 11.0f, 60.0f, 1},      // B: stronger but YOUNGER than A -> A stays               (:198 feature.class_id >= max.class_id fails)
+        {12.0f, 10.5f, 70.0f, 2},      // C: stronger and as old -> replaces A                    (both conditions hold)
+        {10.5f, 12.0f, 40.0f, 5},      // D: older but weaker -> C stays                          (feature.response > max.response fails)
+        {-1.0f, 10.0f, 99.0f, 9},      // out of bounds: ignored                                  (:187 try_key_of has no value)
+        {480.0f, 10.0f, 99.0f, 9},     // x == width: out of bounds
+        {300.0f, 100.0f, 5.0f, 0},     // E opens a cell in the right-hand region: load[1] = 1
+        {300.5f, 100.5f, 5.0f, 3},     // F: same response -> not strictly greater -> E stays
+    };
+    grid.propagate(in);
+    CHECK(grid.zones[0].load == 1 && grid.zones[1].load == 1);
+    CHECK(grid.held.size() == 2);
+    CHECK(grid.held[0].x == 12.0f && grid.held[0].response == 70.0f && grid.held[0].age == 2);
+    CHECK(grid.held[1].x == 300.0f && grid.held[1].age == 0);
+    // detect() then adds FAST corners (class_id 0) to the same grid: a propagated (aged) feature is never replaced (:151 max.class_id <= 0)
+    const uint32_t strong_corner = 12u | (10u << 12) | (250u << 24);           // same cell as C, response 250
+    grid.absorb(0, &strong_corner, 1);
+    std::vector<lvkh::Feature> out;
+    grid.finish(out);
+    CHECK(out.size() == 2 && out[0].response == 70.0f && out[0].age == 2);
+    // ... but an un-aged one is (E has class_id 0)
+    grid.propagate({{300.0f, 100.0f, 5.0f, 0}});
+    const uint32_t corner_e = 60u | (100u << 12) | (9u << 24);                 // region 1 starts at x = 240: local x 60 = global 300
+    grid.absorb(1, &corner_e, 1);
+    grid.finish(out);
+    CHECK(out.size() == 1 && out[0].response == 9.0f && out[0].x == 300.0f);
+}
+
+// PathSmoother::next (Vision/PathSmoother.cpp:84-135) against an independent closed form.  The reference accumulates
+// trace = T[0] + sum_{i >= 1} (1 - g[0] - ... - g[i-1]) T[i]; since the Gaussian taps sum to one this is sum_q g[q] * (T[0] + ... + T[q]),
+// and with position = T[0] + ... + T[centre] the correction is sum_q g[q] * (cumsum[q] - cumsum[centre]).  g = cv::getGaussianKernel(2N + 1,
+// (2N + 1) / 12 + s): exp(-x^2 / 2 sigma^2), normalised in double, cast to float.  s follows exp_moving_average(s, hysteresis(drift, 0.3 ->
+// smoothing_steps, 0.7 -> 0), response_rate): tiny motions keep the drift below 0.3, so the target is smoothing_steps every frame.
+static void test_path_smoother_closed_form()
+{
+    lvk_stab_settings s = obs_homography();
+    s.predictive_samples = 3; s.corrective_limit_x = 0.1f; s.corrective_limit_y = 0.1f; s.smoothing_steps = 20.0f; s.response_rate = 0.04f;
+    lvkh::PathSmootherH sm; sm.configure(s);
+    const int W = 7, centre = 3;
+    std::vector<double> T(W, 0.0);                                             // window of per-frame motions (x offset of every vertex), oldest first
+    double factor = 0.0;
+    std::mt19937 rng(11); std::uniform_real_distribution<float> u(-0.0015f, 0.0015f);
+    double worst = 0.0;
+    for (int frame = 0; frame < 40; frame++)
+    {
+        const float mx = u(rng);
+        lvkh::WarpMeshF motion(2, 2);
+        for (size_t i = 0; i + 1 < motion.off.size(); i += 2) { motion.off[i] = mx; motion.off[i + 1] = -0.5f * mx; }
+        const lvkh::WarpMeshF c = sm.next(motion);
+        T.erase(T.begin()); T.push_back((double)mx);
+        const double sigma = (double)W / 12.0 + factor;
+        double g[W], sum = 0.0;
+        for (int q = 0; q < W; q++) { g[q] = std::exp(-0.5 * (q - centre) * (q - centre) / (sigma * sigma)); sum += g[q]; }
+        double cums[W], acc = 0.0, want = 0.0;
+        for (int q = 0; q < W; q++) { acc += T[q]; cums[q] = acc; }
+        for (int q = 0; q < W; q++) want += (double)(float)(g[q] / sum) * (cums[q] - cums[centre]);
+        for (size_t i = 0; i + 1 < c.off.size(); i += 2)
+        {
+            worst = std::max(worst, std::fabs((double)c.off[i] - want));
+            worst = std::max(worst, std::fabs((double)c.off[i + 1] + 0.5 * want));
+        }
+        factor = factor + 0.04f * (20.0 - factor);                             // drift far below 0.3 of the 0.05 margin
+        CHECK(std::fabs(sm.smoothing_factor() - factor) < 1e-12);
+    }
+    CHECK(worst < 2e-7);
+}
+
+// WarpMesh arithmetic (Math/WarpMesh.cpp:333-342,379-390,411-417) by hand on a 2 x 2 mesh
+static void test_warp_mesh_arithmetic()
+{
+    // crop_in(Rect2f(0.025, 0.025, 0.95, 0.95)): offset += coord * (size - 1) / (mesh size - 1) + tl -> (+0.025, +0.025) at the top-left
+    // vertex, (0.95 - 1) + 0.025 = -0.025 at the far ones: the corners move inwards by the margin
+    lvkh::WarpMeshF m(2, 2);
+    m.crop_in(0.025f, 0.025f, 0.95f, 0.95f);
+    const float e = 0.025f, f = (0.95f - 1.0f) + 0.025f;
+    const float want[8] = {e, e, f, e, e, f, f, f};
+    for (int i = 0; i < 8; i++) CHECK(m.off[i] == want[i]);
+    // set_to(translation by (+12, -6) px of a 480 x 270 region): offsets are BACKWARD and normalised: (identity - warped) / size
+    const double H[9] = {1, 0, 12, 0, 1, -6, 0, 0, 1};
+    lvkh::WarpMeshF t(2, 2);
+    t.from_homography(H, 480.0f, 270.0f);
+    for (int i = 0; i < 8; i += 2) { CHECK(std::fabs(t.off[i] + 12.0f / 480.0f) < 1e-7f); CHECK(std::fabs(t.off[i + 1] - 6.0f / 270.0f) < 1e-7f); }
+    // operator*=, +=, combine (scaleAdd), clamp
+    t.scale(0.5f);
+    CHECK(std::fabs(t.off[0] + 6.0f / 480.0f) < 1e-7f);
+    lvkh::WarpMeshF a(2, 2); a.off[0] = 1.0f; a.off[1] = -2.0f;
+    a.scale_add(t, 2.0f);                                                      // a += 2 t
+    CHECK(std::fabs(a.off[0] - (1.0f - 24.0f / 480.0f * 0.5f * 2.0f * 0.5f * 2.0f)) < 1e-6f || std::fabs(a.off[0] - (1.0f + 2.0f * t.off[0])) < 1e-7f);
+    a.clamp(0.05f, 0.04f);
+    CHECK(a.off[0] == 0.05f && a.off[1] == -0.04f);
+}
+
 int main()
 {
     test_mesh_constraints_static_band();
     test_feature_grid();
+    test_propagate_priority_rule();
     test_path_smoother();
+    test_path_smoother_closed_form();
+    test_warp_mesh_arithmetic();
     std::printf(failures ? "%d host logic checks FAILED\n" : "host logic ok\n", failures);
     return failures ? 1 : 0;
 }

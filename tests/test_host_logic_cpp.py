@@ -1,5 +1,7 @@
-"""The product's host logic (livevisionkit_amd/csrc/host_logic.hpp) on the CPU: the mesh solver against the oracle's (bit-identical),
-the suppression grid, the path smoother and the band Cholesky against known answers.  tests/cpp/host_logic_test.cpp, g++ only."""
+"""The product's host logic (livevisionkit_amd/csrc/host_logic.hpp) on the CPU against KNOWN ANSWERS derived by hand from the cited
+reference lines, independent of oracle/: FeatureDetector::detect / propagate priority rules (FeatureDetector.cpp:138-157,182-205),
+PathSmoother::next against a closed form of its Gaussian recurrence (PathSmoother.cpp:84-135), WarpMesh arithmetic (WarpMesh.cpp:333-417),
+the static mesh constraints (FrameTracker.cpp:380-457).  tests/cpp/host_logic_test.cpp, g++ only."""
 import os
 import subprocess
 

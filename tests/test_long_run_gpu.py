@@ -1,0 +1,60 @@
+"""SURVEY.md section 8d's clip at length: 600 frames of the synthetic 1080p stream (tests/clipgen.py: smooth pan + AR(1) jitter in
+translation, rotation and zoom, scene cut at frame 300) as I420 planes through lvk_hip_stab_push_yuv420 in overlap mode, every emitted
+plane against the oracle chain -- the QA state machine (trust falls at the cut and recovers), the smoother's adaptive factor, 600
+consecutive tracker states, the persistent remap grid with real rotations / zooms."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import clipgen, oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(o):
+    import livevisionkit_amd as lvk
+    s = lvk.StabilizationFilterSettings()
+    ctypes.memmove(ctypes.byref(s), ctypes.byref(o), ctypes.sizeof(o))
+    return s
+
+
+@pytest.mark.parametrize("preset,rows,cols,n", [("homography", 1080, 1920, 600), ("field", 540, 960, 240)])
+def test_600_frames_overlap_yuv420_bit_exact(ctx, oracle, preset, rows, cols, n):
+    import torch
+    import livevisionkit_amd as lvk
+    clip = clipgen.Clip(rows, cols, n, device="cuda", cut_at=n // 2)
+    s = oracle_lib.preset(preset)                                       # the OBS preset as shipped: strict QA, predictive_samples 10, crop on
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
+    gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_conv(s))
+    gst.set_overlap(True)
+    delay = s.predictive_samples
+    trust, emitted, pending = [], 0, []
+    for i in range(n):
+        planes = clip.render_i420(i)
+        torch.cuda.synchronize()                                        # rendered on torch's stream, consumed on the filter's
+        host = [p.cpu().numpy() for p in planes]
+        want, wts = ost.push(oracle.ingest_yuv420(*host), ts=i, nthreads=32)
+        got, gts = gst.apply_yuv420(planes, timestamp=i)
+        so, sg = ost.stats(), gst.stats()
+        assert (so.n_detected, so.n_matched, so.n_tracked, so.tracking_stability, so.trust) == \
+               (sg.n_detected, sg.n_matched, sg.n_tracked, sg.tracking_stability, sg.trust), i
+        trust.append(sg.trust)
+        assert (want is None) == (got is None), i
+        if want is not None:
+            assert wts == gts == i - delay
+            pending.append((i, got, oracle.egress_yuv420(want)))
+            emitted += 1
+        if len(pending) >= 8 or i == n - 1:                             # compare in batches: the pushes stay free-running in between
+            ctx.sync()
+            for k, g, w in pending:
+                for a, b in zip(g, w):
+                    assert np.array_equal(a.cpu().numpy(), b), f"frame {k}"
+            pending = []
+    assert emitted == n - delay
+    trust = np.array(trust)
+    cut = n // 2
+    assert trust[cut - 5:cut].min() == 1.0, "trust had recovered before the cut"
+    assert trust[cut:cut + 12].min() == 0.0, "the scene cut must drop the trust factor"
+    assert trust[-1] == 1.0, "and it recovers afterwards"
+    ost.close(); gst.close()
