@@ -55,6 +55,12 @@ def pmc(kind, counter):
 
 
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+sq = {c: pmc("sq", c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES")}
+if any(sq.values()):
+    with open(os.path.join(dst, f"{tag}_sq_counters_per_kernel.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES (one run), wave-instructions per launch (averages)\n")
+        for k in sorted(set().union(*[set(v) for v in sq.values()])):
+            f.write(k + " " + " ".join("%s=%.0f" % (c, v[k][1] / v[k][0]) for c, v in sq.items() if k in v) + "\n")
 if fetch or write:
     with open(os.path.join(dst, f"{tag}_pmc_traffic.csv"), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), per-launch averages. Units: KiB as reported;\n")
@@ -67,8 +73,10 @@ if fetch or write:
     key = max((k for k in fetch if k.startswith("k_remap")), key=lambda k: fetch[k][0], default=None)      # the remap the pipeline runs
     if key:
         fk = fetch[key][1] / fetch[key][0]; wk = write.get(key, [1, 0.0]); wk = wk[1] / max(1, wk[0])
+        valu = sq["SQ_INSTS_VALU"].get(key)
         json.dump({"rows": rows, "cols": cols, "kernel": key, "fetch_size_KiB": fk, "write_size_KiB": wk,
                    "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+                   "valu_per_px": (valu[1] / valu[0]) * 64.0 / (rows * cols) if valu else None,
                    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request); WRITE_SIZE as reported"},
                   open(os.path.join(dst, "remap_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read())
