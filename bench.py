@@ -270,6 +270,7 @@ def main():
         meshes = filt.meshes()[1]
         srcs = frames[:8] if frames is not None else [clip.render444(i) for i in range(8)]
         dst = torch.empty_like(srcs[0])
+        torch.cuda.synchronize()                                 # the frames are rendered on torch's stream, the remap runs on the filter's
         bgc = tuple(int(v) for v in settings.background)
         with torch.cuda.stream(work_stream):
             for _ in range(3):
