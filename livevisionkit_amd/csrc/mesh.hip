@@ -6,7 +6,7 @@
 //   static rows  -> a constant band matrix, built once per configuration on the host (host_logic.hpp, MeshSolverH::generate);
 //   feature rows -> Q32 fixed-point sums accumulated with integer atomics (exact, order independent)          k_mesh_assemble
 //   N = L D L^T  -> right-looking root-free band factorisation with reciprocal pivots, forward substitution carried along,
-//                   every entry updated in pivot order (binary64, products and differences rounded separately)   k_mesh_solve, phase 1
+//                   every entry updated in pivot order by fused multiply-subtracts (binary64)                        k_mesh_solve, phase 1
 //   L^T          -> column-oriented backward substitution (one wavefront, the rows in flight in registers)       k_mesh_solve, phase 2
 //   inlier flags (L1 reprojection error through the feature's quad) and the normalised mesh offsets             k_mesh_solve, phase 3
 // The previous solution (the reference's m_OptimizedMesh: warm start there, right-hand side of the temporal rows here) stays on the
@@ -25,27 +25,46 @@
 
 namespace {
 
-#ifndef LVK_MESH_NT
-#define LVK_MESH_NT 320
-#endif
-#ifndef LVK_MESH_PER_BAND
-#define LVK_MESH_PER_BAND 1
-#endif
-constexpr int MS_NT = LVK_MESH_NT;          // threads of k_mesh_solve: wavefront 0 walks the pivot chain, the others update the window
-constexpr int MS_BULK = MS_NT - 64;
 #ifndef LVK_MESH_TB
-#define LVK_MESH_TB 7
+#define LVK_MESH_TB 8
 #endif
+#ifndef LVK_MESH_WIN_WAVES
+#define LVK_MESH_WIN_WAVES 4
+#endif
+#ifndef LVK_MESH_FWD_WAVE
+#define LVK_MESH_FWD_WAVE (LVK_MESH_WIN_WAVES + 1)
+#endif
+// k_mesh_solve's wavefronts by role: wavefront 0 walks the pivot chain, wavefront MS_FWD_WAVE carries the forward substitution and stores
+// the columns of L, the others update the window.  (Wavefronts go to the CU's four SIMDs round robin: with three window wavefronts the two
+// light roles share SIMD 0 and every window wavefront has a SIMD of its own.)
+constexpr int MS_WIN_WAVES = LVK_MESH_WIN_WAVES, MS_FWD_WAVE = LVK_MESH_FWD_WAVE;
+constexpr int MS_NT = 64 * (MS_WIN_WAVES + 2);
+constexpr int MS_BULK = 64 * MS_WIN_WAVES;  // window threads
 constexpr int MS_CA = 4, MS_TB = LVK_MESH_TB;   // register tile of a window thread: columns x band offsets
 constexpr int MS_HB_MAX = 103;              // widest band phase 1 holds in registers (meshes up to 16 columns)
 constexpr int MS_WP_MAX = 108;              // window columns: hb + 1 + (MS_CA - 1), rounded up to a multiple of MS_CA
 constexpr int MS_PAD = 8;                   // zeros in front of the LDS columns (negative relative indices of the pivot's own group)
 constexpr int MS_LCOL = MS_PAD + 2 * MS_WP_MAX + 2 * MS_TB + 8;
+// LDS layouts.  All window wavefronts read their operands from the pivot column every step -- 15 values per thread, 23 KB per step
+// through the CU's one LDS pipeline -- at addresses 4 m + MS_TB b + j (m: column group of the tile, b: its band).  In a plain array the
+// 64 lanes of a read fall on a few banks (strides of 4 and 8 doubles over 32 double-wide banks): measured, every read took four passes
+// and the LDS pipeline, not the arithmetic, set the pace of the factorisation.  So the pivot columns are stored with one spare slot
+// after every four entries -- logical 4 y + r at 5 y + r: tiles with different (m + MS_TB / 4 b) hit different banks, equal ones the
+// same address (a broadcast); MS_TB is a multiple of 4 so that r is a compile-time constant of every read.  The hand-over arrays are
+// skewed the same way (one spare slot per band).
+static_assert(MS_TB % 4 == 0 && MS_PAD % 4 == 0, "the padded LDS layout needs band boundaries at multiples of 4");
+constexpr int ms_px(int x) { return 5 * ((x + 64) / 4 - 16) + (x + 64) % 4; }      // padded position of logical index x (x >= -64)
+constexpr int MS_LCOL_P = ms_px(MS_LCOL) + 8;
+constexpr int MS_COL_P = 128 + 128 / MS_TB + 1;                                     // col[]: logical t at t + t / MS_TB
+constexpr int MS_NEXT_BAND = MS_CA * MS_TB + 1;                                     // next[]: one spare slot per band
 constexpr double MS_Q = 4294967296.0;       // Q32
 constexpr int MS_N_MAX = 2048;              // unknowns whose right-hand side fits the workgroup's LDS (16 x 64 vertices)
 constexpr int MS_CHUNK = 16;                // rows of L staged per round of the backward substitution
 constexpr int MS_BANDS = (MS_HB_MAX + MS_TB) / MS_TB;                      // bands of MS_TB band offsets
 constexpr int MS_PF = (MS_BANDS * MS_CA * MS_TB + MS_BULK - 1) / MS_BULK;  // prefetched entries per window thread and column group
+constexpr int ms_tiles(int hb) { int t = 0; for (int b = 0; b < (hb + MS_TB) / MS_TB; b++) t += (hb - MS_TB * b + 3) / MS_CA + 1; return t; }
+static_assert(ms_tiles(MS_HB_MAX) <= MS_BULK, "one register tile per window thread");
+static_assert(MS_BANDS * MS_TB <= 128 && MS_HB_MAX < 128, "a column is two registers per lane of the chain");
 
 struct MeshArgs
 {
@@ -54,7 +73,7 @@ struct MeshArgs
     long long* Nq; long long* gq;           // Q32 sums of the feature rows (same layout as stat / one per unknown)
     double* N; double* g0;                  // the assembled system (k_mesh_prepare)
     float* mesh;                            // previous solution (absolute tracking-frame coordinates), updated on success
-    double* Lc;                             // columns of L: L(i, k) at [k * (hb + 1) + (i - k)], plus MS_NT entries of dump area
+    double* Lc;                             // columns of L: L(i, k) at [k * (hb + 1) + (i - k)]
     int* fidx; float* fw;                   // per feature: the 4 unknown indices (x components) and barycentric weights
     const float2* p1; const float2* p2;     // tracked / matched points
     const int* count; int n_pts;            // number of pairs: *count when count != nullptr (decided on the GPU), else n_pts
@@ -156,130 +175,188 @@ __device__ long long g_mesh_phase[8];
 
 struct FactorShared
 {
-    // pivot column p, by step parity: raw[MS_PAD + x] = N(p + x, p) after all earlier pivots, lcol = the same times the reciprocal pivot
-    // (column p of L); zeros outside 0 .. hb (the updates rely on the padding instead of masks)
-    double raw[2][MS_LCOL], lcol[2][MS_LCOL];
-    double col[2][128];                     // column p + 2 as the window threads leave it after pivot p (read by the chain one step later)
-    double w[MS_N_MAX + 128];               // right-hand side: g, then z = L^-1 g, D^-1 z and finally the solution, in place (+ slack: rows beyond n)
-    double next[MS_BANDS][MS_CA][MS_TB];    // phase 1: per band, the columns that enter its window when the current group is done
+    // pivot column p, by step parity: raw[MS_PAD + x] = N(p + x, p) after all earlier pivots (the entries x = 0, 1 -- the pivot itself and
+    // the row of column p + 1, which is the chain's -- are stored as zeros: to the window threads those columns are spent), lcol = the
+    // column times the reciprocal pivot (column p of L, entry 0 stored as zero); zeros outside 0 .. hb: the updates rely on the padding
+    // instead of masks.  rinv: the reciprocal pivot.
+    double raw[2][MS_LCOL_P], lcol[2][MS_LCOL_P];     // padded layout: logical index x at ms_px(x)
+    double rinv[2];
+    double col[2][MS_COL_P];                   // column p + 2 as the window threads leave it after pivot p (read by the chain one step later)
+    double w[MS_N_MAX + 128];               // right-hand side: g, then D^-1 L^-1 g and finally the solution, in place (+ slack: rows beyond n)
+    double next[MS_BANDS][MS_NEXT_BAND];    // phase 1: per band, the columns that enter its window when the current group is done
     double lt[2][MS_CHUNK][MS_HB_MAX + 1];  // phase 2: rows of L, staged chunk by chunk
     int fail;
 };
 
 // ---- phase 1, look-ahead organisation -----------------------------------------------------------------------------------------------
-// The steps of the elimination are latency bound (a division, two trips through LDS and a workgroup barrier per pivot), and the work
-// that can run in parallel -- the rank-1 update of the window -- does not depend on that chain once the pivot column is known.  So the
-// two run side by side, one step apart, with ONE barrier per step:
-//   * wavefront 0 (the chain) owns the NEXT pivot column.  During step p it takes column p + 1 as the window threads left it after
-//     pivot p - 1 (col[]), applies pivot p to it, forms the reciprocal pivot and the column of L, and publishes both (raw / lcol of
-//     parity p + 1); it also carries the forward substitution and stores the column of L.
-//   * wavefronts 1 .. 8 (the window) apply pivot p (raw / lcol of parity p, published during step p - 1) to their 4 x 7 register tiles;
-//     the column p + 2 goes first and is handed to the chain through col[].
-// Every entry still receives its updates in pivot order with the same operands: bit-identical to the plain loop.
+// The steps of the elimination are latency bound: a single wavefront issues an instruction every 5-7 cycles, whatever it is, so the time
+// of a step is the longest instruction stream between two barriers plus the dependent latencies on it (a trip through LDS, a division).
+// Three roles run side by side, one step apart, with ONE barrier per step:
+//   * the chain (one wavefront) owns the NEXT pivot column.  During step p it takes column p + 1 as the window threads left it after
+//     pivot p - 1 (col[]), applies pivot p to it, forms the reciprocal pivot and the column of L and publishes them (parity p + 1).
+//     Nothing else: ~45 instructions with one LDS read, one division and one LDS write on the dependent path.
+//   * the window (MS_WIN_WAVES wavefronts) applies pivot p (published during step p - 1) to its 4 x MS_TB register tiles; the column
+//     p + 2 goes first and is handed to the chain through col[].
+//   * the forward substitution (one wavefront) applies pivot p to the right-hand side, scales its row p by the reciprocal pivot and
+//     stores column p of L for phase 2.
+// Every entry still receives its updates in pivot order with the same operands: bit-identical to the plain loop of the specification.
 __device__ __forceinline__ double readlane64(double v, int src);
 
-// (Both parts are written without per-entry conditions: the LDS arrays are padded with zeros, entries outside the band are zeros that
-//  stay zeros, and every store is unconditional.  The workgroup's nine wavefronts share ONE scalar unit: exec-mask bookkeeping for
+// (All parts are written without per-entry conditions: the LDS arrays are padded with zeros, entries outside the band are zeros that
+//  stay zeros, and every store is unconditional.  The workgroup's wavefronts share ONE scalar unit: exec-mask bookkeeping for
 //  per-entry branches made the first version of this loop scalar-issue bound -- 125 scalar instructions per step and wavefront.)
 
-// the chain's part of step p: finishes column p + 1 and turns it into pivot data of parity (p + 1)
-__device__ __forceinline__ void chain_step(const MeshArgs& a, FactorShared& s, int p, double& r_prev)
+// the chain's part of step p = p0 + CK (p0 a multiple of MS_CA): finishes column p + 1 and turns it into pivot data of parity (p + 1).
+// r1 = N(p + 1, p), the unscaled entry of the pivot column p in the row of column p + 1 (wave uniform); bad: a pivot was not positive.
+template <int CK>
+__device__ __forceinline__ void chain_step(const MeshArgs& a, FactorShared& s, int p, double& r1, bool& bad)
 {
-    const int lane = (int)threadIdx.x, hb = a.hb, ld = hb + 1, q = p + 1;
+    const int lane = (int)threadIdx.x, q = p + 1;
     if (q >= a.n) return;
-    const double* raw = s.raw[p & 1]; const double* lcol = s.lcol[p & 1];
-    const double r1 = raw[MS_PAD + 1];                                  // N(p + 1, p)
-    const double wq = s.w[q];
-    double c[2], wrow[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-    {
-        const int t = lane + 64 * h;                                    // band offset inside column q; beyond hb everything is zero
-        c[h] = s.col[p & 1][t] - lcol[MS_PAD + 1 + t] * r1;
-        wrow[h] = s.w[q + t];
-    }
-    const double d = readlane64(c[0], 0);
-    if (!(d > 0.0)) { if (lane == 0) s.fail = 1; return; }
+    const double* lcol = s.lcol[CK & 1];
+    const int x1 = ms_px(MS_PAD + 1 + lane), x0 = ms_px(MS_PAD + lane), tc = lane + lane / MS_TB, tc2 = (lane + 64) + (lane + 64) / MS_TB;
+    const double c0 = __builtin_fma(-lcol[x1], r1, s.col[CK & 1][tc]);                 // band offsets t = lane and t = lane + 64 of
+    const double c1 = __builtin_fma(-lcol[x1 + 80], r1, s.col[CK & 1][tc2]);           // column q; beyond hb everything is zero
+    const double d = readlane64(c0, 0);
+    r1 = readlane64(c0, 1);
+    bad = bad || !(d > 0.0);
     const double r = 1.0 / d;
-    double* raw_n = s.raw[q & 1]; double* lcol_n = s.lcol[q & 1];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-    {
-        const int t = lane + 64 * h;
-        const double l = t == 0 ? 0.0 : c[h] * r;
-        raw_n[MS_PAD + t] = c[h]; lcol_n[MS_PAD + t] = l;
-        a.Lc[(size_t)q * ld + min(t, hb + 1 + lane)] = l;               // offsets beyond hb spill into the next columns' slots, which are
-                                                                        // written later (ascending q), or into the dump area at the end
-        s.w[q + t] = wrow[h] - l * wq;                                  // t = 0 and the rows beyond the matrix keep their value (l = 0)
-    }
-    if (lane == 0) s.w[q - 1] = s.w[q - 1] * r_prev;
-    r_prev = r;
+    double* raw_n = s.raw[(CK + 1) & 1]; double* lcol_n = s.lcol[(CK + 1) & 1];
+    raw_n[x0] = lane <= 1 ? 0.0 : c0;
+    raw_n[x0 + 80] = c1;                                                                // ms_px(x + 64) = ms_px(x) + 80
+    lcol_n[x0] = lane == 0 ? 0.0 : c0 * r;
+    lcol_n[x0 + 80] = c1 * r;
+    if (lane == 0) s.rinv[(CK + 1) & 1] = r;
+}
+
+// the forward substitution's part of step p: z(p + t) -= L(p + t, p) z(p) for the rows of the band, row p becomes z(p) / d(p); column p
+// of L goes to global memory for phase 2.  (The wavefront's LDS accesses execute in order: the rows written here are read back by the
+// same wavefront one step later without a barrier.)
+template <int CK>
+__device__ __forceinline__ void forward_step(const MeshArgs& a, FactorShared& s, int p)
+{
+    const int lane = (int)threadIdx.x & 63, hb = a.hb;
+    const double* lcol = s.lcol[CK & 1];
+    const int x0 = ms_px(MS_PAD + lane);
+    const double l0 = lcol[x0], l1 = lcol[x0 + 80];                                                  // l0 of lane 0 is stored as zero
+    const double wq = s.w[p], w0 = s.w[p + lane], w1 = s.w[p + 64 + lane], r = s.rinv[CK & 1];
+    const double n0 = __builtin_fma(-l0, wq, w0);
+    s.w[p + lane] = lane == 0 ? wq * r : n0;                                                        // rows beyond the matrix keep their zeros (l = 0)
+    s.w[p + 64 + lane] = __builtin_fma(-l1, wq, w1);
+    double* Lp = a.Lc + (size_t)p * (hb + 1);
+    if (lane <= hb) Lp[lane] = l0;
+    if (lane + 64 <= hb) Lp[lane + 64] = l1;
 }
 
 // The window.  An entry (column k, band offset t) is touched by pivot p iff (k - p) + t <= hb: a column at distance s from the pivot
 // needs only its offsets t <= hb - s.  The offsets are therefore split into bands of MS_TB, and every band keeps its OWN window of
 // columns: band b (offsets from T = MS_TB b) holds nb(b) = (hb - T + 3) / 4 + 1 column groups -- 27 for the first band, 2 for the last,
-// 221 tiles of 4 x 7 in all instead of the 405 of one common window (of which half would hold entries no pivot reaches yet).  A tile's
+// 177 tiles of 4 x 9 in all instead of the 324 of one common window (of which half would hold entries no pivot reaches yet).  A tile's
 // thread follows the rotation of its band: m = distance (in groups) of its column group from the pivot's, counting down; when its
 // group has been pivoted it takes over the group that enters the band's window, nb(b) groups on.
-__host__ __device__ __forceinline__ int band_groups(int hb, int b) { return (hb - (LVK_MESH_PER_BAND ? MS_TB * b : 0) + 3) / MS_CA + 1; }
+__host__ __device__ __forceinline__ int band_groups(int hb, int b) { return (hb - MS_TB * b + 3) / MS_CA + 1; }
+
+// entries of the column groups that enter the bands' windows when the group at p0 has been pivoted: fetch (N is read once, in band
+// order) and hand-over to the tiles through LDS
+__device__ __forceinline__ void window_fetch(const MeshArgs& a, double (&pf)[MS_PF], int p0, int btid)
+{
+    const int hb = a.hb, ld = hb + 1;
+#pragma unroll
+    for (int q = 0; q < MS_PF; q++)
+    {
+        const int idx = btid + MS_BULK * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
+        const int k = p0 + MS_CA * band_groups(hb, pb) + c, t = MS_TB * pb + ti;
+        const bool in = pb < a.nbands && t <= hb && k + t < a.n;
+        pf[q] = a.N[in ? (size_t)k * ld + t : 0];
+    }
+}
+__device__ __forceinline__ void window_park(const MeshArgs& a, FactorShared& s, const double (&pf)[MS_PF], int p0, int btid)
+{
+    const int hb = a.hb;
+#pragma unroll
+    for (int q = 0; q < MS_PF; q++)
+    {
+        const int idx = btid + MS_BULK * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
+        const int k = p0 + MS_CA * band_groups(hb, pb) + c, t = MS_TB * pb + ti;
+        const bool in = pb < a.nbands && t <= hb && k + t < a.n;
+        if (idx < MS_BANDS * MS_CA * MS_TB) s.next[pb][rem] = in ? pf[q] : 0.0;
+    }
+}
 
 // the window's part of step p, pivot at position CK of its column group
 template <int CK>
 __device__ __forceinline__ void window_step(const MeshArgs& a, FactorShared& s, double (&A)[MS_CA][MS_TB], double (&pf)[MS_PF],
                                             int p, int& m, int nb, int band, bool valid, int btid)
 {
-    const int hb = a.hb, ld = hb + 1, t0 = band * MS_TB;
-    const double* raw = s.raw[p & 1]; const double* lcol = s.lcol[p & 1];
-    // the columns that take over the slots of the pivot's group in each band's window: fetched now, parked in LDS two steps on
-    if (CK == 0)
-    {
-#pragma unroll
-        for (int q = 0; q < MS_PF; q++)
-        {
-            const int idx = btid + MS_BULK * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
-            const int k = p + MS_CA * band_groups(hb, pb) + c, t = MS_TB * pb + ti;
-            const bool in = pb < a.nbands && t <= hb && k + t < a.n;
-            pf[q] = a.N[in ? (size_t)k * ld + t : 0];
-            if (!in) pf[q] = 0.0;
-        }
-    }
-    if (CK == 2)
-    {
-#pragma unroll
-        for (int q = 0; q < MS_PF; q++)
-        {
-            const int idx = btid + MS_BULK * q;
-            if (idx < MS_BANDS * MS_CA * MS_TB) (&s.next[0][0][0])[idx] = pf[q];
-        }
-    }
+    const int t0 = band * MS_TB;
+    const double* raw = s.raw[CK & 1]; const double* lcol = s.lcol[CK & 1];
+    // the columns that take over the slots of a pivoted group in each band's window travel one group ahead: what was fetched a group ago
+    // is parked in LDS now (read at the end of this group), and the fetch for the next group is issued -- four steps of distance, no
+    // step ever waits for global memory (fetch and use in the same group cost a memory latency every fourth step: 800 cycles per step
+    // on average, more than the arithmetic)
+#ifndef LVK_MESH_DBG_NOFETCH
+    if (CK == 0) { window_park(a, s, pf, p, btid); window_fetch(a, pf, p + MS_CA, btid); }
+#endif
     if (valid)
     {
-        const int s0 = m == 0 ? -CK : MS_CA * m - CK;                   // column distance of the tile's first column from the pivot
+        const int s0 = MS_CA * m - CK;                                  // column distance of the tile's first column from the pivot
+        const int yr = 5 * m, yl = 5 * (m + (MS_TB / 4) * band);        // padded positions of MS_PAD + 4 m and MS_PAD + 4 m + t0, less ms_px(MS_PAD)
         double rc[MS_CA], lw[MS_CA + MS_TB - 1];
 #pragma unroll
-        for (int ck = 0; ck < MS_CA; ck++) { const double v = raw[MS_PAD + s0 + ck]; rc[ck] = (s0 + ck <= 1) ? 0.0 : v; }   // spent columns, the pivot, column p + 1 (the chain's)
+        for (int ck = 0; ck < MS_CA; ck++) rc[ck] = raw[yr + ms_px(MS_PAD + ck - CK)];      // zero for spent columns, the pivot and column p + 1 (the chain's)
 #pragma unroll
-        for (int j = 0; j < MS_CA + MS_TB - 1; j++) lw[j] = lcol[MS_PAD + s0 + t0 + j];
+        for (int j = 0; j < MS_CA + MS_TB - 1; j++) lw[j] = lcol[yl + ms_px(MS_PAD + j - CK)];
+#if defined(LVK_MESH_DBG_READS)
+        for (int rr = 1; rr < LVK_MESH_DBG_READS; rr++)
+        {
+            int off = 1024 * (rr & 1);                                                              // other addresses, same bank pattern
+            asm volatile("" : "+v"(off));
+            const double* vl = lcol + off; const double* vr = raw + off;
+            double t0v[MS_CA], t1v[MS_CA + MS_TB - 1];
+#pragma unroll
+            for (int ck = 0; ck < MS_CA; ck++) t0v[ck] = vr[yr + ms_px(MS_PAD + ck - CK)];
+#pragma unroll
+            for (int j = 0; j < MS_CA + MS_TB - 1; j++) t1v[j] = vl[yl + ms_px(MS_PAD + j - CK)];
+#pragma unroll
+            for (int ck = 0; ck < MS_CA; ck++) asm volatile("" :: "v"(t0v[ck]));
+#pragma unroll
+            for (int j = 0; j < MS_CA + MS_TB - 1; j++) asm volatile("" :: "v"(t1v[j]));
+        }
+#endif
+#if defined(LVK_MESH_DBG_FMAS)
+        for (int rr = 1; rr < LVK_MESH_DBG_FMAS; rr++)
+#pragma unroll
+            for (int ck = 0; ck < MS_CA; ck++)
+#pragma unroll
+                for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = __builtin_fma(-lw[ck + ti], rc[ck], A[ck][ti]);
+#endif
         // column p + 2 first: it is the chain's input of the next step
         constexpr int NK = (CK + 2) % MS_CA;
 #pragma unroll
-        for (int ti = 0; ti < MS_TB; ti++) A[NK][ti] = A[NK][ti] - lw[NK + ti] * rc[NK];
+        for (int ti = 0; ti < MS_TB; ti++) A[NK][ti] = __builtin_fma(-lw[NK + ti], rc[NK], A[NK][ti]);
+#ifndef LVK_MESH_DBG_NOHANDOFF
         if (s0 + NK == 2)
+#else
+        if (s0 + NK == 2 && p < 0)
+#endif
 #pragma unroll
-            for (int ti = 0; ti < MS_TB; ti++) s.col[(p + 1) & 1][t0 + ti] = A[NK][ti];
+            for (int ti = 0; ti < MS_TB; ti++) s.col[(CK + 1) & 1][t0 + band + ti] = A[NK][ti];
 #pragma unroll
         for (int ck = 0; ck < MS_CA; ck++)
             if (ck != NK)
 #pragma unroll
-                for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = A[ck][ti] - lw[ck + ti] * rc[ck];
+                for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = __builtin_fma(-lw[ck + ti], rc[ck], A[ck][ti]);
         if (CK == MS_CA - 1)
         {
+#ifndef LVK_MESH_DBG_NOTAKEOVER
             if (m == 0)
+#else
+            if (m == 0 && p < 0)
+#endif
 #pragma unroll
                 for (int ck = 0; ck < MS_CA; ck++)
 #pragma unroll
-                    for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = s.next[band][ck][ti];
+                    for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = s.next[band][ck * MS_TB + ti];
             m = m == 0 ? nb - 1 : m - 1;
         }
     }
@@ -311,25 +388,25 @@ void k_mesh_solve(MeshArgs a)
 #endif
 
     // ---- phase 1: N = L D L^T and w = D^-1 L^-1 g
-    const bool chain = tid < 64;
-    const int btid = tid - 64;                                          // window threads
+    const int wave = tid >> 6;
+    const bool chain = wave == 0, forward = wave == MS_FWD_WAVE;
+    const int btid = (wave - 1 - (wave > MS_FWD_WAVE ? 1 : 0)) * 64 + (tid & 63);      // index among the window threads
     // window thread -> (band, slot), slot-major: neighbouring lanes hold neighbouring BANDS of one column group.  Their operand reads are
-    // then 7 doubles apart (2-way bank conflicts at worst); neighbouring groups of one band are 4 doubles apart -- every fourth lane on
+    // then MS_TB doubles apart (2-way bank conflicts at worst); neighbouring groups of one band are 4 doubles apart -- every fourth lane on
     // the same LDS banks, a 16-way conflict that made the loop twice as slow.
     int band = a.nbands, slot = 0, nb = 1;
-    if (!chain)
+    if (!chain && !forward)
     {
         int rem = btid;
         for (int j = 0; j < band_groups(hb, 0); j++)
         {
-            // bands that have a slot j: band_groups(hb, b) > j
-            const int cnt = LVK_MESH_PER_BAND ? min(a.nbands, (hb + 3 - MS_CA * j) / MS_TB + 1) : a.nbands;
+            const int cnt = min(a.nbands, (hb + 3 - MS_CA * j) / MS_TB + 1);     // bands that have a slot j: band_groups(hb, b) > j
             if (rem < cnt) { band = rem; slot = j; break; }
             rem -= cnt;
         }
         nb = band_groups(hb, min(band, a.nbands - 1));
     }
-    const bool valid = !chain && band < a.nbands;
+    const bool valid = !chain && !forward && band < a.nbands;
     int gdist = slot;                                                   // distance (in column groups) of this tile's group from the pivot's
     if (chain) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);      // the chain is the critical path
     double A[MS_CA][MS_TB], pf[MS_PF];
@@ -339,41 +416,37 @@ void k_mesh_solve(MeshArgs a)
         for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = valid ? load_entry(a, MS_CA * slot + ck, band * MS_TB + ti) : 0.0;
 #pragma unroll
     for (int q = 0; q < MS_PF; q++) pf[q] = 0.0;
-    for (int i = tid; i < 2 * MS_LCOL; i += MS_NT) { (&s.raw[0][0])[i] = 0.0; (&s.lcol[0][0])[i] = 0.0; }
-    for (int i = tid; i < 2 * 128; i += MS_NT) (&s.col[0][0])[i] = 0.0;
-    for (int i = tid; i < MS_BANDS * MS_CA * MS_TB; i += MS_NT) (&s.next[0][0][0])[i] = 0.0;
+    if (!chain && !forward) window_fetch(a, pf, 0, btid);              // parked at step 0, taken over at the end of the first group
+    for (int i = tid; i < 2 * MS_LCOL_P; i += MS_NT) { (&s.raw[0][0])[i] = 0.0; (&s.lcol[0][0])[i] = 0.0; }
+    for (int i = tid; i < 2 * MS_COL_P; i += MS_NT) (&s.col[0][0])[i] = 0.0;
+    for (int i = tid; i < MS_BANDS * MS_NEXT_BAND; i += MS_NT) (&s.next[0][0])[i] = 0.0;
     for (int i = tid; i < n + 128; i += MS_NT) s.w[i] = i < n ? a.g0[i] : 0.0;
     if (tid == 0) s.fail = 0;
     __syncthreads();
     // start-up: pivot 0 straight from N (parity 0), column 1 as the chain's first input
-    double r_prev = 0.0;
+    double r1 = 0.0; bool bad = false;
     if (chain)
     {
         const double d0 = a.N[0];
-        if (!(d0 > 0.0)) { if (tid == 0) s.fail = 1; }
-        else
-        {
-            const double r = 1.0 / d0, w0 = s.w[0];
+        bad = !(d0 > 0.0);
+        const double r = 1.0 / d0;
+        r1 = n > 1 ? load_entry(a, 0, 1) : 0.0;
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-            {
-                const int t = tid + 64 * h;
-                const double c = load_entry(a, 0, min(t, hb + 1)), l = (t >= 1 && t <= hb) ? c * r : 0.0;
-                if (t <= hb) { s.raw[0][MS_PAD + t] = c; s.lcol[0][MS_PAD + t] = l; s.col[0][t] = load_entry(a, 1, t); }
-                a.Lc[t <= hb ? (size_t)t : (size_t)n * ld + tid] = l;
-                if (t >= 1 && t <= hb && t < n) s.w[t] = s.w[t] - l * w0;
-            }
-            r_prev = r;
+        for (int h = 0; h < 2; h++)
+        {
+            const int t = tid + 64 * h;
+            const double c = load_entry(a, 0, t);
+            if (t <= hb) { s.raw[0][ms_px(MS_PAD + t)] = t <= 1 ? 0.0 : c; s.lcol[0][ms_px(MS_PAD + t)] = t == 0 ? 0.0 : c * r; s.col[0][t + t / MS_TB] = load_entry(a, 1, t); }
         }
+        if (tid == 0) s.rinv[0] = r;
     }
     __syncthreads();
 #ifdef LVK_MESH_TIMING
     const long long tm1 = wall_clock64();
 #endif
-    bool ok = s.fail == 0;
 #if defined(LVK_MESH_TIMING) && LVK_MESH_TIMING > 1
     long long pt0 = 0, pt1 = 0;
-    const int pslot = tid == 0 ? 0 : (tid == 64 ? 2 : (tid == 64 + 3 * 64 ? 4 : -1));
+    const int pslot = tid == 0 ? 0 : (tid == 64 * MS_FWD_WAVE ? 2 : (tid == 64 * (MS_FWD_WAVE == 1 ? 2 : 1) ? 4 : -1));
 #define MESH_PROBE_BEGIN() pt0 = (long long)__builtin_readcyclecounter()
 #define MESH_PROBE_MID() do { pt1 = (long long)__builtin_readcyclecounter(); if (pslot >= 0) g_mesh_phase[pslot] += pt1 - pt0; } while (0)
 #define MESH_PROBE_END() do { pt0 = (long long)__builtin_readcyclecounter(); if (pslot >= 0) g_mesh_phase[pslot + 1] += pt0 - pt1; } while (0)
@@ -382,25 +455,27 @@ void k_mesh_solve(MeshArgs a)
 #define MESH_PROBE_MID() do { } while (0)
 #define MESH_PROBE_END() do { } while (0)
 #endif
-    for (int p0 = 0; p0 < n && ok; p0 += MS_CA)
+    for (int p0 = 0; p0 < n; p0 += MS_CA)
     {
 #define LVK_MESH_STEP(CKV)                                                                      \
-        if (ok && p0 + CKV < n)                                                                  \
+        if (p0 + CKV < n)                                                                        \
         {                                                                                        \
             MESH_PROBE_BEGIN();                                                                  \
-            if (chain) chain_step(a, s, p0 + CKV, r_prev);                                       \
+            if (chain) chain_step<CKV>(a, s, p0 + CKV, r1, bad);                                 \
+            else if (forward) forward_step<CKV>(a, s, p0 + CKV);                                 \
             else window_step<CKV>(a, s, A, pf, p0 + CKV, gdist, nb, band, valid, btid);          \
             MESH_PROBE_MID();                                                                    \
             lds_barrier();                                                                       \
             MESH_PROBE_END();                                                                    \
-            ok = s.fail == 0;                                                                    \
         }
         LVK_MESH_STEP(0) LVK_MESH_STEP(1) LVK_MESH_STEP(2) LVK_MESH_STEP(3)
 #undef LVK_MESH_STEP
     }
-    if (!ok) { if (tid == 0) *a.out_status = 3; return; }
-    if (tid == 0) s.w[n - 1] = s.w[n - 1] * r_prev;
+    if (tid == 0 && bad) s.fail = 1;
     __syncthreads();
+#ifndef LVK_MESH_TIMING
+    if (s.fail != 0) { if (tid == 0) *a.out_status = 3; return; }
+#endif
 #ifdef LVK_MESH_TIMING
     const long long tm2 = wall_clock64();
 #endif
@@ -466,9 +541,9 @@ void k_mesh_solve(MeshArgs a)
                 const double l0 = n0, l1 = n1, l2 = n2;
                 if (r + 1 < rows_here) entries(r + 1, n0, n1, n2);
                 const double xj = readlane64(cur, lj);
-                cur = cur - l0 * xj;
-                p1 = p1 - l1 * xj;
-                p2 = p2 - l2 * xj;
+                cur = __builtin_fma(-l0, xj, cur);
+                p1 = __builtin_fma(-l1, xj, p1);
+                p2 = __builtin_fma(-l2, xj, p2);
                 if (lj == 0)
                 {
                     // block B is final: x of its rows; the registers move up one block
@@ -498,7 +573,7 @@ void k_mesh_solve(MeshArgs a)
     {
         printf("mesh solve: init %lld, factor %lld, backsolve %lld (100 MHz ticks), n %d hb %d\n", tm1 - tm0, tm2 - tm1, tm3 - tm2, n, hb);
 #if LVK_MESH_TIMING > 1
-        printf("  per step (shader cycles): chain work %lld wait %lld | window wave 1 work %lld wait %lld | window wave 4 work %lld wait %lld\n",
+        printf("  per step (shader cycles): chain work %lld wait %lld | forward work %lld wait %lld | window work %lld wait %lld\n",
                g_mesh_phase[0] / n, g_mesh_phase[1] / n, g_mesh_phase[2] / n, g_mesh_phase[3] / n, g_mesh_phase[4] / n, g_mesh_phase[5] / n);
         for (int k = 0; k < 8; k++) g_mesh_phase[k] = 0;
 #endif

@@ -15,8 +15,8 @@
 //   S5  banded root-free factorisation N = L D L^T (half bandwidth 2*(3*cols+3)+1), right-looking, pivots as reciprocals (one
 //       division per column, everything else multiplications: the dependent chain per column is one division, one product and one
 //       multiply-subtract -- half of Cholesky's sqrt + division, which is what bounds a GPU implementation), forward substitution
-//       carried along, then D and the column-oriented backward substitution; each entry updated in pivot order -- all binary64,
-//       no contraction;
+//       carried along, then D and the column-oriented backward substitution; each entry updated in pivot order, every update ONE
+//       fused multiply-subtract fma(-l, c, x) (half the dependent instructions of a product and a difference; binary64);
 //   S6  the solution is stored as float (Eigen::VectorXf m_OptimizedMesh); inlier test and offsets as the reference.
 #include "lvk_oracle.h"
 
@@ -163,7 +163,7 @@ int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const floa
     for (int i = 0; i < n; i++) { g[i] = g[i] + (double)gq[i] / Q; N[(size_t)i * (hb + 1)] = N[(size_t)i * (hb + 1)] + 1e-6; }
 
     // S5: root-free banded factorisation N = L D L^T (L unit lower triangular), right-looking, pivots taken as reciprocals, with the
-    // forward substitution carried along.  Column j:  r_j = 1 / N(j, j);  L(i, j) = N(i, j) * r_j;  N(i, k) -= L(i, j) * N(k, j) for
+    // forward substitution carried along.  Column j:  r_j = 1 / N(j, j);  L(i, j) = N(i, j) * r_j;  N(i, k) = fma(-L(i, j), N(k, j), N(i, k)) for
     // j < k <= i in the band (N(k, j): the UNSCALED entry);  g(i) -= L(i, j) * g(j).  Every entry receives its updates in pivot order.
     auto B = [&](int i, int j) -> double& { return N[(size_t)i * (hb + 1) + (i - j)]; };
     std::vector<double> rcp((size_t)n), colraw((size_t)hb + 1);
@@ -178,8 +178,8 @@ int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const floa
         for (int i = j + 1; i <= last; i++)
         {
             const double lij = B(i, j);
-            g[i] = g[i] - lij * g[j];
-            for (int k = j + 1; k <= i; k++) B(i, k) = B(i, k) - lij * colraw[k - j];
+            g[i] = std::fma(-lij, g[j], g[i]);
+            for (int k = j + 1; k <= i; k++) B(i, k) = std::fma(-lij, colraw[k - j], B(i, k));
         }
     }
     // D w = z, then L^T x = w column by column: x(j) = w(j), w(k) -= L(j, k) * x(j) for the rows k of the band above j
@@ -187,7 +187,7 @@ int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const floa
     for (int j = n - 1; j >= 0; j--)
     {
         const int first = std::max(0, j - hb);
-        for (int k = first; k < j; k++) g[k] = g[k] - B(j, k) * g[j];
+        for (int k = first; k < j; k++) g[k] = std::fma(-B(j, k), g[j], g[k]);
     }
     for (int i = 0; i < n; i++) s->mesh[i] = (float)g[i];
 
