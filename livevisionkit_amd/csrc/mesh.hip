@@ -29,7 +29,7 @@ namespace {
 #define LVK_MESH_TB 8
 #endif
 #ifndef LVK_MESH_WIN_WAVES
-#define LVK_MESH_WIN_WAVES 4
+#define LVK_MESH_WIN_WAVES 3
 #endif
 #ifndef LVK_MESH_FWD_WAVE
 #define LVK_MESH_FWD_WAVE (LVK_MESH_WIN_WAVES + 1)
@@ -60,9 +60,11 @@ constexpr int MS_NEXT_BAND = MS_CA * MS_TB + 1;                                 
 constexpr double MS_Q = 4294967296.0;       // Q32
 constexpr int MS_N_MAX = 2048;              // unknowns whose right-hand side fits the workgroup's LDS (16 x 64 vertices)
 constexpr int MS_CHUNK = 16;                // rows of L staged per round of the backward substitution
+constexpr int MS_RING = 192, MS_RPITCH = 196;   // a staged row: L(j, k) at slot k mod 192 (three 64-row blocks cover the band); pitch: rows 4 slots apart in the banks
+static_assert(MS_HB_MAX + 1 <= 128, "three 64-row blocks cover the rows a pivot row reaches");
 constexpr int MS_BANDS = (MS_HB_MAX + MS_TB) / MS_TB;                      // bands of MS_TB band offsets
-constexpr int MS_PF = (MS_BANDS * MS_CA * MS_TB + MS_BULK - 1) / MS_BULK;  // prefetched entries per window thread and column group
-constexpr int ms_tiles(int hb) { int t = 0; for (int b = 0; b < (hb + MS_TB) / MS_TB; b++) t += (hb - MS_TB * b + 3) / MS_CA + 1; return t; }
+constexpr int MS_PF = (MS_BANDS * MS_CA * MS_TB + 63) / 64;                // prefetched entries per lane of the forward wavefront and column group
+constexpr int ms_tiles(int hb) { int t = 0; for (int b = 0; b < (hb + MS_TB) / MS_TB; b++) t += (hb - MS_TB * b + 3) / MS_CA; return t; }
 static_assert(ms_tiles(MS_HB_MAX) <= MS_BULK, "one register tile per window thread");
 static_assert(MS_BANDS * MS_TB <= 128 && MS_HB_MAX < 128, "a column is two registers per lane of the chain");
 
@@ -72,6 +74,7 @@ struct MeshArgs
     const double* stat;                     // static band, column layout: entry (i, k), k <= i <= k + hb, at [k * (hb + 1) + (i - k)]
     long long* Nq; long long* gq;           // Q32 sums of the feature rows (same layout as stat / one per unknown)
     double* N; double* g0;                  // the assembled system (k_mesh_prepare)
+    double* wz;                             // D^-1 L^-1 g, from k_mesh_solve to k_mesh_backsolve
     float* mesh;                            // previous solution (absolute tracking-frame coordinates), updated on success
     double* Lc;                             // columns of L: L(i, k) at [k * (hb + 1) + (i - k)]
     int* fidx; float* fw;                   // per feature: the 4 unknown indices (x components) and barycentric weights
@@ -158,8 +161,9 @@ void k_mesh_prepare(MeshArgs a)
 // entry (k + t, k) of N; 0 outside the matrix
 __device__ __forceinline__ double load_entry(const MeshArgs& a, int k, int t)
 {
-    if (k >= a.n || t > a.hb || k + t >= a.n) return 0.0;
-    return a.N[(size_t)k * (a.hb + 1) + t];
+    const bool in = k < a.n && t <= a.hb && k + t < a.n;
+    const double v = a.N[in ? (size_t)k * (a.hb + 1) + t : 0];          // unconditional load, then a select: the loads of a tile stay in flight together
+    return in ? v : 0.0;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a release fence for GLOBAL memory: it drains the workgroup's
@@ -175,189 +179,232 @@ __device__ long long g_mesh_phase[8];
 
 struct FactorShared
 {
-    // pivot column p, by step parity: raw[MS_PAD + x] = N(p + x, p) after all earlier pivots (the entries x = 0, 1 -- the pivot itself and
-    // the row of column p + 1, which is the chain's -- are stored as zeros: to the window threads those columns are spent), lcol = the
-    // column times the reciprocal pivot (column p of L, entry 0 stored as zero); zeros outside 0 .. hb: the updates rely on the padding
-    // instead of masks.  rinv: the reciprocal pivot.
-    double raw[2][MS_LCOL_P], lcol[2][MS_LCOL_P];     // padded layout: logical index x at ms_px(x)
-    double rinv[2];
-    double col[2][MS_COL_P];                   // column p + 2 as the window threads leave it after pivot p (read by the chain one step later)
-    double w[MS_N_MAX + 128];               // right-hand side: g, then D^-1 L^-1 g and finally the solution, in place (+ slack: rows beyond n)
-    double next[MS_BANDS][MS_NEXT_BAND];    // phase 1: per band, the columns that enter its window when the current group is done
-    double lt[2][MS_CHUNK][MS_HB_MAX + 1];  // phase 2: rows of L, staged chunk by chunk
+    // The two pivot columns of an interval, by interval parity: raw[j][x] = N(p + x, p) after all earlier pivots, lcol[j] = the column times
+    // the reciprocal pivot (column p of L, entry 0 stored as zero), both in the padded layout (logical index MS_PAD + x at ms_px(MS_PAD + x)),
+    // zeros outside 0 .. hb: the updates rely on the padding instead of masks.  To the window threads the columns up to the chain's
+    // two are spent: raw[0] is stored with zeros at x <= 3, raw[1] at x <= 2.  rinv: the reciprocal pivots.
+    double raw[2][2][MS_LCOL_P], lcol[2][2][MS_LCOL_P];
+    double rinv[2][2];
+    double col[2][2][MS_COL_P];             // the two columns behind the interval's pivots as the window threads leave them (read by the chain one interval later)
+    double w[MS_N_MAX + 128];               // right-hand side: g, then D^-1 L^-1 g, in place (+ slack: rows beyond n)
+    double next[MS_BANDS + 1][MS_NEXT_BAND];    // phase 1: per band, the columns that enter its window when the current group is done (+ a spare slot)
     int fail;
 };
 
 // ---- phase 1, look-ahead organisation -----------------------------------------------------------------------------------------------
-// The steps of the elimination are latency bound: a single wavefront issues an instruction every 5-7 cycles, whatever it is, so the time
-// of a step is the longest instruction stream between two barriers plus the dependent latencies on it (a trip through LDS, a division).
-// Three roles run side by side, one step apart, with ONE barrier per step:
-//   * the chain (one wavefront) owns the NEXT pivot column.  During step p it takes column p + 1 as the window threads left it after
-//     pivot p - 1 (col[]), applies pivot p to it, forms the reciprocal pivot and the column of L and publishes them (parity p + 1).
-//     Nothing else: ~45 instructions with one LDS read, one division and one LDS write on the dependent path.
-//   * the window (MS_WIN_WAVES wavefronts) applies pivot p (published during step p - 1) to its 4 x MS_TB register tiles; the column
-//     p + 2 goes first and is handed to the chain through col[].
-//   * the forward substitution (one wavefront) applies pivot p to the right-hand side, scales its row p by the reciprocal pivot and
-//     stores column p of L for phase 2.
+// The elimination is latency bound: a single wavefront issues an instruction every 4-7 cycles, whatever it is, so the time between two
+// barriers is the longest instruction stream plus the dependent latencies on it (a trip through LDS ~100 cycles under load, a division
+// ~110, the barrier ~70) -- the arithmetic of the rank-1 update itself (6.2 K fused multiply-subtracts per pivot) is a quarter of it.
+// Hence: few barriers, little per-barrier overhead.  The pivots go in PAIRS (one interval = two pivots, one barrier), three roles side
+// by side, one interval apart:
+//   * the chain (one wavefront) owns the NEXT pair.  During the interval of the pivots a, a + 1 it takes the columns a + 2, a + 3 as the
+//     window threads left them after pivot a - 1 (col[]), applies a and a + 1 to them, then a + 2 to the second (the column of L it has
+//     just formed, shifted by one lane with a whole-wavefront DPP move), and publishes both pivots (the other parity).
+//   * the window (MS_WIN_WAVES wavefronts) applies a, then a + 1 (published during the previous interval) to its 4 x MS_TB register
+//     tiles and hands the two columns behind the chain's to the chain through col[].
+//   * the forward substitution (one wavefront) applies a, a + 1 to the right-hand side, scales their rows by the reciprocal pivots and
+//     stores the columns a, a + 1 of L for phase 2.
 // Every entry still receives its updates in pivot order with the same operands: bit-identical to the plain loop of the specification.
 __device__ __forceinline__ double readlane64(double v, int src);
+
+// lane j <- lane j + 1 of a binary64 register pair (v_mov_b32_dpp wave_shl:1 moves across the whole wavefront); lane 63 <- `last`
+__device__ __forceinline__ double shift_down1(double v, double last)
+{
+    const long long u = __double_as_longlong(v), e = __double_as_longlong(last);
+    const int lo = __builtin_amdgcn_update_dpp((int)(e & 0xffffffffll), (int)(u & 0xffffffffll), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(u >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 
 // (All parts are written without per-entry conditions: the LDS arrays are padded with zeros, entries outside the band are zeros that
 //  stay zeros, and every store is unconditional.  The workgroup's wavefronts share ONE scalar unit: exec-mask bookkeeping for
 //  per-entry branches made the first version of this loop scalar-issue bound -- 125 scalar instructions per step and wavefront.)
 
-// the chain's part of step p = p0 + CK (p0 a multiple of MS_CA): finishes column p + 1 and turns it into pivot data of parity (p + 1).
-// r1 = N(p + 1, p), the unscaled entry of the pivot column p in the row of column p + 1 (wave uniform); bad: a pivot was not positive.
-template <int CK>
-__device__ __forceinline__ void chain_step(const MeshArgs& a, FactorShared& s, int p, double& r1, bool& bad)
-{
-    const int lane = (int)threadIdx.x, q = p + 1;
-    if (q >= a.n) return;
-    const double* lcol = s.lcol[CK & 1];
-    const int x1 = ms_px(MS_PAD + 1 + lane), x0 = ms_px(MS_PAD + lane), tc = lane + lane / MS_TB, tc2 = (lane + 64) + (lane + 64) / MS_TB;
-    const double c0 = __builtin_fma(-lcol[x1], r1, s.col[CK & 1][tc]);                 // band offsets t = lane and t = lane + 64 of
-    const double c1 = __builtin_fma(-lcol[x1 + 80], r1, s.col[CK & 1][tc2]);           // column q; beyond hb everything is zero
-    const double d = readlane64(c0, 0);
-    r1 = readlane64(c0, 1);
-    bad = bad || !(d > 0.0);
-    const double r = 1.0 / d;
-    double* raw_n = s.raw[(CK + 1) & 1]; double* lcol_n = s.lcol[(CK + 1) & 1];
-    raw_n[x0] = lane <= 1 ? 0.0 : c0;
-    raw_n[x0 + 80] = c1;                                                                // ms_px(x + 64) = ms_px(x) + 80
-    lcol_n[x0] = lane == 0 ? 0.0 : c0 * r;
-    lcol_n[x0 + 80] = c1 * r;
-    if (lane == 0) s.rinv[(CK + 1) & 1] = r;
-}
+// what the chain carries from one interval to the next (wave uniform): the unscaled entries of the two pivot columns it has formed in
+// the rows of the two columns it forms next -- N(a + 2, a), N(a + 3, a), N(a + 2, a + 1), N(a + 3, a + 1) -- and the failure flag
+struct ChainCarry { double a2, a3, b1, b2; bool bad; };
 
-// the forward substitution's part of step p: z(p + t) -= L(p + t, p) z(p) for the rows of the band, row p becomes z(p) / d(p); column p
-// of L goes to global memory for phase 2.  (The wavefront's LDS accesses execute in order: the rows written here are read back by the
-// same wavefront one step later without a barrier.)
-template <int CK>
-__device__ __forceinline__ void forward_step(const MeshArgs& a, FactorShared& s, int p)
+// the chain's part of the interval whose pivot data has parity PAR: finishes the columns c = a + 2 and c + 1 and turns them into the
+// pivot data of the other parity
+template <int PAR>
+__device__ __forceinline__ void chain_interval(const MeshArgs& a, FactorShared& s, int c, ChainCarry& cc)
 {
-    const int lane = (int)threadIdx.x & 63, hb = a.hb;
-    const double* lcol = s.lcol[CK & 1];
-    const int x0 = ms_px(MS_PAD + lane);
-    const double l0 = lcol[x0], l1 = lcol[x0 + 80];                                                  // l0 of lane 0 is stored as zero
-    const double wq = s.w[p], w0 = s.w[p + lane], w1 = s.w[p + 64 + lane], r = s.rinv[CK & 1];
-    const double n0 = __builtin_fma(-l0, wq, w0);
-    s.w[p + lane] = lane == 0 ? wq * r : n0;                                                        // rows beyond the matrix keep their zeros (l = 0)
-    s.w[p + 64 + lane] = __builtin_fma(-l1, wq, w1);
-    double* Lp = a.Lc + (size_t)p * (hb + 1);
-    if (lane <= hb) Lp[lane] = l0;
-    if (lane + 64 <= hb) Lp[lane + 64] = l1;
+    if (c >= a.n) return;
+    const int lane = (int)threadIdx.x;
+    const int x0 = ms_px(MS_PAD + lane), x1 = ms_px(MS_PAD + 1 + lane), x2 = ms_px(MS_PAD + 2 + lane), x3 = ms_px(MS_PAD + 3 + lane);
+    const int tc = lane + lane / MS_TB, tc2 = (lane + 64) + (lane + 64) / MS_TB;
+    const double* la = s.lcol[PAR][0]; const double* lb = s.lcol[PAR][1];
+    // band offsets t = lane (0) and t = lane + 64 (1) of the columns c (C) and c + 1 (D); beyond hb everything is zero
+    double C0 = s.col[PAR][0][tc], C1 = s.col[PAR][0][tc2], D0 = s.col[PAR][1][tc], D1 = s.col[PAR][1][tc2];
+    C0 = __builtin_fma(-la[x2], cc.a2, C0); C1 = __builtin_fma(-la[x2 + 80], cc.a2, C1);           // ms_px(x + 64) = ms_px(x) + 80
+    D0 = __builtin_fma(-la[x3], cc.a3, D0); D1 = __builtin_fma(-la[x3 + 80], cc.a3, D1);
+    C0 = __builtin_fma(-lb[x1], cc.b1, C0); C1 = __builtin_fma(-lb[x1 + 80], cc.b1, C1);
+    D0 = __builtin_fma(-lb[x2], cc.b2, D0); D1 = __builtin_fma(-lb[x2 + 80], cc.b2, D1);
+    const double dc = readlane64(C0, 0), c1 = readlane64(C0, 1);
+    cc.a2 = readlane64(C0, 2); cc.a3 = readlane64(C0, 3);
+    const double rc = 1.0 / dc;
+    const double lc0 = lane == 0 ? 0.0 : C0 * rc, lc1 = C1 * rc;
+    D0 = __builtin_fma(-shift_down1(lc0, readlane64(lc1, 0)), c1, D0);
+    D1 = __builtin_fma(-shift_down1(lc1, 0.0), c1, D1);
+    const double dd = readlane64(D0, 0);
+    cc.b1 = readlane64(D0, 1); cc.b2 = readlane64(D0, 2);
+    cc.bad = cc.bad || !(dc > 0.0) || !(dd > 0.0);
+    const double rd = 1.0 / dd;
+    s.raw[PAR ^ 1][0][x0] = lane <= 3 ? 0.0 : C0; s.raw[PAR ^ 1][0][x0 + 80] = C1;
+    s.lcol[PAR ^ 1][0][x0] = lc0; s.lcol[PAR ^ 1][0][x0 + 80] = lc1;
+    s.raw[PAR ^ 1][1][x0] = lane <= 2 ? 0.0 : D0; s.raw[PAR ^ 1][1][x0 + 80] = D1;
+    s.lcol[PAR ^ 1][1][x0] = lane == 0 ? 0.0 : D0 * rd; s.lcol[PAR ^ 1][1][x0 + 80] = D1 * rd;
+    if (lane == 0) { s.rinv[PAR ^ 1][0] = rc; s.rinv[PAR ^ 1][1] = rd; }
 }
 
 // The window.  An entry (column k, band offset t) is touched by pivot p iff (k - p) + t <= hb: a column at distance s from the pivot
 // needs only its offsets t <= hb - s.  The offsets are therefore split into bands of MS_TB, and every band keeps its OWN window of
-// columns: band b (offsets from T = MS_TB b) holds nb(b) = (hb - T + 3) / 4 + 1 column groups -- 27 for the first band, 2 for the last,
-// 177 tiles of 4 x 9 in all instead of the 324 of one common window (of which half would hold entries no pivot reaches yet).  A tile's
-// thread follows the rotation of its band: m = distance (in groups) of its column group from the pivot's, counting down; when its
-// group has been pivoted it takes over the group that enters the band's window, nb(b) groups on.
-__host__ __device__ __forceinline__ int band_groups(int hb, int b) { return (hb - MS_TB * b + 3) / MS_CA + 1; }
+// column groups: band b (offsets from T = MS_TB b) holds the groups at distance m = 1 .. (hb - T + 3) / 4 from the pivots' group -- 26
+// for the first band, 1 for the last, 182 tiles of 4 x 8 in all instead of the 351 of one common window (of which half would hold
+// entries no pivot reaches yet).  A tile's thread follows the rotation of its band: m counts down; the tile at m = 1 hands its columns
+// to the chain pair by pair and then takes over the group that enters the band's window.
+__host__ __device__ __forceinline__ int band_groups(int hb, int b) { return (hb - MS_TB * b + 3) / MS_CA; }
 
-// entries of the column groups that enter the bands' windows when the group at p0 has been pivoted: fetch (N is read once, in band
-// order) and hand-over to the tiles through LDS
-__device__ __forceinline__ void window_fetch(const MeshArgs& a, double (&pf)[MS_PF], int p0, int btid)
+// Entries of the column groups that enter the bands' windows when the group at p0 has been pivoted: fetch (N is read once, in band
+// order) and hand-over to the tiles through LDS -- the forward-substitution wavefront's job: it has time to spare, the window
+// wavefronts do not.  What does not depend on p0 is worked out once per lane: the entry's offset in N relative to column p0, the
+// last row it touches relative to p0 (the matrix ends at n), and its slot in next[].
+struct FetchPlan { int off[MS_PF], reach[MS_PF], dst[MS_PF]; };
+__device__ __forceinline__ void fetch_plan(const MeshArgs& a, FetchPlan& fp, int lane)
 {
     const int hb = a.hb, ld = hb + 1;
 #pragma unroll
     for (int q = 0; q < MS_PF; q++)
     {
-        const int idx = btid + MS_BULK * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
-        const int k = p0 + MS_CA * band_groups(hb, pb) + c, t = MS_TB * pb + ti;
-        const bool in = pb < a.nbands && t <= hb && k + t < a.n;
-        pf[q] = a.N[in ? (size_t)k * ld + t : 0];
+        const int idx = lane + 64 * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
+        const int k = MS_CA * (band_groups(hb, pb) + 1) + c, t = MS_TB * pb + ti;
+        const bool in = idx < MS_BANDS * MS_CA * MS_TB && pb < a.nbands && t <= hb;
+        fp.off[q] = k * ld + t; fp.reach[q] = in ? k + t : (1 << 29);
+        fp.dst[q] = idx < MS_BANDS * MS_CA * MS_TB ? pb * MS_NEXT_BAND + rem : MS_BANDS * MS_NEXT_BAND;      // beyond the plan: the spare slot
     }
 }
-__device__ __forceinline__ void window_park(const MeshArgs& a, FactorShared& s, const double (&pf)[MS_PF], int p0, int btid)
+__device__ __forceinline__ void window_fetch(const MeshArgs& a, const FetchPlan& fp, double (&pf)[MS_PF], int p0)
 {
-    const int hb = a.hb;
+    const double* col0 = a.N + (size_t)p0 * (a.hb + 1);
 #pragma unroll
-    for (int q = 0; q < MS_PF; q++)
+    for (int q = 0; q < MS_PF; q++) pf[q] = p0 + fp.reach[q] < a.n ? col0[fp.off[q]] : a.N[0];
+}
+__device__ __forceinline__ void window_park(const MeshArgs& a, FactorShared& s, const FetchPlan& fp, const double (&pf)[MS_PF], int p0)
+{
+#pragma unroll
+    for (int q = 0; q < MS_PF; q++) (&s.next[0][0])[fp.dst[q]] = p0 + fp.reach[q] < a.n ? pf[q] : 0.0;
+}
+
+// the forward substitution's part of an interval, pivots p and p + 1: z(p + t) -= L(p + t, p) z(p) for the rows of the band, row p
+// becomes z(p) / d(p); the columns of L go to global memory for phase 2.  (The wavefront's LDS accesses execute in order: rows written
+// here are read back by the same wavefront without a barrier.)
+template <int PAR>
+__device__ __forceinline__ void forward_interval(const MeshArgs& a, FactorShared& s, int p, const FetchPlan& fp, double (&pf)[MS_PF])     // pf: the register set of this group's parity
+{
+    const int lane = (int)threadIdx.x & 63, hb = a.hb;
+    // The columns that take over the slots of a pivoted group in each band's window travel two groups ahead (N was written by another
+    // kernel on other XCDs: the first touch of a line comes from memory): what was fetched two groups ago is parked in LDS now (read
+    // by the window threads at the end of this group), and the fetch for the group after the next is issued into the same registers.
+#ifndef LVK_MESH_DBG_NOFETCH
+    if (PAR == 0) { window_park(a, s, fp, pf, p); window_fetch(a, fp, pf, p + 2 * MS_CA); }
+#endif
+    const int x0 = ms_px(MS_PAD + lane);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
     {
-        const int idx = btid + MS_BULK * q, pb = idx / (MS_CA * MS_TB), rem = idx - pb * (MS_CA * MS_TB), c = rem / MS_TB, ti = rem - c * MS_TB;
-        const int k = p0 + MS_CA * band_groups(hb, pb) + c, t = MS_TB * pb + ti;
-        const bool in = pb < a.nbands && t <= hb && k + t < a.n;
-        if (idx < MS_BANDS * MS_CA * MS_TB) s.next[pb][rem] = in ? pf[q] : 0.0;
+        const double* lcol = s.lcol[PAR][j];
+        const double l0 = lcol[x0], l1 = lcol[x0 + 80];                                             // l0 of lane 0 is stored as zero
+        const double wq = s.w[p + j], w0 = s.w[p + j + lane], w1 = s.w[p + j + 64 + lane], r = s.rinv[PAR][j];
+        const double n0 = __builtin_fma(-l0, wq, w0);
+        s.w[p + j + lane] = lane == 0 ? wq * r : n0;                                                // rows beyond the matrix keep their zeros (l = 0)
+        s.w[p + j + 64 + lane] = __builtin_fma(-l1, wq, w1);
+        double* Lp = a.Lc + (size_t)(p + j) * (hb + 1);
+        if (lane <= hb) Lp[lane] = l0;
+        if (lane + 64 <= hb) Lp[lane + 64] = l1;
     }
 }
 
-// the window's part of step p, pivot at position CK of its column group
-template <int CK>
-__device__ __forceinline__ void window_step(const MeshArgs& a, FactorShared& s, double (&A)[MS_CA][MS_TB], double (&pf)[MS_PF],
-                                            int p, int& m, int nb, int band, bool valid, int btid)
+// the window's part of an interval: the pivots p = p0 + 2 H and p + 1 of the group at p0, pivot data of parity H
+template <int H>
+__device__ __forceinline__ void window_interval(const MeshArgs& a, FactorShared& s, double (&A)[MS_CA][MS_TB],
+                                                int p0, int& m, int nb, int band, bool valid)
 {
-    const int t0 = band * MS_TB;
-    const double* raw = s.raw[CK & 1]; const double* lcol = s.lcol[CK & 1];
-    // the columns that take over the slots of a pivoted group in each band's window travel one group ahead: what was fetched a group ago
-    // is parked in LDS now (read at the end of this group), and the fetch for the next group is issued -- four steps of distance, no
-    // step ever waits for global memory (fetch and use in the same group cost a memory latency every fourth step: 800 cycles per step
-    // on average, more than the arithmetic)
-#ifndef LVK_MESH_DBG_NOFETCH
-    if (CK == 0) { window_park(a, s, pf, p, btid); window_fetch(a, pf, p + MS_CA, btid); }
-#endif
+    constexpr int PAR = H;
     if (valid)
     {
-        const int s0 = MS_CA * m - CK;                                  // column distance of the tile's first column from the pivot
+        const int t0 = band * MS_TB;
         const int yr = 5 * m, yl = 5 * (m + (MS_TB / 4) * band);        // padded positions of MS_PAD + 4 m and MS_PAD + 4 m + t0, less ms_px(MS_PAD)
-        double rc[MS_CA], lw[MS_CA + MS_TB - 1];
+        double rc[2][MS_CA], lw[2][MS_CA + MS_TB - 1];                  // operands of the pivots p0 + 2 H + j: the tile's first column is at distance 4 m - 2 H - j
 #pragma unroll
-        for (int ck = 0; ck < MS_CA; ck++) rc[ck] = raw[yr + ms_px(MS_PAD + ck - CK)];      // zero for spent columns, the pivot and column p + 1 (the chain's)
-#pragma unroll
-        for (int j = 0; j < MS_CA + MS_TB - 1; j++) lw[j] = lcol[yl + ms_px(MS_PAD + j - CK)];
-#if defined(LVK_MESH_DBG_READS)
-        for (int rr = 1; rr < LVK_MESH_DBG_READS; rr++)
+        for (int j = 0; j < 2; j++)
         {
-            int off = 1024 * (rr & 1);                                                              // other addresses, same bank pattern
-            asm volatile("" : "+v"(off));
-            const double* vl = lcol + off; const double* vr = raw + off;
-            double t0v[MS_CA], t1v[MS_CA + MS_TB - 1];
+#ifndef LVK_MESH_DBG_NOREADS
 #pragma unroll
-            for (int ck = 0; ck < MS_CA; ck++) t0v[ck] = vr[yr + ms_px(MS_PAD + ck - CK)];
+            for (int ck = 0; ck < MS_CA; ck++) rc[j][ck] = s.raw[PAR][j][yr + ms_px(MS_PAD + ck - 2 * H - j)];       // zero for the chain's columns
 #pragma unroll
-            for (int j = 0; j < MS_CA + MS_TB - 1; j++) t1v[j] = vl[yl + ms_px(MS_PAD + j - CK)];
-#pragma unroll
-            for (int ck = 0; ck < MS_CA; ck++) asm volatile("" :: "v"(t0v[ck]));
-#pragma unroll
-            for (int j = 0; j < MS_CA + MS_TB - 1; j++) asm volatile("" :: "v"(t1v[j]));
-        }
-#endif
-#if defined(LVK_MESH_DBG_FMAS)
-        for (int rr = 1; rr < LVK_MESH_DBG_FMAS; rr++)
-#pragma unroll
-            for (int ck = 0; ck < MS_CA; ck++)
-#pragma unroll
-                for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = __builtin_fma(-lw[ck + ti], rc[ck], A[ck][ti]);
-#endif
-        // column p + 2 first: it is the chain's input of the next step
-        constexpr int NK = (CK + 2) % MS_CA;
-#pragma unroll
-        for (int ti = 0; ti < MS_TB; ti++) A[NK][ti] = __builtin_fma(-lw[NK + ti], rc[NK], A[NK][ti]);
-#ifndef LVK_MESH_DBG_NOHANDOFF
-        if (s0 + NK == 2)
+            for (int q = 0; q < MS_CA + MS_TB - 1; q++) lw[j][q] = s.lcol[PAR][j][yl + ms_px(MS_PAD + q - 2 * H - j)];
 #else
-        if (s0 + NK == 2 && p < 0)
+#pragma unroll
+            for (int ck = 0; ck < MS_CA; ck++) { rc[j][ck] = 1e-9 * (ck + 1); asm volatile("" : "+v"(rc[j][ck])); }
+#pragma unroll
+            for (int q = 0; q < MS_CA + MS_TB - 1; q++) { lw[j][q] = 1e-9 * (q + 1); asm volatile("" : "+v"(lw[j][q])); }
+#endif
+        }
+        // the columns p + 4, p + 5 first: they are the chain's input of the next interval, and the rest of the update covers the time
+        // their stores take
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+        {
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++)
+            {
+                const int ck = half == 0 ? 2 * H + cc : 2 * (1 - H) + cc;
+#ifndef LVK_MESH_DBG_NOFMA
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = __builtin_fma(-lw[j][ck + ti], rc[j][ck], A[ck][ti]);
+#endif
+            }
+            if (half == 0)
+            {
+#ifdef LVK_MESH_DBG_NOHANDOFF
+                if (m == 1 && p0 < 0)
+#else
+                if (m == 1)
 #endif
 #pragma unroll
-            for (int ti = 0; ti < MS_TB; ti++) s.col[(CK + 1) & 1][t0 + band + ti] = A[NK][ti];
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int ti = 0; ti < MS_TB; ti++) s.col[PAR ^ 1][j][t0 + band + ti] = A[2 * H + j][ti];
+            }
+        }
+#if defined(LVK_MESH_DBG_NOFMA) || defined(LVK_MESH_DBG_NOHANDOFF)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+        {
+#pragma unroll
+            for (int ck = 0; ck < MS_CA; ck++) asm volatile("" :: "v"(rc[j][ck]));
+#pragma unroll
+            for (int q = 0; q < MS_CA + MS_TB - 1; q++) asm volatile("" :: "v"(lw[j][q]));
+        }
 #pragma unroll
         for (int ck = 0; ck < MS_CA; ck++)
-            if (ck != NK)
 #pragma unroll
-                for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = __builtin_fma(-lw[ck + ti], rc[ck], A[ck][ti]);
-        if (CK == MS_CA - 1)
+            for (int ti = 0; ti < MS_TB; ti++) asm volatile("" : "+v"(A[ck][ti]));
+#endif
+        if (H == 1)
         {
 #ifndef LVK_MESH_DBG_NOTAKEOVER
-            if (m == 0)
+            if (m == 1)
 #else
-            if (m == 0 && p < 0)
+            if (m == 1 && p0 < 0)
 #endif
 #pragma unroll
                 for (int ck = 0; ck < MS_CA; ck++)
 #pragma unroll
                     for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = s.next[band][ck * MS_TB + ti];
-            m = m == 0 ? nb - 1 : m - 1;
+            m = m == 1 ? nb : m - 1;
         }
     }
 }
@@ -376,13 +423,13 @@ void k_mesh_solve(MeshArgs a)
     LVK_TRACKER_PRIORITY();
     __shared__ FactorShared s;
     const int tid = (int)threadIdx.x;
-    const int n = a.n, hb = a.hb, ld = hb + 1;
+    const int n = a.n, hb = a.hb;
     const int m = pair_count(a);
     const int flags = *a.flags;
     __syncthreads();
-    if (tid == 0) *a.flags = 0;                                         // cleared for the next frame
-    if (m < a.min_samples) { if (tid == 0) *a.out_status = 1; return; }
-    if (flags & 1) { if (tid == 0) *a.out_status = 2; return; }
+    // *a.flags on exit: 0 = factorised, k_mesh_backsolve goes ahead; 2 = no solution this frame (the status is already with the host)
+    if (m < a.min_samples) { if (tid == 0) { *a.out_status = 1; *a.flags = 2; } return; }
+    if (flags & 1) { if (tid == 0) { *a.out_status = 2; *a.flags = 2; } return; }
 #ifdef LVK_MESH_TIMING
     const long long tm0 = wall_clock64();
 #endif
@@ -391,55 +438,48 @@ void k_mesh_solve(MeshArgs a)
     const int wave = tid >> 6;
     const bool chain = wave == 0, forward = wave == MS_FWD_WAVE;
     const int btid = (wave - 1 - (wave > MS_FWD_WAVE ? 1 : 0)) * 64 + (tid & 63);      // index among the window threads
-    // window thread -> (band, slot), slot-major: neighbouring lanes hold neighbouring BANDS of one column group.  Their operand reads are
-    // then MS_TB doubles apart (2-way bank conflicts at worst); neighbouring groups of one band are 4 doubles apart -- every fourth lane on
-    // the same LDS banks, a 16-way conflict that made the loop twice as slow.
+    // window thread -> (band, slot), slot-major: neighbouring lanes hold neighbouring BANDS of one column group (see the LDS layouts)
     int band = a.nbands, slot = 0, nb = 1;
     if (!chain && !forward)
     {
         int rem = btid;
         for (int j = 0; j < band_groups(hb, 0); j++)
         {
-            const int cnt = min(a.nbands, (hb + 3 - MS_CA * j) / MS_TB + 1);     // bands that have a slot j: band_groups(hb, b) > j
+            const int cnt = min(a.nbands, (hb + 3 - MS_CA * (j + 1)) / MS_TB + 1);     // bands that have a slot j: band_groups(hb, b) > j
             if (rem < cnt) { band = rem; slot = j; break; }
             rem -= cnt;
         }
         nb = band_groups(hb, min(band, a.nbands - 1));
     }
     const bool valid = !chain && !forward && band < a.nbands;
-    int gdist = slot;                                                   // distance (in column groups) of this tile's group from the pivot's
+    int gdist = slot + 1;                                               // distance (in column groups) of this tile's group from the pivots'
     if (chain) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);      // the chain is the critical path
-    double A[MS_CA][MS_TB], pf[MS_PF];
+    double A[MS_CA][MS_TB], pf[2][MS_PF];
 #pragma unroll
     for (int ck = 0; ck < MS_CA; ck++)
 #pragma unroll
-        for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = valid ? load_entry(a, MS_CA * slot + ck, band * MS_TB + ti) : 0.0;
+        for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = load_entry(a, valid ? MS_CA * gdist + ck : n, band * MS_TB + ti);     // invalid threads: zeros
 #pragma unroll
-    for (int q = 0; q < MS_PF; q++) pf[q] = 0.0;
-    if (!chain && !forward) window_fetch(a, pf, 0, btid);              // parked at step 0, taken over at the end of the first group
-    for (int i = tid; i < 2 * MS_LCOL_P; i += MS_NT) { (&s.raw[0][0])[i] = 0.0; (&s.lcol[0][0])[i] = 0.0; }
-    for (int i = tid; i < 2 * MS_COL_P; i += MS_NT) (&s.col[0][0])[i] = 0.0;
+    for (int q = 0; q < MS_PF; q++) pf[0][q] = pf[1][q] = 0.0;
+    FetchPlan fp;
+    fetch_plan(a, fp, tid & 63);
+    if (forward) { window_fetch(a, fp, pf[0], 0); window_fetch(a, fp, pf[1], MS_CA); }      // the groups that enter at the end of the first two groups
+    for (int i = tid; i < 4 * MS_LCOL_P; i += MS_NT) { (&s.raw[0][0][0])[i] = 0.0; (&s.lcol[0][0][0])[i] = 0.0; }
+    for (int i = tid; i < 4 * MS_COL_P; i += MS_NT) (&s.col[0][0][0])[i] = 0.0;
     for (int i = tid; i < MS_BANDS * MS_NEXT_BAND; i += MS_NT) (&s.next[0][0])[i] = 0.0;
     for (int i = tid; i < n + 128; i += MS_NT) s.w[i] = i < n ? a.g0[i] : 0.0;
     if (tid == 0) s.fail = 0;
     __syncthreads();
-    // start-up: pivot 0 straight from N (parity 0), column 1 as the chain's first input
-    double r1 = 0.0; bool bad = false;
-    if (chain)
+    // start-up: the interval before the first -- the chain forms the pivots 0 and 1 from the columns 0, 1 of N with nothing to apply
+    // (pivot data of parity 1 is all zeros); the columns 2, 3 are its input of the first interval
+    for (int t = tid; t <= hb; t += MS_NT)
     {
-        const double d0 = a.N[0];
-        bad = !(d0 > 0.0);
-        const double r = 1.0 / d0;
-        r1 = n > 1 ? load_entry(a, 0, 1) : 0.0;
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-        {
-            const int t = tid + 64 * h;
-            const double c = load_entry(a, 0, t);
-            if (t <= hb) { s.raw[0][ms_px(MS_PAD + t)] = t <= 1 ? 0.0 : c; s.lcol[0][ms_px(MS_PAD + t)] = t == 0 ? 0.0 : c * r; s.col[0][t + t / MS_TB] = load_entry(a, 1, t); }
-        }
-        if (tid == 0) s.rinv[0] = r;
+        s.col[1][0][t + t / MS_TB] = load_entry(a, 0, t); s.col[1][1][t + t / MS_TB] = load_entry(a, 1, t);
+        s.col[0][0][t + t / MS_TB] = load_entry(a, 2, t); s.col[0][1][t + t / MS_TB] = load_entry(a, 3, t);
     }
+    __syncthreads();
+    ChainCarry cc = {0.0, 0.0, 0.0, 0.0, false};
+    if (chain) chain_interval<1>(a, s, 0, cc);
     __syncthreads();
 #ifdef LVK_MESH_TIMING
     const long long tm1 = wall_clock64();
@@ -455,135 +495,169 @@ void k_mesh_solve(MeshArgs a)
 #define MESH_PROBE_MID() do { } while (0)
 #define MESH_PROBE_END() do { } while (0)
 #endif
-    for (int p0 = 0; p0 < n; p0 += MS_CA)
+    // the intervals: the pivots (p0, p0 + 1) with the pivot data of parity 0 (written by the start-up interval), (p0 + 2, p0 + 3) with parity 1
+    for (int p0 = 0; p0 < n; p0 += 2 * MS_CA)
     {
-#define LVK_MESH_STEP(CKV)                                                                      \
-        if (p0 + CKV < n)                                                                        \
-        {                                                                                        \
-            MESH_PROBE_BEGIN();                                                                  \
-            if (chain) chain_step<CKV>(a, s, p0 + CKV, r1, bad);                                 \
-            else if (forward) forward_step<CKV>(a, s, p0 + CKV);                                 \
-            else window_step<CKV>(a, s, A, pf, p0 + CKV, gdist, nb, band, valid, btid);          \
-            MESH_PROBE_MID();                                                                    \
-            lds_barrier();                                                                       \
-            MESH_PROBE_END();                                                                    \
+#define LVK_MESH_INTERVAL(GV, HV)                                                                               \
+        if (p0 + MS_CA * GV + 2 * HV < n)                                                                        \
+        {                                                                                                        \
+            MESH_PROBE_BEGIN();                                                                                  \
+            if (chain) chain_interval<HV>(a, s, p0 + MS_CA * GV + 2 * HV + 2, cc);                               \
+            else if (forward) forward_interval<HV>(a, s, p0 + MS_CA * GV + 2 * HV, fp, pf[GV]);                  \
+            else window_interval<HV>(a, s, A, p0 + MS_CA * GV, gdist, nb, band, valid);                          \
+            MESH_PROBE_MID();                                                                                    \
+            lds_barrier();                                                                                       \
+            MESH_PROBE_END();                                                                                    \
         }
-        LVK_MESH_STEP(0) LVK_MESH_STEP(1) LVK_MESH_STEP(2) LVK_MESH_STEP(3)
-#undef LVK_MESH_STEP
+        LVK_MESH_INTERVAL(0, 0) LVK_MESH_INTERVAL(0, 1) LVK_MESH_INTERVAL(1, 0) LVK_MESH_INTERVAL(1, 1)
+#undef LVK_MESH_INTERVAL
     }
-    if (tid == 0 && bad) s.fail = 1;
+    if (tid == 0 && cc.bad) s.fail = 1;
     __syncthreads();
-#ifndef LVK_MESH_TIMING
-    if (s.fail != 0) { if (tid == 0) *a.out_status = 3; return; }
+#ifdef LVK_MESH_TIMING
+    if (tid == 0) printf("mesh factor: init %lld, factor %lld (100 MHz ticks), n %d hb %d\n", tm1 - tm0, wall_clock64() - tm1, n, hb);
+#if LVK_MESH_TIMING > 1
+    if (tid == 0)
+    {
+        printf("  per pivot (shader cycles): chain work %lld wait %lld | forward work %lld wait %lld | window work %lld wait %lld\n",
+               g_mesh_phase[0] / n, g_mesh_phase[1] / n, g_mesh_phase[2] / n, g_mesh_phase[3] / n, g_mesh_phase[4] / n, g_mesh_phase[5] / n);
+        for (int k = 0; k < 8; k++) g_mesh_phase[k] = 0;
+    }
 #endif
+#endif
+    if (s.fail != 0) { if (tid == 0) { *a.out_status = 3; *a.flags = 2; } return; }
+    for (int i = tid; i < n; i += MS_NT) a.wz[i] = s.w[i];
+    if (tid == 0) *a.flags = 0;
+}
+
+// ---- phase 2 and 3: a kernel of its own (one walking wavefront, eight that stage; the two phases in one kernel spilled registers) ------
+constexpr int MB_NT = 64 + 512;
+struct BackShared
+{
+    double w[MS_N_MAX + 128];               // D^-1 L^-1 g, then the solution, in place
+    double lt[2][MS_CHUNK][MS_RPITCH];      // rows of L as rings, staged round by round
+};
+
+__global__ __launch_bounds__(MB_NT)
+void k_mesh_backsolve(MeshArgs a)
+{
+    LVK_TRACKER_PRIORITY();
+    __shared__ BackShared s;
+    const int tid = (int)threadIdx.x;
+    const int n = a.n, hb = a.hb, ld = hb + 1;
+    const int m = pair_count(a);
+    const int flags = *a.flags;
+    __syncthreads();
+    if (flags & 2) { if (tid == 0) *a.flags = 0; return; }              // cleared for the next frame
 #ifdef LVK_MESH_TIMING
     const long long tm2 = wall_clock64();
 #endif
-
-    // ---- phase 2: L^T x = w column by column: x(j) = w(j); w(k) -= L(j, k) x(j) for the rows k above j in the band.
-    // One wavefront walks the chain with the rows in flight in registers; all threads stage the rows of L it needs, one chunk ahead
-    // (the loads of chunk c + 1 are in flight while the chain runs over chunk c).  L is stored by columns: a chunk of rows is a set of
-    // short contiguous column segments.
-    const int nchunks = (n + MS_CHUNK - 1) / MS_CHUNK;
-    constexpr int PER = ((MS_HB_MAX + MS_CHUNK) * MS_CHUNK + MS_NT - 1) / MS_NT;
-    double stage_a[PER], stage_b[PER];
-    auto fetch = [&](int c, double (&stage)[PER]) {
-        const int ilo = n - (c + 1) * MS_CHUNK;                          // rows ilo .. ilo + MS_CHUNK - 1 (the top chunk may start below 0)
-#pragma unroll
-        for (int q = 0; q < PER; q++)
-        {
-            const int idx = tid + MS_NT * q, kk = idx / MS_CHUNK, rr = idx - kk * MS_CHUNK, i = ilo + rr, k = ilo - hb + kk, t = i - k;
-            const bool in = kk < hb + MS_CHUNK && i >= 0 && k >= 0 && t >= 1 && t <= hb;
-            stage[q] = a.Lc[in ? (size_t)k * ld + t : 0];
-            if (!in) stage[q] = 0.0;
-        }
-    };
-    auto commit = [&](int c, const double (&stage)[PER]) {
-        const int ilo = n - (c + 1) * MS_CHUNK;
-#pragma unroll
-        for (int q = 0; q < PER; q++)
-        {
-            const int idx = tid + MS_NT * q, kk = idx / MS_CHUNK, rr = idx - kk * MS_CHUNK, t = (ilo + rr) - (ilo - hb + kk);
-            if (kk < hb + MS_CHUNK && t >= 1 && t <= hb) s.lt[c & 1][MS_CHUNK - 1 - rr][t] = stage[q];      // row index counted from the chunk's top row
-        }
-    };
-    // chunk c is consumed from LDS while chunk c + 1 waits in registers and chunk c + 2 is in flight (an L2 round trip is several chain chunks long)
-    for (int i = tid; i < 2 * MS_CHUNK; i += MS_NT) (&s.lt[0][0][0])[(size_t)i * (MS_HB_MAX + 1)] = 0.0;     // entry 0 of every staged row: the zero the chain reads for offsets outside the band
-    fetch(0, stage_a); commit(0, stage_a);
-    if (nchunks > 1) fetch(1, stage_a);
+    for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < n ? a.wz[i] : 0.0;
     __syncthreads();
-    // rows of the 64-row blocks B, B - 1, B - 2 (B = the block of row n - 1), one per lane of wavefront 0
-    const int nblocks = (n + 63) / 64;
-    auto block_rows = [&](int b) -> double { const int i = 64 * b + tid; return (b >= 0 && i < n) ? s.w[i] : 0.0; };
-    double cur = 0.0, p1 = 0.0, p2 = 0.0;
-    if (tid < 64) { cur = block_rows(nblocks - 1); p1 = block_rows(nblocks - 2); p2 = block_rows(nblocks - 3); }
-    int B = nblocks - 1;
-    auto chain_chunk = [&](int c) {
-        if (tid < 64)
-        {
-            const int top = n - 1 - c * MS_CHUNK;
-            const int rows_here = min(MS_CHUNK, top + 1);
-            // The three entries of L this lane needs for a row do not depend on the chain: they are read one row ahead.  An offset
-            // outside 1 .. hb reads the row's entry 0, which is zero: the updates below need no masks (the single wavefront of the
-            // chain issues one instruction every ~5 cycles: the row time is its instruction count).
-            auto entries = [&](int r, double& l0, double& l1, double& l2) {
-                const int tc = ((top - r) & 63) - tid;
-                const double* row = s.lt[c & 1][r];
-                l0 = row[(unsigned)(tc - 1) < (unsigned)hb ? tc : 0];
-                l1 = row[tc + 64 <= hb ? tc + 64 : 0];
-                l2 = row[tc + 128 <= hb ? tc + 128 : 0];
-            };
-            double n0, n1, n2;
-            entries(0, n0, n1, n2);
-            for (int r = 0; r < rows_here; r++)
-            {
-                const int lj = (top - r) & 63;
-                const double l0 = n0, l1 = n1, l2 = n2;
-                if (r + 1 < rows_here) entries(r + 1, n0, n1, n2);
-                const double xj = readlane64(cur, lj);
-                cur = __builtin_fma(-l0, xj, cur);
-                p1 = __builtin_fma(-l1, xj, p1);
-                p2 = __builtin_fma(-l2, xj, p2);
-                if (lj == 0)
-                {
-                    // block B is final: x of its rows; the registers move up one block
-                    if (64 * B + tid < n) s.w[64 * B + tid] = cur;
-                    cur = p1; p1 = p2; p2 = block_rows(B - 3);
-                    B--;
-                }
-            }
-        }
-    };
-    for (int c = 0; c < nchunks; c += 2)
+
+    // ---- phase 2: L^T x = w column by column: x(j) = w(j); w(k) = fma(-L(j, k), x(j), w(k)) for the rows k above j in the band.
+    // One wavefront walks the rows j = n - 1 .. 0 with the rows in flight in three registers per lane: register s holds the rows of the
+    // 64-row block b with b mod 3 = s (three blocks cover the band).  The other wavefronts stage the rows of L it needs in LDS, 16 rows per
+    // round, each row as a ring of 192 slots -- L(j, k) at slot k mod 192, zeros outside the band -- so that the walking wavefront reads
+    // its three operands of a row at FIXED addresses (lane, lane + 64, lane + 128) and a row costs it 9 instructions: two readlanes for
+    // x(j), three LDS reads, three fused multiply-subtracts (an earlier version looked the band offsets up per lane: 25 instructions
+    // per row, 77 us per solve; the wavefront's instruction count IS the time of this phase).  The rows run to the next multiple of 16
+    // above n: the extra rows are zeros and change nothing, and every round and every block boundary is aligned.
     {
-        // even chunk: chunk c + 1 sits in stage_a, chunk c + 2 goes to stage_b
-        if (c + 2 < nchunks) fetch(c + 2, stage_b);
-        chain_chunk(c);
-        if (c + 1 < nchunks) commit(c + 1, stage_a);
+        const int n16 = (n + MS_CHUNK - 1) / MS_CHUNK * MS_CHUNK, nchunks = n16 / MS_CHUNK;
+        const int lane = tid & 63;
+        constexpr int STG = MB_NT - 64, PER = (MS_CHUNK * MS_RING + STG - 1) / STG;     // staging threads, ring slots per thread and round
+        static_assert(STG % MS_CHUNK == 0, "a staging thread keeps its row of the round");
+        const int st = tid - 64, srow = st & (MS_CHUNK - 1), sslot = st / MS_CHUNK;      // element q of a staging thread: row srow, slot sslot + (STG / 16) q
+        double stage[2][PER];
+        // rows top - srow of round c (top = n16 - 1 - 16 c): fetch into registers, two rounds ahead of their use
+        auto fetch = [&](int c, double (&reg)[PER]) {
+            const int j = n16 - 1 - MS_CHUNK * c - srow;
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+            {
+                const int slot = sslot + (STG / MS_CHUNK) * q;
+                const int t = (int)((unsigned)(j - slot + 2 * MS_RING) % (unsigned)MS_RING), k = j - t;      // the column whose slot this is: k = j - t, k mod 192 = slot
+                const bool in = slot < MS_RING && j < n && t >= 1 && t <= hb && k >= 0;
+                reg[q] = a.Lc[in ? (size_t)k * ld + t : 0];
+            }
+        };
+        auto commit = [&](int c, const double (&reg)[PER]) {
+            const int j = n16 - 1 - MS_CHUNK * c - srow;
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+            {
+                const int slot = sslot + (STG / MS_CHUNK) * q;
+                const int t = (int)((unsigned)(j - slot + 2 * MS_RING) % (unsigned)MS_RING), k = j - t;
+                const bool in = j < n && t >= 1 && t <= hb && k >= 0;
+                if (slot < MS_RING) s.lt[c & 1][srow][slot] = in ? reg[q] : 0.0;
+            }
+        };
+        // the walking wavefront: blocks B, B - 1, B - 2 (B = the block of row n16 - 1) in the registers of their residues
+        double R[3] = {0.0, 0.0, 0.0};
+        auto block_rows = [&](int b) -> double { const int i = 64 * b + lane; return (b >= 0 && i < n) ? s.w[i] : 0.0; };
+        const int Btop = (n16 - 1) >> 6;
+        if (tid < 64)
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+            {
+                const int b = Btop - d, sgm = b >= 0 ? b % 3 : 0;
+                const double v = block_rows(b);
+                if (b >= 0) { if (sgm == 0) R[0] = v; else if (sgm == 1) R[1] = v; else R[2] = v; }
+            }
+        auto walk = [&](int c, auto sc_tag) {
+            constexpr int SC = decltype(sc_tag)::value;
+            const int top = n16 - 1 - MS_CHUNK * c, B = top >> 6;
+            const double* ring = &s.lt[c & 1][0][lane];
+#pragma unroll
+            for (int r = 0; r < MS_CHUNK; r++)
+            {
+                const double xj = readlane64(R[SC], (top - r) & 63);
+                R[0] = __builtin_fma(-ring[r * MS_RPITCH], xj, R[0]);
+                R[1] = __builtin_fma(-ring[r * MS_RPITCH + 64], xj, R[1]);
+                R[2] = __builtin_fma(-ring[r * MS_RPITCH + 128], xj, R[2]);
+            }
+            if (((top - (MS_CHUNK - 1)) & 63) == 0)
+            {
+                // block B is final: x of its rows; its register takes the rows of block B - 3
+                if (64 * B + lane < n) s.w[64 * B + lane] = R[SC];
+                R[SC] = block_rows(B - 3);
+            }
+        };
+        auto walk_round = [&](int c) {
+            const int sc = ((n16 - 1 - MS_CHUNK * c) >> 6) % 3;
+            if (sc == 0) walk(c, std::integral_constant<int, 0>{});
+            else if (sc == 1) walk(c, std::integral_constant<int, 1>{});
+            else walk(c, std::integral_constant<int, 2>{});
+        };
+        if (tid >= 64)
+        {
+            fetch(0, stage[0]); commit(0, stage[0]);
+            if (nchunks > 1) fetch(1, stage[1]);
+            if (nchunks > 2) fetch(2, stage[0]);
+        }
         __syncthreads();
-        if (c + 1 >= nchunks) break;
-        if (c + 3 < nchunks) fetch(c + 3, stage_a);
-        chain_chunk(c + 1);
-        if (c + 2 < nchunks) commit(c + 2, stage_b);
+        for (int c = 0; c < nchunks; c += 2)
+        {
+            // round c is walked while round c + 1 is written to the other buffer and round c + 3 is fetched
+            if (tid < 64) walk_round(c);
+            else { if (c + 1 < nchunks) commit(c + 1, stage[1]); if (c + 3 < nchunks) fetch(c + 3, stage[1]); }
+            lds_barrier();
+            if (c + 1 >= nchunks) break;
+            if (tid < 64) walk_round(c + 1);
+            else { if (c + 2 < nchunks) commit(c + 2, stage[0]); if (c + 4 < nchunks) fetch(c + 4, stage[0]); }
+            lds_barrier();
+        }
         __syncthreads();
     }
 #ifdef LVK_MESH_TIMING
-    const long long tm3 = wall_clock64();
-    if (tid == 0)
-    {
-        printf("mesh solve: init %lld, factor %lld, backsolve %lld (100 MHz ticks), n %d hb %d\n", tm1 - tm0, tm2 - tm1, tm3 - tm2, n, hb);
-#if LVK_MESH_TIMING > 1
-        printf("  per step (shader cycles): chain work %lld wait %lld | forward work %lld wait %lld | window work %lld wait %lld\n",
-               g_mesh_phase[0] / n, g_mesh_phase[1] / n, g_mesh_phase[2] / n, g_mesh_phase[3] / n, g_mesh_phase[4] / n, g_mesh_phase[5] / n);
-        for (int k = 0; k < 8; k++) g_mesh_phase[k] = 0;
-#endif
-    }
+    if (tid == 0) printf("mesh backsolve: %lld (100 MHz ticks)\n", wall_clock64() - tm2);
 #endif
 
     // ---- phase 3: the solution as float, inlier flags, offsets (FrameTracker.cpp:276-320)
-    for (int i = tid; i < n; i += MS_NT) a.mesh[i] = (float)s.w[i];
+    for (int i = tid; i < n; i += MB_NT) a.mesh[i] = (float)s.w[i];
     __syncthreads();
-    for (int f = tid; f < m; f += MS_NT)
+    for (int f = tid; f < m; f += MB_NT)
     {
         const int* id = a.fidx + 4 * f; const float* wq = a.fw + 4 * f;
         const float x = wq[0] * a.mesh[id[0]] + wq[1] * a.mesh[id[1]] + wq[2] * a.mesh[id[2]] + wq[3] * a.mesh[id[3]];
@@ -592,7 +666,7 @@ void k_mesh_solve(MeshArgs a)
     }
     const float kw = (((float)a.cols / (float)(a.cols - 1)) * a.region_w) / (float)a.cols;
     const float kh = (((float)a.rows / (float)(a.rows - 1)) * a.region_h) / (float)a.rows;
-    for (int v = tid; v < a.cols * a.rows; v += MS_NT)
+    for (int v = tid; v < a.cols * a.rows; v += MB_NT)
     {
         const int r = v / a.cols, c = v - r * a.cols;
         a.out_offsets[2 * v] = ((float)c * kw - a.mesh[2 * v]) / a.region_w;
@@ -631,6 +705,7 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
     lvkh::MeshSolverH host;
     host.generate(cols, rows, gen_w, gen_h, temporal, local);
     LVK_HIP_REQUIRE(ctx, host.hb() <= MS_HB_MAX && host.n() <= MS_N_MAX);      // meshes wider than 16 columns / beyond 16 x 64: not supported by the device solver
+    LVK_HIP_REQUIRE(ctx, band_groups(host.hb(), (host.hb() + MS_TB) / MS_TB - 1) >= 1 && host.n() >= 4);      // every band has a tile that hands its columns to the chain (hb is odd: always)
     auto* s = new lvk_mesh_solver_dev();
     s->ctx = ctx; s->cols = cols; s->rows = rows; s->n = host.n(); s->hb = host.hb(); s->ts_gen = temporal;
     const size_t band = (size_t)s->n * (s->hb + 1);
@@ -640,7 +715,7 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
     if ((e = hipMalloc((void**)&s->d_acc, (band + s->n) * sizeof(long long))) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void**)&s->d_mesh, s->n * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void**)&s->d_Lc, (band + MS_NT) * sizeof(double))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&s->d_N, (band + s->n) * sizeof(double))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&s->d_N, (band + 2 * (size_t)s->n) * sizeof(double))) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void**)&s->d_flags, sizeof(int))) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(s->d_stat, host.static_band().data(), band * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(s->d_mesh, 0, s->n * sizeof(float))) != hipSuccess) return fail(e);
@@ -672,13 +747,14 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
     const size_t band = (size_t)s->n * (s->hb + 1);
     MeshArgs a;
     a.cols = s->cols; a.rows = s->rows; a.n = s->n; a.hb = s->hb; a.nbands = (s->hb + MS_TB) / MS_TB;
-    a.stat = s->d_stat; a.Nq = s->d_acc; a.gq = s->d_acc + band; a.N = s->d_N; a.g0 = s->d_N + band; a.mesh = s->d_mesh; a.Lc = s->d_Lc;
+    a.stat = s->d_stat; a.Nq = s->d_acc; a.gq = s->d_acc + band; a.N = s->d_N; a.g0 = s->d_N + band; a.wz = s->d_N + band + s->n; a.mesh = s->d_mesh; a.Lc = s->d_Lc;
     a.fidx = (int*)d_scratch; a.fw = (float*)d_scratch + 4 * (size_t)std::max(n_pts, 1); a.p1 = d_p1; a.p2 = d_p2; a.count = d_count; a.n_pts = n_pts; a.min_samples = min_samples;
     a.region_w = region_w; a.region_h = region_h; a.ts_gen = s->ts_gen; a.ts_now = temporal_now; a.threshold = threshold;
     a.flags = s->d_flags; a.out_offsets = h_offsets; a.out_mask = h_mask; a.out_status = h_status;
     if (n_pts > 0) hipLaunchKernelGGL(k_mesh_assemble, dim3((unsigned)((n_pts + 127) / 128)), dim3(128), 0, stream, a);
     hipLaunchKernelGGL(k_mesh_prepare, dim3(64), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_mesh_solve, dim3(1), dim3(MS_NT), 0, stream, a);
+    hipLaunchKernelGGL(k_mesh_backsolve, dim3(1), dim3(MB_NT), 0, stream, a);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
