@@ -6,16 +6,17 @@
 //   static rows  -> a constant band matrix, built once per configuration on the host (host_logic.hpp, MeshSolverH::generate);
 //   feature rows -> Q32 fixed-point sums accumulated with integer atomics (exact, order independent)          k_mesh_assemble
 //   N = L D L^T  -> right-looking root-free band factorisation with reciprocal pivots, forward substitution carried along,
-//                   every entry updated in pivot order by fused multiply-subtracts (binary64)                        k_mesh_solve, phase 1
-//   L^T          -> column-oriented backward substitution (one wavefront, the rows in flight in registers)       k_mesh_solve, phase 2
-//   inlier flags (L1 reprojection error through the feature's quad) and the normalised mesh offsets             k_mesh_solve, phase 3
+//                   every entry updated in pivot order by fused multiply-subtracts (binary64)                        k_mesh_solve
+//   L^T          -> column-oriented backward substitution (one wavefront, the rows in flight in registers)       k_mesh_backsolve
+//   inlier flags (L1 reprojection error through the feature's quad) and the normalised mesh offsets             k_mesh_backsolve
 // The previous solution (the reference's m_OptimizedMesh: warm start there, right-hand side of the temporal rows here) stays on the
 // device.  n = 2 * cols * rows unknowns, half bandwidth hb = 2 * (3 * cols + 3) + 1 (512 and 103 for the 16 x 16 mesh of the preset).
 //
-// Phase 1 is one workgroup: the (hb + 1)-column window of the band that a pivot column touches lives in REGISTERS (4 columns x 13
-// band offsets per thread, the slot of a column is its index modulo the window size), the pivot column and its scaled copy go through
-// LDS.  An entry (column k, offset t) is touched by pivot p iff (k - p) + t <= hb: the scaled column is stored zero-padded, so the same
-// straight-line update serves every thread and every step, no masks.
+// The factorisation is one workgroup: the part of the band that the current pivots reach lives in REGISTERS (a 4-column x 8-offset tile
+// per thread, per-band windows), the pivot columns and their scaled copies go through LDS, zero-padded so that the same straight-line
+// update serves every thread and every step.  It is a chain of 512 dependent pivots: what it costs is instruction issue and latency
+// per barrier interval, not arithmetic -- see "phase 1" below for the organisation and what was measured on the way (740 us for the
+// first correct version, 155 us now; 38 us for the backward substitution).
 #include "lvk_hip_internal.hpp"
 #include "host_logic.hpp"
 
@@ -305,23 +306,23 @@ __device__ __forceinline__ void forward_interval(const MeshArgs& a, FactorShared
     // The columns that take over the slots of a pivoted group in each band's window travel two groups ahead (N was written by another
     // kernel on other XCDs: the first touch of a line comes from memory): what was fetched two groups ago is parked in LDS now (read
     // by the window threads at the end of this group), and the fetch for the group after the next is issued into the same registers.
-#ifndef LVK_MESH_DBG_NOFETCH
     if (PAR == 0) { window_park(a, s, fp, pf, p); window_fetch(a, fp, pf, p + 2 * MS_CA); }
-#endif
     const int x0 = ms_px(MS_PAD + lane);
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-    {
-        const double* lcol = s.lcol[PAR][j];
-        const double l0 = lcol[x0], l1 = lcol[x0 + 80];                                             // l0 of lane 0 is stored as zero
-        const double wq = s.w[p + j], w0 = s.w[p + j + lane], w1 = s.w[p + j + 64 + lane], r = s.rinv[PAR][j];
-        const double n0 = __builtin_fma(-l0, wq, w0);
-        s.w[p + j + lane] = lane == 0 ? wq * r : n0;                                                // rows beyond the matrix keep their zeros (l = 0)
-        s.w[p + j + 64 + lane] = __builtin_fma(-l1, wq, w1);
-        double* Lp = a.Lc + (size_t)(p + j) * (hb + 1);
-        if (lane <= hb) Lp[lane] = l0;
-        if (lane + 64 <= hb) Lp[lane + 64] = l1;
-    }
+    // both pivots in registers: the rows p .. p + 127 after pivot p are shifted down one lane (rows p + 1 .. p + 128) for pivot p + 1
+    const double la0 = s.lcol[PAR][0][x0], la1 = s.lcol[PAR][0][x0 + 80], lb0 = s.lcol[PAR][1][x0], lb1 = s.lcol[PAR][1][x0 + 80];   // entry 0 is stored as zero
+    const double ra = s.rinv[PAR][0], rb = s.rinv[PAR][1];
+    const double w0 = s.w[p + lane], w1 = s.w[p + 64 + lane], w2 = s.w[p + 128];
+    const double za = readlane64(w0, 0);
+    const double n0 = __builtin_fma(-la0, za, w0), n1 = __builtin_fma(-la1, za, w1);                // rows beyond the matrix keep their zeros (l = 0)
+    const double zb = readlane64(n0, 1);
+    const double m0 = __builtin_fma(-lb0, zb, shift_down1(n0, readlane64(n1, 0)));
+    const double m1 = __builtin_fma(-lb1, zb, shift_down1(n1, w2));
+    if (lane == 0) s.w[p] = za * ra;
+    s.w[p + 1 + lane] = lane == 0 ? zb * rb : m0;
+    s.w[p + 65 + lane] = m1;
+    double* Lp = a.Lc + (size_t)p * (hb + 1);
+    if (lane <= hb) { Lp[lane] = la0; Lp[hb + 1 + lane] = lb0; }
+    if (lane + 64 <= hb) { Lp[lane + 64] = la1; Lp[hb + 1 + lane + 64] = lb1; }
 }
 
 // the window's part of an interval: the pivots p = p0 + 2 H and p + 1 of the group at p0, pivot data of parity H
@@ -338,17 +339,10 @@ __device__ __forceinline__ void window_interval(const MeshArgs& a, FactorShared&
 #pragma unroll
         for (int j = 0; j < 2; j++)
         {
-#ifndef LVK_MESH_DBG_NOREADS
 #pragma unroll
             for (int ck = 0; ck < MS_CA; ck++) rc[j][ck] = s.raw[PAR][j][yr + ms_px(MS_PAD + ck - 2 * H - j)];       // zero for the chain's columns
 #pragma unroll
             for (int q = 0; q < MS_CA + MS_TB - 1; q++) lw[j][q] = s.lcol[PAR][j][yl + ms_px(MS_PAD + q - 2 * H - j)];
-#else
-#pragma unroll
-            for (int ck = 0; ck < MS_CA; ck++) { rc[j][ck] = 1e-9 * (ck + 1); asm volatile("" : "+v"(rc[j][ck])); }
-#pragma unroll
-            for (int q = 0; q < MS_CA + MS_TB - 1; q++) { lw[j][q] = 1e-9 * (q + 1); asm volatile("" : "+v"(lw[j][q])); }
-#endif
         }
         // the columns p + 4, p + 5 first: they are the chain's input of the next interval, and the rest of the update covers the time
         // their stores take
@@ -359,47 +353,23 @@ __device__ __forceinline__ void window_interval(const MeshArgs& a, FactorShared&
             for (int cc = 0; cc < 2; cc++)
             {
                 const int ck = half == 0 ? 2 * H + cc : 2 * (1 - H) + cc;
-#ifndef LVK_MESH_DBG_NOFMA
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
                     for (int ti = 0; ti < MS_TB; ti++) A[ck][ti] = __builtin_fma(-lw[j][ck + ti], rc[j][ck], A[ck][ti]);
-#endif
             }
             if (half == 0)
             {
-#ifdef LVK_MESH_DBG_NOHANDOFF
-                if (m == 1 && p0 < 0)
-#else
                 if (m == 1)
-#endif
 #pragma unroll
                     for (int j = 0; j < 2; j++)
 #pragma unroll
                         for (int ti = 0; ti < MS_TB; ti++) s.col[PAR ^ 1][j][t0 + band + ti] = A[2 * H + j][ti];
             }
         }
-#if defined(LVK_MESH_DBG_NOFMA) || defined(LVK_MESH_DBG_NOHANDOFF)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-        {
-#pragma unroll
-            for (int ck = 0; ck < MS_CA; ck++) asm volatile("" :: "v"(rc[j][ck]));
-#pragma unroll
-            for (int q = 0; q < MS_CA + MS_TB - 1; q++) asm volatile("" :: "v"(lw[j][q]));
-        }
-#pragma unroll
-        for (int ck = 0; ck < MS_CA; ck++)
-#pragma unroll
-            for (int ti = 0; ti < MS_TB; ti++) asm volatile("" : "+v"(A[ck][ti]));
-#endif
         if (H == 1)
         {
-#ifndef LVK_MESH_DBG_NOTAKEOVER
             if (m == 1)
-#else
-            if (m == 1 && p0 < 0)
-#endif
 #pragma unroll
                 for (int ck = 0; ck < MS_CA; ck++)
 #pragma unroll
