@@ -190,10 +190,19 @@ public:
     {
         m_w = s.detection_width; m_h = s.detection_height;
         const int gc = cv_round((float)m_w * s.max_feature_density), gr = cv_round((float)m_h * s.max_feature_density);
-        if (gc != m_gc || gr != m_gr || m_cells.empty()) { m_gc = gc; m_gr = gr; m_cells.assign((size_t)gc * gr, -1); m_used = 0; }
+        if (gc != m_gc || gr != m_gr || m_cells.empty()) { m_gc = gc; m_gr = gr; m_cells.assign((size_t)gc * gr, -1); m_used = 0; m_used_cells.clear(); }
         m_cw = (float)m_w / (float)m_gc; m_ch = (float)m_h / (float)m_gr;
+        // distribution_quality's 4 x 4 bucket of every cell, with the arithmetic of SpatialMap.tpp:589-625 (a table: the per-frame loop visits the occupied cells only)
+        m_bucket.assign((size_t)m_gc * m_gr, 0);
+        if (m_gc > 4 && m_gr > 4)
+        {
+            const float sw = (float)m_gc / 4.0f, sh = (float)m_gr / 4.0f;
+            for (int y = 0; y < m_gr; y++)
+                for (int x = 0; x < m_gc; x++) m_bucket[(size_t)y * m_gc + x] = (uint8_t)((size_t)((float)y / sh) * 4 + (size_t)((float)x / sw));
+        }
         m_zc = s.detection_regions_x; m_zr = s.detection_regions_y;
         m_zw = (float)m_w / (float)m_zc; m_zh = (float)m_h / (float)m_zr;
+        m_icw = 1.0 / (double)m_cw; m_ich = 1.0 / (double)m_ch; m_izw = 1.0 / (double)m_zw; m_izh = 1.0 / (double)m_zh;
         zones.clear();
         for (int r = 0; r < m_zr; r++)
             for (int c = 0; c < m_zc; c++)
@@ -226,7 +235,7 @@ public:
         {
             Feature f{(float)(kp[i] & 0xFFFu) + z.x, (float)((kp[i] >> 12) & 0xFFFu) + z.y, (float)(kp[i] >> 24), 0};
             long& cell = m_cells[cell_of(f.x, f.y)];
-            if (cell < 0) { cell = (long)held.size(); m_used++; held.push_back(f); }
+            if (cell < 0) { cell = (long)held.size(); m_used++; m_used_cells.push_back((uint32_t)(&cell - m_cells.data())); held.push_back(f); }
             else if (f.response > held[(size_t)cell].response && held[(size_t)cell].age <= 0) held[(size_t)cell] = f;
         }
         const size_t n = (size_t)count;
@@ -241,7 +250,7 @@ public:
         out.swap(held);
         held.clear();
         const float q = quality();
-        std::fill(m_cells.begin(), m_cells.end(), -1); m_used = 0;
+        clear_cells();
         return q;
     }
 
@@ -253,8 +262,8 @@ public:
             long& cell = m_cells[cell_of(f.x, f.y)];
             if (cell < 0)
             {
-                cell = (long)held.size(); m_used++;
-                zones[(size_t)(f.y / m_zh) * (size_t)m_zc + (size_t)(f.x / m_zw)].load++;
+                cell = (long)held.size(); m_used++; m_used_cells.push_back((uint32_t)(&cell - m_cells.data()));
+                zones[quot(f.y, m_zh, m_izh) * (size_t)m_zc + quot(f.x, m_zw, m_izw)].load++;
                 held.push_back(f);
             }
             else if (f.response > held[(size_t)cell].response && f.age >= held[(size_t)cell].age) held[(size_t)cell] = f;
@@ -263,7 +272,7 @@ public:
 
     void reset()       // FeatureDetector::reset: the grid and the loads are cleared, the held features are not (reference behaviour)
     {
-        std::fill(m_cells.begin(), m_cells.end(), -1); m_used = 0;
+        clear_cells();
         for (Zone& z : zones) z.load = 0;
     }
 
@@ -271,26 +280,43 @@ public:
     std::vector<Feature> held;               // m_Features: propagated features waiting for the next detect()
 
 private:
-    size_t cell_of(float x, float y) const { return (size_t)(y / m_ch) * (size_t)m_gc + (size_t)(x / m_cw); }
+    // (size_t)(a / b) for a >= 0, b > 0 without the division: the binary64 product with 1 / b, rounded to binary32, is within one
+    // binary32 ulp of the binary32 quotient, so the truncations agree unless an integer is that close -- then the division decides.
+    // (Four divisions per feature were most of the 7 us per frame this bookkeeping cost on the critical path between two frames' kernels.)
+    static size_t quot(float a, float b, double inv_b)
+    {
+        const float q = (float)((double)a * inv_b);
+        const int k = (int)q;
+        const float fr = q - (float)k;
+        if (fr > 1e-3f && fr < 0.999f) return (size_t)k;
+        return (size_t)(a / b);
+    }
+    size_t cell_of(float x, float y) const { return quot(y, m_ch, m_ich) * (size_t)m_gc + quot(x, m_cw, m_icw); }
+    void clear_cells()
+    {
+        for (uint32_t c : m_used_cells) m_cells[c] = -1;
+        m_used_cells.clear(); m_used = 0;
+    }
 
     float quality() const                    // SpatialMap::distribution_quality
     {
         if (m_used == 0) return 1.0f;
         if (m_gc <= 4 || m_gr <= 4) return (float)m_used / (float)m_cells.size();
-        const float sw = (float)m_gc / 4.0f, sh = (float)m_gr / 4.0f;
+        // every occupied cell beyond `ideal` in its bucket counts once: the sum does not depend on the order the cells are visited in
         size_t bucket[16] = {0};
         const size_t ideal = (size_t)((float)m_used / 16.0f);
         float excess = 0.0f;
-        for (int y = 0; y < m_gr; y++)
-            for (int x = 0; x < m_gc; x++)
-                if (m_cells[(size_t)y * m_gc + x] >= 0)
-                    if (++bucket[(size_t)((float)y / sh) * 4 + (size_t)((float)x / sw)] > ideal) excess += 1.0f;
+        for (uint32_t c : m_used_cells)
+            if (++bucket[m_bucket[c]] > ideal) excess += 1.0f;
         return 1.0f - (excess / (float)(m_used - ideal));
     }
 
     int m_w = 0, m_h = 0, m_gc = 0, m_gr = 0, m_zc = 1, m_zr = 1;
     float m_cw = 1, m_ch = 1, m_zw = 1, m_zh = 1;
+    double m_icw = 1, m_ich = 1, m_izw = 1, m_izh = 1;
     std::vector<long> m_cells;
+    std::vector<uint32_t> m_used_cells;      // indices of the occupied cells (what quality() and the clearing visit)
+    std::vector<uint8_t> m_bucket;
     size_t m_used = 0, m_min_load = 0, m_target = 0;
     bool m_force = false;
 };
