@@ -22,7 +22,8 @@ def _pairs(rng, n, region, frame, outliers=0.11):
     return a, b.astype(np.float32)
 
 
-@pytest.mark.parametrize("mesh,region", [((16, 16), (480, 270)), ((16, 16), (256, 256)), ((2, 2), (256, 256)), ((5, 7), (320, 180)), ((16, 9), (480, 270)), ((3, 40), (200, 600))])
+@pytest.mark.parametrize("mesh,region", [((16, 16), (480, 270)), ((16, 16), (256, 256)), ((2, 2), (256, 256)), ((5, 7), (320, 180)), ((16, 9), (480, 270)), ((3, 40), (200, 600)),
+                                         ((16, 64), (480, 1200)), ((4, 3), (320, 180)), ((9, 11), (300, 300)), ((13, 5), (480, 270))])
 def test_mesh_solver_bit_exact_over_frames(ctx, oracle, mesh, region):
     cols, rows = mesh
     rng = np.random.default_rng(cols * 100 + rows)
