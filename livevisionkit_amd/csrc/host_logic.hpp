@@ -203,6 +203,10 @@ public:
         m_zc = s.detection_regions_x; m_zr = s.detection_regions_y;
         m_zw = (float)m_w / (float)m_zc; m_zh = (float)m_h / (float)m_zr;
         m_icw = 1.0 / (double)m_cw; m_ich = 1.0 / (double)m_ch; m_izw = 1.0 / (double)m_zw; m_izh = 1.0 / (double)m_zh;
+        // FAST corners have integer coordinates: their cell column / row come from tables filled with the very expression cell_of() evaluates
+        m_col_of.resize((size_t)m_w); m_row_of.resize((size_t)m_h);
+        for (int x = 0; x < m_w; x++) m_col_of[(size_t)x] = (uint16_t)(size_t)((float)x / m_cw);
+        for (int y = 0; y < m_h; y++) m_row_of[(size_t)y] = (uint16_t)(size_t)((float)y / m_ch);
         zones.clear();
         for (int r = 0; r < m_zr; r++)
             for (int c = 0; c < m_zc; c++)
@@ -231,10 +235,13 @@ public:
     void absorb(size_t zone, const uint32_t* kp, int count)
     {
         Zone& z = zones[zone];
+        const bool integral = z.x == std::floor(z.x) && z.y == std::floor(z.y) && z.x >= 0.0f && z.y >= 0.0f;
         for (int i = 0; i < count; i++)
         {
             Feature f{(float)(kp[i] & 0xFFFu) + z.x, (float)((kp[i] >> 12) & 0xFFFu) + z.y, (float)(kp[i] >> 24), 0};
-            long& cell = m_cells[cell_of(f.x, f.y)];
+            const size_t xi = (size_t)f.x, yi = (size_t)f.y;
+            const size_t ci = (integral && xi < m_col_of.size() && yi < m_row_of.size()) ? (size_t)m_row_of[yi] * (size_t)m_gc + m_col_of[xi] : cell_of(f.x, f.y);
+            long& cell = m_cells[ci];
             if (cell < 0) { cell = (long)held.size(); m_used++; m_used_cells.push_back((uint32_t)(&cell - m_cells.data())); held.push_back(f); }
             else if (f.response > held[(size_t)cell].response && held[(size_t)cell].age <= 0) held[(size_t)cell] = f;
         }
@@ -317,6 +324,7 @@ private:
     std::vector<long> m_cells;
     std::vector<uint32_t> m_used_cells;      // indices of the occupied cells (what quality() and the clearing visit)
     std::vector<uint8_t> m_bucket;
+    std::vector<uint16_t> m_col_of, m_row_of;
     size_t m_used = 0, m_min_load = 0, m_target = 0;
     bool m_force = false;
 };
