@@ -527,7 +527,11 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
 // kept elements below m never move; the hole with descending rank j (1 = highest dropped index) receives what position n - j
 // holds at that moment, which is that position's own element if it was kept, or else whatever was moved into it when IT was a
 // hole (rank i < j, i.e. the content of position n - i) -- a chain that ends at a kept tail element.
-constexpr int CMP_NT = 1024, CMP_CAP = 4096;
+// Block size: 256 threads for up to 1024 pairs (the usual 600-800), 1024 beyond.  A 1024-thread block needs 4 free wave slots on every
+// SIMD of one CU at the same moment; next to the persistent remap grid (4 waves per SIMD) and the flow kernel's last blocks it was placed
+// ~4 us late every frame (in-kernel timeline, scripts/timeline_free.py) -- on the critical chain of the frame.
+constexpr int CMP_CAP = 4096;
+template <int CMP_NT>
 __global__ __launch_bounds__(CMP_NT)
 void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
                      float2* __restrict__ p1, float2* __restrict__ p2, int* __restrict__ count, int* __restrict__ host_count,
@@ -557,6 +561,7 @@ void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__
     }
     __syncthreads();
     // exclusive prefix count of dropped elements over the reversed index j = n - 1 - i; thread t owns j = 4t .. 4t + 3
+    static_assert(CMP_NT == 1024 || CMP_NT == 256, "4 elements per thread: 4096 or 1024 pairs");
     int loc[4], sum = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -635,8 +640,12 @@ int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float
                              const float2* d_und, float region_w, float region_h)
 {
     LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n >= 0 && n <= CMP_CAP);
-    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(CMP_NT), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
-                       d_und, region_w, region_h);
+    if (n <= 1024)
+        hipLaunchKernelGGL(k_match_compact<256>, dim3(1), dim3(256), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
+                           d_und, region_w, region_h);
+    else
+        hipLaunchKernelGGL(k_match_compact<1024>, dim3(1), dim3(1024), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
+                           d_und, region_w, region_h);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

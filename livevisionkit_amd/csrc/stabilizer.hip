@@ -301,6 +301,7 @@ int lvk_hip_stab::alloc_tracker_buffers()
 
 void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameTracker.cpp:97-104)
 {
+    finish_post();                              // the last frame's bookkeeping first: the detector keeps its propagated features across a reset
     tracking_stability = 0.0f;
     tracked.clear();
     grid.reset();
@@ -443,6 +444,12 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
     prof_end(pe);
     trace.mark(HostTrace::DOWN_PYR_LAUNCH);
+    // The previous frame's list bookkeeping (fast_filter, ageing, the suppression grid's re-seed) runs HERE, in the shadow of the two kernels
+    // just launched: the next kernel of this frame (optical flow) cannot start before they are done anyway, while at the end of the
+    // previous push those 9 us delayed this frame's first launch -- the tracker chain and the host take turns, and that turn-taking, not
+    // either of them, bounds the frame rate.
+    finish_post();
+    if (post_error) { post_error = false; return fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter disagrees with the host's"); }
     if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return LVK_HIP_OK; }
 
     // ---- FeatureDetector::detect
@@ -792,6 +799,7 @@ int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     LVK_HIP_REQUIRE(st->ctx, settings);
+    st->finish_post();
     return st->configure(*settings);
 }
 
@@ -811,6 +819,7 @@ int lvk_hip_stab_draw_trackers(lvk_hip_stab* st)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());                                           // StreamBuffer::newest: !is_empty()
+    st->finish_post();
     const QueuedFrame& f = st->queue.back();
     double r[3], g[3], b[3];
     overlay_colours(f.format, r, g, b);
@@ -976,14 +985,13 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
 
     enqueue();
     WarpMeshF correction = st->smoother.next(motion);
-    if (st->queue.size() != st->queue_capacity) { st->finish_post(); return LVK_HIP_OK; }   // !ready(): output.release()
+    if (st->queue.size() != st->queue_capacity) return LVK_HIP_OK;                          // !ready(): output.release()
     if (st->s.crop_to_stable_region) correction += st->smoother.scene_crop();
     st->last_correction = correction;
     st->trace.mark(HostTrace::SMOOTH);
     const int erc = emit(&correction);
     st->trace.mark(HostTrace::REMAP_LAUNCH);
-    st->finish_post();
-    return erc;
+    return erc;                                                                             // finish_post(): at the next push, or when the lists are read
 }
 
 int lvk_hip_stab::ensure_pool(int rows, int cols)
@@ -1125,6 +1133,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
 int lvk_hip_stab_get_stats(const lvk_hip_stab* st, lvk_stab_stats* o)
 {
     if (!st || !o) return LVK_HIP_ERR_ARG;
+    const_cast<lvk_hip_stab*>(st)->finish_post();
     o->tracking_stability = st->tracking_stability; o->scene_quality = st->scene_quality; o->trust = st->trust;
     o->distribution = st->last_distribution; o->n_detected = st->last_detected; o->n_matched = st->last_matched;
     o->n_tracked = (int)st->tracked.size(); o->frame_delay = st->s.predictive_samples;
@@ -1146,6 +1155,7 @@ int lvk_hip_stab_get_meshes(const lvk_hip_stab* st, float* motion, float* correc
 int lvk_hip_stab_get_features(const lvk_hip_stab* st, float* xy_resp_age, int cap)
 {
     if (!st || !xy_resp_age) return LVK_HIP_ERR_ARG;
+    const_cast<lvk_hip_stab*>(st)->finish_post();
     const int n = std::min(cap, (int)st->tracked.size());
     for (int i = 0; i < n; i++)
     {

@@ -39,6 +39,38 @@ int main()
         auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
         printf("kernel %d us: launch call %.2f us, flag seen %.2f us after launch, hipStreamSynchronize returns %.2f us after the flag (medians)\n", spin / 100, med(a), med(b), med(c));
     }
+    // a third way: spin on hipStreamQuery
+    for (int spin : {2000, 8000})
+    {
+        std::vector<double> b, c;
+        for (int i = 1; i <= 300; i++)
+        {
+            const auto t0 = clk::now();
+            hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, st, flag, i + 7 + spin * 1000, spin);
+            while (*(volatile int*)flag != i + 7 + spin * 1000) { __builtin_ia32_pause(); }
+            const auto t2 = clk::now();
+            while (hipStreamQuery(st) != hipSuccess) { }
+            const auto t3 = clk::now();
+            b.push_back(std::chrono::duration<double, std::micro>(t2 - t0).count());
+            c.push_back(std::chrono::duration<double, std::micro>(t3 - t2).count());
+        }
+        std::sort(b.begin(), b.end()); std::sort(c.begin(), c.end());
+        printf("kernel %d us: flag seen %.2f us after launch, a hipStreamQuery spin succeeds %.2f us after the flag (medians)\n", spin / 100, b[b.size() / 2], c[c.size() / 2]);
+    }
+    for (int spin : {2000, 8000})
+    {
+        std::vector<double> b;
+        for (int i = 1; i <= 300; i++)
+        {
+            const auto t0 = clk::now();
+            hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, st, flag, -i, spin);
+            while (hipStreamQuery(st) != hipSuccess) { }
+            const auto t3 = clk::now();
+            b.push_back(std::chrono::duration<double, std::micro>(t3 - t0).count());
+        }
+        std::sort(b.begin(), b.end());
+        printf("kernel %d us: launch + hipStreamQuery spin %.2f us (median)\n", spin / 100, b[b.size() / 2]);
+    }
     // and the plain way: launch + synchronize, no polling
     for (int spin : {2000, 8000})
     {

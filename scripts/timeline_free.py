@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import clipgen  # noqa: E402
 import livevisionkit_amd as lvk  # noqa: E402
 
 SLOTS, RING = 4, 8192
@@ -17,7 +18,7 @@ UNITS = {"imgproc": ["area", "pyramid"], "pyrlk": ["flow"], "motion": ["hypothes
 
 
 def main():
-    rows, cols, pool, steps = 2160, 3840, 24, 700
+    rows, cols, pool, steps = 2160, 3840, 64, 700
     device = torch.device("cuda", 0)
     lvk.shard.bind_to_gpu_numa(0)
     ws = torch.cuda.Stream(device)
@@ -25,9 +26,9 @@ def main():
     filt = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
     filt.configure(lvk.StabilizationFilterSettings.obs_preset("homography"))
     filt.set_overlap(True)
-    frames = bench.make_frame_pool(rows, cols, pool, seed=0x4C564B31, device=device)
-    planes = [ctx.egress_yuv420(f) for f in frames]
-    ctx.sync()
+    clip = clipgen.Clip(rows, cols, 600, device=device, cut_at=None)                 # the bench's clip, first `pool` poses
+    planes = [clip.render_i420(i) for i in range(pool)]
+    torch.cuda.synchronize()
     outs = [tuple(torch.empty_like(p) for p in planes[0]) for _ in range(4)]
     pa = [filt.prepare_yuv420(p) for p in planes]; oa = [filt.prepare_yuv420(o) for o in outs]
     torch.cuda.synchronize()
