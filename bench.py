@@ -265,7 +265,7 @@ def main():
 
     # the same remap kernel alone on the GPU at full occupancy (the timed region runs its occupancy-capped `_co` variant next to the tracker)
     standalone_us = None
-    if rank == 0 and args.lens != "two-pass":
+    if rank == 0 and world == 1 and args.lens != "two-pass":
         torch.cuda.synchronize()
         meshes = filt.meshes()[1]
         srcs = frames[:8] if frames is not None else [clip.render444(i) for i in range(8)]
@@ -289,7 +289,7 @@ def main():
     # filter's output stream (lvk_hip_stab_output_stream), no host synchronisation inside the loop.  The push itself orders the bulk
     # stream behind the uploads the tracking stream waits for (no explicit wait on the output stream here).
     pcie = None
-    if rank == 0 and yuv420 and not args.no_pcie and not args.no_overlap:
+    if rank == 0 and world == 1 and yuv420 and not args.no_pcie and not args.no_overlap:
         try:
             nsteps = 1000
             hpool = min(pool, 48)
