@@ -283,10 +283,6 @@ public:
         for (Zone& z : zones) z.load = 0;
     }
 
-    std::vector<Zone> zones;
-    std::vector<Feature> held;               // m_Features: propagated features waiting for the next detect()
-
-private:
     // (size_t)(a / b) for a >= 0, b > 0 without the division: the binary64 product with 1 / b, rounded to binary32, is within one
     // binary32 ulp of the binary32 quotient, so the truncations agree unless an integer is that close -- then the division decides.
     // (Four divisions per feature were most of the 7 us per frame this bookkeeping cost on the critical path between two frames' kernels.)
@@ -298,6 +294,10 @@ private:
         if (fr > 1e-3f && fr < 0.999f) return (size_t)k;
         return (size_t)(a / b);
     }
+    std::vector<Zone> zones;
+    std::vector<Feature> held;               // m_Features: propagated features waiting for the next detect()
+
+private:
     size_t cell_of(float x, float y) const { return quot(y, m_ch, m_ich) * (size_t)m_gc + quot(x, m_cw, m_icw); }
     void clear_cells()
     {

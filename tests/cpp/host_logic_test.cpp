@@ -222,8 +222,36 @@ static void test_warp_mesh_arithmetic()
     CHECK(a.off[0] == 0.05f && a.off[1] == -0.04f);
 }
 
+// FeatureGridH::quot must be (size_t)(a / b) for every a >= 0: random values, and the neighbourhood of every multiple of b (where the
+// product with the reciprocal and the division can land on different sides of an integer)
+static void test_truncated_quotient()
+{
+    std::mt19937 rng(11);
+    const float divisors[] = {256.0f / 51.0f, 480.0f / 96.0f, 270.0f / 54.0f, 128.0f, 135.0f, 1920.0f / 384.0f, 7.0f / 3.0f};
+    for (float b : divisors)
+    {
+        const double inv = 1.0 / (double)b;
+        for (int i = 0; i < 200000; i++)
+        {
+            const float a = (float)(rng() % 4096000) / 1000.0f;
+            CHECK(lvkh::FeatureGridH::quot(a, b, inv) == (size_t)(a / b));
+        }
+        for (int k = 0; k < 2000; k++)
+        {
+            float a = (float)k * b;
+            for (int u = -3; u <= 3; u++)
+            {
+                float v = a;
+                for (int s2 = 0; s2 < (u < 0 ? -u : u); s2++) v = std::nextafter(v, u < 0 ? -1.0f : 1e9f);
+                if (v >= 0.0f) CHECK(lvkh::FeatureGridH::quot(v, b, inv) == (size_t)(v / b));
+            }
+        }
+    }
+}
+
 int main()
 {
+    test_truncated_quotient();
     test_mesh_constraints_static_band();
     test_feature_grid();
     test_propagate_priority_rule();
