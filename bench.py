@@ -147,6 +147,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("LVK_BENCH_SHARE_GPU") == "1":         # functional test of the N > 1 path on a box with fewer GPUs than ranks
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
