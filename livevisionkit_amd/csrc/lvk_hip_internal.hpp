@@ -180,6 +180,12 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
 int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
                              float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
                              const float2* d_und = nullptr, float region_w = 0.0f, float region_h = 0.0f);   // d_und: lens-corrected (prev | matched), see k_match_compact
+// both in two kernels (the hypotheses kernel compacts the flow result itself): same results; n <= 1024 pairs
+constexpr int LVK_COMPACT_RANSAC_MAX = 1024;
+int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
+                              float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
+                              const float2* d_und, float region_wf, float region_hf,
+                              double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask);
 
 struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)

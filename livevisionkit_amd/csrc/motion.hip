@@ -212,25 +212,128 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
     return true;
 }
 
+// ---- fast_filter on the GPU (see lvk_launch_match_compact) ---------------------------------------------------------------------------
+// The host algorithm (Functions/Container.tpp:97-121) walks k = n-1 .. 0 and, for every dropped k, swaps element k with the last element
+// of the still-kept prefix.  Closed form of the result: with r dropped elements, m = n - r, the kept elements below m never move; the hole
+// with descending rank j (1 = highest dropped index) receives what position n - j holds at that moment, which is that position's own
+// element if it was kept, or else whatever was moved into it when IT was a hole (rank i < j, i.e. the content of position n - i) -- a
+// chain that ends at a kept tail element.
+constexpr int CMP_CAP = 4096;
+// One block of CMP_NT threads over n <= 4 CMP_NT pairs: fills s_keep (the effective status flags) and s_above (per element, the number
+// of dropped elements with a higher index) and returns m.  mirror: also copy the raw flow result to device-visible host memory.
+template <int CMP_NT>
+__device__ __forceinline__ int compact_plan(const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
+                                            const float2* __restrict__ und, float region_w, float region_h,
+                                            unsigned short* s_above, uint8_t* s_keep, int* s_wave, bool mirror,
+                                            float2* __restrict__ host_matched, uint8_t* __restrict__ host_status)
+{
+    static_assert(CMP_NT == 1024 || CMP_NT == 256, "4 elements per thread: 4096 or 1024 pairs");
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += CMP_NT)
+    {
+        uint8_t k = status[i];
+        if (und)
+        {
+            // fused lens mode: a match whose lens-corrected positions leave the tracking region is dropped (not visible in the corrected frame)
+            const float2 a = und[i], b = und[n + i];
+            const bool inside = a.x >= 0.0f && a.x < region_w && a.y >= 0.0f && a.y < region_h && b.x >= 0.0f && b.x < region_w && b.y >= 0.0f && b.y < region_h;
+            if (!inside) k = 0;
+        }
+        s_keep[i] = k;
+        if (mirror) { host_status[i] = k; host_matched[i] = matched[i]; }
+    }
+    __syncthreads();
+    // exclusive prefix count of dropped elements over the reversed index j = n - 1 - i; thread t owns j = 4t .. 4t + 3
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const int j = 4 * t + q;
+        loc[q] = sum;
+        sum += (j < n && !s_keep[n - 1 - j]) ? 1 : 0;
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((t & 63) >= o) inc += v; }
+    if ((t & 63) == 63) s_wave[t >> 6] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < CMP_NT / 64; w++) { const int v = s_wave[w]; total += v; if (w < (t >> 6)) base += v; }
+    const int excl = base + inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const int j = 4 * t + q;
+        if (j < n) s_above[n - 1 - j] = (unsigned short)(excl + loc[q]);
+    }
+    __syncthreads();
+    return n - total;
+}
+// the element that ends up at position i < m
+__device__ __forceinline__ int compact_source(int i, int n, const unsigned short* s_above, const uint8_t* s_keep)
+{
+    if (s_keep[i]) return i;
+    int p = n - ((int)s_above[i] + 1);
+    while (!s_keep[p]) p = n - ((int)s_above[p] + 1);
+    return p;
+}
+
 // One wavefront per hypothesis.  STAGED: the point pairs are first copied into LDS with one coalesced sweep, so the
 // voting loop is not a chain of dependent global-memory round trips.
-template <bool STAGED>
+// What the fused variant needs besides: the raw flow result (prev | matched | status) and where the compacted pairs, their count and the
+// host mirrors go (k_match_compact's arguments).
+struct CompactArgs
+{
+    const float2* prev; const float2* matched; const uint8_t* status; const float2* und; float region_w, region_h;
+    float2* p1; float2* p2; int* count; int* host_count; float2* host_matched; uint8_t* host_status;
+};
+
+// FUSED: fast_filter runs inside this kernel -- every block derives the compacted pairs straight into its LDS copy (the staging sweep
+// it does anyway), block 0 also writes them, the count and the host mirrors out for k_ransac_finalize and the host.  One kernel and
+// one kernel boundary less on the critical chain of a frame (k_match_compact: 3.5 us + 4-8 us of gaps around it).
+template <bool STAGED, bool FUSED = false>
 __global__ __launch_bounds__(NT)
 void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
-                         double* __restrict__ hyp_H, long long* __restrict__ hyp_score)
+                         double* __restrict__ hyp_H, long long* __restrict__ hyp_score, CompactArgs ca)
 {
     LVK_TL(0);
     LVK_TRACKER_PRIORITY();
-    if (n_dev) n = min(*n_dev, n);                          // pair count decided on the GPU (k_match_compact); n = capacity
-    if (n < (full ? 4 : 2)) { if (threadIdx.x == 0) hyp_score[blockIdx.x] = -1; return; }
+    static_assert(!FUSED || STAGED, "the fused variant compacts into the LDS copy");
     __shared__ double sA[64], sb[8], sH[9];
     __shared__ int s_ok;
     __shared__ long long s_scratch[NT / 64];
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
-    if (STAGED)
+    if (FUSED)
     {
-        for (int i = threadIdx.x; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+        __shared__ unsigned short s_above[FUSED ? 4 * NT : 1];
+        __shared__ uint8_t s_keep[FUSED ? 4 * NT : 1];
+        __shared__ int s_wave[NT / 64];
+        const bool first = blockIdx.x == 0;
+        const int m = compact_plan<NT>(ca.matched, ca.status, n, ca.und, ca.region_w, ca.region_h, s_above, s_keep, s_wave, first, ca.host_matched, ca.host_status);
+        const float2* pair_prev = ca.und ? ca.und : ca.prev;
+        const float2* pair_next = ca.und ? ca.und + n : ca.matched;
+        for (int i = threadIdx.x; i < m; i += NT)
+        {
+            const int src = compact_source(i, n, s_above, s_keep);
+            const float2 a = pair_prev[src], b = pair_next[src];
+            s_p1[i] = a; s_p2[i] = b;
+            if (first) { ca.p1[i] = a; ca.p2[i] = b; }
+        }
+        if (first && threadIdx.x == 0) { *ca.count = m; *ca.host_count = m; }
         __syncthreads();
+        n = m;
+        if (n < (full ? 4 : 2)) { if (threadIdx.x == 0) hyp_score[blockIdx.x] = -1; return; }
+    }
+    else
+    {
+        if (n_dev) n = min(*n_dev, n);                      // pair count decided on the GPU (k_match_compact); n = capacity
+        if (n < (full ? 4 : 2)) { if (threadIdx.x == 0) hyp_score[blockIdx.x] = -1; return; }
+        if (STAGED)
+        {
+            for (int i = threadIdx.x; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+            __syncthreads();
+        }
     }
     const float2* p1 = STAGED ? s_p1 : g1;
     const float2* p2 = STAGED ? s_p2 : g2;
@@ -522,15 +625,10 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     if (lane == 0) *out_ninl = ninl;
 }
 
-// fast_filter on the GPU (see lvk_launch_match_compact).  The host algorithm walks k = n-1 .. 0 and, for every dropped k, swaps
-// element k with the last element of the still-kept prefix.  Closed form of the result: with r dropped elements, m = n - r, the
-// kept elements below m never move; the hole with descending rank j (1 = highest dropped index) receives what position n - j
-// holds at that moment, which is that position's own element if it was kept, or else whatever was moved into it when IT was a
-// hole (rank i < j, i.e. the content of position n - i) -- a chain that ends at a kept tail element.
+// fast_filter as a kernel of its own (the field preset, lens pairs beyond the fused variant's capacity).
 // Block size: 256 threads for up to 1024 pairs (the usual 600-800), 1024 beyond.  A 1024-thread block needs 4 free wave slots on every
-// SIMD of one CU at the same moment; next to the persistent remap grid (4 waves per SIMD) and the flow kernel's last blocks it was placed
-// ~4 us late every frame (in-kernel timeline, scripts/timeline_free.py) -- on the critical chain of the frame.
-constexpr int CMP_CAP = 4096;
+// SIMD of one CU at the same moment; next to the persistent remap grid (4 waves per SIMD) and the flow kernel's last blocks it is placed
+// several microseconds late.
 template <int CMP_NT>
 __global__ __launch_bounds__(CMP_NT)
 void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
@@ -544,59 +642,14 @@ void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__
     __shared__ uint8_t s_keep[CMP_CAP];
     __shared__ int s_wave[CMP_NT / 64];
     const int t = threadIdx.x;
-    // fused lens mode: `und` holds the lens-corrected positions (previous | matched); they are what the motion is estimated from,
-    // and a match whose corrected positions leave the tracking region is dropped (it is not visible in the corrected frame)
+    // fused lens mode: `und` holds the lens-corrected positions (previous | matched); they are what the motion is estimated from
     const float2* pair_prev = und ? und : prev;
     const float2* pair_next = und ? und + n : matched;
-    for (int i = t; i < n; i += CMP_NT)
-    {
-        uint8_t k = status[i];
-        if (und)
-        {
-            const float2 a = und[i], b = und[n + i];
-            const bool inside = a.x >= 0.0f && a.x < region_w && a.y >= 0.0f && a.y < region_h && b.x >= 0.0f && b.x < region_w && b.y >= 0.0f && b.y < region_h;
-            if (!inside) k = 0;
-        }
-        s_keep[i] = k; host_status[i] = k; host_matched[i] = matched[i];
-    }
-    __syncthreads();
-    // exclusive prefix count of dropped elements over the reversed index j = n - 1 - i; thread t owns j = 4t .. 4t + 3
-    static_assert(CMP_NT == 1024 || CMP_NT == 256, "4 elements per thread: 4096 or 1024 pairs");
-    int loc[4], sum = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        const int j = 4 * t + q;
-        loc[q] = sum;
-        sum += (j < n && !s_keep[n - 1 - j]) ? 1 : 0;
-    }
-    int inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((t & 63) >= o) inc += v; }
-    if ((t & 63) == 63) s_wave[t >> 6] = inc;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < CMP_NT / 64; w++) { const int v = s_wave[w]; total += v; if (w < (t >> 6)) base += v; }
-    const int excl = base + inc - sum;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        const int j = 4 * t + q;
-        if (j < n) s_above[n - 1 - j] = (unsigned short)(excl + loc[q]);
-    }
-    __syncthreads();
-    const int m = n - total;
+    const int m = compact_plan<CMP_NT>(matched, status, n, und, region_w, region_h, s_above, s_keep, s_wave, true, host_matched, host_status);
     if (t == 0) { *count = m; *host_count = m; }
     for (int i = t; i < m; i += CMP_NT)
     {
-        int src = i;
-        if (!s_keep[i])
-        {
-            int p = n - ((int)s_above[i] + 1);
-            while (!s_keep[p]) p = n - ((int)s_above[p] + 1);
-            src = p;
-        }
+        const int src = compact_source(i, n, s_above, s_keep);
         p1[i] = pair_prev[src]; p2[i] = pair_next[src];
     }
 }
@@ -621,13 +674,13 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     const double t2 = threshold * threshold;
     if (n <= LDS_POINTS)
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, CompactArgs{});
         hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     else
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score);
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, CompactArgs{});
         hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
@@ -646,6 +699,29 @@ int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float
     else
         hipLaunchKernelGGL(k_match_compact<1024>, dim3(1), dim3(1024), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
                            d_und, region_w, region_h);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+// fast_filter + RANSAC in two kernels instead of three: the hypotheses kernel compacts the flow result itself (see k_ransac_hypotheses,
+// FUSED).  Same arguments and results as lvk_launch_match_compact followed by lvk_launch_ransac(.., d_count); n <= 1024 pairs.
+int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
+                              float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
+                              const float2* d_und, float region_wf, float region_hf,
+                              double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask)
+{
+    LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n > 0 && n <= 4 * NT && n <= LDS_POINTS);
+    LVK_HIP_REQUIRE(ctx, d_ws && d_H && d_ninl && d_mask);
+    double* hyp_H = (double*)d_ws;
+    long long* hyp_score = (long long*)(hyp_H + K_HYPOTHESES * 9);
+    uint8_t* mask_a = (uint8_t*)(hyp_score + K_HYPOTHESES);
+    uint8_t* mask_b = mask_a + (((size_t)n + 255) & ~(size_t)255);
+    const double t2 = threshold * threshold;
+    const CompactArgs ca{d_prev, d_matched, d_status, d_und, region_wf, region_hf, d_p1, d_p2, d_count, h_count, h_matched, h_status};
+    hipLaunchKernelGGL((k_ransac_hypotheses<true, true>), dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, (const float2*)nullptr, (const float2*)nullptr, n, (const int*)nullptr,
+                       t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
+    hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, (const float2*)d_p1, (const float2*)d_p2, n, (const int*)d_count, t2, full_homography ? 1 : 0,
+                       region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

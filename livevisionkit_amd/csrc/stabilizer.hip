@@ -495,8 +495,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
             if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
                                                 d_pts, n, d_matched, n, d_und)) != LVK_HIP_OK) return rc;
         }
-        if ((rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
-                                           lens ? d_und : nullptr, (float)cur_w, (float)cur_h)) != LVK_HIP_OK) return rc;
+        const bool fused_compact = !field && n <= LVK_COMPACT_RANSAC_MAX;        // the RANSAC's first kernel compacts the flow result itself
+        if (!fused_compact && (rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
+                                                             lens ? d_und : nullptr, (float)cur_w, (float)cur_h)) != LVK_HIP_OK) return rc;
         prof_end(pe);
         pe = prof_begin(LVK_STAGE_MOTION);
         if (field)
@@ -504,6 +505,12 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
             // estimate_local_motions (FrameTracker.cpp:200-321): least-squares mesh through the matches, solved on the device
             if ((rc = lvk_launch_mesh_solve(mesh_dev, st, d_mesh_scratch, d_p1, d_p1 + cap_features, d_count, n, s.min_motion_samples, (float)cur_w, (float)cur_h,
                                             s.temporal_smoothing, s.acceptance_threshold, h_offsets, h_mask, h_mesh_status)) != LVK_HIP_OK) return rc;
+        }
+        else if (fused_compact)
+        {
+            if ((rc = lvk_launch_compact_ransac(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
+                                                lens ? d_und : nullptr, (float)cur_w, (float)cur_h,
+                                                s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
         }
         else if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count)) != LVK_HIP_OK) return rc;
         prof_end(pe);
