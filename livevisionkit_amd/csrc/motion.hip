@@ -167,10 +167,10 @@ __device__ long long score_model(const double* H, const float2* __restrict__ p1,
         if (in) { score += (long long)((1.0 - e2 / t2) * 1024.0); cnt++; }
         if (mask) mask[i] = in ? 1 : 0;
     }
-    score = block_sum_ll(score, scratch);
-    cnt = block_sum_ll(cnt, scratch);
-    if (ninl) *ninl = (int)cnt;
-    return score;
+    // one block reduction for both: the score of a pair is below 2^10, so the sum over <= 2^22 pairs stays below bit 40
+    const long long both = block_sum_ll(score + (cnt << 40), scratch);
+    if (ninl) *ninl = (int)(both >> 40);
+    return both & ((1ll << 40) - 1);
 }
 
 // Whole-wave: lane 0 assembles the system / closed form, all lanes take part in the solve.
@@ -480,7 +480,7 @@ __device__ __forceinline__ void refit_sums_partial(const float2* __restrict__ p1
     store_totals<W, 4>(acc, 10, A, b, std::make_integer_sequence<int, NS>{});
 }
 
-__device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
+__device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
                       double cx, double cy, double sc, double* A, double* b, double* H)
 {
     const int lane = threadIdx.x;
@@ -498,20 +498,30 @@ __device__ bool refit(bool full, const float2* __restrict__ p1, const float2* __
         __shared__ int s_ok;
         __shared__ int s_solved8;
         bool ok = solve_n<8>(A, b, &s_solved8);
-        if (lane == 0)
+        // H = T^-1 Hn T, normalised by its last entry: entry q by lane q of wave 0 (every entry is its own expression of Hn, T, T^-1; the
+        // nine of them one after another in a single lane were 0.5 us of every refit round)
+        if (lane < 64)
         {
             if (ok)
             {
                 const double Hn[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
-                const double T[9] = {sc, 0, -cx * sc, 0, sc, -cy * sc, 0, 0, 1};
-                const double Ti[9] = {1.0 / sc, 0, cx, 0, 1.0 / sc, cy, 0, 0, 1};
-                double M[9], R[9];
-                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r * 3 + c] = (Hn[r * 3] * T[c] + Hn[r * 3 + 1] * T[3 + c]) + Hn[r * 3 + 2] * T[6 + c];
-                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[r * 3 + c] = (Ti[r * 3] * M[c] + Ti[r * 3 + 1] * M[3 + c]) + Ti[r * 3 + 2] * M[6 + c];
-                if (fabs(R[8]) < 1e-12) ok = false;
-                else for (int q = 0; q < 9; q++) H[q] = R[q] / R[8];
+                // T = [sc 0 -cx sc; 0 sc -cy sc; 0 0 1], T^-1 = [1/sc 0 cx; 0 1/sc cy; 0 0 1]: column c of T and row r of T^-1 by selects (same
+                // operand values as the indexed arrays of the sequential form, zeros included)
+                const double isc = 1.0 / sc, tx = -cx * sc, ty = -cy * sc;
+                auto entry = [&](int r, int c) -> double {
+                    const double t0 = c == 0 ? sc : (c == 2 ? tx : 0.0), t1 = c == 1 ? sc : (c == 2 ? ty : 0.0), t2 = c == 2 ? 1.0 : 0.0;
+                    const double i0 = r == 0 ? isc : 0.0, i1 = r == 1 ? isc : 0.0, i2 = r == 0 ? cx : (r == 1 ? cy : 1.0);
+                    double Mc[3];                                                              // column c of M = Hn T
+#pragma unroll
+                    for (int k = 0; k < 3; k++) Mc[k] = (Hn[k * 3] * t0 + Hn[k * 3 + 1] * t1) + Hn[k * 3 + 2] * t2;
+                    return (i0 * Mc[0] + i1 * Mc[1]) + i2 * Mc[2];
+                };
+                const int q = lane < 9 ? lane : 8;
+                const double Rq = entry(q / 3, q % 3), R8 = entry(2, 2);
+                if (fabs(R8) < 1e-12) ok = false;
+                else if (lane < 9) H[lane] = Rq / R8;
             }
-            s_ok = ok ? 1 : 0;
+            if (lane == 0) s_ok = ok ? 1 : 0;
         }
         __syncthreads();
         return s_ok != 0;
