@@ -144,7 +144,16 @@ struct lvk_hip_stab
     int queue_kind = 0;                        // who owns the queued frames: 0 = queue empty, 1 = borrowed from the caller, 2 = pool slots
     std::function<int()> deferred_ingest;      // the newest frame's 4:2:0 conversion, not yet launched (see lvk_hip_stab_push_yuv420)
     int run_deferred_ingest() { auto f = std::move(deferred_ingest); deferred_ingest = nullptr; return f ? f() : LVK_HIP_OK; }
-    hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame (runs on remap_stream in overlap mode)
+    hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame
+    // Overlap mode with a frame delay: the conversion runs on the TRACKING stream, in the slot that stream has free between the last
+    // kernel of a frame's chain and the first of the next frame's (the host's turn: ~25 us) -- behind an event the push waits on instead
+    // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which
+    // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
+    hipEvent_t chain_done = nullptr;
+    bool chain_event_armed = false, ingest_on_tracker = false, tracker_ingest_capable = false;
+    std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr
+    std::vector<char> slot_read_armed;
+    int slot_index(const void* p) const { for (size_t i = 0; i < pool_all.size(); i++) if (pool_all[i] == p) return (int)i; return -1; }
     int pending_slot = -1;
     // Overlap mode: what the caller enqueued on the context's stream before a push (a decode / copy that fills the frame or the planes)
     // must be visible to the kernels of the bulk stream that read it.  The event is recorded when the push starts -- before the tracker's
@@ -200,7 +209,7 @@ struct lvk_hip_stab
     int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion);
 
     // ---- YUV420 front/back end: pool of packed frames the planes are converted into
-    std::vector<void*> pool_all, pool_free;
+    std::vector<void*> pool_all; std::deque<void*> pool_free;      // free slots are reused oldest first: the remap that read a slot is long done
     void* pool_out = nullptr;
     int pool_rows = 0, pool_cols = 0;
     int ensure_pool(int rows, int cols);
@@ -522,13 +531,29 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         prof_end(pe);
     }
     trace.mark(HostTrace::LK_LAUNCH);
+    if (deferred_ingest && tracker_ingest_capable)
+    {
+        // Where the conversion goes: a bulk stream that is idle (a caller that synchronises every frame) takes it now, next to the
+        // chain -- the remap that follows then has the GPU to itself; a bulk stream that is still busy with the previous remap (a
+        // free-running caller) would only get to it after that, so it goes behind the chain on this stream, and the push waits for
+        // the chain through an event instead of for the stream.
+        const hipError_t q = hipStreamQuery(remap_stream);
+        if (q != hipSuccess) (void)hipGetLastError();
+        ingest_on_tracker = q == hipErrorNotReady;
+        if (ingest_on_tracker && chained)
+        {
+            if (!chain_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));
+            LVK_HIP_CHECK(ctx, hipEventRecord(chain_done, st)); chain_event_armed = true;
+        }
+    }
     if (deferred_ingest && (rc = run_deferred_ingest()) != LVK_HIP_OK) return rc;
     if (lens && !chained)
     {
         if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
                                             d_pts, n, h_matched, n, h_und)) != LVK_HIP_OK) return rc;
     }
-    LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (chain_event_armed) { chain_event_armed = false; LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done)); }
+    else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     trace.mark(HostTrace::LK_SYNC);
 
     if (chained)
@@ -702,6 +727,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     }
     for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventDestroy(st->remap_done[i]);
     if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
+    if (st->chain_done) (void)hipEventDestroy(st->chain_done);
     if (st->caller_ready) (void)hipEventDestroy(st->caller_ready);
     for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete st;
@@ -945,8 +971,19 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222
         if (side && st->pool_frames)
         {
-            // 4:2:0 path in overlap mode: the slot is next written by an ingest on this same stream, i.e. after the remap that is
-            // reading it now -- stream order is all the protection it needs (no event, no host wait)
+            // 4:2:0 path in overlap mode: the slot is next written by an ingest -- on this same stream, i.e. after the remap that is
+            // reading it now (stream order is all the protection it needs), or on the tracking stream behind this event
+            if (st->tracker_ingest_capable)
+            {
+                const int si = st->slot_index(f.d_ptr);
+                if (si >= 0)
+                {
+                    if (!st->slot_read_done[(size_t)si]) { hipError_t e = hipEventCreateWithFlags(&st->slot_read_done[(size_t)si], hipEventDisableTiming); if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
+                    hipError_t e = hipEventRecord(st->slot_read_done[(size_t)si], rs);
+                    if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
+                    st->slot_read_armed[(size_t)si] = 1;
+                }
+            }
             if (released) *released = f.d_ptr;
         }
         else if (side)
@@ -1019,7 +1056,7 @@ int lvk_hip_stab::ensure_pool(int rows, int cols)
     {
         void* p = nullptr;
         LVK_HIP_CHECK(ctx, hipMalloc(&p, (size_t)rows * cols * 3));
-        pool_all.push_back(p); pool_free.push_back(p);
+        pool_all.push_back(p); pool_free.push_back(p); slot_read_done.push_back(nullptr); slot_read_armed.push_back(0);
     }
     return LVK_HIP_OK;
 }
@@ -1027,7 +1064,8 @@ int lvk_hip_stab::ensure_pool(int rows, int cols)
 void lvk_hip_stab::free_pool()
 {
     for (void* p : pool_all) (void)hipFree(p);
-    pool_all.clear(); pool_free.clear();
+    for (hipEvent_t e : slot_read_done) if (e) (void)hipEventDestroy(e);
+    pool_all.clear(); pool_free.clear(); slot_read_done.clear(); slot_read_armed.clear();
     if (pool_out) { (void)hipFree(pool_out); pool_out = nullptr; }
     pool_rows = pool_cols = 0;
 }
@@ -1083,14 +1121,23 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         }
         LVK_HIP_REQUIRE(ctx, !st->pool_free.empty());
     }
-    void* slot = st->pool_free.back(); st->pool_free.pop_back();
+    void* slot = st->pool_free.front(); st->pool_free.pop_front();
     // The packed frame is only read by the remap `predictive_samples` pushes later (the tracker reads the luma plane itself), so in
     // overlap mode the conversion runs on the remap stream, off the tracker's critical path; same-stream order protects the slot.
     const bool side_ingest = st->overlap && st->s.stabilize_output;
-    hipStream_t is = side_ingest ? st->remap_stream : ctx->stream;
+    // a delayed frame (its remap is launched after later synchronisations of the tracking stream) may be converted on either stream: track() decides
+    st->tracker_ingest_capable = side_ingest && st->queue_capacity > 1;
+    st->ingest_on_tracker = false;
     int pe = 0;
     auto do_ingest = [=]() -> int {
-        if (side_ingest) { const int w = st->bulk_stream_sees_caller_work(); if (w != LVK_HIP_OK) return w; }
+        const bool on_tracker = side_ingest && st->ingest_on_tracker;
+        hipStream_t is = (side_ingest && !on_tracker) ? st->remap_stream : ctx->stream;
+        if (side_ingest && !on_tracker) { const int w = st->bulk_stream_sees_caller_work(); if (w != LVK_HIP_OK) return w; }
+        if (on_tracker)
+        {
+            const int si = st->slot_index(slot);
+            if (si >= 0 && st->slot_read_armed[(size_t)si]) { st->slot_read_armed[(size_t)si] = 0; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(is, st->slot_read_done[(size_t)si], 0)); }
+        }
         const int pi = st->prof_begin(LVK_STAGE_INGEST, is);
         const int r = lvk_launch_ingest_yuv420(ctx, is, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
         st->prof_end(pi, is);
