@@ -151,6 +151,8 @@ struct lvk_hip_stab
     // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
     hipEvent_t chain_done = nullptr;
     bool chain_event_armed = false, ingest_on_tracker = false, tracker_ingest_capable = false;
+    // tests: LVK_HIP_INGEST_PLACEMENT=tracker|bulk pins the placement that is otherwise decided per push (see track())
+    int ingest_placement = [] { const char* e = std::getenv("LVK_HIP_INGEST_PLACEMENT"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
     std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr
     std::vector<char> slot_read_armed;
     int slot_index(const void* p) const { for (size_t i = 0; i < pool_all.size(); i++) if (pool_all[i] == p) return (int)i; return -1; }
@@ -539,7 +541,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         // the chain through an event instead of for the stream.
         const hipError_t q = hipStreamQuery(remap_stream);
         if (q != hipSuccess) (void)hipGetLastError();
-        ingest_on_tracker = q == hipErrorNotReady;
+        ingest_on_tracker = ingest_placement == 1 || (ingest_placement == 0 && q == hipErrorNotReady);
         if (ingest_on_tracker && chained)
         {
             if (!chain_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));

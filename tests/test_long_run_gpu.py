@@ -58,3 +58,39 @@ def test_600_frames_overlap_yuv420_bit_exact(ctx, oracle, preset, rows, cols, n)
     assert trust[cut:cut + 12].min() == 0.0, "the scene cut must drop the trust factor"
     assert trust[-1] == 1.0, "and it recovers afterwards"
     ost.close(); gst.close()
+
+
+@pytest.mark.parametrize("placement", ["tracker", "bulk", None])
+def test_free_running_pushes_bit_exact(oracle, placement, monkeypatch):
+    """40 pushes of a 4K I420 stream back to back, no synchronisation in between (what bench.py times): the 4:2:0 conversion of a push then
+    finds the bulk stream still busy with the previous remap and goes behind the tracker chain on the tracking stream (per-slot events,
+    the push waiting for the chain through an event).  Both placements pinned, and the per-push decision, against the oracle."""
+    import torch
+    import livevisionkit_amd as lvk
+    if placement: monkeypatch.setenv("LVK_HIP_INGEST_PLACEMENT", placement)
+    else: monkeypatch.delenv("LVK_HIP_INGEST_PLACEMENT", raising=False)
+    rows, cols, n = 2160, 3840, 40
+    clip = clipgen.Clip(rows, cols, n, device="cuda", cut_at=None)
+    s = oracle_lib.preset("homography")
+    s.predictive_samples = 4
+    ws = torch.cuda.Stream()
+    ctx = lvk.Context(0, stream=ws)
+    gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_conv(s))
+    gst.set_overlap(True)
+    planes = [clip.render_i420(i) for i in range(n)]
+    torch.cuda.synchronize()
+    got = [gst.apply_yuv420(planes[i], timestamp=i) for i in range(n)]          # free running
+    ctx.sync()
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
+    emitted = 0
+    for i in range(n):
+        want, wts = ost.push(oracle.ingest_yuv420(*[p.cpu().numpy() for p in planes[i]]), ts=i, nthreads=32)
+        g, gts = got[i]
+        assert (want is None) == (g is None), i
+        if want is not None:
+            assert wts == gts
+            for a, b in zip(g, oracle.egress_yuv420(want)):
+                assert np.array_equal(a.cpu().numpy(), b), f"frame {i} ({placement})"
+            emitted += 1
+    assert emitted == n - s.predictive_samples
+    ost.close(); gst.close(); ctx.close()
