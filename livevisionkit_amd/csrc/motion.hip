@@ -71,14 +71,17 @@ __device__ bool solve_n(double* A, double* b, int* s_verdict)
         {
             if (ok)
             {
+                // pivot search in column i: every lane scans its own column (no cross-lane traffic), lane i's verdict is broadcast
                 int piv = i;
-                double best = fabs(lane_value(a[i], i));
+                double best = fabs(a[i]);
 #pragma unroll
                 for (int j = i + 1; j < N; j++)
                 {
-                    const double v = fabs(lane_value(a[j], i));
+                    const double v = fabs(a[j]);
                     if (v > best) { best = v; piv = j; }
                 }
+                piv = __builtin_amdgcn_readlane(piv, i);
+                best = lane_value(best, i);
                 if (best < 1e-10) ok = false;
                 else
                 {
@@ -90,7 +93,7 @@ __device__ bool solve_n(double* A, double* b, int* s_verdict)
                     for (int j = i + 1; j < N; j++)
                     {
                         const double f = lane_value(a[j], i) * inv;
-                        if (q > i) a[j] = a[j] - f * a[i];
+                        a[j] = a[j] - f * a[i];                 // (the columns q <= i of the rows below the pivot are never read again: no mask)
                     }
                 }
             }
@@ -484,6 +487,9 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
                       double cx, double cy, double sc, double* A, double* b, double* H)
 {
     const int lane = threadIdx.x;
+#ifdef LVK_RANSAC_TIMING
+    const long long r0 = wall_clock64(); long long r1 = 0, r2 = 0;
+#endif
     if (full)
     {
         static_assert(NT == 256, "four waves, four partials per lane");
@@ -495,9 +501,15 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
             default: refit_sums_full<3>(p1, p2, n, mask, cx, cy, sc, A, b); break;
         }
         __syncthreads();
+#ifdef LVK_RANSAC_TIMING
+        r1 = wall_clock64();
+#endif
         __shared__ int s_ok;
         __shared__ int s_solved8;
         bool ok = solve_n<8>(A, b, &s_solved8);
+#ifdef LVK_RANSAC_TIMING
+        r2 = wall_clock64();
+#endif
         // H = T^-1 Hn T, normalised by its last entry: entry q by lane q of wave 0 (every entry is its own expression of Hn, T, T^-1; the
         // nine of them one after another in a single lane were 0.5 us of every refit round)
         if (lane < 64)
@@ -524,6 +536,9 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
             if (lane == 0) s_ok = ok ? 1 : 0;
         }
         __syncthreads();
+#ifdef LVK_RANSAC_TIMING
+        if (lane == 0) printf("  refit: sums %lld, solve %lld, normalise %lld\n", r1 - r0, r2 - r1, wall_clock64() - r2);
+#endif
         return s_ok != 0;
     }
     else
@@ -584,6 +599,13 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     uint8_t* mask_a = STAGED ? s_mask[0] : gmask_a;
     uint8_t* mask_b = STAGED ? s_mask[1] : gmask_b;
     const int m = full ? 4 : 2;
+#ifdef LVK_RANSAC_TIMING
+    long long tt[16]; int nt_ = 0;
+#define RT_MARK() do { if (nt_ < 16) tt[nt_++] = wall_clock64(); } while (0)
+#else
+#define RT_MARK() do { } while (0)
+#endif
+    RT_MARK();
     // argmax over the hypotheses: highest score, lowest index on ties
     long long best = -1; int best_h = -1;
     for (int h = lane; h < K_HYPOTHESES; h += NT)
@@ -615,15 +637,19 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     __syncthreads();
     uint8_t* cur = mask_a; uint8_t* trial = mask_b;
     int ninl = 0;
+    RT_MARK();
     long long best_score = score_model(sBest, p1, p2, n, t2, cur, &ninl, s_scratch);
     __syncthreads();
+    RT_MARK();
     for (int round = 0; round < LO_ROUNDS; round++)
     {
         if (ninl < m) break;
         if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH)) break;
+        RT_MARK();
         int nt = 0;
         const long long s = score_model(sH, p1, p2, n, t2, trial, &nt, s_scratch);
         __syncthreads();
+        RT_MARK();
         if (s <= best_score) break;
         best_score = s; ninl = nt;
         if (lane < 9) sBest[lane] = sH[lane];
@@ -633,6 +659,15 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     for (int i = lane; i < n; i += NT) out_mask[i] = cur[i];
     if (lane < 9) out_H[lane] = sBest[lane];
     if (lane == 0) *out_ninl = ninl;
+#ifdef LVK_RANSAC_TIMING
+    RT_MARK();
+    if (lane == 0)
+    {
+        printf("finalize n %d ninl %d (100 MHz ticks): stage+argmax, score, then (refit, score) per round, output:", n, ninl);
+        for (int k = 1; k < nt_; k++) printf(" %lld", tt[k] - tt[k - 1]);
+        printf("\n");
+    }
+#endif
 }
 
 // fast_filter as a kernel of its own (the field preset, lens pairs beyond the fused variant's capacity).
