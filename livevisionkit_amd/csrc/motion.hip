@@ -53,7 +53,7 @@ __device__ __forceinline__ double lane_value(double v, int src_lane)          //
 // Gaussian elimination with partial pivoting of the N x N system (A, b) in LDS, N <= 8, executed by wave 0 of the block entirely
 // in registers: lane q holds column q of A (lane N: the right-hand side), pivots and multipliers travel by v_readlane, so a
 // pivot step needs neither LDS nor a barrier.  Every element sees exactly the operations of the sequential algorithm in the same
-// order (f = A[j][i] * (1 / A[i][i]); A[j][q] -= f * A[i][q]; back substitution s -= A[i][q] * x[q], q ascending), so the result
+// order (f = A[j][i] * (1 / A[i][i]); A[j][q] -= f * A[i][q]; back substitution s -= A[i][q] * x[q], q ascending, x = s * (1 / A[i][i])), so the result
 // is bit-identical to it.  Must be called by every thread of the block (one block barrier at the end); the solution replaces b,
 // all threads return the same verdict.
 template <int N>
@@ -66,6 +66,9 @@ __device__ bool solve_n(double* A, double* b, int* s_verdict)
 #pragma unroll
         for (int r = 0; r < N; r++) a[r] = q < N ? A[r * N + q] : (q == N ? b[r] : 0.0);
         bool ok = true;
+        double rcp[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) rcp[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
@@ -89,6 +92,7 @@ __device__ bool solve_n(double* A, double* b, int* s_verdict)
                     for (int r = i + 1; r < N; r++)
                         if (piv == r) { const double t = a[i]; a[i] = a[r]; a[r] = t; }          // wave-uniform row swap
                     const double inv = 1.0 / lane_value(a[i], i);
+                    rcp[i] = inv;
 #pragma unroll
                     for (int j = i + 1; j < N; j++)
                     {
@@ -107,7 +111,7 @@ __device__ bool solve_n(double* A, double* b, int* s_verdict)
                 double sum = lane_value(a[i], N);
 #pragma unroll
                 for (int c = i + 1; c < N; c++) sum = sum - lane_value(a[i], c) * x[c];
-                x[i] = sum / lane_value(a[i], i);
+                x[i] = sum * rcp[i];                            // the reciprocal pivot of the elimination
             }
             if (q == 0)
             {

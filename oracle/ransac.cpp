@@ -54,9 +54,12 @@ bool draw_sample(int h, int n, int m, int* idx)
     return got == m;
 }
 
-// Gaussian elimination with partial pivoting, n <= 8.  A is n x n row major, overwritten.
+// Gaussian elimination with partial pivoting, n <= 8.  A is n x n row major, overwritten.  Pivots enter as reciprocals, in the
+// elimination AND in the back substitution (x_i = s_i * (1 / a_ii): the reciprocals do not depend on the solution, so the sixteen
+// dependent divisions of the textbook form -- what a GPU wavefront spends most of this solve waiting for -- become eight).
 bool solve_n(double* A, double* b, int n)
 {
+    double rcp[8];
     for (int i = 0; i < n; i++)
     {
         int piv = i;
@@ -64,6 +67,7 @@ bool solve_n(double* A, double* b, int n)
         if (std::fabs(A[piv * n + i]) < 1e-10) return false;
         if (piv != i) { for (int q = 0; q < n; q++) std::swap(A[i * n + q], A[piv * n + q]); std::swap(b[i], b[piv]); }
         const double inv = 1.0 / A[i * n + i];
+        rcp[i] = inv;
         for (int j = i + 1; j < n; j++)
         {
             const double f = A[j * n + i] * inv;
@@ -75,7 +79,7 @@ bool solve_n(double* A, double* b, int n)
     {
         double s = b[i];
         for (int q = i + 1; q < n; q++) s = s - A[i * n + q] * b[q];
-        b[i] = s / A[i * n + i];
+        b[i] = s * rcp[i];
     }
     return true;
 }
