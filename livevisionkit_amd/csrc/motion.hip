@@ -387,12 +387,42 @@ __device__ __forceinline__ double lane_plus(double v)
 constexpr int tri_row(int id, int n) { int a = 0; while (id >= n - a) { id -= n - a; a++; } return a; }
 constexpr int tri_col(int id, int n) { int a = 0; while (id >= n - a) { id -= n - a; a++; } return a + id; }
 
-// one term of sum ID for one point pair (ID is a compile-time constant so that r0 / r1 stay in registers)
+// one term of sum ID for one point pair (ID is a compile-time constant so that r0 / r1 stay in registers).
+// The rows are r0 = (x, y, 1, 0, 0, 0, -xu, -yu) and r1 = (0, 0, 0, x, y, 1, -xv, -yv): most products have a structural 0 or 1 in them.
+// Without fast-math the compiler must still multiply by the zeros (0 * t is -0 or NaN for some t); here the inputs are finite, a term
+// with a structural zero factor is +-0, adding +-0 to the other product leaves it unchanged unless that is a zero too, and an accumulator
+// that starts at +0 can never become -0 -- so the structural zeros are dropped at compile time and every sum keeps its exact value
+// (28 multiplications and 40 additions per pair instead of 88 and 88).
+constexpr int row_kind0(int k) { return k < 2 ? 2 : (k == 2 ? 1 : (k < 6 ? 0 : 2)); }      // 0: structural zero, 1: one, 2: a variable
+constexpr int row_kind1(int k) { return k < 3 ? 0 : (k < 5 ? 2 : (k == 5 ? 1 : 2)); }
+template <int KA, int KC>
+__device__ __forceinline__ double structured_product(double a, double c) { if constexpr (KA == 1) return c; else if constexpr (KC == 1) return a; else return a * c; }
+template <int ID>
+constexpr bool full_term_is_zero()
+{
+    if (ID < 36) { const int a = tri_row(ID, 8), c = tri_col(ID, 8); return (row_kind0(a) == 0 || row_kind0(c) == 0) && (row_kind1(a) == 0 || row_kind1(c) == 0); }
+    return false;
+}
 template <int ID>
 __device__ __forceinline__ double full_term(const double (&r0)[8], const double (&r1)[8], double u, double v)
 {
-    if constexpr (ID < 36) { constexpr int a = tri_row(ID, 8), c = tri_col(ID, 8); return r0[a] * r0[c] + r1[a] * r1[c]; }
-    else return r0[ID - 36] * u + r1[ID - 36] * v;
+    if constexpr (ID < 36)
+    {
+        constexpr int a = tri_row(ID, 8), c = tri_col(ID, 8);
+        constexpr bool z0 = row_kind0(a) == 0 || row_kind0(c) == 0, z1 = row_kind1(a) == 0 || row_kind1(c) == 0;
+        if constexpr (z0 && z1) return 0.0;
+        else if constexpr (z1) return structured_product<row_kind0(a), row_kind0(c)>(r0[a], r0[c]);
+        else if constexpr (z0) return structured_product<row_kind1(a), row_kind1(c)>(r1[a], r1[c]);
+        else return structured_product<row_kind0(a), row_kind0(c)>(r0[a], r0[c]) + structured_product<row_kind1(a), row_kind1(c)>(r1[a], r1[c]);
+    }
+    else
+    {
+        constexpr int k = ID - 36;
+        constexpr bool z0 = row_kind0(k) == 0, z1 = row_kind1(k) == 0;
+        if constexpr (z1) return structured_product<row_kind0(k), 2>(r0[k], u);
+        else if constexpr (z0) return structured_product<row_kind1(k), 2>(r1[k], v);
+        else return structured_product<row_kind0(k), 2>(r0[k], u) + structured_product<row_kind1(k), 2>(r1[k], v);
+    }
 }
 template <int ID>
 __device__ __forceinline__ double partial_term(const double (&r0)[4], const double (&r1)[4], double u, double v)
@@ -403,7 +433,11 @@ __device__ __forceinline__ double partial_term(const double (&r0)[4], const doub
 template <int W, int NS, int... K>
 __device__ __forceinline__ void add_full_terms(double (&acc)[NS], const double (&r0)[8], const double (&r1)[8], double u, double v, std::integer_sequence<int, K...>)
 {
-    ((acc[K] = acc[K] + full_term<W + 4 * K>(r0, r1, u, v)), ...);
+    auto one = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (!full_term_is_zero<W + 4 * k>()) acc[k] = acc[k] + full_term<W + 4 * k>(r0, r1, u, v);      // (a sum of structural zeros stays +0)
+    };
+    (one(std::integral_constant<int, K>{}), ...);
 }
 template <int W, int NS, int... K>
 __device__ __forceinline__ void add_partial_terms(double (&acc)[NS], const double (&r0)[4], const double (&r1)[4], double u, double v, std::integer_sequence<int, K...>)
