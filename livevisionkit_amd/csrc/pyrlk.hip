@@ -254,13 +254,18 @@ __device__ __forceinline__ void stage_one_window(uint8_t* __restrict__ tb, const
 //
 // LDS per level: dtile[(win_h+1) * tw] short2 derivative samples, the cached patches I, Ix, Iy (int16 each, win_w * win_h), etile =
 // image window with a 1-px ring, jtile = next-frame window; then one LevelState per level.
+// WIN: the (square) window as a compile-time constant -- the walks over the window, its LDS pitches and the staging loops then fold
+// (the tracker's window is always 11 x 11: FrameTracker.cpp:33); 0: the window of the arguments.
+template <int WIN>
 __global__ __launch_bounds__(64 * LVK_MAX_PYR_LEVELS)
 void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, float2* __restrict__ prev_copy, int n,
              float2* __restrict__ next_pts, uint8_t* __restrict__ status,
-             int win_w, int win_h, int max_count, double epsilon_sq, float min_eig_threshold, int level_bytes)
+             int win_w_arg, int win_h_arg, int max_count, double epsilon_sq, float min_eig_threshold, int level_bytes_arg)
 {
     LVK_TL(0);
     LVK_TRACKER_PRIORITY();
+    const int win_w = WIN ? WIN : win_w_arg, win_h = WIN ? WIN : win_h_arg;
+    const int level_bytes = WIN ? (int)lvk_pyrlk_part_offset(WIN, WIN) : level_bytes_arg;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int pt = blockIdx.x;                                                // grid = n
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,10 +458,20 @@ int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next,
     epsilon = std::min(std::max(epsilon, 0.), 10.);
     epsilon *= epsilon;
     const size_t lds = lvk_pyrlk_lds_bytes(win_w, win_h, prev.nlevels);
-    if (lds > 48 * 1024)
-        LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyrlk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_pyrlk, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
-                       d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h));
+    if (win_w == 11 && win_h == 11)
+    {
+        if (lds > 48 * 1024)
+            LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyrlk<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_pyrlk<11>, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
+                           d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h));
+    }
+    else
+    {
+        if (lds > 48 * 1024)
+            LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyrlk<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_pyrlk<0>, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
+                           d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h));
+    }
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
