@@ -283,6 +283,10 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
     const float FLT_SCALE = 1.f / (1 << 20);
     const int top = prev.nlevels - 1;
 
+#ifdef LVK_LK_TIMING
+    long long lt[8]; int ln = 0; int iters_total = 0;
+    lt[ln++] = wall_clock64();
+#endif
     // ---- phase A: this wave's level
     {
         const int level = wave;
@@ -360,8 +364,14 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
         }
         if (lane == 0) states[level] = st;
     }
+#ifdef LVK_LK_TIMING
+    lt[ln++] = wall_clock64();
+#endif
     __syncthreads();
     if (wave != 0) return;
+#ifdef LVK_LK_TIMING
+    lt[ln++] = wall_clock64();
+#endif
 
     // ---- phase B: coarse to fine
     float outx = 0.f, outy = 0.f;
@@ -430,8 +440,22 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
                 break;
             }
             pdx = dx; pdy = dy;
+#ifdef LVK_LK_TIMING
+            iters_total++;
+#endif
         }
+#ifdef LVK_LK_TIMING
+        if (ln < 8) lt[ln++] = wall_clock64();
+#endif
     }
+#ifdef LVK_LK_TIMING
+    if (lane == 0 && (pt == 0 || pt == 300) && n > 400)
+    {
+        printf("pyrlk pt %d (100 MHz ticks): phase A %lld, barrier %lld, levels", pt, lt[1] - lt[0], lt[2] - lt[1]);
+        for (int k = 3; k < ln; k++) printf(" %lld", lt[k] - lt[k - 1]);
+        printf(" | full iterations %d\n", iters_total);
+    }
+#endif
     if (lane == 0)
     {
         next_pts[pt] = make_float2(outx, outy);
