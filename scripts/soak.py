@@ -5,12 +5,13 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import livevisionkit_amd as lvk
-import bench
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import clipgen
 ctx = lvk.Context(0, stream=torch.cuda.Stream())
 s = lvk.StabilizationFilterSettings.obs_preset("homography")
 f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); f.configure(s); f.set_overlap(True)
-frames = bench.make_frame_pool(1080, 1920, 16, 1, torch.device("cuda", 0))
-planes = [ctx.egress_yuv420(x) for x in frames]; ctx.sync()
+clip = clipgen.Clip(1080, 1920, 16, device=torch.device("cuda", 0), cut_at=None)
+planes = [clip.render_i420(i) for i in range(16)]; torch.cuda.synchronize()
 pa = [f.prepare_yuv420(p) for p in planes]; outs = [tuple(torch.empty_like(q) for q in planes[0]) for _ in range(4)]; oa = [f.prepare_yuv420(o) for o in outs]
 f.set_profiling(True, stages=("remap",))
 free0 = torch.cuda.mem_get_info()[0]
