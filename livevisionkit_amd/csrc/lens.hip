@@ -100,40 +100,14 @@ void build_offsets(const lvk_camera_params& c, int rows, int cols, std::vector<f
     }
 }
 
-// One thread per point: F^-1 of the fused lens map in binary64 (two passes of {remove the crop_in term, the 5 fixed-point
-// iterations of cv::undistortPoints, apply P}); tracked points live at tracking resolution, the model at frame resolution.
-struct LensModelD { double d[17]; };
-
+// One thread per point (lvk_lens_undistort_point, lvk_hip_internal.hpp)
 __global__ void k_lens_undistort(LensModelD M, double sx, double sy, const float2* __restrict__ a, int na,
                                  const float2* __restrict__ b, int nb, float2* __restrict__ out)
 {
     LVK_TRACKER_PRIORITY();                        // part of the tracker chain in the fused lens mode
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= na + nb) return;
-    const float2 p = i < na ? a[i] : b[i - na];
-    const double nfx = M.d[0], nfy = M.d[1], ncx = M.d[2], ncy = M.d[3], fx = M.d[4], fy = M.d[5], cx = M.d[6], cy = M.d[7];
-    const double k1 = M.d[8], k2 = M.d[9], p1 = M.d[10], p2 = M.d[11], k3 = M.d[12];
-    const double kxc = M.d[13], vxc = M.d[14], kyc = M.d[15], vyc = M.d[16];
-    const double s = (double)p.x * sx, t = (double)p.y * sy;
-    double u = s, v = t;
-    for (int pass = 0; pass < 2; pass++)
-    {
-        const double s1 = s - (u * kxc + vxc), t1 = t - (v * kyc + vyc);
-        const double x0 = (s1 - cx) / fx, y0 = (t1 - cy) / fy;
-        double x = x0, y = y0;
-        for (int j = 0; j < 5; j++)
-        {
-            const double r2 = x * x + y * y;
-            const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
-            if (icdist < 0) { x = x0; y = y0; break; }
-            const double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
-            const double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-            x = (x0 - dX) * icdist;
-            y = (y0 - dY) * icdist;
-        }
-        u = x * nfx + ncx; v = y * nfy + ncy;
-    }
-    out[i] = make_float2((float)(u / sx), (float)(v / sy));
+    out[i] = lvk_lens_undistort_point(M, sx, sy, i < na ? a[i] : b[i - na]);
 }
 
 } // namespace

@@ -154,10 +154,13 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
                     void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts);
 
 // Pyramidal LK (pyrlk.hip)
+struct LensModel;
 int lvk_pyramid_geometry(int rows, int cols, int max_level, int win_w, int win_h, int* lrows, int* lcols);
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
                      float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig,
-                     float2* d_prev_copy = nullptr);     // pts may be device-visible host memory; d_prev_copy receives a device copy
+                     float2* d_prev_copy = nullptr,      // pts may be device-visible host memory; d_prev_copy receives a device copy
+                     const LensModel* lens = nullptr, double lens_sx = 0.0, double lens_sy = 0.0, float2* d_und = nullptr);
+                     // lens + d_und: the flow kernel also writes the lens-corrected (previous | matched) positions, 2 n entries (fused lens mode)
 
 // Image pyramid + Scharr derivative images of one tracking frame, resident in HBM.
 struct DevicePyramid
@@ -211,6 +214,35 @@ int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src
 // d = nfx, nfy, ncx, ncy (new camera matrix), fx, fy, cx, cy, k1, k2, p1, p2, k3, kxc, vxc, kyc, vyc (crop_in term, pixels);
 // f = the binary32 kernel parameters: 1/nfx, 1/nfy, then d[2..16] rounded.
 struct LensModel { double d[17]; float f[17]; int view[4]; };
+// F^-1 of the fused lens map for one tracked point, binary64 (two passes of {remove the crop_in term, the 5 fixed-point iterations of
+// cv::undistortPoints, apply P}); the points live at tracking resolution (sx, sy: frame / tracking size), the model at frame resolution.
+struct LensModelD { double d[17]; };
+__device__ __forceinline__ float2 lvk_lens_undistort_point(const LensModelD& M, double sx, double sy, float2 p)
+{
+    const double nfx = M.d[0], nfy = M.d[1], ncx = M.d[2], ncy = M.d[3], fx = M.d[4], fy = M.d[5], cx = M.d[6], cy = M.d[7];
+    const double k1 = M.d[8], k2 = M.d[9], p1 = M.d[10], p2 = M.d[11], k3 = M.d[12];
+    const double kxc = M.d[13], vxc = M.d[14], kyc = M.d[15], vyc = M.d[16];
+    const double s = (double)p.x * sx, t = (double)p.y * sy;
+    double u = s, v = t;
+    for (int pass = 0; pass < 2; pass++)
+    {
+        const double s1 = s - (u * kxc + vxc), t1 = t - (v * kyc + vyc);
+        const double x0 = (s1 - cx) / fx, y0 = (t1 - cy) / fy;
+        double x = x0, y = y0;
+        for (int j = 0; j < 5; j++)
+        {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            if (icdist < 0) { x = x0; y = y0; break; }
+            const double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+        u = x * nfx + ncx; v = y * nfy + ncy;
+    }
+    return make_float2((float)(u / sx), (float)(v / sy));
+}
 struct LensArgs { float f[17]; };
 int lvk_lens_model_build(const lvk_camera_params& params, int rows, int cols, LensModel& out);
 // (a | b)[i] raw tracking-frame points -> lens-corrected positions, binary64, written to out[0 .. na + nb)

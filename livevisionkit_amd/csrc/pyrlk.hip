@@ -256,11 +256,14 @@ __device__ __forceinline__ void stage_one_window(uint8_t* __restrict__ tb, const
 // image window with a 1-px ring, jtile = next-frame window; then one LevelState per level.
 // WIN: the (square) window as a compile-time constant -- the walks over the window, its LDS pitches and the staging loops then fold
 // (the tracker's window is always 11 x 11: FrameTracker.cpp:33); 0: the window of the arguments.
-template <int WIN>
+// LENS (fused lens mode): the feature's block also writes the lens-corrected positions of its point pair -- (previous | matched), what
+// the motion is estimated from -- instead of a kernel of its own between the flow and the motion estimate.
+struct LensPointArgs { LensModelD model; double sx, sy; float2* und; };
+template <int WIN, bool LENS>
 __global__ __launch_bounds__(64 * LVK_MAX_PYR_LEVELS)
 void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, float2* __restrict__ prev_copy, int n,
              float2* __restrict__ next_pts, uint8_t* __restrict__ status,
-             int win_w_arg, int win_h_arg, int max_count, double epsilon_sq, float min_eig_threshold, int level_bytes_arg)
+             int win_w_arg, int win_h_arg, int max_count, double epsilon_sq, float min_eig_threshold, int level_bytes_arg, LensPointArgs la)
 {
     LVK_TL(0);
     LVK_TRACKER_PRIORITY();
@@ -461,6 +464,12 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
         next_pts[pt] = make_float2(outx, outy);
         status[pt] = ok ? 1 : 0;
     }
+    if (LENS && lane < 2)
+    {
+        // lane 0: the previous position, lane 1: the matched one (the same function k_lens_undistort applies, point by point)
+        const float2 q = lvk_lens_undistort_point(la.model, la.sx, la.sy, lane == 0 ? p0 : make_float2(outx, outy));
+        la.und[lane == 0 ? pt : n + pt] = q;
+    }
 }
 
 } // namespace
@@ -472,7 +481,8 @@ size_t lvk_pyrlk_lds_bytes(int win_w, int win_h, int nlevels)
 }
 
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
-                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig, float2* d_prev_copy)
+                     float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig, float2* d_prev_copy,
+                     const LensModel* lens, double lens_sx, double lens_sy, float2* d_und)
 {
     LVK_HIP_REQUIRE(ctx, prev.nlevels >= 1 && prev.nlevels == next.nlevels && prev.nlevels <= LVK_MAX_PYR_LEVELS);
     LVK_HIP_REQUIRE(ctx, win_w >= 3 && win_h >= 3 && win_w <= 31 && win_h <= 31);
@@ -482,20 +492,20 @@ int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next,
     epsilon = std::min(std::max(epsilon, 0.), 10.);
     epsilon *= epsilon;
     const size_t lds = lvk_pyrlk_lds_bytes(win_w, win_h, prev.nlevels);
-    if (win_w == 11 && win_h == 11)
-    {
+    LensPointArgs la{};
+    const bool with_lens = lens != nullptr && d_und != nullptr;
+    if (with_lens) { for (int i = 0; i < 17; i++) la.model.d[i] = lens->d[i]; la.sx = lens_sx; la.sy = lens_sy; la.und = d_und; }
+    auto launch = [&](auto kernel) -> int {
         if (lds > 48 * 1024)
-            LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyrlk<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_pyrlk<11>, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
-                           d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h));
-    }
-    else
-    {
-        if (lds > 48 * 1024)
-            LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyrlk<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_pyrlk<0>, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
-                           d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h));
-    }
+            LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(n), dim3(64 * prev.nlevels), lds, ctx->stream, prev, next, d_prev_pts, d_prev_copy, n,
+                           d_next_pts, d_status, win_w, win_h, max_count, epsilon, (float)min_eig, (int)lvk_pyrlk_part_offset(win_w, win_h), la);
+        return LVK_HIP_OK;
+    };
+    int lrc;
+    if (win_w == 11 && win_h == 11) lrc = with_lens ? launch(k_pyrlk<11, true>) : launch(k_pyrlk<11, false>);
+    else lrc = with_lens ? launch(k_pyrlk<0, true>) : launch(k_pyrlk<0, false>);
+    if (lrc != LVK_HIP_OK) return lrc;
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

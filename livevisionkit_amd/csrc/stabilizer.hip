@@ -499,13 +499,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     pe = prof_begin(LVK_STAGE_PYRLK);
     if (chained)
     {
-        if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, h_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG, d_pts)) != LVK_HIP_OK) return rc;
-        if (lens)
-        {
-            // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks)
-            if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
-                                                d_pts, n, d_matched, n, d_und)) != LVK_HIP_OK) return rc;
-        }
+        // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks); the flow
+        // kernel writes them itself (d_und: previous | matched)
+        if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, h_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG, d_pts,
+                                   lens ? &lens_model : nullptr, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h, lens ? d_und : nullptr)) != LVK_HIP_OK) return rc;
         const bool fused_compact = !field && n <= LVK_COMPACT_RANSAC_MAX;        // the RANSAC's first kernel compacts the flow result itself
         if (!fused_compact && (rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
                                                              lens ? d_und : nullptr, (float)cur_w, (float)cur_h)) != LVK_HIP_OK) return rc;
