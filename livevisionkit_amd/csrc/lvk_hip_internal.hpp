@@ -23,6 +23,7 @@ struct PyrArgs { PyrLevel lv[LVK_MAX_PYR_LEVELS]; int nlevels; };
 
 struct lvk_hip_ctx
 {
+    int co_blocks_per_cu = 0;               // persistent remap grid of the overlap mode: blocks per CU for the next launch (0: the default)
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;

@@ -619,7 +619,8 @@ inline dim3 lvk_co_grid(lvk_hip_ctx* ctx, int dst_rows, int dst_cols)
     int& n = cus[ctx->device & 63];
     if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) n = 256;
     const unsigned full = remap_grid(dst_rows, dst_cols).x;
-    const unsigned persistent = (unsigned)(((n * LVK_CO_WAVES) / NUM_XCD) * NUM_XCD);
+    const int per_cu = ctx->co_blocks_per_cu > 0 ? ctx->co_blocks_per_cu : LVK_CO_WAVES;
+    const unsigned persistent = (unsigned)(((n * per_cu) / NUM_XCD) * NUM_XCD);
     return dim3(full < persistent ? full : persistent);
 }
 

@@ -151,6 +151,7 @@ struct lvk_hip_stab
     // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
     hipEvent_t chain_done = nullptr;
     bool chain_event_armed = false, ingest_on_tracker = false, tracker_ingest_capable = false;
+    bool bulk_busy_at_push = false;            // the previous remap was still running when this push began: a free-running caller
     // tests: LVK_HIP_INGEST_PLACEMENT=tracker|bulk pins the placement that is otherwise decided per push (see track())
     int ingest_placement = [] { const char* e = std::getenv("LVK_HIP_INGEST_PLACEMENT"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
     std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr
@@ -925,6 +926,13 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     if (produced) *produced = 0;
     if (released) *released = nullptr;
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
+    st->bulk_busy_at_push = false;
+    if (st->overlap && st->remap_stream)
+    {
+        const hipError_t q = hipStreamQuery(st->remap_stream);
+        if (q != hipSuccess) (void)hipGetLastError();
+        st->bulk_busy_at_push = q == hipErrorNotReady;
+    }
     // 3-channel VideoFrame formats (VideoFrame.cpp:170-306): YUV tracks channel 0, BGR / RGB track cvtColor(..2GRAY); the remap
     // runs the YUV or the RGB EASU program by the frame's format (Image.cpp:36-41).  GRAY / 4-channel frames are not on this path.
     LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
@@ -948,6 +956,11 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         // so the remap may run on its own stream concurrently with the next frame's tracking
         const bool side = st->overlap && mesh && st->s.stabilize_output;
         hipStream_t rs = side ? st->remap_stream : ctx->stream;
+        // The persistent grid leaves room for the tracker's blocks: 4 remap blocks per CU when the caller runs free (the next frame's
+        // chain starts while this remap runs; 5 or 6 starve it: 8 450 / 7 700 instead of 8 780 frames/s), 5 when the bulk stream was idle as
+        // this push began -- a caller that waits for every frame, whose remap mostly has the GPU to itself (p50 latency -3 %).
+        static const int pinned = [] { const char* e = std::getenv("LVK_HIP_CO_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments
+        ctx->co_blocks_per_cu = side ? (pinned > 0 ? pinned : (st->bulk_busy_at_push ? 4 : 5)) : 0;
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
