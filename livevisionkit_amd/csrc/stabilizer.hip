@@ -151,7 +151,11 @@ struct lvk_hip_stab
     // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
     hipEvent_t chain_done = nullptr;
     bool chain_event_armed = false, ingest_on_tracker = false, tracker_ingest_capable = false;
-    bool bulk_busy_at_push = false;            // the previous remap was still running when this push began: a free-running caller
+    bool bulk_busy_at_push = false;            // the previous remap was still running when this push began
+    // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
+    // for its frames synchronises and reads back in between: at least a remap's duration)
+    bool caller_runs_free = false;
+    std::chrono::steady_clock::time_point last_push_end{};
     // tests: LVK_HIP_INGEST_PLACEMENT=tracker|bulk pins the placement that is otherwise decided per push (see track())
     int ingest_placement = [] { const char* e = std::getenv("LVK_HIP_INGEST_PLACEMENT"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
     std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr
@@ -933,6 +937,8 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         if (q != hipSuccess) (void)hipGetLastError();
         st->bulk_busy_at_push = q == hipErrorNotReady;
     }
+    st->caller_runs_free = st->bulk_busy_at_push ||
+                           (st->last_push_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - st->last_push_end < std::chrono::microseconds(15));
     // 3-channel VideoFrame formats (VideoFrame.cpp:170-306): YUV tracks channel 0, BGR / RGB track cvtColor(..2GRAY); the remap
     // runs the YUV or the RGB EASU program by the frame's format (Image.cpp:36-41).  GRAY / 4-channel frames are not on this path.
     LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
@@ -956,22 +962,23 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         // so the remap may run on its own stream concurrently with the next frame's tracking
         const bool side = st->overlap && mesh && st->s.stabilize_output;
         hipStream_t rs = side ? st->remap_stream : ctx->stream;
-        // The persistent grid leaves room for the tracker's blocks: 4 remap blocks per CU when the caller runs free (the next frame's
-        // chain starts while this remap runs; 5 or 6 starve it: 8 450 / 7 700 instead of 8 780 frames/s), 5 when the bulk stream was idle as
-        // this push began -- a caller that waits for every frame, whose remap mostly has the GPU to itself (p50 latency -3 %).
-        static const int pinned = [] { const char* e = std::getenv("LVK_HIP_CO_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments
-        ctx->co_blocks_per_cu = side ? (pinned > 0 ? pinned : (st->bulk_busy_at_push ? 4 : 5)) : 0;
+        // The persistent grid (4 remap blocks per CU) leaves room for the tracker's blocks of the NEXT frame; 5 or 6 starve them (8 450 /
+        // 7 700 instead of 8 780 frames/s).  That only matters to a caller that runs free: one that waits for every frame (the previous
+        // push ended long ago and the bulk stream is idle) gets the full grid -- the remap then has the GPU to itself (p50 latency -6 %).
+        static const int pinned = [] { const char* e = std::getenv("LVK_HIP_CO_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments: blocks per CU, always
+        const bool persistent = side && (pinned > 0 || st->caller_runs_free);
+        ctx->co_blocks_per_cu = pinned;
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
         if (mesh && o420 && o420->y)
         {
             rc = lvk_launch_warpmesh_apply_420(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, o420->y, o420->y_step, o420->u, o420->u_step, o420->v, o420->v_step,
-                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, st->lens ? &st->lens_args : nullptr, side);
+                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, st->lens ? &st->lens_args : nullptr, persistent);
             o420->used = true;
         }
         else if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
-                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr, side);
+                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr, persistent);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
@@ -1099,6 +1106,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
     if (released && !*released && !st->orphaned.empty()) { *released = st->orphaned.front(); st->orphaned.pop_front(); }
     st->trace.mark(HostTrace::EXIT);
+    st->last_push_end = std::chrono::steady_clock::now();
     return rc;
 }
 
@@ -1193,6 +1201,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         if (produced) *produced = 1;
     }
     st->trace.mark(HostTrace::EXIT);
+    st->last_push_end = std::chrono::steady_clock::now();
     return LVK_HIP_OK;
 }
 
