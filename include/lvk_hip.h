@@ -56,7 +56,9 @@ int  lvk_hip_ctx_wait(lvk_hip_ctx* ctx, lvk_hip_ctx* producer);
  * Replace cv::UMat(USAGE_ALLOCATE_DEVICE_MEMORY) allocation / upload / download (Data/VideoFrame.cpp:27-29).
  * Like OpenCV's OpenCL buffer pool, lvk_hip_free keeps the block for the next lvk_hip_malloc of the same size (no device
  * synchronisation, no allocation in steady state; at most 4 GiB are kept, lvk_hip_trim gives them back).  A freed block may be
- * handed out again at once: work that still uses it must be on this context's stream, or have been fenced with lvk_hip_ctx_wait. */
+ * handed out again at once: work that still uses it must be on this context's stream, or have been fenced with lvk_hip_ctx_wait.
+ * A block freed through another live context of the process goes back to the pool of the context that allocated it; freeing a block
+ * that already sits in a pool (a double free) returns LVK_HIP_ERR_ARG. */
 int lvk_hip_malloc(lvk_hip_ctx* ctx, size_t bytes, void** d_ptr);
 int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr);
 int lvk_hip_trim(lvk_hip_ctx* ctx);
@@ -139,7 +141,9 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
  * weights are those in force when the reference (re)generates the constraints (:74-82); region / temporal_now those of the call.
  * Outputs: inlier flag per pair (L1 reprojection error < threshold) and the cols x rows x 2 normalised backward offsets of the motion
  * mesh.  Returns 0, or 2 / 3 when no estimate is possible (a point in the mesh's last cell row / column, singular system).
- * Solved on the device (normal equations, band L D L^T in binary64); meshes up to 16 columns x 96 rows. */
+ * Solved on the device (normal equations, band L D L^T in binary64).  Any mesh size the remap takes (cols x rows x 8 bytes <= 64 KB,
+ * up to 167 columns): meshes up to 16 columns and 2048 unknowns (16 x 64 vertices) run the register-window kernels (the 16 x 16 preset:
+ * ~0.2 ms), larger or wider ones (17 x 17, 32 x 32, ...) generic kernels with the same arithmetic and the same bits (milliseconds). */
 typedef struct lvk_hip_mesh_solver lvk_hip_mesh_solver;
 int  lvk_hip_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_region_w, float gen_region_h,
                                 float temporal_smoothing, float local_smoothing, int max_points, lvk_hip_mesh_solver** out);

@@ -10,6 +10,11 @@
 
 static thread_local std::string g_create_error;
 
+// Every block lvk_hip_malloc has handed out, process wide, with the context that owns it: lvk_hip_free through ANOTHER context returns the
+// block to its owner's pool (no stale entry stays behind), and a second free of a block that already sits in a pool is refused.
+static std::mutex g_owner_mutex;
+static std::map<void*, lvk_hip_ctx*> g_block_owner;
+
 extern "C" {
 
 const char* lvk_hip_version(void) { return "lvk-hip 0.1 (gfx950)"; }
@@ -70,6 +75,10 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
     for (auto& kv : ctx->areatabs) { (void)hipFree(kv.second.range); (void)hipFree(kv.second.tab); }
     for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
     for (hipEvent_t e : ctx->wait_events) (void)hipEventDestroy(e);
+    {
+        std::lock_guard<std::mutex> glock(g_owner_mutex);
+        for (auto& kv : ctx->pool_sizes) g_block_owner.erase(kv.first);      // blocks still out there are plain device memory from now on
+    }
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
@@ -100,14 +109,19 @@ int lvk_hip_malloc(lvk_hip_ctx* ctx, size_t bytes, void** d_ptr)
         {
             *d_ptr = it->second;
             ctx->pool_cached_bytes -= bytes;
+            ctx->pool_cached.erase(it->second);
             ctx->pool_free.erase(it);
             return LVK_HIP_OK;
         }
     }
     LVK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     LVK_HIP_CHECK(ctx, hipMalloc(d_ptr, bytes));
-    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-    ctx->pool_sizes[*d_ptr] = bytes;
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        ctx->pool_sizes[*d_ptr] = bytes;
+    }
+    std::lock_guard<std::mutex> glock(g_owner_mutex);
+    g_block_owner[*d_ptr] = ctx;
     return LVK_HIP_OK;
 }
 
@@ -115,18 +129,32 @@ int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     if (!d_ptr) return LVK_HIP_OK;
+    lvk_hip_ctx* caller = ctx;
+    {
+        // a block of another (live) context goes back to ITS pool
+        std::lock_guard<std::mutex> glock(g_owner_mutex);
+        auto o = g_block_owner.find(d_ptr);
+        if (o != g_block_owner.end()) ctx = o->second;
+    }
     {
         std::lock_guard<std::mutex> lock(ctx->pool_mutex);
         auto it = ctx->pool_sizes.find(d_ptr);
+        if (it != ctx->pool_sizes.end() && ctx->pool_cached.count(d_ptr))
+            return caller->fail(LVK_HIP_ERR_ARG, "lvk_hip_free: block freed twice");
         if (it != ctx->pool_sizes.end() && ctx->pool_cached_bytes + it->second <= lvk_hip_ctx::kPoolMaxCachedBytes)
         {
             ctx->pool_free.emplace(it->second, d_ptr);
+            ctx->pool_cached.insert(d_ptr);
             ctx->pool_cached_bytes += it->second;
             return LVK_HIP_OK;
         }
         if (it != ctx->pool_sizes.end()) ctx->pool_sizes.erase(it);
     }
-    LVK_HIP_CHECK(ctx, hipFree(d_ptr));
+    {
+        std::lock_guard<std::mutex> glock(g_owner_mutex);
+        g_block_owner.erase(d_ptr);
+    }
+    LVK_HIP_CHECK(caller, hipFree(d_ptr));
     return LVK_HIP_OK;
 }
 
@@ -134,8 +162,13 @@ int lvk_hip_trim(lvk_hip_ctx* ctx)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    {
+        std::lock_guard<std::mutex> glock(g_owner_mutex);
+        for (auto& kv : ctx->pool_free) g_block_owner.erase(kv.second);
+    }
     for (auto& kv : ctx->pool_free) { ctx->pool_sizes.erase(kv.second); (void)hipFree(kv.second); }
     ctx->pool_free.clear();
+    ctx->pool_cached.clear();
     ctx->pool_cached_bytes = 0;
     return LVK_HIP_OK;
 }

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <set>
 #include <mutex>
 #include <utility>
 
@@ -45,6 +46,7 @@ struct lvk_hip_ctx
     std::mutex pool_mutex;
     std::multimap<size_t, void*> pool_free;
     std::map<void*, size_t> pool_sizes;            // every live block of this context -> its size
+    std::set<void*> pool_cached;                   // the blocks that sit in pool_free right now (a second free of one is refused)
     size_t pool_cached_bytes = 0;
     static constexpr size_t kPoolMaxCachedBytes = (size_t)4 << 30;
 

@@ -21,6 +21,7 @@
 #include "host_logic.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -500,6 +501,32 @@ void k_mesh_solve(MeshArgs a)
     if (tid == 0) *a.flags = 0;
 }
 
+// phase 3 of both solvers: the solution as float (Eigen::VectorXf m_OptimizedMesh), inlier flags, offsets (FrameTracker.cpp:276-320);
+// sol: the solution in binary64 (LDS or global), visible to every thread of the workgroup
+__device__ __forceinline__ void finish_solution(const MeshArgs& a, const double* sol, int tid, int nthreads, int m)
+{
+    const int n = a.n;
+    for (int i = tid; i < n; i += nthreads) a.mesh[i] = (float)sol[i];
+    __syncthreads();
+    for (int f = tid; f < m; f += nthreads)
+    {
+        const int* id = a.fidx + 4 * f; const float* wq = a.fw + 4 * f;
+        const float x = wq[0] * a.mesh[id[0]] + wq[1] * a.mesh[id[1]] + wq[2] * a.mesh[id[2]] + wq[3] * a.mesh[id[3]];
+        const float y = wq[0] * a.mesh[id[0] + 1] + wq[1] * a.mesh[id[1] + 1] + wq[2] * a.mesh[id[2] + 1] + wq[3] * a.mesh[id[3] + 1];
+        a.out_mask[f] = (fabsf(x - a.p2[f].x) + fabsf(y - a.p2[f].y)) < a.threshold ? 1 : 0;
+    }
+    const float kw = (((float)a.cols / (float)(a.cols - 1)) * a.region_w) / (float)a.cols;
+    const float kh = (((float)a.rows / (float)(a.rows - 1)) * a.region_h) / (float)a.rows;
+    for (int v = tid; v < a.cols * a.rows; v += nthreads)
+    {
+        const int r = v / a.cols, c = v - r * a.cols;
+        a.out_offsets[2 * v] = ((float)c * kw - a.mesh[2 * v]) / a.region_w;
+        a.out_offsets[2 * v + 1] = ((float)r * kh - a.mesh[2 * v + 1]) / a.region_h;
+    }
+    __syncthreads();
+    if (tid == 0) { __threadfence_system(); *a.out_status = 0; }
+}
+
 // ---- phase 2 and 3: a kernel of its own (one walking wavefront, eight that stage; the two phases in one kernel spilled registers) ------
 constexpr int MB_NT = 64 + 512;
 struct BackShared
@@ -625,25 +652,84 @@ void k_mesh_backsolve(MeshArgs a)
 #endif
 
     // ---- phase 3: the solution as float, inlier flags, offsets (FrameTracker.cpp:276-320)
-    for (int i = tid; i < n; i += MB_NT) a.mesh[i] = (float)s.w[i];
+    finish_solution(a, s.w, tid, MB_NT, m);
+}
+
+// ---- the same factorisation for ANY mesh (WarpMesh.cpp:34-41,79-90 allows every N x M; FrameTracker.cpp:57-92 takes every motion_resolution) --
+// k_mesh_solve keeps the window of the band in registers, which fits half bandwidths up to 103 (16 columns) and 2048 unknowns.  Wider
+// meshes (motion_resolution 17 x 17, 32 x 32, ...) and the tiny ones below its tile shapes run the SAME specification -- pivot order, one
+// fused multiply-subtract per entry and pivot, reciprocal pivots: every entry sees the same operands in the same order, hence the same
+// bits -- straight out of global memory (the band of a 32 x 32 mesh is 3.3 MB: L2 / MALL resident), one workgroup of 1024 threads, two
+// barriers per pivot: ~2-3 us per pivot, a few milliseconds per solve.  Not a fast path: the presets never get here (2 x 2 meshes take
+// the homography route, 16 x 16 the register-window solver).
+constexpr int MG_NT = 1024;
+constexpr int MG_HB_MAX = 1023;             // LDS copies of the pivot column (2 x 8 KB); motion_resolution up to 167 columns
+
+__global__ __launch_bounds__(MG_NT)
+void k_mesh_solve_generic(MeshArgs a)
+{
+    LVK_TRACKER_PRIORITY();
+    __shared__ double raw[MG_HB_MAX + 1], lc[MG_HB_MAX + 1];
+    __shared__ int bad;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = a.n, hb = a.hb, ld = hb + 1;
+    const int m = pair_count(a);
+    const int flags = *a.flags;
+    if (tid == 0) bad = 0;
     __syncthreads();
-    for (int f = tid; f < m; f += MB_NT)
+    if (m < a.min_samples) { if (tid == 0) { *a.out_status = 1; *a.flags = 2; } return; }
+    if (flags & 1) { if (tid == 0) { *a.out_status = 2; *a.flags = 2; } return; }
+    double* N = a.N; double* g = a.g0;
+    for (int j = 0; j < n; j++)
     {
-        const int* id = a.fidx + 4 * f; const float* wq = a.fw + 4 * f;
-        const float x = wq[0] * a.mesh[id[0]] + wq[1] * a.mesh[id[1]] + wq[2] * a.mesh[id[2]] + wq[3] * a.mesh[id[3]];
-        const float y = wq[0] * a.mesh[id[0] + 1] + wq[1] * a.mesh[id[1] + 1] + wq[2] * a.mesh[id[2] + 1] + wq[3] * a.mesh[id[3] + 1];
-        a.out_mask[f] = (fabsf(x - a.p2[f].x) + fabsf(y - a.p2[f].y)) < a.threshold ? 1 : 0;
+        const int len = min(n - 1 - j, hb);                             // rows j + 1 .. j + len are reached by pivot j
+        const double d = N[(size_t)j * ld];
+        const double r = 1.0 / d;
+        if (tid == 0 && !(d > 0.0)) bad = 1;
+        for (int t = 1 + tid; t <= len; t += MG_NT)
+        {
+            const double v = N[(size_t)j * ld + t];
+            raw[t] = v; lc[t] = v * r;
+            a.Lc[(size_t)j * ld + t] = v * r;
+        }
+        __syncthreads();
+        const double gj = g[j];
+        // right-hand side, then row j of D^-1 L^-1 g
+        for (int t = 1 + tid; t <= len; t += MG_NT) g[j + t] = __builtin_fma(-lc[t], gj, g[j + t]);
+        if (tid == 0) a.wz[j] = gj * r;
+        // N(i, k) = fma(-L(i, j), N(k, j), N(i, k)) for j < k <= i <= j + len: a wavefront per column k, lanes over the rows
+        for (int kk = 1 + wave; kk <= len; kk += MG_NT / 64)
+        {
+            const double c = raw[kk];
+            double* col = N + (size_t)(j + kk) * ld;
+            for (int t = lane; t <= len - kk; t += 64) col[t] = __builtin_fma(-lc[kk + t], c, col[t]);
+        }
+        __syncthreads();
     }
-    const float kw = (((float)a.cols / (float)(a.cols - 1)) * a.region_w) / (float)a.cols;
-    const float kh = (((float)a.rows / (float)(a.rows - 1)) * a.region_h) / (float)a.rows;
-    for (int v = tid; v < a.cols * a.rows; v += MB_NT)
-    {
-        const int r = v / a.cols, c = v - r * a.cols;
-        a.out_offsets[2 * v] = ((float)c * kw - a.mesh[2 * v]) / a.region_w;
-        a.out_offsets[2 * v + 1] = ((float)r * kh - a.mesh[2 * v + 1]) / a.region_h;
-    }
+    if (bad) { if (tid == 0) { *a.out_status = 3; *a.flags = 2; } return; }
+    if (tid == 0) *a.flags = 0;
+}
+
+__global__ __launch_bounds__(MG_NT)
+void k_mesh_backsolve_generic(MeshArgs a)
+{
+    LVK_TRACKER_PRIORITY();
+    const int tid = (int)threadIdx.x;
+    const int n = a.n, hb = a.hb, ld = hb + 1;
+    const int m = pair_count(a);
+    const int flags = *a.flags;
     __syncthreads();
-    if (tid == 0) { __threadfence_system(); *a.out_status = 0; }
+    if (flags & 2) { if (tid == 0) *a.flags = 0; return; }
+    double* w = a.wz;
+    // L^T x = w column by column: x(j) = w(j); w(k) = fma(-L(j, k), x(j), w(k)) for the rows k above j in the band
+    for (int j = n - 1; j >= 1; j--)
+    {
+        const double xj = w[j];
+        const int first = max(0, j - hb);
+        for (int k = first + tid; k < j; k += MG_NT) w[k] = __builtin_fma(-a.Lc[(size_t)k * ld + (j - k)], xj, w[k]);
+        __syncthreads();
+    }
+    finish_solution(a, w, tid, MG_NT, m);
 }
 
 } // namespace
@@ -657,6 +743,7 @@ struct lvk_mesh_solver_dev
     double* d_stat = nullptr; long long* d_acc = nullptr;   // d_acc: Nq (n * ld) then gq (n), one allocation, one memset per solve
     float* d_mesh = nullptr; double* d_Lc = nullptr; double* d_N = nullptr;      // d_N: band then right-hand side
     int* d_flags = nullptr;
+    bool generic = false;                   // k_mesh_solve_generic / k_mesh_backsolve_generic (meshes outside the register-window solver's shapes)
 };
 
 void lvk_mesh_solver_free(lvk_mesh_solver_dev* s)
@@ -674,10 +761,14 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
     *out = nullptr;
     lvkh::MeshSolverH host;
     host.generate(cols, rows, gen_w, gen_h, temporal, local);
-    LVK_HIP_REQUIRE(ctx, host.hb() <= MS_HB_MAX && host.n() <= MS_N_MAX);      // meshes wider than 16 columns / beyond 16 x 64: not supported by the device solver
-    LVK_HIP_REQUIRE(ctx, band_groups(host.hb(), (host.hb() + MS_TB) / MS_TB - 1) >= 1 && host.n() >= 4);      // every band has a tile that hands its columns to the chain (hb is odd: always)
+    // the register-window solver: meshes up to 16 columns (half bandwidth 103) and 16 x 64 vertices, every band with a tile that hands its
+    // columns to the chain; everything else (17 x 17, 32 x 32, ...) takes the generic kernels -- same specification, same bits
+    const bool force_generic = std::getenv("LVK_HIP_MESH_GENERIC") != nullptr;      // tests: the generic kernels on the preset's mesh
+    const bool fast = host.hb() <= MS_HB_MAX && host.n() <= MS_N_MAX && host.n() >= 4 && band_groups(host.hb(), (host.hb() + MS_TB) / MS_TB - 1) >= 1;
+    LVK_HIP_REQUIRE(ctx, host.hb() <= MG_HB_MAX);                           // motion_resolution beyond 167 columns
     auto* s = new lvk_mesh_solver_dev();
     s->ctx = ctx; s->cols = cols; s->rows = rows; s->n = host.n(); s->hb = host.hb(); s->ts_gen = temporal;
+    s->generic = !fast || force_generic;
     const size_t band = (size_t)s->n * (s->hb + 1);
     auto fail = [&](hipError_t e) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); };
     hipError_t e;
@@ -723,8 +814,16 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
     a.flags = s->d_flags; a.out_offsets = h_offsets; a.out_mask = h_mask; a.out_status = h_status;
     if (n_pts > 0) hipLaunchKernelGGL(k_mesh_assemble, dim3((unsigned)((n_pts + 127) / 128)), dim3(128), 0, stream, a);
     hipLaunchKernelGGL(k_mesh_prepare, dim3(216), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_mesh_solve, dim3(1), dim3(MS_NT), 0, stream, a);
-    hipLaunchKernelGGL(k_mesh_backsolve, dim3(1), dim3(MB_NT), 0, stream, a);
+    if (s->generic)
+    {
+        hipLaunchKernelGGL(k_mesh_solve_generic, dim3(1), dim3(MG_NT), 0, stream, a);
+        hipLaunchKernelGGL(k_mesh_backsolve_generic, dim3(1), dim3(MG_NT), 0, stream, a);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_mesh_solve, dim3(1), dim3(MS_NT), 0, stream, a);
+        hipLaunchKernelGGL(k_mesh_backsolve, dim3(1), dim3(MB_NT), 0, stream, a);
+    }
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

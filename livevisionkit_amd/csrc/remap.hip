@@ -708,12 +708,14 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
     const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
     LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
 
-    void* d_mesh = nullptr; int stage_slot = 0;
-    int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot);
-    if (rc != LVK_HIP_OK) return rc;
+    // the tables first: once the mesh is staged nothing may fail before lvk_stage_consumed (a slot whose event was never re-recorded
+    // could be rewritten while its copy is still in flight)
     const LinTabEntry *xtab = nullptr, *ytab = nullptr;
+    int rc;
     if ((rc = lvk_get_lintab(ctx, mesh_cols, src_cols, false, &xtab)) != LVK_HIP_OK) return rc;
     if ((rc = lvk_get_lintab(ctx, mesh_rows, src_rows, true, &ytab)) != LVK_HIP_OK) return rc;
+    void* d_mesh = nullptr; int stage_slot = 0;
+    if ((rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot)) != LVK_HIP_OK) return rc;
 
     const dim3 block(256), grid = remap_grid(src_rows, src_cols), cogrid = lvk_co_grid(ctx, src_rows, src_cols);
     if (lens)
@@ -723,8 +725,10 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
         LVK_LAUNCH_REMAP(k_remap_mesh, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols,
                          xtab, ytab, pack_bg(bg));
 #undef LVK_LAUNCH_REMAP
-    LVK_HIP_CHECK(ctx, hipGetLastError());
-    return lvk_stage_consumed(ctx, stage_slot, stream);             // the slot is free again once this kernel has read the mesh
+    const hipError_t le = hipGetLastError();
+    rc = lvk_stage_consumed(ctx, stage_slot, stream);               // the slot is free again once this kernel has read the mesh (also after a failed launch)
+    if (le != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(le));
+    return rc;
 }
 
 // lvk::remap(src, dst, offset_map, background) with the map resident in HBM (Functions/Image.cpp:28-81): dst and map have
@@ -843,12 +847,12 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
     {
         const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
         LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
-        void* d_mesh = nullptr;
-        int rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot);
-        if (rc != LVK_HIP_OK) return rc;
-        const LinTabEntry *xtab = nullptr, *ytab = nullptr;
+        const LinTabEntry *xtab = nullptr, *ytab = nullptr;          // before the mesh is staged (see lvk_launch_remap_mesh)
+        int rc;
         if ((rc = lvk_get_lintab(ctx, mesh_cols, cols, false, &xtab)) != LVK_HIP_OK) return rc;
         if ((rc = lvk_get_lintab(ctx, mesh_rows, rows, true, &ytab)) != LVK_HIP_OK) return rc;
+        void* d_mesh = nullptr;
+        if ((rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot)) != LVK_HIP_OK) return rc;
         if (lens)
         {
             if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
@@ -860,8 +864,10 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
             else hipLaunchKernelGGL(k_remap_mesh_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
         }
     }
-    LVK_HIP_CHECK(ctx, hipGetLastError());
-    return stage_slot >= 0 ? lvk_stage_consumed(ctx, stage_slot, stream) : LVK_HIP_OK;
+    const hipError_t le = hipGetLastError();
+    const int src = stage_slot >= 0 ? lvk_stage_consumed(ctx, stage_slot, stream) : LVK_HIP_OK;
+    if (le != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(le));
+    return src;
 }
 
 extern "C" {

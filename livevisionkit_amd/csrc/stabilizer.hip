@@ -77,6 +77,7 @@ struct lvk_hip_stab
     lvk_hip_ctx* ctx = nullptr;
     lvk_stab_settings s{};
     bool configured = false;
+    bool buffers_ok = false;                   // the tracker's buffers match the committed settings (false after a failed allocation)
 
     // ---- tracker device state
     DevicePyramid pyr[2];
@@ -121,7 +122,6 @@ struct lvk_hip_stab
     struct MeshGen { int cols = 0, rows = 0; float w = 0, h = 0, temporal = 0, local = 0; } mesh_gen;
     lvk_mesh_solver_dev* mesh_dev = nullptr;
     void* d_mesh_scratch = nullptr; float* h_offsets = nullptr; int* h_mesh_status = nullptr; size_t h_offsets_floats = 0;
-    int ensure_mesh_solver();
     lvk_stab_settings tracker_s{};             // FrameTracker::m_Settings (what the tracker was last configured with)
     std::vector<Feature> tracked;
     std::vector<FastRegion> plan;
@@ -150,7 +150,7 @@ struct lvk_hip_stab
     // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which
     // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
     hipEvent_t chain_done = nullptr;
-    bool chain_event_armed = false, ingest_on_tracker = false, tracker_ingest_capable = false;
+    bool ingest_on_tracker = false, tracker_ingest_capable = false;
     bool bulk_busy_at_push = false;            // the previous remap was still running when this push began
     // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
     // for its frames synchronises and reads back in between: at least a remap's duration)
@@ -367,6 +367,41 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     // the remap kernels take the mesh through a staging slot
     LVK_HIP_REQUIRE(ctx, (size_t)st.motion_width * (size_t)st.motion_height * 2 * sizeof(float) <= lvk_hip_ctx::kStageBytes);
 
+    // ---- everything that can be refused is decided BEFORE any state changes: a configure() that returns an error leaves the filter as it was
+    lvk_stab_settings prev_tracker = tracker_s;
+    MeshGen gen = mesh_gen;
+    if (gen.cols == 0)
+    {
+        // The reference's FrameTracker member is default-constructed first: FrameTracker(FrameTrackerSettings{}) generates the
+        // mesh constraints for a 16x16 mesh over its default 256x256 region with weights 1.0 / 20.0 (FrameTracker.cpp:41-53,
+        // FrameTracker.hpp:31-44).  configure() below then only regenerates them when the motion resolution changes.
+        lvk_stab_default_settings(&prev_tracker);
+        prev_tracker.motion_width = 16; prev_tracker.motion_height = 16;
+        gen = MeshGen{16, 16, 256.0f, 256.0f, prev_tracker.temporal_smoothing, prev_tracker.local_smoothing};
+    }
+    const bool regenerate = st.motion_width != prev_tracker.motion_width || st.motion_height != prev_tracker.motion_height;
+    // FrameTracker.cpp:74-82: new region, but the PREVIOUS settings' smoothing weights; m_OptimizedMesh starts from zero again
+    if (regenerate) gen = MeshGen{st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height, prev_tracker.temporal_smoothing, prev_tracker.local_smoothing};
+    lvk_mesh_solver_dev* new_solver = nullptr;
+    float* new_offsets = nullptr;
+    const size_t want_offsets = (size_t)st.motion_width * st.motion_height * 2;
+    if (st.track_local_motions)
+    {
+        // the mesh the tracker solves for has the motion resolution; a configuration whose constraints were generated for another one
+        // (cannot happen: a resolution change regenerates them) would index past the mesh
+        LVK_HIP_REQUIRE(ctx, gen.cols == st.motion_width && gen.rows == st.motion_height);
+        if (regenerate || !mesh_dev)
+        {
+            const int mrc = lvk_mesh_solver_create(ctx, gen.cols, gen.rows, gen.w, gen.h, gen.temporal, gen.local, &new_solver);
+            if (mrc != LVK_HIP_OK) return mrc;
+        }
+        if (h_offsets_floats < want_offsets && hipHostMalloc((void**)&new_offsets, want_offsets * sizeof(float), hipHostMallocDefault) != hipSuccess)
+        { lvk_mesh_solver_free(new_solver); return fail(LVK_HIP_ERR_RUNTIME, "mesh offsets: pinned allocation failed"); }
+        if (!h_mesh_status && hipHostMalloc((void**)&h_mesh_status, sizeof(int), hipHostMallocDefault) != hipSuccess)
+        { lvk_mesh_solver_free(new_solver); if (new_offsets) (void)hipHostFree(new_offsets); return fail(LVK_HIP_ERR_RUNTIME, "mesh status: pinned allocation failed"); }
+    }
+
+    // ---- commit
     if (configured && s.stabilize_output != st.stabilize_output && remap_stream)
     {
         // the 4:2:0 conversions change streams with this flag: drain the bulk stream so that no pool slot is shared across the switch
@@ -377,20 +412,18 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
     const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
                                 || st.max_feature_density != s.max_feature_density;
-    if (mesh_gen.cols == 0)
+    mesh_gen = gen;
+    if (regenerate || new_solver)
     {
-        // The reference's FrameTracker member is default-constructed first: FrameTracker(FrameTrackerSettings{}) generates the
-        // mesh constraints for a 16x16 mesh over its default 256x256 region with weights 1.0 / 20.0 (FrameTracker.cpp:41-53,
-        // FrameTracker.hpp:31-44).  configure() below then only regenerates them when the motion resolution changes.
-        lvk_stab_default_settings(&tracker_s);
-        tracker_s.motion_width = 16; tracker_s.motion_height = 16;
-        mesh_gen = MeshGen{16, 16, 256.0f, 256.0f, tracker_s.temporal_smoothing, tracker_s.local_smoothing};
+        // the solver of the previous motion resolution (or none): nothing on the stream may still be using it
+        if (mesh_dev) { (void)hipStreamSynchronize(ctx->stream); lvk_mesh_solver_free(mesh_dev); }
+        mesh_dev = new_solver;
     }
-    if (st.motion_width != tracker_s.motion_width || st.motion_height != tracker_s.motion_height)
+    if (new_offsets)
     {
-        // FrameTracker.cpp:74-82: new region, but the PREVIOUS settings' smoothing weights; m_OptimizedMesh starts from zero again
-        mesh_gen = MeshGen{st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height, tracker_s.temporal_smoothing, tracker_s.local_smoothing};
-        if (mesh_dev) { LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); lvk_mesh_solver_free(mesh_dev); mesh_dev = nullptr; }
+        (void)hipStreamSynchronize(ctx->stream);
+        if (h_offsets) (void)hipHostFree(h_offsets);
+        h_offsets = new_offsets; h_offsets_floats = want_offsets;
     }
     tracker_s = st;
     smoother.configure(st);
@@ -404,39 +437,22 @@ int lvk_hip_stab::configure(const lvk_stab_settings& st)
     if (configured && res_changed && initialized) grid.reset();                          // FrameTracker.cpp:86-91
     s = st;
     configured = true;
-    if (st.track_local_motions) { const int mrc = ensure_mesh_solver(); if (mrc != LVK_HIP_OK) return mrc; }
-    if (layout_changed)
+    if (layout_changed || !buffers_ok)
     {
         // New tracking geometry: the cached frame no longer matches, which costs one nullopt frame exactly as the
-        // reference's size check does (FrameTracker.cpp:120-124).
+        // reference's size check does (FrameTracker.cpp:120-124).  (An allocation failure here -- out of device memory -- leaves the
+        // filter unusable until a later configure() succeeds: buffers_ok stays false and every push reports it.)
+        buffers_ok = false;
         int rc = alloc_tracker_buffers();
         if (rc != LVK_HIP_OK) return rc;
-        if (res_changed)
+        if (res_changed || pyr_w != s.detection_width || pyr_h != s.detection_height)
         {
             if ((rc = alloc_pyramids()) != LVK_HIP_OK) return rc;
             prev_w = prev_h = cur_w = cur_h = 0;
         }
+        buffers_ok = true;
     }
     return LVK_HIP_OK;
-}
-
-// The device-side least-squares solver of the vector-field preset, for the constraints as the reference would have generated them
-int lvk_hip_stab::ensure_mesh_solver()
-{
-    const size_t want = (size_t)s.motion_width * s.motion_height * 2;
-    if (h_offsets_floats < want)
-    {
-        if (h_offsets) (void)hipHostFree(h_offsets);
-        h_offsets = nullptr; h_offsets_floats = 0;
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_offsets, want * sizeof(float), hipHostMallocDefault));
-        h_offsets_floats = want;
-    }
-    if (!h_mesh_status) LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mesh_status, sizeof(int), hipHostMallocDefault));
-    if (mesh_dev) return LVK_HIP_OK;
-    // the mesh the tracker solves for has the motion resolution; a configuration whose constraints were generated for another one
-    // (cannot happen through configure(): a resolution change regenerates them) would index past the mesh
-    LVK_HIP_REQUIRE(ctx, mesh_gen.cols == s.motion_width && mesh_gen.rows == s.motion_height);
-    return lvk_mesh_solver_create(ctx, mesh_gen.cols, mesh_gen.rows, mesh_gen.w, mesh_gen.h, mesh_gen.temporal, mesh_gen.local, &mesh_dev);
 }
 
 // FrameTracker::track (FrameTracker.cpp:108-196)
@@ -466,7 +482,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // either of them, bounds the frame rate.
     finish_post();
     if (post_error) { post_error = false; return fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter disagrees with the host's"); }
-    if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return LVK_HIP_OK; }
+    // A push that ends before the chain's synchronisation below still has the downscale reading the caller's Y plane (4:2:0 entry, luma_pix
+    // == 1: "the input planes are consumed before the call returns"): wait for it.  Packed frames stay borrowed until they are released.
+    auto leave_early = [&]() -> int { if (luma_pix == 1) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LVK_HIP_OK; };
+    if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return leave_early(); }
 
     // ---- FeatureDetector::detect
     grid.plan(plan);
@@ -488,7 +507,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         if (plan[i].active) grid.absorb(i, h_fast_out + i * (size_t)fast_cap, std::min(h_fast_counts[i], fast_cap));
     const float distribution = grid.finish(tracked);
     last_distribution = distribution; last_detected = (int)tracked.size();
-    if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return LVK_HIP_OK; }
+    if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return leave_early(); }
     if (tracked.size() > cap_features) return fail(LVK_HIP_ERR_RUNTIME, "feature count exceeds the suppression grid capacity");
 
     trace.mark(HostTrace::GRID);
@@ -535,6 +554,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         prof_end(pe);
     }
     trace.mark(HostTrace::LK_LAUNCH);
+    bool chain_event_armed = false;              // local: an error return below must not leave a stale event armed for the next push
     if (deferred_ingest && tracker_ingest_capable)
     {
         // Where the conversion goes: a bulk stream that is idle (a caller that synchronises every frame) takes it now, next to the
@@ -556,7 +576,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
                                             d_pts, n, h_matched, n, h_und)) != LVK_HIP_OK) return rc;
     }
-    if (chain_event_armed) { chain_event_armed = false; LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done)); }
+    if (chain_event_armed) LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done));
     else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     trace.mark(HostTrace::LK_SYNC);
 
@@ -791,6 +811,12 @@ static int stab_set_overlap(lvk_hip_stab* st, bool enable, lvk_hip_ctx* bulk)
         for (int i = 0; i < 2; i++)
             if (!st->remap_done[i]) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[i], hipEventDisableTiming));
     }
+    else if (st->remap_stream && !st->remap_stream_owned)
+    {
+        // a caller-owned bulk stream is let go of when the overlap ends (lvk_hip.h: NULL = overlap off): the caller may destroy that context
+        // now, and nothing here -- lvk_hip_sync through aux_streams, configure(), destroy -- touches its stream again
+        const int rc = stab_detach_bulk_stream(st); if (rc != LVK_HIP_OK) return rc;
+    }
     st->overlap = enable;
     return LVK_HIP_OK;
 }
@@ -930,6 +956,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     if (produced) *produced = 0;
     if (released) *released = nullptr;
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
+    if (!st->buffers_ok) return ctx->fail(LVK_HIP_ERR_RUNTIME, "the last configure() failed while allocating the tracker's buffers: configure again");
     st->bulk_busy_at_push = false;
     if (st->overlap && st->remap_stream)
     {
@@ -1187,6 +1214,8 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
         LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
     }
+    // same contract without a tracker pass (delay-only mode, stabilize_output off): nothing has synchronised behind the conversion yet
+    else if (!st->s.stabilize_output) LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (rc != LVK_HIP_OK) return rc;
     if (prod && o420.used) { if (produced) *produced = 1; }                // the fused remap + egress kernel has written the planes
     else if (prod)

@@ -1,0 +1,99 @@
+"""Object-lifetime contracts of the C-ABI (round-2 ADVICE): the memory pool refuses a double free and routes a block freed through another
+context back to its owner; a caller-owned bulk context may be destroyed once the overlap has been switched off; a 4:2:0 push that
+ends before the tracker's synchronisation (first frame) has consumed the caller's planes on return."""
+import ctypes as _c
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pool_double_free_and_cross_context_free(ctx):
+    import livevisionkit_amd as lvk
+    L = ctx.lib
+    other = lvk.Context(0)
+    p = _c.c_void_p(); q = _c.c_void_p()
+    assert L.lvk_hip_malloc(ctx.handle, 1 << 20, _c.byref(p)) == 0
+    assert L.lvk_hip_free(ctx.handle, p) == 0
+    assert L.lvk_hip_free(ctx.handle, p) != 0                      # second free of a pooled block: refused, the pool keeps ONE copy
+    assert b"twice" in L.lvk_hip_last_error(ctx.handle)
+    a = _c.c_void_p(); b = _c.c_void_p()
+    assert L.lvk_hip_malloc(ctx.handle, 1 << 20, _c.byref(a)) == 0 and a.value == p.value      # the pooled block comes back once ...
+    assert L.lvk_hip_malloc(ctx.handle, 1 << 20, _c.byref(b)) == 0 and b.value != a.value       # ... and only once
+    # freed through ANOTHER context: goes back to the pool of the context that allocated it
+    assert L.lvk_hip_free(other.handle, a) == 0
+    assert L.lvk_hip_malloc(ctx.handle, 1 << 20, _c.byref(q)) == 0 and q.value == a.value
+    assert L.lvk_hip_free(ctx.handle, q) == 0 and L.lvk_hip_free(ctx.handle, b) == 0
+    assert L.lvk_hip_trim(ctx.handle) == 0
+    other.close()
+
+
+def test_bulk_context_may_be_destroyed_after_overlap_off(ctx, oracle):
+    """lvk_hip.h: lvk_hip_stab_set_bulk_context(st, NULL) = overlap off.  The stabilizer then lets go of the caller's stream: the bulk
+    context is destroyed and the filter keeps running (lvk_hip_sync, configure with a stabilize_output toggle, destroy) bit-exactly."""
+    import torch
+    import livevisionkit_amd as lvk
+    L = ctx.lib
+    frames, _ = synth.make_clip(180, 320, 14, seed=5, jitter=1.0)
+    so = oracle_lib.preset("homography", predictive_samples=2)
+    sg = lvk.StabilizationFilterSettings(); _c.memmove(_c.byref(sg), _c.byref(so), _c.sizeof(so))
+    ost = oracle_lib.OracleStabilizer(oracle, so)
+    gst = lvk.StabilizationFilter(sg, context=ctx)
+    bulk = lvk.Context(0, stream=torch.cuda.Stream())
+    ctx._check(L.lvk_hip_stab_set_bulk_context(gst.handle, bulk.handle))
+    for i, f in enumerate(frames):
+        if i == 6:
+            ctx._check(L.lvk_hip_stab_set_bulk_context(gst.handle, None))
+            bulk.close()                                            # the caller's context (and with it nothing the filter still refers to)
+            bulk = None
+        if i == 9:
+            off = so.__class__(); _c.memmove(_c.byref(off), _c.byref(so), _c.sizeof(so)); off.stabilize_output = 0
+            ost.configure(off); sgo = lvk.StabilizationFilterSettings(); _c.memmove(_c.byref(sgo), _c.byref(off), _c.sizeof(off)); gst.configure(sgo)
+        want, _ = ost.push(f, ts=i)
+        got, _ = gst.apply(torch.from_numpy(f).cuda(), timestamp=i)
+        ctx.sync()
+        torch.cuda.synchronize()
+        assert (want is None) == (got is None), i
+        if want is not None:
+            assert np.array_equal(got.cpu().numpy(), want), i
+    ost.close(); gst.close()
+
+
+def test_first_yuv420_push_has_consumed_its_planes(ctx, oracle):
+    """The planes of lvk_hip_stab_push_yuv420 are the caller's again when the call returns -- also for a push that leaves track() before
+    its synchronisation (the first frame; a frame with too few features): overwriting them right away must not change what was tracked."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = synth.make_clip(1080, 1920, 6, seed=21, jitter=1.0)
+    so = oracle_lib.preset("homography", predictive_samples=2)
+    sg = lvk.StabilizationFilterSettings(); _c.memmove(_c.byref(sg), _c.byref(so), _c.sizeof(so))
+    ost = oracle_lib.OracleStabilizer(oracle, so)
+    gst = lvk.StabilizationFilter(sg, context=ctx)
+    gst.set_overlap(True)
+    planes_d = None
+    for i, f in enumerate(frames):
+        planes = oracle.egress_yuv420(f)
+        packed = oracle.ingest_yuv420(*planes)
+        want, _ = ost.push(packed, ts=i)
+        if planes_d is None:
+            planes_d = tuple(torch.from_numpy(p).cuda() for p in planes)
+        else:
+            for d, p in zip(planes_d, planes):
+                d.copy_(torch.from_numpy(p))
+        torch.cuda.synchronize()
+        got, _ = gst.apply_yuv420(planes_d, timestamp=i)
+        # the call has returned: scribble over the planes on another stream at once
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for d in planes_d:
+                d.fill_(17)
+        ctx.sync(); torch.cuda.synchronize()
+        so_, sg_ = ost.stats(), gst.stats()
+        assert (so_.n_detected, so_.n_matched, so_.n_tracked) == (sg_.n_detected, sg_.n_matched, sg_.n_tracked), i
+        assert (want is None) == (got is None), i
+        if want is not None:
+            for a, b in zip(got, oracle.egress_yuv420(want)):
+                assert np.array_equal(a.cpu().numpy(), b), i
+    ost.close(); gst.close()

@@ -23,8 +23,15 @@ def _pairs(rng, n, region, frame, outliers=0.11):
 
 
 @pytest.mark.parametrize("mesh,region", [((16, 16), (480, 270)), ((16, 16), (256, 256)), ((2, 2), (256, 256)), ((5, 7), (320, 180)), ((16, 9), (480, 270)), ((3, 40), (200, 600)),
-                                         ((16, 64), (480, 1200)), ((4, 3), (320, 180)), ((9, 11), (300, 300)), ((13, 5), (480, 270))])
-def test_mesh_solver_bit_exact_over_frames(ctx, oracle, mesh, region):
+                                         ((16, 64), (480, 1200)), ((4, 3), (320, 180)), ((9, 11), (300, 300)), ((13, 5), (480, 270)),
+                                         # beyond the register-window kernels (Math/WarpMesh.cpp:34-41,79-90 allows any N x M): the generic kernels
+                                         ((17, 17), (480, 270)), ((32, 32), (480, 270)), ((20, 6), (480, 270)), ((16, 70), (480, 1300)), ((40, 3), (640, 120)),
+                                         # ... and the generic kernels on the preset's own mesh (LVK_HIP_MESH_GENERIC): same bits as the fast ones
+                                         ((16, 16, "generic"), (480, 270)), ((2, 2, "generic"), (256, 256))])
+def test_mesh_solver_bit_exact_over_frames(ctx, oracle, mesh, region, monkeypatch):
+    if len(mesh) == 3:
+        monkeypatch.setenv("LVK_HIP_MESH_GENERIC", "1")
+        mesh = mesh[:2]
     cols, rows = mesh
     rng = np.random.default_rng(cols * 100 + rows)
     ref = oracle_lib.OracleMeshSolver(oracle, cols, rows, gen_region=region)

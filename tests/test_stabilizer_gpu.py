@@ -168,6 +168,44 @@ def test_stabilizer_field_preset_direct_construction_quirk(ctx, oracle, clip):
     assert _run_pair(oracle, ctx, frames[:10], oracle_lib.preset("field", predictive_samples=3)) == 7
 
 
+@pytest.mark.parametrize("mesh", [(17, 17), (32, 32)])
+def test_stabilizer_field_preset_large_motion_resolution(ctx, oracle, clip, mesh):
+    """motion_resolution beyond the register-window mesh solver (Math/WarpMesh.cpp:34-41,79-90 and FrameTracker.cpp:57-92 take any size):
+    the generic device kernels, same specification -- whole filter bit-exact against the oracle, overlap mode included."""
+    frames, _ = clip
+    field = oracle_lib.preset("field", predictive_samples=3, min_scene_quality=0.4, min_tracking_quality=0.2, motion_width=mesh[0], motion_height=mesh[1])
+    assert _run_pair(oracle, ctx, frames[:12], oracle_lib.preset("default"), then_configure=field, overlap=mesh == (32, 32)) == 9
+
+
+def test_refused_configure_leaves_the_filter_untouched(ctx, oracle, clip):
+    """A configure() the library refuses (here: a motion mesh wider than the device solver's 167 columns; also an out-of-range quality)
+    returns an error and changes NOTHING: the following pushes match an oracle that never saw the call (round-2 ADVICE: the state used
+    to be committed before the solver could fail)."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    s = oracle_lib.preset("field", predictive_samples=3, min_scene_quality=0.4, min_tracking_quality=0.2)
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
+    gst = lvk.StabilizationFilter(_to_settings(oracle_lib.preset("default")), context=ctx); gst.configure(_to_settings(s))
+    gst.set_overlap(True)
+    for i, f in enumerate(frames[:14]):
+        if i == 6:
+            for bad in (oracle_lib.preset("field", motion_width=200, motion_height=40, detection_width=320, detection_height=180, predictive_samples=7),
+                        oracle_lib.preset("field", min_scene_quality=1.5, predictive_samples=2)):
+                with pytest.raises(Exception):
+                    gst.configure(_to_settings(bad))
+        want, _ = ost.push(f, ts=i)
+        got, _ = gst.apply(torch.from_numpy(f).cuda(), timestamp=i)
+        ctx.sync()
+        assert (want is None) == (got is None), i
+        if want is not None:
+            assert np.array_equal(got.cpu().numpy(), want), i
+        mo, _ = ost.meshes(); mg, _ = gst.meshes()
+        assert np.array_equal(mo.view(np.uint32), mg.view(np.uint32)), i
+    assert gst.frame_delay() == 3
+    ost.close(); gst.close()
+
+
 def test_stabilizer_library_defaults_local_motion_2x2(ctx, oracle, clip):
     """The CLI's configuration: library defaults = local-motion least squares on a 2x2 mesh (8 unknowns), 256x256 tracking."""
     frames, _ = clip
