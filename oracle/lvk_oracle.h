@@ -106,6 +106,16 @@ int lvko_find_homography(const float* pts1, const float* pts2, int n, double thr
 int lvko_estimate_affine_partial(const float* pts1, const float* pts2, int n, double threshold, double region_w, double region_h,
                                  double H[9], uint8_t* mask);
 
+/* Row a9, REFERENCE-SEMANTICS leg (oracle/usac_ref.cpp): the published algorithm of what FrameTracker.cpp:337-371 calls --
+ * cv::findHomography(UsacParams{MAGSAC, LO_SIGMA, 50 iterations, ...}) and cv::estimateAffinePartial2D(RANSAC, thr, 50) of OpenCV 4.8 --
+ * restated from knowledge of the upstream sources (unpinned: OpenCV is absent).  NOT the product's specification (that is the pair
+ * above, frozen); used by tests/test_usac_semantics.py to bound the distance between the two.  max_thr: MAGSAC's maximum threshold
+ * (<= 0: max(7.5, threshold)); rng_state: UsacParams::randomGeneratorState (the reference leaves it 0); final_lo: the one local
+ * optimisation of the best model after a loop that ended before any had run (see usac_ref.cpp). */
+int lvko_usac_find_homography(const float* pts1, const float* pts2, int n, double threshold, double max_thr, unsigned rng_state, int final_lo,
+                              double H[9], uint8_t* mask, int* iters);
+int lvko_ref_estimate_affine_partial(const float* pts1, const float* pts2, int n, double threshold, double H[9], uint8_t* mask);
+
 /* ------------------------------------------------------------------------------------------------
  * Rows a1/a2/a5/a6/a8/a11/a12/a13: the stateful filter (oracle/stabilizer.cpp).
  * lvko_stab_settings flattens lvk::StabilizationFilterSettings (Filters/StabilizationFilter.hpp:28-39 and its
@@ -155,6 +165,7 @@ int lvko_stab_push_fmt(lvko_stab* st, const uint8_t* frame, int step, int rows, 
 void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* out);
 int lvko_stab_get_meshes(const lvko_stab* st, float* motion, float* correction, int cap_floats);
 int lvko_stab_get_features(const lvko_stab* st, float* xy_resp_age, int cap);
+int lvko_stab_get_matches(const lvko_stab* st, float* p1, float* p2, int cap_pairs, int* estimator);   /* debug tap: pairs of the last estimate */
 
 
 /* ------------------------------------------------------------------------------------------------

@@ -243,6 +243,7 @@ struct Tracker
     double last_H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     int last_detected = 0, last_matched = 0;
     float last_distribution = 0.0f;
+    std::vector<float> last_p1, last_p2; int last_estimator = 0;    // the pairs the last motion estimate saw; 0 none, 1 homography, 2 affine fallback, 3 mesh
 
     void configure(const lvko_stab_settings& st)                    // FrameTracker.cpp:57-93
     {
@@ -285,7 +286,7 @@ struct Tracker
         cur_w = s.detection_width; cur_h = s.detection_height;
         cur.resize((size_t)cur_w * cur_h);
         lvko_luma_area_resize(frame, step, pix_stride, luma_channel, rows, cols, cur.data(), cur_w, cur_h, cur_w);
-        last_detected = last_matched = 0; last_distribution = 0.0f;
+        last_detected = last_matched = 0; last_distribution = 0.0f; last_estimator = 0;
         if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return false; }
 
         const float distribution = det.detect(cur.data(), cur_w, tracked);
@@ -340,6 +341,8 @@ struct Tracker
         inlier_status.assign(m, 0);
         const std::vector<float> raw_matched = matched_pts;                      // propagation stays in raw coordinates
         if (lens_model) { tracked_pts = und_t; matched_pts = und_m; }
+        last_p1 = tracked_pts; last_p2 = matched_pts;
+        last_estimator = s.track_local_motions ? 3 : (distribution > 0.6f ? 1 : 2);
         if (s.track_local_motions)
         {
             if (lvko_mesh_solver_solve(solver, tracked_pts.data(), matched_pts.data(), m, (float)cur_w, (float)cur_h,
@@ -644,6 +647,18 @@ void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* o)
     o->smoothing_factor = st->smoother.smoothing_factor;
     o->frame_delay = st->s.predictive_samples;
     for (int i = 0; i < 9; i++) o->homography[i] = st->tracker.last_H[i];
+}
+
+// debug tap: the (tracked, matched) pairs the last motion estimate was computed from (after fast_filter, FrameTracker.cpp:149);
+// *estimator: 0 no estimate ran for the last frame, 1 findHomography, 2 estimateAffinePartial2D, 3 estimate_local_motions
+int lvko_stab_get_matches(const lvko_stab* st, float* p1, float* p2, int cap_pairs, int* estimator)
+{
+    const int n = (int)st->tracker.last_p1.size() / 2;
+    if (estimator) *estimator = st->tracker.last_estimator;
+    if (n > cap_pairs) return -1;
+    std::memcpy(p1, st->tracker.last_p1.data(), (size_t)n * 2 * sizeof(float));
+    std::memcpy(p2, st->tracker.last_p2.data(), (size_t)n * 2 * sizeof(float));
+    return n;
 }
 
 int lvko_stab_get_meshes(const lvko_stab* st, float* motion, float* correction, int cap_floats)

@@ -281,6 +281,26 @@ class Oracle:
         rc = fn(_p(p1, _f32p), _p(p2, _f32p), len(p1), float(threshold), float(region[0]), float(region[1]), _p(H, _f64p), _p(mask, _u8p))
         return rc, H.reshape(3, 3), mask
 
+    def usac_find_homography(self, p1, p2, threshold, max_thr=0.0, rng_state=0, final_lo=True):
+        """Reference-semantics leg (oracle/usac_ref.cpp): cv::findHomography(UsacParams) as FrameTracker.cpp:337-357 configures it."""
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8); it = _c.c_int(0)
+        fn = self.lib.lvko_usac_find_homography
+        fn.restype = _c.c_int
+        fn.argtypes = [_f32p, _f32p, _c.c_int, _c.c_double, _c.c_double, _c.c_uint, _c.c_int, _f64p, _u8p, _c.POINTER(_c.c_int)]
+        rc = fn(_p(p1, _f32p), _p(p2, _f32p), len(p1), float(threshold), float(max_thr), int(rng_state), int(bool(final_lo)), _p(H, _f64p), _p(mask, _u8p), _c.byref(it))
+        return rc, H.reshape(3, 3), mask, it.value
+
+    def ref_estimate_affine_partial(self, p1, p2, threshold):
+        """Reference-semantics leg: cv::estimateAffinePartial2D(RANSAC, thr, 50) + FromAffineMatrix (FrameTracker.cpp:364-371)."""
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        H = np.zeros(9, np.float64); mask = np.zeros(len(p1), np.uint8)
+        fn = self.lib.lvko_ref_estimate_affine_partial
+        fn.restype = _c.c_int
+        fn.argtypes = [_f32p, _f32p, _c.c_int, _c.c_double, _f64p, _u8p]
+        rc = fn(_p(p1, _f32p), _p(p2, _f32p), len(p1), float(threshold), _p(H, _f64p), _p(mask, _u8p))
+        return rc, H.reshape(3, 3), mask
+
     def mesh_to_map(self, mesh, rows, cols):
         mesh = np.ascontiguousarray(mesh, np.float32)
         out = np.zeros((rows, cols, 2), np.float32)
@@ -472,6 +492,14 @@ class OracleStabilizer:
         a = np.zeros((cap, 4), np.float32)
         n = self.L.lvko_stab_get_features(self.h, _p(a, _f32p), cap)
         return a[:n].copy()
+
+    def matches(self, cap=8192):
+        """(tracked, matched, estimator) of the last frame's motion estimate; estimator 0 = none ran, 1 homography, 2 affine fallback, 3 mesh."""
+        a = np.zeros((cap, 2), np.float32); b = np.zeros((cap, 2), np.float32); e = _c.c_int(0)
+        self.L.lvko_stab_get_matches.restype = _c.c_int
+        self.L.lvko_stab_get_matches.argtypes = [_c.c_void_p, _f32p, _f32p, _c.c_int, _c.POINTER(_c.c_int)]
+        n = self.L.lvko_stab_get_matches(self.h, _p(a, _f32p), _p(b, _f32p), cap, _c.byref(e))
+        return a[:max(n, 0)].copy(), b[:max(n, 0)].copy(), e.value
 
 
 _inst = None

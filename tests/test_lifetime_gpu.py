@@ -37,7 +37,7 @@ def test_bulk_context_may_be_destroyed_after_overlap_off(ctx, oracle):
     import torch
     import livevisionkit_amd as lvk
     L = ctx.lib
-    frames, _ = synth.make_clip(180, 320, 14, seed=5, jitter=1.0)
+    frames, _ = synth.make_clip(360, 640, 14, seed=5, jitter=1.0)
     so = oracle_lib.preset("homography", predictive_samples=2)
     sg = lvk.StabilizationFilterSettings(); _c.memmove(_c.byref(sg), _c.byref(so), _c.sizeof(so))
     ost = oracle_lib.OracleStabilizer(oracle, so)
