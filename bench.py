@@ -30,6 +30,94 @@ VALU_PEAK_SPEC = 78.6e12              # fp32 lane-instructions / s: 157.3 TFLOP/
 VALU_PEAK_MEASURED = 64.6e12          # scripts/valu_peak.hip at the clock the chip sustains under this kernel's load
 
 
+def _gpu_sysfs_dir(pci_bus_id=None):
+    """/sys/class/drm/cardN/device of the GPU (matched by PCI bus id when given, else the first amdgpu card with a clock file)."""
+    import glob
+    cands = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    for d in cands:
+        try:
+            if pci_bus_id and pci_bus_id.lower() in os.path.realpath(d).lower():
+                return d
+        except OSError:
+            pass
+    for d in cands:
+        if os.path.exists(os.path.join(d, "pp_dpm_sclk")) or os.path.exists(os.path.join(d, "gpu_busy_percent")):
+            return d
+    return None
+
+
+def _read_gpu_sensors(d):
+    """(shader clock MHz, socket power W) from the amdgpu sysfs / hwmon files; None where the file is missing."""
+    import glob
+    mhz = watts = None
+    for f in glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input")):
+        try:
+            mhz = int(open(f).read()) / 1e6; break
+        except (OSError, ValueError):
+            pass
+    if mhz is None:
+        try:
+            for line in open(os.path.join(d, "pp_dpm_sclk")):
+                if "*" in line:
+                    mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+    for name in ("power1_average", "power1_input"):
+        for f in glob.glob(os.path.join(d, "hwmon", "hwmon*", name)):
+            try:
+                watts = int(open(f).read()) / 1e6; break
+            except (OSError, ValueError):
+                pass
+        if watts is not None:
+            break
+    return mhz, watts
+
+
+def sampler_main(argv):
+    """`bench.py --gpu-sampler <sysfs dir> <seconds> <period ms>`: a process of its own (no GIL shared with the timed loop) that samples the
+    GPU's shader clock and socket power and prints one JSON list of [unix time, MHz, W] when told to stop (a line on stdin) or timed out."""
+    d, seconds, period = argv[0], float(argv[1]), float(argv[2]) / 1e3
+    out, end = [], time.time() + seconds
+    import select
+    while time.time() < end:
+        mhz, watts = _read_gpu_sensors(d)
+        out.append([time.time(), mhz, watts])
+        if select.select([sys.stdin], [], [], period)[0]:
+            break
+    print(json.dumps(out), flush=True)
+
+
+class GpuSampler:
+    def __init__(self, pci_bus_id=None, seconds=60.0, period_ms=2.0):
+        import subprocess
+        self.proc = None
+        d = _gpu_sysfs_dir(pci_bus_id)
+        if d is None:
+            return
+        self.dir = d
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gpu-sampler", d, str(seconds), str(period_ms)],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+    def stop(self):
+        if self.proc is None:
+            return []
+        try:
+            out, _ = self.proc.communicate("stop\n", timeout=10)
+            return json.loads(out.strip().splitlines()[-1])
+        except Exception:
+            return []
+
+    @staticmethod
+    def window(samples, t0, t1):
+        """mean / min / max clock and mean power of the samples taken inside [t0, t1] (unix time)."""
+        sel = [s for s in samples if t0 <= s[0] <= t1]
+        mhz = [s[1] for s in sel if s[1] is not None]; w = [s[2] for s in sel if s[2] is not None]
+        if not sel:
+            return None
+        return {"samples": len(sel), "clock_mhz": {"mean": float(np.mean(mhz)), "min": float(np.min(mhz)), "max": float(np.max(mhz))} if mhz else None,
+                "power_w": float(np.mean(w)) if w else None}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,7 +315,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampler = None
+    if rank == 0:
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id) if hasattr(props, "pci_bus_id") else None
+            sampler = GpuSampler(bus)
+            time.sleep(0.3)                                  # the sampler process is up before the timed region begins
+        except Exception:
+            sampler = None
     barrier()
+    wall0 = time.time()
     t0 = time.perf_counter()
     emitted = 0
     stamps = [t0]
@@ -237,13 +335,23 @@ def main():
         stamps.append(time.perf_counter())
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    wall1 = time.time()
     free_running = np.diff(np.array(stamps)) * 1e3          # host time per push in the free-running timed region
     barrier()
-    # the roofline needs >= 64 event samples of the remap whatever --steps was: keep the same free-running loop going (outside `value`)
-    extra = max(0, 64 * 8 - args.steps)
-    for _ in range(extra):
-        step()
+    # SUSTAINED rate ("steady state, >= 600 frames"): the same free-running loop kept going for at least 600 more
+    # pushes right behind the timed region -- a --steps 20 timed region is 2.6 ms, of which the pipeline fill after the barrier and the
+    # un-overlapped last remap are 6-8 %.  Outside `value` (the contract times exactly --steps), reported beside it; it also gives the
+    # roofline its >= 64 event samples of the remap whatever --steps was.
+    n_sustained = max(600, 64 * 8 - args.steps)
+    ts0 = time.perf_counter(); wall2 = time.time()
+    sustained_emitted = 0
+    for _ in range(n_sustained):
+        out, _ = step()
+        sustained_emitted += 1 if out is not None else 0
     torch.cuda.synchronize()
+    sustained_s = time.perf_counter() - ts0
+    wall3 = time.time()
+    sensor_samples = sampler.stop() if sampler is not None else []
     prof = filt.profile()
     filt.set_profiling(False)
     stats = filt.stats()
@@ -361,6 +469,10 @@ def main():
             pcie = {"error": repr(e)}
 
     elapsed_max, total_frames = lvk.shard.reduce_timing(elapsed, emitted)
+    sustained_max, sustained_frames = lvk.shard.reduce_timing(sustained_s, sustained_emitted)
+    rank_reports = lvk.shard.gather_rank_reports({
+        "rank": rank, "device": local_rank, "clip_seed": 0x4C564B31 + rank, "frames": emitted, "elapsed_s": elapsed, "frames_per_s": emitted / elapsed,
+        "sustained_frames_per_s": sustained_emitted / sustained_s, "numa_cpus": (f"{numa_cpus[0]}-{numa_cpus[-1]} ({len(numa_cpus)})" if numa_cpus else "unbound")})
 
     result = None
     if rank == 0:
@@ -405,6 +517,13 @@ def main():
                                f"cycled; rendered on the GPU in {t_gen:.1f} s",
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective (gloo barrier only)",
                        "frames_in_hbm": pool, "host_cpus_bound": len(numa_cpus)},
+            "sustained": {"frames": int(sustained_frames), "frames_per_s": sustained_frames / sustained_max, "ms_per_frame": sustained_max / n_sustained * 1e3,
+                          "note": "the free-running loop continued for >= 600 pushes right after the timed region (SURVEY 8d's steady state); "
+                                  "whole job, max over ranks; not `value`"},
+            "gpu_sensors": {"timed_region": GpuSampler.window(sensor_samples, wall0, wall1), "sustained_region": GpuSampler.window(sensor_samples, wall2, wall3),
+                            "source": "amdgpu sysfs hwmon (freq1_input = shader clock, power1_average = socket power), sampled every 2 ms by a separate process"}
+                           if sensor_samples else None,
+            "ranks": rank_reports,
             "latency_ms": dict(percentiles(lat), samples=len(lat)),
             "free_running_ms": percentiles(free_running, (10, 50, 90, 99)),
             "stage_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof_all.items()},
@@ -417,6 +536,9 @@ def main():
                          # ~ the whole SIMD time): `binding` names that roofline and `valu_*` price the kernel against it.
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         # NOT measured by this run: rocprofv3 --pmc passes of the same command (scripts/pmc_remap.sh), kept under profiles/
+                         "traffic_source": "profiles/remap_pmc_traffic.json (separate rocprofv3 --pmc run of this command; FETCH_SIZE x2 + WRITE_SIZE per launch)" if traffic else None,
+                         "valu_instr_per_px_source": "profiles/remap_pmc_traffic.json (SQ_INSTS_VALU x 64 / pixels, separate rocprofv3 --pmc run)" if counters else "default (no counter file for this configuration)",
                          "avg_launch_us": remap_s * 1e6 if remap_s else None, "launches": remap_n,
                          "binding": "valu",
                          "valu_instr_per_px": valu_per_px,
@@ -431,8 +553,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
             oracle = oracle_lib.load()
-            ncpu = os.cpu_count() or 1
-            nthreads = min(ncpu, 64)
+            # every CPU this process may run on (the NUMA node of the GPU when bound: 128 on the pool's 2 x EPYC 9575F boxes); the oracle's
+            # parallel loops are row / point chunks, one thread per CPU
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            nthreads = max(1, min(ncpu, 128))
             fps, dt, done = cpu_baseline(oracle, clip, args.preset, nthreads, args.cpu_budget, args.format,
                                          lens_params if args.lens == "fused" else None, delay)
             result["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nthreads, "kind": "port",
@@ -452,4 +576,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--gpu-sampler":
+        sampler_main(sys.argv[2:])
+    else:
+        main()

@@ -25,6 +25,17 @@ def reduce_timing(elapsed_s, units, device=None):
     return float(t.item()), int(u.item())
 
 
+def gather_rank_reports(report):
+    """Every rank's small report dict (stream seed, device, frames, seconds, NUMA CPUs ...) on every rank, in rank order.  Bookkeeping
+    for the bench line only -- a gloo object gather, nothing of the data path."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [report]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, report)
+    return out
+
+
 def _parse_cpulist(text):
     cpus = []
     for part in text.strip().split(","):

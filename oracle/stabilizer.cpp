@@ -656,8 +656,11 @@ int lvko_stab_get_matches(const lvko_stab* st, float* p1, float* p2, int cap_pai
     const int n = (int)st->tracker.last_p1.size() / 2;
     if (estimator) *estimator = st->tracker.last_estimator;
     if (n > cap_pairs) return -1;
-    std::memcpy(p1, st->tracker.last_p1.data(), (size_t)n * 2 * sizeof(float));
-    std::memcpy(p2, st->tracker.last_p2.data(), (size_t)n * 2 * sizeof(float));
+    if (n > 0)
+    {
+        std::memcpy(p1, st->tracker.last_p1.data(), (size_t)n * 2 * sizeof(float));
+        std::memcpy(p2, st->tracker.last_p2.data(), (size_t)n * 2 * sizeof(float));
+    }
     return n;
 }
 

@@ -148,6 +148,39 @@ int run_golden(const char* clip_path, int n, int rows, int cols, const char* out
         }
         std::printf("golden %s: %d frames\n", name, emitted);
     }
+    // The same clip through VideoFilter::stream (Filters/VideoFilter.cpp:62-209): reader thread -> filter thread -> this thread's callback,
+    // frames crossing threads (and HIP streams) twice.  Appended to out.raw like the apply() runs: the Python side holds them to the same
+    // sha-256s -- stream() is pixel-checked, not only counted.
+    struct ClipCapture : cv::VideoCapture
+    {
+        const std::vector<uint8_t>& clip; int n, rows, cols, i = 0;
+        ClipCapture(const std::vector<uint8_t>& c, int n_, int r, int co) : clip(c), n(n_), rows(r), cols(co) {}
+        bool isOpened() const override { return true; }
+        double get(int) const override { return 0.0; }
+        bool read(lvk::VideoFrame& f) override
+        {
+            if (i >= n) return false;
+            f.upload(clip.data() + (size_t)i * rows * cols * 3, rows, cols, lvk::VideoFrame::YUV, 1000 + i);
+            i++;
+            return true;
+        }
+    };
+    for (const char* name : {"homography", "field"})
+    {
+        lvk::StabilizationFilter filter;
+        filter.configure(golden_settings(name));
+        ClipCapture cap(clip, n, rows, cols);
+        int emitted = 0; bool ok = true;
+        filter.stream(cap, [&](lvk::Frame& frame) {
+            ok = ok && frame.timestamp == (uint64_t)(1000 + emitted);
+            frame.download(host.data());
+            std::fwrite(host.data(), 1, host.size(), out);
+            emitted++;
+            return false;
+        });
+        if (!ok) { std::printf("golden stream: bad timestamp\n"); return 1; }
+        std::printf("golden stream %s: %d frames\n", name, emitted);
+    }
     std::fclose(out);
     return 0;
 }

@@ -49,8 +49,10 @@ def test_facade_emits_the_golden_frames(tmp_path):
     exe = _build(tmp_path, ["-DRUN_ON_GPU"])
     out = subprocess.check_output([exe, "--golden", str(tmp_path / "clip.raw"), str(n), str(rows), str(cols), str(tmp_path / "out.raw")], timeout=300).decode()
     assert f"golden homography: {n - 3} frames" in out and f"golden field: {n - 3} frames" in out
-    got = np.frombuffer((tmp_path / "out.raw").read_bytes(), np.uint8).reshape(2, n - 3, rows, cols, 3)
-    for k, name in enumerate(("homography", "field")):
+    # ... and through VideoFilter::stream (3 threads, Filters/VideoFilter.cpp:62-209): the same frames
+    assert f"golden stream homography: {n - 3} frames" in out and f"golden stream field: {n - 3} frames" in out
+    got = np.frombuffer((tmp_path / "out.raw").read_bytes(), np.uint8).reshape(4, n - 3, rows, cols, 3)
+    for k, name in enumerate(("homography", "field", "homography", "field")):
         want = d[name + "_sha"][3:]
         for i in range(n - 3):
             sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(got[k, i]).tobytes()).digest(), np.uint8)

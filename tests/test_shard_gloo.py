@@ -32,6 +32,8 @@ def test_timing_reduction_two_ranks_gloo(tmp_path):
         el, units = shard.reduce_timing(1.0 + rank, 100 * (rank + 1))
         assert el == 2.0 and units == 300, (el, units)
         assert shard.streams_for_rank(8, rank, world) == list(range(rank, 8, 2))
+        reps = shard.gather_rank_reports({{"rank": rank, "seed": 100 + rank}})
+        assert [r["rank"] for r in reps] == [0, 1] and [r["seed"] for r in reps] == [100, 101]
         dist.destroy_process_group()
         print("ok", rank)
     """))
