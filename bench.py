@@ -403,68 +403,42 @@ def main():
         try:
             nsteps = 1000
             hpool = min(pool, 48)
-            host_in = [tuple(p.cpu().pin_memory() for p in planes[k]) for k in range(hpool)]
-            K = 4
-            dev_in = [tuple(torch.empty_like(p) for p in planes[0]) for _ in range(K)]
-            dev_in_args = [filt.prepare_yuv420(d) for d in dev_in]
-            host_out = [tuple(torch.empty_like(p, device="cpu").pin_memory() for p in planes[0]) for _ in range(4)]
-            up = torch.cuda.Stream(device); down = torch.cuda.Stream(device)
-            out_stream = filt.output_stream()
-            ev_up = [torch.cuda.Event() for _ in range(K)]
-            ev_out = [torch.cuda.Event() for _ in range(4)]; ev_down = [None] * 4
-
-            def upload(i):
-                with torch.cuda.stream(up):
-                    for d, h in zip(dev_in[i % K], host_in[i % hpool]):
-                        d.copy_(h, non_blocking=True)
-                    ev_up[i % K].record(up)
+            host_in = [filt.host_planes(rows, cols, nv12) for _ in range(hpool)]            # pinned, contiguous I420 / NV12 frames (the OBS layout)
+            for k in range(hpool):
+                for dst, p in zip(host_in[k], planes[k]):
+                    dst[...] = p.cpu().numpy()
+            host_out = [filt.host_planes(rows, cols, nv12) for _ in range(4)]
+            in_args = [filt.prepare_yuv420_host(p) for p in host_in]
+            out_args = [filt.prepare_yuv420_host(p) for p in host_out]
 
             def run(n, base):
-                upload(base)
                 for i in range(base, base + n):
-                    upload(i + 1)
-                    work_stream.wait_event(ev_up[i % K])
-                    if ev_down[i & 3] is not None:
-                        out_stream.wait_event(ev_down[i & 3])          # the output planes of 4 pushes ago have left the device
-                    res, _ = filt.apply_yuv420_prepared(dev_in_args[i % K], i, outs_args[i & 3])
-                    if res is not None:
-                        ev_out[i & 3].record(out_stream)
-                        down.wait_event(ev_out[i & 3])
-                        with torch.cuda.stream(down):                  # downloads run beside the next frame's remap
-                            for h, d in zip(host_out[i & 3], outs[i & 3]):
-                                h.copy_(d, non_blocking=True)
-                            ev_down[i & 3] = torch.cuda.Event(); ev_down[i & 3].record(down)
-            torch.cuda.synchronize()
+                    filt.apply_yuv420_host_prepared(in_args[i % hpool], i, out_args[i & 3])
+            torch.cuda.synchronize(); ctx.sync()
             run(100, step_no[0]); step_no[0] += 100
-            torch.cuda.synchronize()
+            ctx.sync()
             tp = time.perf_counter()
             run(nsteps, step_no[0]); step_no[0] += nsteps
-            torch.cuda.synchronize()
+            ctx.sync()
             dtp = time.perf_counter() - tp
-            mb = sum(p.numel() for p in planes[0]) / 1e6
-            # per-frame latency with the transfers inside (BASELINE's p99 ms/frame for host-resident frames): upload the planes, push,
-            # download the emitted planes, synchronise -- one frame at a time, nothing prefetched
+            mb = rows * cols * 1.5 / 1e6
+            # per-frame latency with the transfers inside (BASELINE's p99 ms/frame for host-resident frames): push the host planes, wait
+            # for the emitted host planes -- one frame at a time
             lat_pcie = []
             for i in range(step_no[0], step_no[0] + 500):
                 tl = time.perf_counter()
-                upload(i)
-                work_stream.wait_event(ev_up[i % K])
-                res, _ = filt.apply_yuv420_prepared(dev_in_args[i % K], i, outs_args[i & 3])
-                if res is not None:
-                    ev_out[i & 3].record(out_stream)
-                    down.wait_event(ev_out[i & 3])
-                    with torch.cuda.stream(down):
-                        for h, d in zip(host_out[i & 3], outs[i & 3]):
-                            h.copy_(d, non_blocking=True)
-                torch.cuda.synchronize()
+                filt.apply_yuv420_host_prepared(in_args[i % hpool], i, out_args[i & 3])
+                ctx.sync()
                 lat_pcie.append((time.perf_counter() - tl) * 1e3)
             step_no[0] += 500
             pcie = {"value": nsteps / dtp, "unit": "frames/s", "host_to_device_MB_per_frame": mb, "device_to_host_MB_per_frame": mb,
                     "GBps_each_way": nsteps / dtp * mb / 1e3,
-                    "latency_ms": dict(percentiles(lat_pcie), samples=len(lat_pcie), note="upload + push + download + synchronise, one frame at a time"),
-                    "note": "same stream, I420 planes in pinned host memory; uploads prefetched one frame ahead on their own stream, downloads on a third "
-                            "stream behind an event on the filter's output stream; not the headline value (inputs of `value` are resident in HBM)"}
-            del host_in, host_out, dev_in
+                    "link_ceiling": "profiles/r03_pcie_probe.txt: 55 GB/s one way, 46.8 GB/s each way at once (one copy-engine stream per direction) = 3760 frames/s",
+                    "latency_ms": dict(percentiles(lat_pcie), samples=len(lat_pcie), note="lvk_hip_stab_push_yuv420_host + lvk_hip_sync per frame: upload, "
+                                       "track, remap written straight into the pinned output planes; one frame at a time"),
+                    "note": "lvk_hip_stab_push_yuv420_host: I420 planes in pinned host memory in and out (SURVEY 8d's metric for host-resident frames); luma "
+                            "uploaded first, one copy stream per direction, free-running; not the headline value (inputs of `value` are resident in HBM)"}
+            del host_in, host_out
         except Exception as e:          # the extra pass must never break the contract line
             pcie = {"error": repr(e)}
 
@@ -553,10 +527,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
             oracle = oracle_lib.load()
-            # every CPU this process may run on (the NUMA node of the GPU when bound: 128 on the pool's 2 x EPYC 9575F boxes); the oracle's
-            # parallel loops are row / point chunks, one thread per CPU
+            # one thread per PHYSICAL core of the CPUs this process may run on (the NUMA node of the GPU when bound: 64 cores / 128 SMT threads on
+            # the pool's 2 x EPYC 9575F boxes).  Measured in round 3: 128 threads give 7.5 frames/s, 64 give 10.5 -- the row-parallel stages
+            # are memory-bound and the SMT siblings only add contention.
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            nthreads = max(1, min(ncpu, 128))
+            nthreads = max(1, min(ncpu // 2 if ncpu >= 16 else ncpu, 64))
             fps, dt, done = cpu_baseline(oracle, clip, args.preset, nthreads, args.cpu_budget, args.format,
                                          lens_params if args.lens == "fused" else None, delay)
             result["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nthreads, "kind": "port",

@@ -299,6 +299,20 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
                               void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,
                               int* produced, uint64_t* out_timestamp);
 
+/* The same path for frames that live in HOST memory -- FrameIngest::upload_planes -> to_ocl -> filter -> to_obs -> download_planes
+ * (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602): h_* / oh_* are planes in PINNED host memory (lvk_hip_host_malloc,
+ * hipHostMalloc or hipHostRegister; contiguous planes, the OBS layout, travel as one copy).  The library schedules the transfers: luma
+ * first (the tracker starts while the chroma planes are still on the link), one copy stream per direction; the output planes are either
+ * written by the remap kernel itself (a caller that waits for every frame: lowest latency) or downloaded behind it (a free-running
+ * caller: highest rate) -- same pixels.  Input planes are consumed when the call returns; output planes are complete after
+ * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed). */
+int  lvk_hip_stab_push_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
+                                   int rows, int cols, uint64_t timestamp,
+                                   void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
+                                   int* produced, uint64_t* out_timestamp);
+int  lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr);      /* pinned, device-visible host memory */
+int  lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr);
+
 /* Optional: run the bulk kernels (4:2:0 ingest, the output remap) on a second, low-priority HIP stream so that they overlap the
  * tracking of the next frame (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches,
  * Functions/Image.cpp:76); the remap then uses its occupancy-capped variants.  With overlap enabled d_out is complete only after

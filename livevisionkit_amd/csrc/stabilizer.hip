@@ -215,6 +215,28 @@ struct lvk_hip_stab
     void finish_post();
     int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion);
 
+    // ---- host-resident frames (lvk_hip_stab_push_yuv420_host): the transfers either side of the 4:2:0 path.  One copy stream per
+    // direction (scripts/pcie_probe.hip, profiles/r03_pcie_probe.txt: ONE copy engine stream each way moves 46.8 GB/s each way at once,
+    // two per direction fall to 31), the luma plane first so that the tracker starts while the chroma planes are still on the link.
+    struct HostIO
+    {
+        static constexpr int K_IN = 2, K_OUT = 3;
+        hipStream_t up = nullptr, down = nullptr;
+        int rows = 0, cols = 0;
+        void* d_in[K_IN] = {nullptr, nullptr}; void* d_out[K_OUT] = {nullptr, nullptr, nullptr};      // contiguous planes: Y | U | V  (or Y | UV)
+        hipEvent_t y_done[K_IN] = {}, c_done[K_IN] = {}, out_ready[K_OUT] = {}, down_done[K_OUT] = {};
+        bool down_armed[K_OUT] = {false, false, false};
+        int in_next = 0, out_next = 0, last_down = -1;       // last_down: slot of the newest download (its event orders a later direct write behind it)
+        std::chrono::steady_clock::time_point last_end{};      // when the previous host push returned
+    } hostio;
+    bool host_free_running_hint = false;                 // lvk_hip_stab_push_yuv420_host's own finding, for the push it wraps
+    hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
+    hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
+    int ensure_hostio(int rows, int cols);
+    void free_hostio();
+    bool caller_free_running_now();
+    int host_sink_mode = [] { const char* e = std::getenv("LVK_HIP_HOST_SINK"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();      // tests: direct | copy
+
     // ---- YUV420 front/back end: pool of packed frames the planes are converted into
     std::vector<void*> pool_all; std::deque<void*> pool_free;      // free slots are reused oldest first: the remap that read a slot is long done
     void* pool_out = nullptr;
@@ -742,6 +764,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     if (st->h_mesh_status) (void)hipHostFree(st->h_mesh_status);
     st->pyr[0].release(); st->pyr[1].release();
     st->free_pool();
+    st->free_hostio();
     if (st->remap_stream)
     {
         (void)hipStreamSynchronize(st->remap_stream);
@@ -957,15 +980,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     if (released) *released = nullptr;
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
     if (!st->buffers_ok) return ctx->fail(LVK_HIP_ERR_RUNTIME, "the last configure() failed while allocating the tracker's buffers: configure again");
-    st->bulk_busy_at_push = false;
-    if (st->overlap && st->remap_stream)
-    {
-        const hipError_t q = hipStreamQuery(st->remap_stream);
-        if (q != hipSuccess) (void)hipGetLastError();
-        st->bulk_busy_at_push = q == hipErrorNotReady;
-    }
-    st->caller_runs_free = st->bulk_busy_at_push ||
-                           (st->last_push_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - st->last_push_end < std::chrono::microseconds(15));
+    st->caller_runs_free = st->caller_free_running_now() || st->host_free_running_hint;
     // 3-channel VideoFrame formats (VideoFrame.cpp:170-306): YUV tracks channel 0, BGR / RGB track cvtColor(..2GRAY); the remap
     // runs the YUV or the RGB EASU program by the frame's format (Image.cpp:36-41).  GRAY / 4-channel frames are not on this path.
     LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
@@ -996,6 +1011,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         const bool persistent = side && (pinned > 0 || st->caller_runs_free);
         ctx->co_blocks_per_cu = pinned;
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
+        if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(rs, e, 0)); }
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
         if (mesh && o420 && o420->y)
@@ -1082,6 +1098,62 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
     const int erc = emit(&correction);
     st->trace.mark(HostTrace::REMAP_LAUNCH);
     return erc;                                                                             // finish_post(): at the next push, or when the lists are read
+}
+
+// a free-running caller: the bulk stream still busy with the previous remap, or this push beginning within 15 us of the previous one's return
+// (a caller that waits for its frames synchronises and reads back in between: at least a remap's duration)
+bool lvk_hip_stab::caller_free_running_now()
+{
+    bulk_busy_at_push = false;
+    if (overlap && remap_stream)
+    {
+        const hipError_t q = hipStreamQuery(remap_stream);
+        if (q != hipSuccess) (void)hipGetLastError();
+        bulk_busy_at_push = q == hipErrorNotReady;
+    }
+    return bulk_busy_at_push || (last_push_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - last_push_end < std::chrono::microseconds(15));
+}
+
+int lvk_hip_stab::ensure_hostio(int rows, int cols)
+{
+    HostIO& h = hostio;
+    if (h.rows == rows && h.cols == cols && h.up) return LVK_HIP_OK;
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
+    free_hostio();
+    const size_t bytes = (size_t)rows * cols + 2 * (size_t)((rows + 1) / 2) * ((cols + 1) / 2);
+    for (auto& p : h.d_in) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
+    for (auto& p : h.d_out) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
+    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.up, hipStreamNonBlocking));
+    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.down, hipStreamNonBlocking));
+    ctx->aux_streams.push_back(h.up); ctx->aux_streams.push_back(h.down);          // lvk_hip_sync() covers the transfers
+    for (int i = 0; i < HostIO::K_IN; i++)
+    {
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.y_done[i], hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.c_done[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < HostIO::K_OUT; i++)
+    {
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.out_ready[i], hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.down_done[i], hipEventDisableTiming));
+        h.down_armed[i] = false;
+    }
+    h.rows = rows; h.cols = cols; h.in_next = h.out_next = 0; h.last_down = -1;
+    return LVK_HIP_OK;
+}
+
+void lvk_hip_stab::free_hostio()
+{
+    HostIO& h = hostio;
+    auto& aux = ctx->aux_streams;
+    for (hipStream_t s : {h.up, h.down})
+        if (s) { (void)hipStreamSynchronize(s); aux.erase(std::remove(aux.begin(), aux.end(), s), aux.end()); (void)hipStreamDestroy(s); }
+    h.up = h.down = nullptr;
+    for (auto& p : h.d_in) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto& p : h.d_out) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto* arr : {h.y_done, h.c_done}) for (int i = 0; i < HostIO::K_IN; i++) if (arr[i]) { (void)hipEventDestroy(arr[i]); arr[i] = nullptr; }
+    for (auto* arr : {h.out_ready, h.down_done}) for (int i = 0; i < HostIO::K_OUT; i++) if (arr[i]) { (void)hipEventDestroy(arr[i]); arr[i] = nullptr; }
+    h.rows = h.cols = 0;
 }
 
 int lvk_hip_stab::ensure_pool(int rows, int cols)
@@ -1185,6 +1257,8 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
             const int si = st->slot_index(slot);
             if (si >= 0 && st->slot_read_armed[(size_t)si]) { st->slot_read_armed[(size_t)si] = 0; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(is, st->slot_read_done[(size_t)si], 0)); }
         }
+        // host-resident frames: the planes are still arriving on the upload stream
+        for (hipEvent_t& e : st->ingest_wait) if (e) { LVK_HIP_CHECK(ctx, hipStreamWaitEvent(is, e, 0)); e = nullptr; }
         const int pi = st->prof_begin(LVK_STAGE_INGEST, is);
         const int r = lvk_launch_ingest_yuv420(ctx, is, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
         st->prof_end(pi, is);
@@ -1223,6 +1297,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         // the emitted frame has the geometry of the pool (all pooled frames share it)
         LVK_HIP_REQUIRE(ctx, o_y && o_u && (nv12 || o_v));
         hipStream_t es = (st->overlap && st->s.stabilize_output) ? st->remap_stream : ctx->stream;
+        if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(es, e, 0)); }
         pe = st->prof_begin(LVK_STAGE_EGRESS, es);
         rc = lvk_launch_egress_yuv420(ctx, es, st->pool_out, 3 * cols, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12);
         st->prof_end(pe, es);
@@ -1231,6 +1306,127 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     }
     st->trace.mark(HostTrace::EXIT);
     st->last_push_end = std::chrono::steady_clock::now();
+    return LVK_HIP_OK;
+}
+
+// Host-resident frames: FrameIngest::upload_planes -> to_ocl -> StabilizationFilter::filter -> to_obs -> download_planes in one call
+// (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602, VisionFilter.cpp:151-212) -- SURVEY.md section 8d's metric ("p99 ms/frame
+// including H2D of the input and D2H of the output when frames are host-resident").  h_* / oh_*: planes in PINNED host memory
+// (lvk_hip_host_malloc, hipHostMalloc, hipHostRegister).  What the link gives (profiles/r03_pcie_probe.txt): 55 GB/s one way, 46.8 GB/s
+// each way with ONE copy-engine stream per direction at once, 31 with two per direction -- so:
+//   in:  one upload stream; the luma plane goes first and the tracker's stream waits for IT only (downscale, pyramid, flow and the motion
+//        estimate run while the chroma planes are still on the link); the 4:2:0 conversion waits for both.  Planes that are contiguous in
+//        host memory (the OBS frame layout, FrameIngest.cpp:441-453 "uploads are done in bulk") travel as one copy each.
+//   out: a caller that waits for every frame gets the planes written by the remap kernel ITSELF into the pinned host planes (zero copy:
+//        the stores go over the link as they are produced -- no remap -> download serialisation, ~0.1 ms less per frame); a caller that
+//        runs free gets remap -> device planes -> one download on the download stream behind an event (a copy engine both ways is the
+//        faster pair when the link is saturated: 46.8 vs 43 GB/s).  Same pixels either way.
+// Input planes are consumed when the call returns; output planes are complete after lvk_hip_sync().
+int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
+                                  int rows, int cols, uint64_t timestamp,
+                                  void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
+                                  int* produced, uint64_t* out_timestamp)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    if (produced) *produced = 0;
+    LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
+    LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
+    int rc = st->ensure_hostio(rows, cols);
+    if (rc != LVK_HIP_OK) return rc;
+    lvk_hip_stab::HostIO& io = st->hostio;
+    const int k = io.in_next; io.in_next = (k + 1) % lvk_hip_stab::HostIO::K_IN;
+    const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;                     // chroma plane geometry (bytes per row)
+    uint8_t* d_y = (uint8_t*)io.d_in[k];
+    uint8_t* d_u = d_y + (size_t)rows * cols;
+    uint8_t* d_v = nv12 ? d_u : d_u + (size_t)crows * ccols;
+    // (the staging slot is free: the kernels that read it -- downscale, conversion -- were complete when the push that used it returned)
+    auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height, hipMemcpyKind kind, hipStream_t s) -> hipError_t {
+        if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, kind, s);
+        return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
+    };
+    LVK_HIP_CHECK(ctx, copy_plane(d_y, cols, h_y, y_step, cols, rows, hipMemcpyHostToDevice, io.up));
+    LVK_HIP_CHECK(ctx, hipEventRecord(io.y_done[k], io.up));
+    if (!nv12 && u_step == ccols && v_step == ccols && (const uint8_t*)h_v == (const uint8_t*)h_u + (size_t)crows * ccols)
+        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_u, h_u, 2 * (size_t)crows * ccols, hipMemcpyHostToDevice, io.up));      // U | V contiguous: one copy
+    else
+    {
+        LVK_HIP_CHECK(ctx, copy_plane(d_u, ccols, h_u, u_step, ccols, crows, hipMemcpyHostToDevice, io.up));
+        if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(d_v, ccols, h_v, v_step, ccols, crows, hipMemcpyHostToDevice, io.up));
+    }
+    LVK_HIP_CHECK(ctx, hipEventRecord(io.c_done[k], io.up));
+    LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, io.y_done[k], 0));           // the tracker needs the luma plane only
+    st->ingest_wait[0] = io.y_done[k]; st->ingest_wait[1] = io.c_done[k];
+
+    // where the output planes are written.  A free-running caller: the bulk stream or the download stream still busy, or this call beginning
+    // within 15 us of the previous one's return.
+    const bool have_out = oh_y && oh_u && (nv12 || oh_v);
+    bool runs_free = st->caller_free_running_now();
+    if (!runs_free && io.last_down >= 0) { const hipError_t q = hipEventQuery(io.down_done[io.last_down]); if (q != hipSuccess) { (void)hipGetLastError(); runs_free = q == hipErrorNotReady; } }
+    runs_free = runs_free || (io.last_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - io.last_end < std::chrono::microseconds(15));
+    st->host_free_running_hint = runs_free;
+    const bool direct = have_out && (st->host_sink_mode == 1 || (st->host_sink_mode == 0 && !runs_free));
+    const int j = io.out_next;
+    uint8_t* o_y = nullptr; uint8_t* o_u = nullptr; uint8_t* o_v = nullptr;
+    int oys = oy_step, ous = ou_step, ovs = ov_step;
+    if (have_out && !direct)
+    {
+        o_y = (uint8_t*)io.d_out[j]; o_u = o_y + (size_t)rows * cols; o_v = nv12 ? o_u : o_u + (size_t)crows * ccols;
+        oys = cols; ous = ccols; ovs = ccols;
+        if (io.down_armed[j]) st->remap_wait = io.down_done[j];                      // the download that last read this slot
+    }
+    else if (have_out)
+    {
+        o_y = (uint8_t*)oh_y; o_u = (uint8_t*)oh_u; o_v = (uint8_t*)oh_v;
+        // a download of an earlier frame may still be writing the caller's (possibly the same) host planes: the kernel's stores follow it
+        if (io.last_down >= 0 && io.down_armed[io.last_down]) st->remap_wait = io.down_done[io.last_down];
+    }
+    int prod = 0;
+    rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, &prod, out_timestamp);
+    st->remap_wait = nullptr;
+    st->ingest_wait[0] = st->ingest_wait[1] = nullptr;
+    st->host_free_running_hint = false;
+    // "consumed on return": the conversion (which waited for both uploads) has finished in every mode by now; the event costs nothing then
+    LVK_HIP_CHECK(ctx, hipEventSynchronize(io.c_done[k]));
+    if (rc != LVK_HIP_OK) return rc;
+    if (prod && have_out && !direct)
+    {
+        io.out_next = (j + 1) % lvk_hip_stab::HostIO::K_OUT;
+        hipStream_t os = (hipStream_t)lvk_hip_stab_output_stream(st);
+        LVK_HIP_CHECK(ctx, hipEventRecord(io.out_ready[j], os));
+        LVK_HIP_CHECK(ctx, hipStreamWaitEvent(io.down, io.out_ready[j], 0));
+        const bool out_contiguous = oy_step == cols && ou_step == ccols && (uint8_t*)oh_u == (uint8_t*)oh_y + (size_t)rows * cols &&
+                                    (nv12 || (ov_step == ccols && (uint8_t*)oh_v == (uint8_t*)oh_u + (size_t)crows * ccols));
+        if (out_contiguous)
+            LVK_HIP_CHECK(ctx, hipMemcpyAsync(oh_y, o_y, (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols, hipMemcpyDeviceToHost, io.down));
+        else
+        {
+            LVK_HIP_CHECK(ctx, copy_plane(oh_y, oy_step, o_y, cols, cols, rows, hipMemcpyDeviceToHost, io.down));
+            LVK_HIP_CHECK(ctx, copy_plane(oh_u, ou_step, o_u, ccols, ccols, crows, hipMemcpyDeviceToHost, io.down));
+            if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(oh_v, ov_step, o_v, ccols, ccols, crows, hipMemcpyDeviceToHost, io.down));
+        }
+        LVK_HIP_CHECK(ctx, hipEventRecord(io.down_done[j], io.down));
+        io.down_armed[j] = true; io.last_down = j;
+    }
+    if (produced) *produced = prod;
+    io.last_end = std::chrono::steady_clock::now();
+    return LVK_HIP_OK;
+}
+
+// Pinned host memory for the planes of lvk_hip_stab_push_yuv420_host (what obs_source_frame buffers would be registered as)
+int lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr)
+{
+    if (!ctx || !h_ptr) return LVK_HIP_ERR_ARG;
+    LVK_HIP_REQUIRE(ctx, bytes > 0);
+    LVK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LVK_HIP_CHECK(ctx, hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr)
+{
+    if (!ctx) return LVK_HIP_ERR_ARG;
+    if (h_ptr) LVK_HIP_CHECK(ctx, hipHostFree(h_ptr));
     return LVK_HIP_OK;
 }
 

@@ -188,6 +188,39 @@ class StabilizationFilter:
             self.ctx._check(rc)
         return (dst["planes"], ots.value) if produced.value else (None, None)
 
+    # ---- host-resident frames (FrameIngest::upload_planes ... download_planes, FrameIngest.cpp:415-474,567-602)
+    def host_planes(self, rows, cols, nv12=False):
+        """One pinned, CONTIGUOUS 4:2:0 frame (the OBS layout): returns numpy views (y, u, v) / (y, uv) of one lvk_hip_host_malloc block."""
+        import numpy as np
+        n = rows * cols * 3 // 2
+        p = _c.c_void_p()
+        self.ctx._check(self.lib.lvk_hip_host_malloc(self.ctx.handle, n, _c.byref(p)))
+        self._host_blocks = getattr(self, "_host_blocks", []); self._host_blocks.append(p)
+        buf = np.ctypeslib.as_array((_c.c_uint8 * n).from_address(p.value))
+        y = buf[:rows * cols].reshape(rows, cols)
+        if nv12:
+            return y, buf[rows * cols:].reshape(rows // 2, cols // 2, 2)
+        q = rows * cols // 4
+        return y, buf[rows * cols:rows * cols + q].reshape(rows // 2, cols // 2), buf[rows * cols + q:].reshape(rows // 2, cols // 2)
+
+    def prepare_yuv420_host(self, planes):
+        """ctypes argument block of host planes (numpy uint8 arrays in pinned memory) for apply_yuv420_host_prepared."""
+        nv12 = len(planes) == 2
+        y, u = planes[0], planes[1]
+        v = u if nv12 else planes[2]
+        args = (_c.c_void_p(y.ctypes.data), _c.c_int(y.strides[0]), _c.c_void_p(u.ctypes.data), _c.c_int(u.strides[0]),
+                _c.c_void_p(v.ctypes.data), _c.c_int(v.strides[0]))
+        return {"args": args, "nv12": _c.c_int(1 if nv12 else 0), "rows": _c.c_int(y.shape[0]), "cols": _c.c_int(y.shape[1]), "planes": planes}
+
+    def apply_yuv420_host_prepared(self, src, timestamp, dst):
+        """lvk_hip_stab_push_yuv420_host: pinned host planes in, pinned host planes out (complete after Context.sync())."""
+        produced = self._produced; ots = self._ots
+        rc = self.lib.lvk_hip_stab_push_yuv420_host(self.handle, *src["args"], src["nv12"], src["rows"], src["cols"], timestamp,
+                                                    *dst["args"], self._produced_ref, self._ots_ref)
+        if rc != 0:
+            self.ctx._check(rc)
+        return (dst["planes"], ots.value) if produced.value else (None, None)
+
     # ---- StabilizationFilter (Filters/StabilizationFilter.hpp:46-62)
     def restart(self):
         self.ctx._check(self.lib.lvk_hip_stab_restart(self.handle)); self._borrowed.clear()
@@ -275,6 +308,9 @@ class StabilizationFilter:
         if getattr(self, "handle", None):
             self.lib.lvk_hip_stab_destroy(self.handle)
             self.handle = None
+        for p in getattr(self, "_host_blocks", []):
+            self.lib.lvk_hip_host_free(self.ctx.handle, p)
+        self._host_blocks = []
 
     def __del__(self):
         try:

@@ -1,0 +1,111 @@
+"""Host-resident frames (SURVEY.md section 8d's metric; FrameIngest::upload_planes / download_planes, Modules/OBS-Plugin/Interop/
+FrameIngest.cpp:415-474,567-602): lvk_hip_stab_push_yuv420_host against the oracle and against the device-resident entry point.
+Both output routes -- the remap kernel writing the pinned host planes itself ("direct") and remap -> device planes -> download ("copy")
+-- and the per-push choice between them must give the same bytes; contiguous (one copy) and pitched (2-D copies) planes; I420 and NV12."""
+import ctypes as _c
+
+import numpy as np
+import pytest
+
+from tests import clipgen, oracle_lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(lvk, so):
+    sg = lvk.StabilizationFilterSettings()
+    _c.memmove(_c.byref(sg), _c.byref(so), _c.sizeof(so))
+    return sg
+
+
+@pytest.mark.parametrize("sink", ["direct", "copy", "auto"])
+@pytest.mark.parametrize("nv12", [False, True])
+def test_host_push_matches_the_oracle(ctx, oracle, monkeypatch, sink, nv12):
+    import livevisionkit_amd as lvk
+    if sink != "auto":
+        monkeypatch.setenv("LVK_HIP_HOST_SINK", sink)
+    rows, cols, n = 540, 960, 14
+    frames, _ = synth.make_clip(rows, cols, n, seed=31, jitter=1.0)
+    so = oracle_lib.preset("homography", predictive_samples=3)
+    ost = oracle_lib.OracleStabilizer(oracle, so)
+    gst = lvk.StabilizationFilter(_settings(lvk, so), context=ctx)
+    gst.set_overlap(True)
+    ins = [gst.host_planes(rows, cols, nv12) for _ in range(2)]
+    outs = [gst.host_planes(rows, cols, nv12) for _ in range(3)]
+    ins_a = [gst.prepare_yuv420_host(p) for p in ins]; outs_a = [gst.prepare_yuv420_host(p) for p in outs]
+    emitted = 0
+    for i, f in enumerate(frames):
+        planes = oracle.egress_yuv420(f, nv12=nv12)
+        want, _ = ost.push(oracle.ingest_yuv420(*planes), ts=i)
+        for dst, src in zip(ins[i % 2], planes):
+            dst[...] = src
+        got, ts = gst.apply_yuv420_host_prepared(ins_a[i % 2], i, outs_a[i % 3])
+        for dst in ins[i % 2]:
+            dst[...] = 99                                # consumed on return: scribbling over the input must not matter
+        if sink == "auto" and i % 3:
+            ctx.sync()                                   # a caller that sometimes waits, sometimes runs free: both routes in one stream
+        assert (want is None) == (got is None), i
+        if want is not None:
+            ctx.sync()
+            assert ts == i - 3
+            for a, b in zip(got, oracle.egress_yuv420(want, nv12=nv12)):
+                assert np.array_equal(np.asarray(a), b), (i, sink, nv12)
+            emitted += 1
+    assert emitted == n - 3
+    ost.close(); gst.close()
+
+
+@pytest.mark.parametrize("preset", ["homography", "field"])
+def test_host_push_equals_device_push_at_4k(ctx, preset, monkeypatch):
+    """3840 x 2160, free-running: the host entry point (pitched input planes: 2-D copies; contiguous output: one download) emits exactly
+    the planes of lvk_hip_stab_push_yuv420 on the same clip; then the direct route on the same stream."""
+    import torch
+    import livevisionkit_amd as lvk
+    rows, cols, n = 2160, 3840, 26
+    clip = clipgen.Clip(rows, cols, n, device="cuda")
+    planes = [clip.render_i420(i) for i in range(n)]
+    torch.cuda.synchronize()
+    s = lvk.StabilizationFilterSettings.obs_preset(preset, predictive_samples=4)
+
+    def device_run():
+        f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); f.configure(s); f.set_overlap(True)
+        outs = []
+        for i in range(n):
+            got, _ = f.apply_yuv420(planes[i], timestamp=i)
+            if got is not None:
+                ctx.sync(); outs.append([p.cpu().numpy().copy() for p in got])
+        f.close()
+        return outs
+
+    def host_run(sink):
+        if sink:
+            monkeypatch.setenv("LVK_HIP_HOST_SINK", sink)
+        else:
+            monkeypatch.delenv("LVK_HIP_HOST_SINK", raising=False)
+        f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); f.configure(s); f.set_overlap(True)
+        pad = 64
+        hy = torch.empty((rows, cols + pad), dtype=torch.uint8).pin_memory(); hu = torch.empty((rows // 2, cols // 2 + pad), dtype=torch.uint8).pin_memory()
+        hv = torch.empty((rows // 2, cols // 2 + pad), dtype=torch.uint8).pin_memory()
+        src = (hy.numpy()[:, :cols], hu.numpy()[:, :cols // 2], hv.numpy()[:, :cols // 2])
+        ring = [f.host_planes(rows, cols) for _ in range(n)]
+        ring_a = [f.prepare_yuv420_host(p) for p in ring]
+        emitted = []
+        for i in range(n):
+            for dst, p in zip(src, planes[i]):
+                dst[...] = p.cpu().numpy()
+            got, _ = f.apply_yuv420_host_prepared(f.prepare_yuv420_host(src), i, ring_a[i])          # no synchronisation between the pushes
+            if got is not None:
+                emitted.append(i)
+        ctx.sync()
+        outs = [[np.array(p) for p in ring[i]] for i in emitted]
+        f.close()
+        return outs
+
+    want = device_run()
+    assert len(want) == n - 4
+    for sink in ("copy", "direct", None):
+        got = host_run(sink)
+        assert len(got) == len(want)
+        for k, (a, b) in enumerate(zip(got, want)):
+            for pa, pb in zip(a, b):
+                assert np.array_equal(pa, pb), (preset, sink, k)
