@@ -412,7 +412,12 @@ def main():
             out_args = [filt.prepare_yuv420_host(p) for p in host_out]
 
             def run(n, base):
+                # a streaming caller with frames queued ahead (VideoFilter::stream's reader thread): frame i + 1 is announced -- its upload
+                # starts -- before frame i is pushed
+                filt.prefetch_yuv420_host_prepared(in_args[base % hpool])
                 for i in range(base, base + n):
+                    if i + 1 < base + n:
+                        filt.prefetch_yuv420_host_prepared(in_args[(i + 1) % hpool])
                     filt.apply_yuv420_host_prepared(in_args[i % hpool], i, out_args[i & 3])
             torch.cuda.synchronize(); ctx.sync()
             run(100, step_no[0]); step_no[0] += 100
@@ -433,11 +438,14 @@ def main():
             step_no[0] += 500
             pcie = {"value": nsteps / dtp, "unit": "frames/s", "host_to_device_MB_per_frame": mb, "device_to_host_MB_per_frame": mb,
                     "GBps_each_way": nsteps / dtp * mb / 1e3,
-                    "link_ceiling": "profiles/r03_pcie_probe.txt: 55 GB/s one way, 46.8 GB/s each way at once (one copy-engine stream per direction) = 3760 frames/s",
+                    "link_ceiling": "profiles/r03_pcie_probe.txt: 55 GB/s one way; both ways at once 46.8 GB/s each with a copy engine per direction (3760 frames/s), "
+                                    "43 with a copy engine up and kernel stores down (3470 frames/s -- what this path runs: the runtime performs D2H copies of this "
+                                    "process with a blit kernel), 36-40 with kernels both ways",
                     "latency_ms": dict(percentiles(lat_pcie), samples=len(lat_pcie), note="lvk_hip_stab_push_yuv420_host + lvk_hip_sync per frame: upload, "
                                        "track, remap written straight into the pinned output planes; one frame at a time"),
-                    "note": "lvk_hip_stab_push_yuv420_host: I420 planes in pinned host memory in and out (SURVEY 8d's metric for host-resident frames); luma "
-                            "uploaded first, one copy stream per direction, free-running; not the headline value (inputs of `value` are resident in HBM)"}
+                    "note": "lvk_hip_stab_push_yuv420_host with one frame of upload look-ahead (lvk_hip_stab_prefetch_yuv420_host): I420 planes in pinned host memory "
+                            "in and out (SURVEY 8d's metric for host-resident frames), output planes written by the remap kernel itself, free-running; not the "
+                            "headline value (inputs of `value` are resident in HBM)"}
             del host_in, host_out
         except Exception as e:          # the extra pass must never break the contract line
             pcie = {"error": repr(e)}

@@ -310,6 +310,12 @@ int  lvk_hip_stab_push_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_st
                                    int rows, int cols, uint64_t timestamp,
                                    void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
                                    int* produced, uint64_t* out_timestamp);
+/* Look-ahead for streaming callers (the reader thread of VideoFilter::stream, Filters/VideoFilter.cpp:62-209, uploads ahead of the
+ * filter thread): starts the upload of the planes that the NEXT lvk_hip_stab_push_yuv420_host call will push (same pointers), so that
+ * the link carries frame n + 1 while frame n is tracked: announce frame n + 1, then push frame n.  Announced frames are pushed in the
+ * order announced, at most two outstanding; the planes stay the caller's until their push returns. */
+int  lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step,
+                                       int nv12, int rows, int cols);
 int  lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr);      /* pinned, device-visible host memory */
 int  lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr);
 

@@ -89,6 +89,7 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
 int lvk_hip_sync(lvk_hip_ctx* ctx)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
+    for (auto& hook : ctx->sync_hooks) { const int rc = hook.second(); if (rc != LVK_HIP_OK) return rc; }
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (hipStream_t s : ctx->aux_streams) LVK_HIP_CHECK(ctx, hipStreamSynchronize(s));
     return LVK_HIP_OK;

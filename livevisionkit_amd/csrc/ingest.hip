@@ -254,6 +254,26 @@ int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
     return LVK_HIP_OK;
 }
 
+// Plain byte mover for planes that cross the host link under the library's control (lvk_hip_stab_push_yuv420_host): a few workgroups
+// with 16-byte accesses saturate the link (scripts/pcie_probe.hip: 64 blocks = 52-56 GB/s either way) and leave the CUs to the filter.
+__global__ __launch_bounds__(256)
+void k_copy_bytes(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+int lvk_launch_copy_bytes(lvk_hip_ctx* ctx, hipStream_t stream, void* dst, const void* src, size_t bytes, int blocks)
+{
+    LVK_HIP_REQUIRE(ctx, dst && src && ((uintptr_t)dst & 15) == 0 && ((uintptr_t)src & 15) == 0 && blocks > 0);
+    const size_t n16 = bytes / 16; const int tail = (int)(bytes - n16 * 16);
+    hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, n16,
+                       (const uint8_t*)src + n16 * 16, (uint8_t*)dst + n16 * 16, tail);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
 extern "C" {
 
 int lvk_hip_ingest_yuv420(lvk_hip_ctx* ctx, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <functional>
 #include <map>
 #include <set>
 #include <mutex>
@@ -40,6 +41,9 @@ struct lvk_hip_ctx
 
     // extra streams owned by objects of this context (synchronised by lvk_hip_sync as well)
     std::vector<hipStream_t> aux_streams;
+    // work that objects of this context still have to enqueue before "everything is complete" can be waited for (deferred downloads):
+    // (owner, hook) pairs run by lvk_hip_sync ahead of the stream synchronisations
+    std::vector<std::pair<void*, std::function<int()>>> sync_hooks;
 
     // lvk_hip_malloc / lvk_hip_free: freed blocks are kept by size and handed out again (cv::UMat's OpenCL buffer pool plays this role
     // in the reference: Image.cpp:53,116 `dst.create` allocates nothing in steady state).  Guarded: frames may be dropped on any thread.
@@ -209,6 +213,8 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
                              const void* d_v, int v_step, int nv12, int rows, int cols, void* d_dst, int dst_step);
 int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                              void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
+
+int lvk_launch_copy_bytes(lvk_hip_ctx* ctx, hipStream_t stream, void* dst, const void* src, size_t bytes, int blocks);      // 16-byte aligned
 
 int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                          void* d_dst, int dst_step, const void* d_map, int map_step, const uint8_t bg[3], int yuv);

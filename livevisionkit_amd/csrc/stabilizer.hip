@@ -221,11 +221,16 @@ struct lvk_hip_stab
     struct HostIO
     {
         static constexpr int K_IN = 2, K_OUT = 3;
-        hipStream_t up = nullptr, down = nullptr;
+        hipStream_t up = nullptr, up2 = nullptr, down = nullptr, down2 = nullptr;
+        struct Pending { bool valid = false; int slot = 0; void* y; void* u; void* v; int ys, us, vs, nv12; } pending;      // a download not yet handed to the copy engine
         int rows = 0, cols = 0;
         void* d_in[K_IN] = {nullptr, nullptr}; void* d_out[K_OUT] = {nullptr, nullptr, nullptr};      // contiguous planes: Y | U | V  (or Y | UV)
         hipEvent_t y_done[K_IN] = {}, c_done[K_IN] = {}, out_ready[K_OUT] = {}, down_done[K_OUT] = {};
         bool down_armed[K_OUT] = {false, false, false};
+        bool y_is_c[K_IN] = {false, false};                      // the slot's frame came as one copy: c_done covers the luma plane too
+        // look-ahead (lvk_hip_stab_prefetch_yuv420_host): the planes whose upload is already under way, and the slot they go to
+        struct Ahead { int slot; const void* key[3]; int rows, cols, nv12; };
+        std::deque<Ahead> ahead;                                // in upload order; a push consumes the oldest
         int in_next = 0, out_next = 0, last_down = -1;       // last_down: slot of the newest download (its event orders a later direct write behind it)
         std::chrono::steady_clock::time_point last_end{};      // when the previous host push returned
     } hostio;
@@ -233,8 +238,15 @@ struct lvk_hip_stab
     hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
     hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
     int ensure_hostio(int rows, int cols);
+    int flush_download(bool wait);
+    int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
     void free_hostio();
     bool caller_free_running_now();
+    // experiments (scripts/host_feed_probe.py, scripts/host_feed_matrix.sh): LVK_HIP_HOST_UP2=0 every upload on ONE stream (default: announced frames
+    // alternate between two, see host_upload); LVK_HIP_HOST_H2D=<blocks> the uploads as copy kernels of that many workgroups instead of hipMemcpyAsync
+    double host_trace_acc[6] = {0, 0, 0, 0, 0, 0}; long host_trace_n = 0;      // LVK_HIP_HOST_TRACE: us inside lvk_hip_stab_push_yuv420_host, by phase
+    int host_up2 = [] { const char* e = std::getenv("LVK_HIP_HOST_UP2"); return e ? std::atoi(e) : 1; }();
+    int host_h2d_blocks = [] { const char* e = std::getenv("LVK_HIP_HOST_H2D"); return e ? std::atoi(e) : 0; }();
     int host_sink_mode = [] { const char* e = std::getenv("LVK_HIP_HOST_SINK"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();      // tests: direct | copy
 
     // ---- YUV420 front/back end: pool of packed frames the planes are converted into
@@ -585,7 +597,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         // the chain through an event instead of for the stream.
         const hipError_t q = hipStreamQuery(remap_stream);
         if (q != hipSuccess) (void)hipGetLastError();
-        ingest_on_tracker = ingest_placement == 1 || (ingest_placement == 0 && q == hipErrorNotReady);
+        // (host-resident frames whose chroma planes are still on the link: behind the chain as well -- on the bulk stream the conversion would
+        //  hold the output remap back until they have arrived)
+        ingest_on_tracker = ingest_placement == 1 || (ingest_placement == 0 && (q == hipErrorNotReady || ingest_wait[0] != nullptr));
         if (ingest_on_tracker && chained)
         {
             if (!chain_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));
@@ -758,6 +772,10 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     if (!st) return;
     (void)hipStreamSynchronize(st->ctx->stream);
     st->trace.dump();
+    if (st->trace.on && st->host_trace_n)
+        std::fprintf(stderr, "[lvk host trace] push_yuv420_host, us/frame: uploads enqueued %.1f, stream wait + sink choice %.1f, inner push %.1f, chroma wait %.1f, download enqueued %.1f\n",
+                     st->host_trace_acc[0] / st->host_trace_n, st->host_trace_acc[1] / st->host_trace_n, st->host_trace_acc[2] / st->host_trace_n,
+                     st->host_trace_acc[3] / st->host_trace_n, st->host_trace_acc[4] / st->host_trace_n);
     st->free_tracker_buffers();
     lvk_mesh_solver_free(st->mesh_dev);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
@@ -1126,7 +1144,10 @@ int lvk_hip_stab::ensure_hostio(int rows, int cols)
     for (auto& p : h.d_out) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
     LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.up, hipStreamNonBlocking));
     LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.down, hipStreamNonBlocking));
-    ctx->aux_streams.push_back(h.up); ctx->aux_streams.push_back(h.down);          // lvk_hip_sync() covers the transfers
+    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.up2, hipStreamNonBlocking));
+    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.down2, hipStreamNonBlocking));
+    ctx->aux_streams.push_back(h.up); ctx->aux_streams.push_back(h.down); ctx->aux_streams.push_back(h.up2); ctx->aux_streams.push_back(h.down2);
+    ctx->sync_hooks.emplace_back((void*)this, [this]() { return flush_download(true); });          // lvk_hip_sync() covers the transfers
     for (int i = 0; i < HostIO::K_IN; i++)
     {
         LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.y_done[i], hipEventDisableTiming));
@@ -1138,7 +1159,7 @@ int lvk_hip_stab::ensure_hostio(int rows, int cols)
         LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.down_done[i], hipEventDisableTiming));
         h.down_armed[i] = false;
     }
-    h.rows = rows; h.cols = cols; h.in_next = h.out_next = 0; h.last_down = -1;
+    h.rows = rows; h.cols = cols; h.in_next = h.out_next = 0; h.last_down = -1; h.ahead.clear();
     return LVK_HIP_OK;
 }
 
@@ -1146,14 +1167,104 @@ void lvk_hip_stab::free_hostio()
 {
     HostIO& h = hostio;
     auto& aux = ctx->aux_streams;
-    for (hipStream_t s : {h.up, h.down})
+    { auto& hooks = ctx->sync_hooks; hooks.erase(std::remove_if(hooks.begin(), hooks.end(), [this](const auto& kv) { return kv.first == (void*)this; }), hooks.end()); }
+    h.pending.valid = false;
+    for (hipStream_t s : {h.up, h.down, h.up2, h.down2})
         if (s) { (void)hipStreamSynchronize(s); aux.erase(std::remove(aux.begin(), aux.end(), s), aux.end()); (void)hipStreamDestroy(s); }
-    h.up = h.down = nullptr;
+    h.up = h.down = h.up2 = h.down2 = nullptr;
     for (auto& p : h.d_in) { if (p) (void)hipFree(p); p = nullptr; }
     for (auto& p : h.d_out) { if (p) (void)hipFree(p); p = nullptr; }
     for (auto* arr : {h.y_done, h.c_done}) for (int i = 0; i < HostIO::K_IN; i++) if (arr[i]) { (void)hipEventDestroy(arr[i]); arr[i] = nullptr; }
     for (auto* arr : {h.out_ready, h.down_done}) for (int i = 0; i < HostIO::K_OUT; i++) if (arr[i]) { (void)hipEventDestroy(arr[i]); arr[i] = nullptr; }
     h.rows = h.cols = 0;
+}
+
+// The uploads of one host frame into staging slot k, on the upload stream.
+//   * pushed now (the caller waits for this frame): luma, event, chroma, event -- the tracker starts on the luma plane while the chroma planes
+//     are still on the link;
+//   * announced ahead (the link is the bottleneck, not this frame's latency): ONE copy when the planes are contiguous.  A copy engine
+//     that has to wait for anything but its own previous copy -- here: the event between the two copies -- is restarted by the
+//     runtime's signal handler 60-80 us late (timeline in profiles/r03_host_feed_timeline.txt): 341 us of link time per frame instead of 265.
+int lvk_hip_stab::host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead)
+{
+    HostIO& io = hostio;
+    const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;
+    uint8_t* d_y = (uint8_t*)io.d_in[k];
+    uint8_t* d_u = d_y + (size_t)rows * cols;
+    uint8_t* d_v = nv12 ? d_u : d_u + (size_t)crows * ccols;
+    int rc;
+    // (the staging slot is free: the kernels that read it -- downscale, conversion -- were complete when the push that used it returned)
+    auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height, hipStream_t s) -> hipError_t {
+        if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, hipMemcpyHostToDevice, s);
+        return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, s);
+    };
+    const bool contiguous = y_step == cols && u_step == ccols && (const uint8_t*)h_u == (const uint8_t*)h_y + (size_t)rows * cols &&
+                            (nv12 || (v_step == ccols && (const uint8_t*)h_v == (const uint8_t*)h_u + (size_t)crows * ccols));
+    if (ahead && contiguous)
+    {
+        const size_t bytes = (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols;
+        // one upload stream per staging slot: hipMemcpyAsync blocks the HOST while an earlier copy of the same stream is still in flight
+        // (measured: the next frame's tracker chain was launched 90 us after the previous upload had ended)
+        hipStream_t us = (host_up2 && (k & 1)) ? io.up2 : io.up;
+        if (host_h2d_blocks > 0 && ((uintptr_t)h_y & 15) == 0) { if ((rc = lvk_launch_copy_bytes(ctx, us, d_y, h_y, bytes, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
+        else LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_y, h_y, bytes, hipMemcpyHostToDevice, us));
+        LVK_HIP_CHECK(ctx, hipEventRecord(io.c_done[k], us));
+        io.y_is_c[k] = true;
+        return LVK_HIP_OK;
+    }
+    io.y_is_c[k] = false;
+    hipStream_t cs = io.up;                                                          // luma and chroma of a frame pushed now: one stream, in order
+    const bool kernel_up = host_h2d_blocks > 0 && y_step == cols && ((uintptr_t)h_y & 15) == 0 && ((uintptr_t)h_u & 15) == 0 && ((size_t)rows * cols) % 16 == 0;
+    if (kernel_up) { if ((rc = lvk_launch_copy_bytes(ctx, io.up, d_y, h_y, (size_t)rows * cols, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
+    else LVK_HIP_CHECK(ctx, copy_plane(d_y, cols, h_y, y_step, cols, rows, io.up));
+    LVK_HIP_CHECK(ctx, hipEventRecord(io.y_done[k], io.up));
+    if (!nv12 && u_step == ccols && v_step == ccols && (const uint8_t*)h_v == (const uint8_t*)h_u + (size_t)crows * ccols)
+    {
+        if (kernel_up) { if ((rc = lvk_launch_copy_bytes(ctx, cs, d_u, h_u, 2 * (size_t)crows * ccols, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
+        else LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_u, h_u, 2 * (size_t)crows * ccols, hipMemcpyHostToDevice, cs));      // U | V contiguous: one copy
+    }
+    else
+    {
+        LVK_HIP_CHECK(ctx, copy_plane(d_u, ccols, h_u, u_step, ccols, crows, cs));
+        if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(d_v, ccols, h_v, v_step, ccols, crows, cs));
+    }
+    LVK_HIP_CHECK(ctx, hipEventRecord(io.c_done[k], cs));
+    return LVK_HIP_OK;
+}
+
+// Deferred download (LVK_HIP_HOST_SINK=copy): the D2H copy of an emitted frame is handed to the runtime only once the remap that wrote the
+// device planes is KNOWN to be complete, on a stream with nothing pending -- a copy that has to wait for a kernel is performed by the
+// runtime with a blit kernel (which saturates the link's write queue and stalls every other kernel), an unencumbered one by a copy engine.
+// wait = false: only if the remap has finished (polled at the start and at the end of the following push); true: wait for it.
+int lvk_hip_stab::flush_download(bool wait)
+{
+    HostIO& io = hostio;
+    if (!io.pending.valid) return LVK_HIP_OK;
+    const int j = io.pending.slot;
+    const hipError_t q = hipEventQuery(io.out_ready[j]);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); if (!wait) return LVK_HIP_OK; LVK_HIP_CHECK(ctx, hipEventSynchronize(io.out_ready[j])); }
+    else if (q != hipSuccess) return fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(q));
+    const int rows = io.rows, cols = io.cols, nv12 = io.pending.nv12, crows = rows / 2, ccols = nv12 ? cols : cols / 2;
+    uint8_t* o_y = (uint8_t*)io.d_out[j]; uint8_t* o_u = o_y + (size_t)rows * cols; uint8_t* o_v = nv12 ? o_u : o_u + (size_t)crows * ccols;
+    hipStream_t ds = (j & 1) ? io.down2 : io.down;           // (hipMemcpyAsync blocks the host while an earlier copy of the same stream is in flight)
+    auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height) -> hipError_t {
+        if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, hipMemcpyDeviceToHost, ds);
+        return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, ds);
+    };
+    const auto& p = io.pending;
+    const bool contiguous = p.ys == cols && p.us == ccols && (uint8_t*)p.u == (uint8_t*)p.y + (size_t)rows * cols &&
+                            (nv12 || (p.vs == ccols && (uint8_t*)p.v == (uint8_t*)p.u + (size_t)crows * ccols));
+    if (contiguous) LVK_HIP_CHECK(ctx, hipMemcpyAsync(p.y, o_y, (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols, hipMemcpyDeviceToHost, ds));
+    else
+    {
+        LVK_HIP_CHECK(ctx, copy_plane(p.y, p.ys, o_y, cols, cols, rows));
+        LVK_HIP_CHECK(ctx, copy_plane(p.u, p.us, o_u, ccols, ccols, crows));
+        if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(p.v, p.vs, o_v, ccols, ccols, crows));
+    }
+    LVK_HIP_CHECK(ctx, hipEventRecord(io.down_done[j], ds));
+    io.down_armed[j] = true; io.last_down = j;
+    io.pending.valid = false;
+    return LVK_HIP_OK;
 }
 
 int lvk_hip_stab::ensure_pool(int rows, int cols)
@@ -1309,6 +1420,27 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     return LVK_HIP_OK;
 }
 
+// Look-ahead for streaming callers (the reader thread of VideoFilter::stream uploads frames ahead of the filter thread,
+// Filters/VideoFilter.cpp:62-209): starts the upload of the planes that the NEXT lvk_hip_stab_push_yuv420_host call will push, so that the
+// link is busy with frame n + 1 while frame n is tracked: announce frame n + 1, THEN push frame n.  Announced frames are pushed in order; at
+// most two may be outstanding.  The planes stay the caller's until their push has returned.
+int lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
+    LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
+    int rc = st->ensure_hostio(rows, cols);
+    if (rc != LVK_HIP_OK) return rc;
+    lvk_hip_stab::HostIO& io = st->hostio;
+    // two staging slots: the frame being pushed and the one on the link -- at most two announced frames that have not been pushed yet
+    LVK_HIP_REQUIRE(ctx, io.ahead.size() < (size_t)lvk_hip_stab::HostIO::K_IN);
+    const int k = io.in_next; io.in_next = (k + 1) % lvk_hip_stab::HostIO::K_IN;
+    if ((rc = st->host_upload(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, k, true)) != LVK_HIP_OK) return rc;
+    io.ahead.push_back({k, {h_y, h_u, nv12 ? h_u : h_v}, rows, cols, nv12 ? 1 : 0});
+    return LVK_HIP_OK;
+}
+
 // Host-resident frames: FrameIngest::upload_planes -> to_ocl -> StabilizationFilter::filter -> to_obs -> download_planes in one call
 // (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602, VisionFilter.cpp:151-212) -- SURVEY.md section 8d's metric ("p99 ms/frame
 // including H2D of the input and D2H of the output when frames are host-resident").  h_* / oh_*: planes in PINNED host memory
@@ -1335,37 +1467,39 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     int rc = st->ensure_hostio(rows, cols);
     if (rc != LVK_HIP_OK) return rc;
     lvk_hip_stab::HostIO& io = st->hostio;
-    const int k = io.in_next; io.in_next = (k + 1) % lvk_hip_stab::HostIO::K_IN;
+    if ((rc = st->flush_download(false)) != LVK_HIP_OK) return rc;
+    auto tr_last = std::chrono::steady_clock::now();
+    auto tr_mark = [&](int k) { if (!st->trace.on) return; const auto now = std::chrono::steady_clock::now(); st->host_trace_acc[k] += std::chrono::duration<double, std::micro>(now - tr_last).count(); tr_last = now; };
     const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;                     // chroma plane geometry (bytes per row)
+    int k;
+    if (!io.ahead.empty())
+    {
+        // its upload has been under way since the look-ahead call; look-ahead frames are pushed in the order they were announced
+        const auto a = io.ahead.front();
+        LVK_HIP_REQUIRE(ctx, a.key[0] == h_y && a.key[1] == h_u && a.key[2] == (nv12 ? h_u : h_v) && a.rows == rows && a.cols == cols && a.nv12 == (nv12 ? 1 : 0));
+        io.ahead.pop_front();
+        k = a.slot;
+    }
+    else
+    {
+        k = io.in_next; io.in_next = (k + 1) % lvk_hip_stab::HostIO::K_IN;
+        if ((rc = st->host_upload(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, k, false)) != LVK_HIP_OK) return rc;
+    }
     uint8_t* d_y = (uint8_t*)io.d_in[k];
     uint8_t* d_u = d_y + (size_t)rows * cols;
     uint8_t* d_v = nv12 ? d_u : d_u + (size_t)crows * ccols;
-    // (the staging slot is free: the kernels that read it -- downscale, conversion -- were complete when the push that used it returned)
-    auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height, hipMemcpyKind kind, hipStream_t s) -> hipError_t {
-        if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, kind, s);
-        return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
-    };
-    LVK_HIP_CHECK(ctx, copy_plane(d_y, cols, h_y, y_step, cols, rows, hipMemcpyHostToDevice, io.up));
-    LVK_HIP_CHECK(ctx, hipEventRecord(io.y_done[k], io.up));
-    if (!nv12 && u_step == ccols && v_step == ccols && (const uint8_t*)h_v == (const uint8_t*)h_u + (size_t)crows * ccols)
-        LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_u, h_u, 2 * (size_t)crows * ccols, hipMemcpyHostToDevice, io.up));      // U | V contiguous: one copy
-    else
-    {
-        LVK_HIP_CHECK(ctx, copy_plane(d_u, ccols, h_u, u_step, ccols, crows, hipMemcpyHostToDevice, io.up));
-        if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(d_v, ccols, h_v, v_step, ccols, crows, hipMemcpyHostToDevice, io.up));
-    }
-    LVK_HIP_CHECK(ctx, hipEventRecord(io.c_done[k], io.up));
-    LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, io.y_done[k], 0));           // the tracker needs the luma plane only
-    st->ingest_wait[0] = io.y_done[k]; st->ingest_wait[1] = io.c_done[k];
+    tr_mark(0);
+    LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, io.y_is_c[k] ? io.c_done[k] : io.y_done[k], 0));           // the tracker needs the luma plane only
+    st->ingest_wait[0] = io.y_is_c[k] ? nullptr : io.y_done[k]; st->ingest_wait[1] = io.c_done[k];
 
-    // where the output planes are written.  A free-running caller: the bulk stream or the download stream still busy, or this call beginning
-    // within 15 us of the previous one's return.
+    // where the output planes are written: by the remap kernel itself, straight into the pinned host planes (measured, 4K, free running:
+    // 2 800 frames/s against 2 490 for remap -> device planes -> download, whose D2H copy the runtime performs with a blit KERNEL that
+    // saturates the link's write queue and stalls every other kernel's memory traffic while it runs -- timelines under profiles/).
+    // LVK_HIP_HOST_SINK=copy keeps the download route for comparison.
     const bool have_out = oh_y && oh_u && (nv12 || oh_v);
-    bool runs_free = st->caller_free_running_now();
-    if (!runs_free && io.last_down >= 0) { const hipError_t q = hipEventQuery(io.down_done[io.last_down]); if (q != hipSuccess) { (void)hipGetLastError(); runs_free = q == hipErrorNotReady; } }
-    runs_free = runs_free || (io.last_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - io.last_end < std::chrono::microseconds(15));
-    st->host_free_running_hint = runs_free;
-    const bool direct = have_out && (st->host_sink_mode == 1 || (st->host_sink_mode == 0 && !runs_free));
+    st->host_free_running_hint = st->caller_free_running_now() ||
+                                 (io.last_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - io.last_end < std::chrono::microseconds(15));
+    const bool direct = have_out && st->host_sink_mode != 2;
     const int j = io.out_next;
     uint8_t* o_y = nullptr; uint8_t* o_u = nullptr; uint8_t* o_v = nullptr;
     int oys = oy_step, ous = ou_step, ovs = ov_step;
@@ -1373,42 +1507,40 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     {
         o_y = (uint8_t*)io.d_out[j]; o_u = o_y + (size_t)rows * cols; o_v = nv12 ? o_u : o_u + (size_t)crows * ccols;
         oys = cols; ous = ccols; ovs = ccols;
+        if (io.pending.valid && io.pending.slot == j) { if ((rc = st->flush_download(true)) != LVK_HIP_OK) return rc; }
         if (io.down_armed[j]) st->remap_wait = io.down_done[j];                      // the download that last read this slot
     }
     else if (have_out)
     {
         o_y = (uint8_t*)oh_y; o_u = (uint8_t*)oh_u; o_v = (uint8_t*)oh_v;
         // a download of an earlier frame may still be writing the caller's (possibly the same) host planes: the kernel's stores follow it
+        if ((rc = st->flush_download(true)) != LVK_HIP_OK) return rc;
         if (io.last_down >= 0 && io.down_armed[io.last_down]) st->remap_wait = io.down_done[io.last_down];
     }
     int prod = 0;
+    tr_mark(1);
     rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, &prod, out_timestamp);
     st->remap_wait = nullptr;
     st->ingest_wait[0] = st->ingest_wait[1] = nullptr;
     st->host_free_running_hint = false;
+    tr_mark(2);
     // "consumed on return": the conversion (which waited for both uploads) has finished in every mode by now; the event costs nothing then
     LVK_HIP_CHECK(ctx, hipEventSynchronize(io.c_done[k]));
+    tr_mark(3);
     if (rc != LVK_HIP_OK) return rc;
+    if ((rc = st->flush_download(false)) != LVK_HIP_OK) return rc;                  // the previous frame's remap has usually finished by now
     if (prod && have_out && !direct)
     {
+        if ((rc = st->flush_download(true)) != LVK_HIP_OK) return rc;               // (one deferred download at a time)
         io.out_next = (j + 1) % lvk_hip_stab::HostIO::K_OUT;
         hipStream_t os = (hipStream_t)lvk_hip_stab_output_stream(st);
         LVK_HIP_CHECK(ctx, hipEventRecord(io.out_ready[j], os));
-        LVK_HIP_CHECK(ctx, hipStreamWaitEvent(io.down, io.out_ready[j], 0));
-        const bool out_contiguous = oy_step == cols && ou_step == ccols && (uint8_t*)oh_u == (uint8_t*)oh_y + (size_t)rows * cols &&
-                                    (nv12 || (ov_step == ccols && (uint8_t*)oh_v == (uint8_t*)oh_u + (size_t)crows * ccols));
-        if (out_contiguous)
-            LVK_HIP_CHECK(ctx, hipMemcpyAsync(oh_y, o_y, (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols, hipMemcpyDeviceToHost, io.down));
-        else
-        {
-            LVK_HIP_CHECK(ctx, copy_plane(oh_y, oy_step, o_y, cols, cols, rows, hipMemcpyDeviceToHost, io.down));
-            LVK_HIP_CHECK(ctx, copy_plane(oh_u, ou_step, o_u, ccols, ccols, crows, hipMemcpyDeviceToHost, io.down));
-            if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(oh_v, ov_step, o_v, ccols, ccols, crows, hipMemcpyDeviceToHost, io.down));
-        }
-        LVK_HIP_CHECK(ctx, hipEventRecord(io.down_done[j], io.down));
-        io.down_armed[j] = true; io.last_down = j;
+        io.pending.valid = true; io.pending.slot = j; io.pending.y = oh_y; io.pending.u = oh_u; io.pending.v = oh_v;
+        io.pending.ys = oy_step; io.pending.us = ou_step; io.pending.vs = ov_step; io.pending.nv12 = nv12 ? 1 : 0;
+        io.down_armed[j] = false;
     }
     if (produced) *produced = prod;
+    tr_mark(4); st->host_trace_n++;
     io.last_end = std::chrono::steady_clock::now();
     return LVK_HIP_OK;
 }

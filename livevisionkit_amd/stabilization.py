@@ -212,6 +212,12 @@ class StabilizationFilter:
                 _c.c_void_p(v.ctypes.data), _c.c_int(v.strides[0]))
         return {"args": args, "nv12": _c.c_int(1 if nv12 else 0), "rows": _c.c_int(y.shape[0]), "cols": _c.c_int(y.shape[1]), "planes": planes}
 
+    def prefetch_yuv420_host_prepared(self, src):
+        """lvk_hip_stab_prefetch_yuv420_host: start the upload of the planes the NEXT apply_yuv420_host_prepared call will push."""
+        rc = self.lib.lvk_hip_stab_prefetch_yuv420_host(self.handle, *src["args"], src["nv12"], src["rows"], src["cols"])
+        if rc != 0:
+            self.ctx._check(rc)
+
     def apply_yuv420_host_prepared(self, src, timestamp, dst):
         """lvk_hip_stab_push_yuv420_host: pinned host planes in, pinned host planes out (complete after Context.sync())."""
         produced = self._produced; ots = self._ots

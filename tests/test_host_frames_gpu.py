@@ -89,11 +89,25 @@ def test_host_push_equals_device_push_at_4k(ctx, preset, monkeypatch):
         src = (hy.numpy()[:, :cols], hu.numpy()[:, :cols // 2], hv.numpy()[:, :cols // 2])
         ring = [f.host_planes(rows, cols) for _ in range(n)]
         ring_a = [f.prepare_yuv420_host(p) for p in ring]
+        # a second input set (contiguous, lvk_hip_host_malloc) alternates with the pitched one; from frame 8 on the NEXT frame is announced
+        # (lvk_hip_stab_prefetch_yuv420_host: one whole-frame copy on alternating upload streams) before the current one is pushed
+        srcs = [src, f.host_planes(rows, cols), f.host_planes(rows, cols)]
+        srcs_a = [f.prepare_yuv420_host(p) for p in srcs]
         emitted = []
-        for i in range(n):
-            for dst, p in zip(src, planes[i]):
+
+        def fill(i):
+            for dst, p in zip(srcs[i % 3], planes[i]):
                 dst[...] = p.cpu().numpy()
-            got, _ = f.apply_yuv420_host_prepared(f.prepare_yuv420_host(src), i, ring_a[i])          # no synchronisation between the pushes
+        fill(0)
+        for i in range(n):
+            if i == 8:
+                f.prefetch_yuv420_host_prepared(srcs_a[i % 3])  # announced frames are pushed in the order announced: this one first
+            if i >= 8 and i + 1 < n:
+                fill(i + 1)                                    # (its buffer was consumed when push i - 2 returned)
+                f.prefetch_yuv420_host_prepared(srcs_a[(i + 1) % 3])
+            got, _ = f.apply_yuv420_host_prepared(srcs_a[i % 3], i, ring_a[i])          # no synchronisation between the pushes
+            if i < 8 and i + 1 < n:
+                fill(i + 1)
             if got is not None:
                 emitted.append(i)
         ctx.sync()
