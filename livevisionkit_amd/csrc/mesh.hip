@@ -502,11 +502,13 @@ void k_mesh_solve(MeshArgs a)
 }
 
 // phase 3 of both solvers: the solution as float (Eigen::VectorXf m_OptimizedMesh), inlier flags, offsets (FrameTracker.cpp:276-320);
-// sol: the solution in binary64 (LDS or global), visible to every thread of the workgroup
-__device__ __forceinline__ void finish_solution(const MeshArgs& a, const double* sol, int tid, int nthreads, int m)
+// sol(i): the solution in binary64 (a functor, so that an LDS array stays an LDS access: handing k_mesh_backsolve's shared array over as a
+// generic pointer cost it 32 VGPRs and put 112 bytes of its walking wavefront's state into scratch -- 43 -> 89 us), visible to every thread
+template <class Sol>
+__device__ __forceinline__ void finish_solution(const MeshArgs& a, Sol sol, int tid, int nthreads, int m)
 {
     const int n = a.n;
-    for (int i = tid; i < n; i += nthreads) a.mesh[i] = (float)sol[i];
+    for (int i = tid; i < n; i += nthreads) a.mesh[i] = (float)sol(i);
     __syncthreads();
     for (int f = tid; f < m; f += nthreads)
     {
@@ -652,7 +654,7 @@ void k_mesh_backsolve(MeshArgs a)
 #endif
 
     // ---- phase 3: the solution as float, inlier flags, offsets (FrameTracker.cpp:276-320)
-    finish_solution(a, s.w, tid, MB_NT, m);
+    finish_solution(a, [&](int i) { return s.w[i]; }, tid, MB_NT, m);
 }
 
 // ---- the same factorisation for ANY mesh (WarpMesh.cpp:34-41,79-90 allows every N x M; FrameTracker.cpp:57-92 takes every motion_resolution) --
@@ -729,7 +731,7 @@ void k_mesh_backsolve_generic(MeshArgs a)
         for (int k = first + tid; k < j; k += MG_NT) w[k] = __builtin_fma(-a.Lc[(size_t)k * ld + (j - k)], xj, w[k]);
         __syncthreads();
     }
-    finish_solution(a, w, tid, MG_NT, m);
+    finish_solution(a, [&](int i) { return w[i]; }, tid, MG_NT, m);
 }
 
 } // namespace

@@ -1,5 +1,5 @@
 #!/bin/bash
-python -m pytest tests/test_host_frames_gpu.py -x -q 2>&1 | tail -5
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --quality-frames 0 2>/dev/null | python -c "
+python -m pytest tests/test_mesh_gpu.py tests/test_stabilizer_gpu.py -x -q 2>&1 | tail -3
+python bench.py --preset field --steps 600 --warmup 50 --no-cpu-baseline --no-pcie --quality-frames 0 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['sustained']['frames_per_s']); p=d['pcie_inclusive']; print(p.get('value'), p.get('latency_ms'), p.get('error'))"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['sustained']['frames_per_s'], d['latency_ms'], d['stage_us'])"
