@@ -70,8 +70,29 @@ constexpr int ms_tiles(int hb) { int t = 0; for (int b = 0; b < (hb + MS_TB) / M
 static_assert(ms_tiles(MS_HB_MAX) <= MS_BULK, "one register tile per window thread");
 static_assert(MS_BANDS * MS_TB <= 128 && MS_HB_MAX < 128, "a column is two registers per lane of the chain");
 
+// One block of the nested dissection (oracle S5'): a band system of its own -- the block's vertex rows, then its separators --
+// of which only the first n_elim pivots are eliminated.
+struct MeshBlockDev
+{
+    int n, hb, n_elim, nbands;
+    double* N; double* g0; double* wz; double* Lc; double* Rc; double* T;      // Rc: unscaled pivot columns (layout of Lc); T: trailing (n - n_elim)^2 window, row major
+    const int* xs_of;                       // separator position n_elim + q -> index into the separator system's solution
+    const int* nat_of;                      // own position -> natural unknown index
+};
+
 struct MeshArgs
 {
+    // ---- nested dissection (nd != 0): kernels launched with one workgroup per block take n, hb, ... and the arrays from blocks[blockIdx.x]
+    int nd, nblocks, n_elim, n_nat;         // n_elim: pivots to eliminate (n for a whole system); n_nat: unknowns of the whole mesh
+    const MeshBlockDev* blocks;
+    double* Rc; double* T;                  // (per block, see MeshBlockDev)
+    const int* ndst; const int* gdst;       // k_mesh_prepare: natural band entry / unknown -> position in the blocks' arrays (or -1)
+    const int* ssrc; const int* gsrc; int s_entries, ns;      // k_nd_sep_assemble: separator band entry / unknown -> its (<= 2) sources in T / wz of the blocks
+    const double* Tall; const double* wzall;
+    double* xs;                             // separator solution (binary64)
+    double* X;                              // solution in natural order (binary64), gathered from the blocks
+    const int* sep_nat;                     // separator unknown -> natural index
+    unsigned* ticket;                       // last-block-done counter of the block-parallel kernels
     int cols, rows, n, hb, nbands;          // nbands: bands of MS_TB band offsets covering 0 .. hb
     const double* stat;                     // static band, column layout: entry (i, k), k <= i <= k + hb, at [k * (hb + 1) + (i - k)]
     long long* Nq; long long* gq;           // Q32 sums of the feature rows (same layout as stat / one per unknown)
@@ -142,6 +163,9 @@ void k_mesh_prepare(MeshArgs a)
     const int ld = a.hb + 1;
     const size_t band = (size_t)a.n * ld;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // nested dissection: every entry of the natural system goes to its place in ONE block's band (a.ndst / a.gdst; -1: structurally zero);
+    // status bits of the frame for the kernels that follow (they only read *a.flags)
+    if (a.nd && blockIdx.x == 0 && threadIdx.x == 0 && pair_count(a) < a.min_samples) atomicOr(a.flags, 8);
     for (size_t at = (size_t)blockIdx.x * blockDim.x + threadIdx.x; at < band + a.n; at += stride)
     {
         if (at < band)
@@ -149,13 +173,14 @@ void k_mesh_prepare(MeshArgs a)
             const long long q = a.Nq[at]; a.Nq[at] = 0;
             double v = a.stat[at] + (double)q / MS_Q;
             if (at % ld == 0) v = v + 1e-6;
-            a.N[at] = v;
+            if (!a.ndst) a.N[at] = v;
+            else { const int d = a.ndst[at]; if (d >= 0) a.N[d] = v; }
         }
         else
         {
             const size_t i = at - band;
             const long long q = a.gq[i]; a.gq[i] = 0;
-            a.g0[i] = (double)a.ts_gen * (double)(a.ts_now * a.mesh[i]) + (double)q / MS_Q;
+            a.g0[a.gdst ? a.gdst[i] : (int)i] = (double)a.ts_gen * (double)(a.ts_now * a.mesh[i]) + (double)q / MS_Q;
         }
     }
 }
@@ -250,8 +275,15 @@ __device__ __forceinline__ void chain_interval(const MeshArgs& a, FactorShared& 
     D1 = __builtin_fma(-shift_down1(lc1, 0.0), c1, D1);
     const double dd = readlane64(D0, 0);
     cc.b1 = readlane64(D0, 1); cc.b2 = readlane64(D0, 2);
-    cc.bad = cc.bad || !(dc > 0.0) || !(dd > 0.0);
+    cc.bad = cc.bad || (c < a.n_elim && !(dc > 0.0)) || (c + 1 < a.n_elim && !(dd > 0.0));      // (a block's held-back separator pivots are formed one interval ahead and never used)
     const double rd = 1.0 / dd;
+    if (a.Rc && c < a.n_elim)
+    {
+        // the unscaled pivot columns: what a block's trailing separator window is rebuilt from after the early stop (k_mesh_solve's epilogue)
+        double* Rp = a.Rc + (size_t)c * (a.hb + 1);
+        if (lane <= a.hb) { Rp[lane] = C0; Rp[a.hb + 1 + lane] = D0; }
+        if (lane + 64 <= a.hb) { Rp[lane + 64] = C1; Rp[a.hb + 1 + lane + 64] = D1; }
+    }
     s.raw[PAR ^ 1][0][x0] = lane <= 3 ? 0.0 : C0; s.raw[PAR ^ 1][0][x0 + 80] = C1;
     s.lcol[PAR ^ 1][0][x0] = lc0; s.lcol[PAR ^ 1][0][x0 + 80] = lc1;
     s.raw[PAR ^ 1][1][x0] = lane <= 2 ? 0.0 : D0; s.raw[PAR ^ 1][1][x0 + 80] = D1;
@@ -394,13 +426,27 @@ void k_mesh_solve(MeshArgs a)
     LVK_TRACKER_PRIORITY();
     __shared__ FactorShared s;
     const int tid = (int)threadIdx.x;
+    if (a.blocks)
+    {
+        const MeshBlockDev b = a.blocks[blockIdx.x];
+        a.n = b.n; a.hb = b.hb; a.nbands = b.nbands; a.n_elim = b.n_elim; a.N = b.N; a.g0 = b.g0; a.wz = b.wz; a.Lc = b.Lc; a.Rc = b.Rc; a.T = b.T;
+    }
     const int n = a.n, hb = a.hb;
     const int m = pair_count(a);
     const int flags = *a.flags;
     __syncthreads();
+    if (a.nd)
+    {
+        // nested dissection: the kernels of a solve only READ the status bits of earlier kernels (1 a feature outside the mesh, 4 a
+        // factorisation broke down, 8 too few pairs) and OR their own in; the last kernel reports and clears them
+        if (flags & 0xf) return;
+    }
+    else
+    {
     // *a.flags on exit: 0 = factorised, k_mesh_backsolve goes ahead; 2 = no solution this frame (the status is already with the host)
     if (m < a.min_samples) { if (tid == 0) { *a.out_status = 1; *a.flags = 2; } return; }
     if (flags & 1) { if (tid == 0) { *a.out_status = 2; *a.flags = 2; } return; }
+    }
 #ifdef LVK_MESH_TIMING
     const long long tm0 = wall_clock64();
 #endif
@@ -467,10 +513,11 @@ void k_mesh_solve(MeshArgs a)
 #define MESH_PROBE_END() do { } while (0)
 #endif
     // the intervals: the pivots (p0, p0 + 1) with the pivot data of parity 0 (written by the start-up interval), (p0 + 2, p0 + 3) with parity 1
-    for (int p0 = 0; p0 < n; p0 += 2 * MS_CA)
+    const int n_elim = a.n_elim;
+    for (int p0 = 0; p0 < n_elim; p0 += 2 * MS_CA)
     {
 #define LVK_MESH_INTERVAL(GV, HV)                                                                               \
-        if (p0 + MS_CA * GV + 2 * HV < n)                                                                        \
+        if (p0 + MS_CA * GV + 2 * HV < n_elim)                                                                   \
         {                                                                                                        \
             MESH_PROBE_BEGIN();                                                                                  \
             if (chain) chain_interval<HV>(a, s, p0 + MS_CA * GV + 2 * HV + 2, cc);                               \
@@ -496,9 +543,53 @@ void k_mesh_solve(MeshArgs a)
     }
 #endif
 #endif
-    if (s.fail != 0) { if (tid == 0) { *a.out_status = 3; *a.flags = 2; } return; }
+    if (s.fail != 0) { if (tid == 0) { if (a.nd) atomicOr(a.flags, 4); else { *a.out_status = 3; *a.flags = 2; } } return; }
     for (int i = tid; i < n; i += MS_NT) a.wz[i] = s.w[i];
-    if (tid == 0) *a.flags = 0;
+    if (!a.nd) { if (tid == 0) *a.flags = 0; return; }
+    if (!a.T) return;
+    // ---- a block of the nested dissection: what its pivots left of the separator x separator window.  The window itself lived in the
+    // registers of the update above and is gone; every entry is rebuilt from its original value and the columns of L and of the unscaled
+    // pivots in pivot order -- the same fused multiply-subtracts with the same operands the right-looking update applies to it.
+    __syncthreads();                                                    // the columns of L / the raw columns are in memory (this workgroup wrote them)
+    {
+        const int ns = n - n_elim, ld = hb + 1;
+        for (int e = tid; e < ns * ns; e += MS_NT)
+        {
+            const int li = e / ns, lk = e - li * ns;
+            if (lk > li) continue;
+            const int i = n_elim + li, k = n_elim + lk;
+            double acc = a.N[(size_t)k * ld + (i - k)];
+            for (int j = max(0, i - hb); j < n_elim; j++) acc = __builtin_fma(-a.Lc[(size_t)j * ld + (i - j)], a.Rc[(size_t)j * ld + (k - j)], acc);
+            a.T[(size_t)li * ns + lk] = acc;
+        }
+    }
+}
+
+// The separator system of the nested dissection: S = sum of the blocks' trailing windows, g = sum of their reduced right-hand sides, in
+// ascending block order starting from +0 (at most two blocks meet in an entry); band layout of k_mesh_solve.
+__global__ __launch_bounds__(256)
+void k_nd_sep_assemble(MeshArgs a)
+{
+    LVK_TRACKER_PRIORITY();
+    if (*a.flags & 0xf) return;
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e < a.s_entries)
+    {
+        double v = 0.0;
+        const int s0 = a.ssrc[2 * e], s1 = a.ssrc[2 * e + 1];
+        if (s0 >= 0) v = v + a.Tall[s0];
+        if (s1 >= 0) v = v + a.Tall[s1];
+        a.N[e] = v;
+    }
+    else if (e < a.s_entries + a.ns)
+    {
+        const int q = e - a.s_entries;
+        double v = 0.0;
+        const int s0 = a.gsrc[2 * q], s1 = a.gsrc[2 * q + 1];
+        if (s0 >= 0) v = v + a.wzall[s0];
+        if (s1 >= 0) v = v + a.wzall[s1];
+        a.g0[q] = v;
+    }
 }
 
 // phase 3 of both solvers: the solution as float (Eigen::VectorXf m_OptimizedMesh), inlier flags, offsets (FrameTracker.cpp:276-320);
@@ -542,16 +633,31 @@ void k_mesh_backsolve(MeshArgs a)
 {
     LVK_TRACKER_PRIORITY();
     __shared__ BackShared s;
+    __shared__ unsigned s_last;
     const int tid = (int)threadIdx.x;
+    // nested dissection: either the separator system (a whole system whose solution goes to a.xs) or one block per workgroup (its
+    // separators' values given; the solutions are gathered in a.X and the last workgroup to finish runs phase 3 for the whole mesh)
+    const bool nd_block = a.blocks != nullptr, nd_sep = a.nd && !nd_block;
+    const int* xs_of = nullptr; const int* nat_of = nullptr;
+    if (nd_block)
+    {
+        const MeshBlockDev b = a.blocks[blockIdx.x];
+        a.n = b.n; a.hb = b.hb; a.n_elim = b.n_elim; a.wz = b.wz; a.Lc = b.Lc; xs_of = b.xs_of; nat_of = b.nat_of;
+    }
     const int n = a.n, hb = a.hb, ld = hb + 1;
     const int m = pair_count(a);
     const int flags = *a.flags;
     __syncthreads();
-    if (flags & 2) { if (tid == 0) *a.flags = 0; return; }              // cleared for the next frame
+    if (!a.nd && (flags & 2)) { if (tid == 0) *a.flags = 0; return; }   // cleared for the next frame
+    if (nd_sep && (flags & 0xf)) return;
+    const bool dead = nd_block && (flags & 0xf);                        // no solution this frame: only the last workgroup's report is left to do
 #ifdef LVK_MESH_TIMING
     const long long tm2 = wall_clock64();
 #endif
-    for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < n ? a.wz[i] : 0.0;
+    if (!dead)
+    {
+    if (nd_block) for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < a.n_elim ? a.wz[i] : (i < n ? a.xs[xs_of[i - a.n_elim]] : 0.0);
+    else for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < n ? a.wz[i] : 0.0;
     __syncthreads();
 
     // ---- phase 2: L^T x = w column by column: x(j) = w(j); w(k) = fma(-L(j, k), x(j), w(k)) for the rows k above j in the band.
@@ -652,6 +758,31 @@ void k_mesh_backsolve(MeshArgs a)
 #ifdef LVK_MESH_TIMING
     if (tid == 0) printf("mesh backsolve: %lld (100 MHz ticks)\n", wall_clock64() - tm2);
 #endif
+    }   // !dead
+
+    if (nd_sep) { for (int i = tid; i < n; i += MB_NT) a.xs[i] = s.w[i]; return; }
+    if (nd_block)
+    {
+        if (!dead) for (int i = tid; i < a.n_elim; i += MB_NT) a.X[nat_of[i]] = s.w[i];
+        __threadfence();                                                // this workgroup's part of X before its ticket
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(a.ticket, 1u) == (unsigned)a.nblocks - 1u ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();                                                // the other workgroups' parts after theirs
+        if (tid == 0) *a.ticket = 0;
+        if (dead)
+        {
+            if (tid == 0) { *a.out_status = (flags & 8) ? 1 : ((flags & 1) ? 2 : 3); *a.flags = 0; }
+            return;
+        }
+        for (int q = tid; q < a.ns; q += MB_NT) a.X[a.sep_nat[q]] = a.xs[q];
+        __syncthreads();
+        a.n = a.n_nat;
+        const double* X = a.X;
+        finish_solution(a, [&](int i) { return __builtin_nontemporal_load(X + i); }, tid, MB_NT, m);
+        return;
+    }
 
     // ---- phase 3: the solution as float, inlier flags, offsets (FrameTracker.cpp:276-320)
     finish_solution(a, [&](int i) { return s.w[i]; }, tid, MB_NT, m);
@@ -679,8 +810,12 @@ void k_mesh_solve_generic(MeshArgs a)
     const int flags = *a.flags;
     if (tid == 0) bad = 0;
     __syncthreads();
-    if (m < a.min_samples) { if (tid == 0) { *a.out_status = 1; *a.flags = 2; } return; }
-    if (flags & 1) { if (tid == 0) { *a.out_status = 2; *a.flags = 2; } return; }
+    if (a.nd) { if (flags & 0xf) return; }                          // (the separator system of a very tall mesh: see k_mesh_solve)
+    else
+    {
+        if (m < a.min_samples) { if (tid == 0) { *a.out_status = 1; *a.flags = 2; } return; }
+        if (flags & 1) { if (tid == 0) { *a.out_status = 2; *a.flags = 2; } return; }
+    }
     double* N = a.N; double* g = a.g0;
     for (int j = 0; j < n; j++)
     {
@@ -708,8 +843,8 @@ void k_mesh_solve_generic(MeshArgs a)
         }
         __syncthreads();
     }
-    if (bad) { if (tid == 0) { *a.out_status = 3; *a.flags = 2; } return; }
-    if (tid == 0) *a.flags = 0;
+    if (bad) { if (tid == 0) { if (a.nd) atomicOr(a.flags, 4); else { *a.out_status = 3; *a.flags = 2; } } return; }
+    if (tid == 0 && !a.nd) *a.flags = 0;
 }
 
 __global__ __launch_bounds__(MG_NT)
@@ -721,7 +856,8 @@ void k_mesh_backsolve_generic(MeshArgs a)
     const int m = pair_count(a);
     const int flags = *a.flags;
     __syncthreads();
-    if (flags & 2) { if (tid == 0) *a.flags = 0; return; }
+    if (!a.nd && (flags & 2)) { if (tid == 0) *a.flags = 0; return; }
+    if (a.nd && (flags & 0xf)) return;
     double* w = a.wz;
     // L^T x = w column by column: x(j) = w(j); w(k) = fma(-L(j, k), x(j), w(k)) for the rows k above j in the band
     for (int j = n - 1; j >= 1; j--)
@@ -731,6 +867,7 @@ void k_mesh_backsolve_generic(MeshArgs a)
         for (int k = first + tid; k < j; k += MG_NT) w[k] = __builtin_fma(-a.Lc[(size_t)k * ld + (j - k)], xj, w[k]);
         __syncthreads();
     }
+    if (a.nd) { for (int i = tid; i < n; i += MG_NT) a.xs[i] = w[i]; return; }      // the separator system's solution
     finish_solution(a, [&](int i) { return w[i]; }, tid, MG_NT, m);
 }
 
@@ -746,12 +883,24 @@ struct lvk_mesh_solver_dev
     float* d_mesh = nullptr; double* d_Lc = nullptr; double* d_N = nullptr;      // d_N: band then right-hand side
     int* d_flags = nullptr;
     bool generic = false;                   // k_mesh_solve_generic / k_mesh_backsolve_generic (meshes outside the register-window solver's shapes)
+    // nested dissection (8 .. 16 columns, >= 9 rows): the blocks' band systems and the separator system, all built once per configuration
+    bool nd = false;
+    int nblocks = 0, ns = 0, hbs = 0, s_entries = 0;
+    bool sep_generic = false;
+    MeshBlockDev* d_blocks = nullptr;
+    double* d_nd = nullptr;                 // one allocation: per block N | g | wz | Lc | Rc | T, then the separator system S | gs | wzs | Lcs | xs, then X
+    int* d_ndi = nullptr;                   // one allocation: ndst | gdst | ssrc | gsrc | sep_nat | per block xs_of, nat_of
+    size_t off_Nall = 0, off_wzall = 0, off_Tall = 0, off_S = 0, off_gs = 0, off_wzs = 0, off_Lcs = 0, off_xs = 0, off_X = 0;
+    size_t ioff_ndst = 0, ioff_gdst = 0, ioff_ssrc = 0, ioff_gsrc = 0, ioff_sepnat = 0;
+    unsigned* d_ticket = nullptr;
 };
+
+static bool nd_applies(int cols, int rows) { return cols >= 8 && cols <= 16 && rows >= 9; }     // oracle S5' (the register-window kernels' column range)
 
 void lvk_mesh_solver_free(lvk_mesh_solver_dev* s)
 {
     if (!s) return;
-    void* dev[] = {s->d_stat, s->d_acc, s->d_mesh, s->d_Lc, s->d_N, s->d_flags};
+    void* dev[] = {s->d_stat, s->d_acc, s->d_mesh, s->d_Lc, s->d_N, s->d_flags, s->d_blocks, s->d_nd, s->d_ndi, s->d_ticket};
     for (void* p : dev) if (p) (void)hipFree(p);
     delete s;
 }
@@ -785,6 +934,142 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
     if ((e = hipMemset(s->d_Lc, 0, (band + MS_NT) * sizeof(double))) != hipSuccess) return fail(e);
     if ((e = hipMemset(s->d_acc, 0, (band + s->n) * sizeof(long long))) != hipSuccess) return fail(e);       // kept clear by k_mesh_prepare
     if ((e = hipMemset(s->d_flags, 0, sizeof(int))) != hipSuccess) return fail(e);                            // kept clear by k_mesh_solve
+    if (nd_applies(cols, rows) && !force_generic)
+    {
+        // ---- nested dissection (oracle S5'): separator rows 4, 8, ...; blocks = the rows between them, each followed by its separators
+        const int W = 2 * cols, n = s->n, hb = s->hb, ld = hb + 1;
+        std::vector<int> seps;
+        for (int r = 4; r <= rows - 1; r += 4) seps.push_back(r);
+        const int K = (int)seps.size();
+        struct Blk { std::vector<int> rows; int own; int n, hb, n_elim, ns; size_t N, g, wz, Lc, Rc, T; size_t ixs, inat; };
+        std::vector<Blk> blks;
+        for (int k = 0; k <= K; k++)
+        {
+            const int first = k == 0 ? 0 : seps[k - 1] + 1, last = k < K ? seps[k] - 1 : rows - 1;
+            if (first > last) continue;
+            Blk b{};
+            for (int r = first; r <= last; r++) b.rows.push_back(r);
+            b.own = (int)b.rows.size();
+            if (k > 0) b.rows.push_back(seps[k - 1]);
+            if (k < K) b.rows.push_back(seps[k]);
+            b.n = (int)b.rows.size() * W; b.n_elim = b.own * W; b.ns = b.n - b.n_elim; b.hb = std::min(b.n - 1, hb);
+            blks.push_back(b);
+        }
+        s->nblocks = (int)blks.size(); s->ns = K * W; s->hbs = std::min(s->ns - 1, 2 * W - 1);
+        bool blocks_fit = true;
+        for (const Blk& b : blks)
+            blocks_fit = blocks_fit && b.hb <= MS_HB_MAX && b.n <= MS_N_MAX && b.n >= 4 && band_groups(b.hb, (b.hb + MS_TB) / MS_TB - 1) >= 1;
+        if (!blocks_fit) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_ARG, "mesh solver: a block of the nested dissection does not fit the register-window kernels"); }
+        s->sep_generic = !(s->hbs <= MS_HB_MAX && s->ns <= MS_N_MAX && s->ns >= 4 && band_groups(s->hbs, (s->hbs + MS_TB) / MS_TB - 1) >= 1);
+        if (s->sep_generic && s->hbs > MG_HB_MAX) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_ARG, "mesh solver: separator system too wide"); }
+        // layout of the binary64 arena
+        size_t at = 0;
+        auto take = [&](size_t count) { const size_t o = at; at += (count + 1) & ~(size_t)1; return o; };
+        s->off_Nall = at;
+        for (Blk& b : blks) b.N = take((size_t)b.n * (b.hb + 1));
+        for (Blk& b : blks) b.g = take(b.n);
+        s->off_wzall = at;
+        for (Blk& b : blks) b.wz = take(b.n);
+        for (Blk& b : blks) b.Lc = take((size_t)b.n * (b.hb + 1) + MS_NT);
+        for (Blk& b : blks) b.Rc = take((size_t)b.n * (b.hb + 1) + MS_NT);
+        s->off_Tall = at;
+        for (Blk& b : blks) b.T = take((size_t)b.ns * b.ns);
+        const size_t lds = s->hbs + 1;
+        s->off_S = take((size_t)s->ns * lds); s->off_gs = take(s->ns); s->off_wzs = take(s->ns); s->off_Lcs = take((size_t)s->ns * lds + MS_NT);
+        s->off_xs = take(s->ns); s->off_X = take(n);
+        const size_t doubles = at;
+        // index tables
+        std::vector<int> tab;
+        auto itake = [&](size_t count) { const size_t o = tab.size(); tab.resize(o + count, -1); return o; };
+        s->ioff_ndst = itake((size_t)n * ld); s->ioff_gdst = itake(n);
+        s->s_entries = s->ns * (int)lds;
+        s->ioff_ssrc = itake(2 * (size_t)s->s_entries); s->ioff_gsrc = itake(2 * (size_t)s->ns); s->ioff_sepnat = itake(s->ns);
+        for (Blk& b : blks) { b.ixs = itake(std::max(b.ns, 1)); b.inat = itake(b.n_elim); }
+        // where every vertex row sits: (block, slot) of its owning block (separators: the block ABOVE), and the slots it has as a separator
+        auto sep_index = [&](int row) { for (int k = 0; k < K; k++) if (seps[k] == row) return k; return -1; };
+        auto slot_of = [&](const Blk& b, int row) { for (size_t q = 0; q < b.rows.size(); q++) if (b.rows[q] == row) return (int)q; return -1; };
+        auto owner_of = [&](int row) {                                    // block whose band holds the row's own entries and right-hand side
+            for (int bi = 0; bi < (int)blks.size(); bi++)
+            {
+                const int q = slot_of(blks[bi], row);
+                if (q < 0) continue;
+                if (q < blks[bi].own || row > blks[bi].rows[0]) return bi;    // an own row, or the separator BELOW the block
+            }
+            return -1;
+        };
+        const std::vector<double>& stat = host.static_band();
+        for (int k = 0; k < n; k++)
+            for (int t = 0; t <= hb && k + t < n; t++)
+            {
+                const int i = k + t, ri = i / W, rk = k / W;
+                // the block that holds both: an own row decides; two rows of the same separator go to its owner
+                int bi = -1;
+                for (int cand = 0; cand < (int)blks.size() && bi < 0; cand++)
+                {
+                    const int qi = slot_of(blks[cand], ri), qk = slot_of(blks[cand], rk);
+                    if (qi < 0 || qk < 0) continue;
+                    const bool own_i = qi < blks[cand].own, own_k = qk < blks[cand].own;
+                    if (own_i || own_k) bi = cand;
+                    else if (ri == rk && owner_of(ri) == cand) bi = cand;
+                }
+                const size_t src = (size_t)k * ld + t;
+                if (bi < 0)
+                {
+                    if (stat[src] != 0.0) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_RUNTIME, "mesh solver: a constraint couples two blocks of the nested dissection"); }
+                    continue;
+                }
+                const Blk& b = blks[bi];
+                const int pi = slot_of(b, ri) * W + i % W, pk = slot_of(b, rk) * W + k % W;
+                const int hi = std::max(pi, pk), lo = std::min(pi, pk);
+                if (hi - lo > b.hb)
+                {
+                    if (stat[src] != 0.0) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_RUNTIME, "mesh solver: a constraint leaves a block's band"); }
+                    continue;
+                }
+                tab[s->ioff_ndst + src] = (int)(b.N - s->off_Nall + (size_t)lo * (b.hb + 1) + (hi - lo));
+            }
+        for (int i = 0; i < n; i++)
+        {
+            const int bi = owner_of(i / W);
+            tab[s->ioff_gdst + i] = (int)(blks[bi].g - s->off_Nall + (size_t)slot_of(blks[bi], i / W) * W + i % W);      // (g follows N in the arena)
+        }
+        for (int bi = 0; bi < (int)blks.size(); bi++)
+        {
+            const Blk& b = blks[bi];
+            for (int p = 0; p < b.n_elim; p++) tab[b.inat + p] = b.rows[p / W] * W + p % W;
+            for (int q = 0; q < b.ns; q++) tab[b.ixs + q] = sep_index(b.rows[(b.n_elim + q) / W]) * W + q % W;
+            // this block's trailing window into the separator system (blocks in ascending order fill source 0, then source 1)
+            for (int li = 0; li < b.ns; li++)
+            {
+                const int si = tab[b.ixs + li];
+                int* gs = &tab[s->ioff_gsrc + 2 * (size_t)si];
+                gs[gs[0] < 0 ? 0 : 1] = (int)(b.wz - s->off_wzall + b.n_elim + li);
+                for (int lk = 0; lk <= li; lk++)
+                {
+                    const int sk = tab[b.ixs + lk];                         // (the separator above comes first: sk <= si)
+                    int* ss = &tab[s->ioff_ssrc + 2 * ((size_t)sk * lds + (si - sk))];
+                    ss[ss[0] < 0 ? 0 : 1] = (int)(b.T - s->off_Tall + (size_t)li * b.ns + lk);
+                }
+            }
+        }
+        for (int k = 0; k < K; k++) for (int c = 0; c < W; c++) tab[s->ioff_sepnat + (size_t)k * W + c] = seps[k] * W + c;
+        if ((e = hipMalloc((void**)&s->d_nd, doubles * sizeof(double))) != hipSuccess) return fail(e);
+        if ((e = hipMemset(s->d_nd, 0, doubles * sizeof(double))) != hipSuccess) return fail(e);       // structural zeros of the blocks' bands, columns of L beyond n_elim
+        if ((e = hipMalloc((void**)&s->d_ndi, tab.size() * sizeof(int))) != hipSuccess) return fail(e);
+        if ((e = hipMemcpy(s->d_ndi, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        std::vector<MeshBlockDev> hb_(blks.size());
+        for (size_t bi = 0; bi < blks.size(); bi++)
+        {
+            const Blk& b = blks[bi];
+            hb_[bi] = MeshBlockDev{b.n, b.hb, b.n_elim, (b.hb + MS_TB) / MS_TB, s->d_nd + b.N, s->d_nd + b.g, s->d_nd + b.wz, s->d_nd + b.Lc, s->d_nd + b.Rc,
+                                   b.ns > 0 ? s->d_nd + b.T : nullptr, s->d_ndi + b.ixs, s->d_ndi + b.inat};
+        }
+        if ((e = hipMalloc((void**)&s->d_blocks, hb_.size() * sizeof(MeshBlockDev))) != hipSuccess) return fail(e);
+        if ((e = hipMemcpy(s->d_blocks, hb_.data(), hb_.size() * sizeof(MeshBlockDev), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        if ((e = hipMalloc((void**)&s->d_ticket, sizeof(unsigned))) != hipSuccess) return fail(e);
+        if ((e = hipMemset(s->d_ticket, 0, sizeof(unsigned))) != hipSuccess) return fail(e);
+        s->nd = true; s->generic = false;
+    }
     *out = s;
     return LVK_HIP_OK;
 }
@@ -814,7 +1099,40 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
     a.fidx = (int*)d_scratch; a.fw = (float*)d_scratch + 4 * (size_t)std::max(n_pts, 1); a.p1 = d_p1; a.p2 = d_p2; a.count = d_count; a.n_pts = n_pts; a.min_samples = min_samples;
     a.region_w = region_w; a.region_h = region_h; a.ts_gen = s->ts_gen; a.ts_now = temporal_now; a.threshold = threshold;
     a.flags = s->d_flags; a.out_offsets = h_offsets; a.out_mask = h_mask; a.out_status = h_status;
+    a.nd = 0; a.nblocks = 0; a.n_elim = s->n; a.n_nat = s->n; a.blocks = nullptr; a.Rc = nullptr; a.T = nullptr; a.ndst = nullptr; a.gdst = nullptr;
+    a.ssrc = nullptr; a.gsrc = nullptr; a.s_entries = 0; a.ns = 0; a.Tall = nullptr; a.wzall = nullptr; a.xs = nullptr; a.X = nullptr; a.sep_nat = nullptr; a.ticket = nullptr;
     if (n_pts > 0) hipLaunchKernelGGL(k_mesh_assemble, dim3((unsigned)((n_pts + 127) / 128)), dim3(128), 0, stream, a);
+    if (s->nd)
+    {
+        // nested dissection: scatter into the blocks' bands | the blocks side by side | separator system | the blocks' backward substitutions
+        // side by side, the last one to finish runs phase 3
+        MeshArgs p = a;
+        p.nd = 1; p.ndst = s->d_ndi + s->ioff_ndst; p.gdst = s->d_ndi + s->ioff_gdst; p.N = s->d_nd + s->off_Nall; p.g0 = s->d_nd + s->off_Nall;
+        hipLaunchKernelGGL(k_mesh_prepare, dim3(216), dim3(256), 0, stream, p);
+        MeshArgs f = a;
+        f.nd = 1; f.blocks = s->d_blocks; f.nblocks = s->nblocks; f.xs = s->d_nd + s->off_xs; f.X = s->d_nd + s->off_X; f.sep_nat = s->d_ndi + s->ioff_sepnat;
+        f.ns = s->ns; f.ticket = s->d_ticket;
+        hipLaunchKernelGGL(k_mesh_solve, dim3((unsigned)s->nblocks), dim3(MS_NT), 0, stream, f);
+        MeshArgs q = a;
+        q.nd = 1; q.n = s->ns; q.hb = s->hbs; q.nbands = (s->hbs + MS_TB) / MS_TB; q.n_elim = s->ns;
+        q.N = s->d_nd + s->off_S; q.g0 = s->d_nd + s->off_gs; q.wz = s->d_nd + s->off_wzs; q.Lc = s->d_nd + s->off_Lcs; q.xs = s->d_nd + s->off_xs;
+        q.ssrc = s->d_ndi + s->ioff_ssrc; q.gsrc = s->d_ndi + s->ioff_gsrc; q.s_entries = s->s_entries; q.ns = s->ns;
+        q.Tall = s->d_nd + s->off_Tall; q.wzall = s->d_nd + s->off_wzall;
+        hipLaunchKernelGGL(k_nd_sep_assemble, dim3((unsigned)((s->s_entries + s->ns + 255) / 256)), dim3(256), 0, stream, q);
+        if (s->sep_generic)
+        {
+            hipLaunchKernelGGL(k_mesh_solve_generic, dim3(1), dim3(MG_NT), 0, stream, q);
+            hipLaunchKernelGGL(k_mesh_backsolve_generic, dim3(1), dim3(MG_NT), 0, stream, q);
+        }
+        else
+        {
+            hipLaunchKernelGGL(k_mesh_solve, dim3(1), dim3(MS_NT), 0, stream, q);
+            hipLaunchKernelGGL(k_mesh_backsolve, dim3(1), dim3(MB_NT), 0, stream, q);
+        }
+        hipLaunchKernelGGL(k_mesh_backsolve, dim3((unsigned)s->nblocks), dim3(MB_NT), 0, stream, f);
+        LVK_HIP_CHECK(ctx, hipGetLastError());
+        return LVK_HIP_OK;
+    }
     hipLaunchKernelGGL(k_mesh_prepare, dim3(216), dim3(256), 0, stream, a);
     if (s->generic)
     {

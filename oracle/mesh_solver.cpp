@@ -17,6 +17,17 @@
 //       multiply-subtract -- half of Cholesky's sqrt + division, which is what bounds a GPU implementation), forward substitution
 //       carried along, then D and the column-oriented backward substitution; each entry updated in pivot order, every update ONE
 //       fused multiply-subtract fma(-l, c, x) (half the dependent instructions of a product and a difference; binary64);
+//   S5' (round 3) NESTED DISSECTION for meshes of 8..16 columns and >= 9 rows (the OBS vector-field preset's 16 x 16): the only constraints
+//       that couple vertex rows more than one row apart are the 3 x 3 quads, which start at rows 0, 4, 8, ... and end three rows further
+//       down (FrameTracker.cpp:410-426) -- no constraint couples a row above row 4k with a row below it.  So the rows 4, 8, 12, ... are
+//       SEPARATORS (32 unknowns each for 16 columns); the blocks between them -- rows 0..3, 5..7, 9..11, 13..15 -- are independent once the
+//       separators are held back: each block is eliminated on its own (S5's right-looking band L D L^T in the order [block rows, separator
+//       above, separator below], stopped after the block's own pivots; every coupling stays within the same 3-row band), the trailing
+//       separator x separator windows of the blocks are ADDED (ascending block order; the original separator entries and right-hand side go
+//       into the block ABOVE the separator, the others start from +0) into the separator system (block tridiagonal, half bandwidth
+//       4 cols - 1), which is factorised and solved with S5 itself; then every block substitutes backwards with its separators' values
+//       given.  Same minimiser (tests/test_mesh_lstsq.py: 1e-6 of numpy's lstsq); the dependent pivot chain that bounds the GPU
+//       implementation shrinks from 512 to 128 + 96 -- four workgroups instead of one for most of it.
 //   S6  the solution is stored as float (Eigen::VectorXf m_OptimizedMesh); inlier test and offsets as the reference.
 #include "lvk_oracle.h"
 
@@ -29,7 +40,146 @@ namespace {
 
 struct Triplet { int row, col; float val; };
 
+// S5: root-free banded factorisation M = L D L^T (L unit lower triangular) of the n x n band matrix M (row layout: entry (i, j),
+// i - hb <= j <= i, at M[i * (hb + 1) + (i - j)]), right-looking, pivots taken as reciprocals, with the forward substitution carried along,
+// stopped after the first n_elim pivots.  Column j:  r_j = 1 / M(j, j);  L(i, j) = M(i, j) * r_j;  M(i, k) = fma(-L(i, j), M(k, j), M(i, k))
+// for j < k <= i in the band (M(k, j): the UNSCALED entry);  g(i) = fma(-L(i, j), g(j), g(i)).  Every entry receives its updates in pivot
+// order.  On return the columns j < n_elim hold L, rcp their reciprocal pivots, and the rows / entries >= n_elim what the eliminated pivots
+// left of them (the Schur complement and the reduced right-hand side).
+bool eliminate(int n, int hb, int n_elim, std::vector<double>& M, std::vector<double>& g, std::vector<double>& rcp)
+{
+    auto B = [&](int i, int j) -> double& { return M[(size_t)i * (hb + 1) + (i - j)]; };
+    std::vector<double> colraw((size_t)hb + 1);
+    rcp.assign((size_t)n, 0.0);
+    for (int j = 0; j < n_elim; j++)
+    {
+        const double d = B(j, j);
+        if (!(d > 0.0)) return false;
+        const double r = 1.0 / d;
+        rcp[j] = r;
+        const int last = std::min(n - 1, j + hb);
+        for (int i = j + 1; i <= last; i++) { colraw[i - j] = B(i, j); B(i, j) = B(i, j) * r; }      // keep the unscaled column for the updates
+        for (int i = j + 1; i <= last; i++)
+        {
+            const double lij = B(i, j);
+            g[i] = std::fma(-lij, g[j], g[i]);
+            for (int k = j + 1; k <= i; k++) B(i, k) = std::fma(-lij, colraw[k - j], B(i, k));
+        }
+    }
+    return true;
+}
+
+// L^T x = w column by column over the rows n - 1 .. 0: x(j) = w(j), w(k) = fma(-L(j, k), x(j), w(k)) for the rows k of the band above j
+// that were eliminated (k < n_elim; rows >= n_elim carry given values)
+void back_substitute(int n, int hb, int n_elim, const std::vector<double>& M, std::vector<double>& w)
+{
+    for (int j = n - 1; j >= 0; j--)
+    {
+        const int first = std::max(0, j - hb), lastk = std::min(j, n_elim);
+        for (int k = first; k < lastk; k++) w[k] = std::fma(-M[(size_t)j * (hb + 1) + (j - k)], w[j], w[k]);
+    }
+}
+
+bool solve_band(int n, int hb, std::vector<double>& N, std::vector<double>& g)
+{
+    std::vector<double> rcp;
+    if (!eliminate(n, hb, n, N, g, rcp)) return false;
+    for (int j = 0; j < n; j++) g[j] = g[j] * rcp[j];          // D w = z
+    back_substitute(n, hb, n, N, g);
+    return true;
+}
+
+// ---- S5': nested dissection (see the header)
+bool nd_applies(int cols, int rows) { return cols >= 8 && cols <= 16 && rows >= 9; }
+
+struct NdBlock { std::vector<int> rows; int own_rows; };          // vertex rows in elimination order: the block's own rows, then its separators
+
+std::vector<NdBlock> nd_blocks(int rows, std::vector<int>& seps)
+{
+    seps.clear();
+    for (int r = 4; r <= rows - 1; r += 4) seps.push_back(r);
+    std::vector<NdBlock> out;
+    for (size_t k = 0; k <= seps.size(); k++)
+    {
+        const int first = k == 0 ? 0 : seps[k - 1] + 1, last = k < seps.size() ? seps[k] - 1 : rows - 1;
+        if (first > last) continue;                                 // (the last row is a separator: nothing below it)
+        NdBlock b;
+        for (int r = first; r <= last; r++) b.rows.push_back(r);
+        b.own_rows = (int)b.rows.size();
+        if (k > 0) b.rows.push_back(seps[k - 1]);                   // separator above
+        if (k < seps.size()) b.rows.push_back(seps[k]);             // separator below
+        out.push_back(b);
+    }
+    return out;
+}
+
+// N: the assembled system in natural order (row layout, half bandwidth hb), g: right-hand side in, solution out
+bool solve_nd(int cols, int rows, int hb, const std::vector<double>& N, std::vector<double>& g)
+{
+    const int W = 2 * cols;                                         // unknowns per vertex row
+    std::vector<int> seps;
+    const std::vector<NdBlock> blocks = nd_blocks(rows, seps);
+    const int K = (int)seps.size(), ns = K * W, hbs = std::min(ns - 1, 2 * W - 1);
+    auto nat = [&](int i, int j) -> double {                        // entry (i, j) of the natural matrix, 0 outside its band
+        if (i < j) std::swap(i, j);
+        return i - j <= hb ? N[(size_t)i * (hb + 1) + (i - j)] : 0.0;
+    };
+    auto sep_index = [&](int row) { for (int k = 0; k < K; k++) if (seps[k] == row) return k; return -1; };
+    std::vector<double> S((size_t)ns * (hbs + 1), 0.0), gs((size_t)ns, 0.0);
+    struct Done { int n, hbb, n_elim; std::vector<double> M, w; };
+    std::vector<Done> done(blocks.size());
+    for (size_t b = 0; b < blocks.size(); b++)
+    {
+        const NdBlock& blk = blocks[b];
+        const int nb = (int)blk.rows.size() * W, n_elim = blk.own_rows * W, hbb = std::min(nb - 1, hb);
+        Done& d = done[b];
+        d.n = nb; d.hbb = hbb; d.n_elim = n_elim;
+        d.M.assign((size_t)nb * (hbb + 1), 0.0); d.w.assign((size_t)nb, 0.0);
+        auto natural_of = [&](int pos) { return blk.rows[pos / W] * W + pos % W; };
+        // a separator's own entries and right-hand side belong to the block ABOVE it (its "separator below" slot)
+        auto owned = [&](int pos) { const int slot = pos / W; return slot < blk.own_rows || (blk.rows[slot] > blk.rows[0]); };
+        for (int i = 0; i < nb; i++)
+        {
+            for (int j = std::max(0, i - hbb); j <= i; j++)
+            {
+                const bool sep_sep = i >= n_elim && j >= n_elim;
+                d.M[(size_t)i * (hbb + 1) + (i - j)] = (sep_sep && !(owned(i) && owned(j))) ? 0.0 : nat(natural_of(i), natural_of(j));
+            }
+            d.w[i] = (i >= n_elim && !owned(i)) ? 0.0 : g[natural_of(i)];
+            // (the order keeps every coupling inside the band: nothing of the system may fall outside it)
+            for (int j = 0; j < i - hbb; j++) if (nat(natural_of(i), natural_of(j)) != 0.0) return false;
+        }
+        std::vector<double> rcp;
+        if (!eliminate(nb, hbb, n_elim, d.M, d.w, rcp)) return false;
+        for (int j = 0; j < n_elim; j++) d.w[j] = d.w[j] * rcp[j];
+        // the trailing window into the separator system, ascending block order
+        for (int i = n_elim; i < nb; i++)
+        {
+            const int si = sep_index(blk.rows[i / W]) * W + i % W;
+            gs[si] = gs[si] + d.w[i];
+            for (int j = n_elim; j <= i; j++)
+            {
+                const int sj = sep_index(blk.rows[j / W]) * W + j % W;
+                const int hi = std::max(si, sj), lo = std::min(si, sj);
+                S[(size_t)hi * (hbs + 1) + (hi - lo)] = S[(size_t)hi * (hbs + 1) + (hi - lo)] + d.M[(size_t)i * (hbb + 1) + (i - j)];
+            }
+        }
+    }
+    if (!solve_band(ns, hbs, S, gs)) return false;
+    for (size_t b = 0; b < blocks.size(); b++)
+    {
+        const NdBlock& blk = blocks[b];
+        Done& d = done[b];
+        for (int i = d.n_elim; i < d.n; i++) d.w[i] = gs[sep_index(blk.rows[i / W]) * W + i % W];
+        back_substitute(d.n, d.hbb, d.n_elim, d.M, d.w);
+        for (int i = 0; i < d.n_elim; i++) g[blk.rows[i / W] * W + i % W] = d.w[i];
+    }
+    for (int k = 0; k < K; k++) for (int c = 0; c < W; c++) g[seps[k] * W + c] = gs[k * W + c];
+    return true;
+}
+
 } // namespace
+
 
 struct lvko_mesh_solver
 {
@@ -162,33 +312,8 @@ int lvko_mesh_solver_solve(lvko_mesh_solver* s, const float* tracked, const floa
     for (size_t k = 0; k < N.size(); k++) N[k] = N[k] + (double)Nq[k] / Q;
     for (int i = 0; i < n; i++) { g[i] = g[i] + (double)gq[i] / Q; N[(size_t)i * (hb + 1)] = N[(size_t)i * (hb + 1)] + 1e-6; }
 
-    // S5: root-free banded factorisation N = L D L^T (L unit lower triangular), right-looking, pivots taken as reciprocals, with the
-    // forward substitution carried along.  Column j:  r_j = 1 / N(j, j);  L(i, j) = N(i, j) * r_j;  N(i, k) = fma(-L(i, j), N(k, j), N(i, k)) for
-    // j < k <= i in the band (N(k, j): the UNSCALED entry);  g(i) -= L(i, j) * g(j).  Every entry receives its updates in pivot order.
-    auto B = [&](int i, int j) -> double& { return N[(size_t)i * (hb + 1) + (i - j)]; };
-    std::vector<double> rcp((size_t)n), colraw((size_t)hb + 1);
-    for (int j = 0; j < n; j++)
-    {
-        const double d = B(j, j);
-        if (!(d > 0.0)) return -2;
-        const double r = 1.0 / d;
-        rcp[j] = r;
-        const int last = std::min(n - 1, j + hb);
-        for (int i = j + 1; i <= last; i++) { colraw[i - j] = B(i, j); B(i, j) = B(i, j) * r; }      // keep the unscaled column for the updates
-        for (int i = j + 1; i <= last; i++)
-        {
-            const double lij = B(i, j);
-            g[i] = std::fma(-lij, g[j], g[i]);
-            for (int k = j + 1; k <= i; k++) B(i, k) = std::fma(-lij, colraw[k - j], B(i, k));
-        }
-    }
-    // D w = z, then L^T x = w column by column: x(j) = w(j), w(k) -= L(j, k) * x(j) for the rows k of the band above j
-    for (int j = 0; j < n; j++) g[j] = g[j] * rcp[j];
-    for (int j = n - 1; j >= 0; j--)
-    {
-        const int first = std::max(0, j - hb);
-        for (int k = first; k < j; k++) g[k] = std::fma(-B(j, k), g[j], g[k]);
-    }
+    if (nd_applies(s->cols, s->rows)) { if (!solve_nd(s->cols, s->rows, hb, N, g)) return -2; }
+    else if (!solve_band(n, hb, N, g)) return -2;
     for (int i = 0; i < n; i++) s->mesh[i] = (float)g[i];
 
     // inlier status (:279-310): L1 reprojection error of each feature through its quad

@@ -26,11 +26,16 @@ def _pairs(rng, n, region, frame, outliers=0.11):
                                          ((16, 64), (480, 1200)), ((4, 3), (320, 180)), ((9, 11), (300, 300)), ((13, 5), (480, 270)),
                                          # beyond the register-window kernels (Math/WarpMesh.cpp:34-41,79-90 allows any N x M): the generic kernels
                                          ((17, 17), (480, 270)), ((32, 32), (480, 270)), ((20, 6), (480, 270)), ((16, 70), (480, 1300)), ((40, 3), (640, 120)),
-                                         # ... and the generic kernels on the preset's own mesh (LVK_HIP_MESH_GENERIC): same bits as the fast ones
-                                         ((16, 16, "generic"), (480, 270)), ((2, 2, "generic"), (256, 256))])
+                                         # ... and the generic kernels on meshes the register-window kernels take too (LVK_HIP_MESH_GENERIC): same bits
+                                         ((16, 8, "generic"), (480, 270)), ((5, 7, "generic"), (320, 180)), ((2, 2, "generic"), (256, 256)),
+                                         # nested dissection (oracle S5': 8..16 columns, >= 9 rows -- (16, 16), (16, 9), (16, 64), (9, 11), (16, 70) above):
+                                         # a last row that is itself a separator, a one-row last block, narrow meshes, odd column counts
+                                         ((16, 13), (480, 270)), ((12, 10), (480, 270)), ((8, 9), (320, 180)), ((9, 14), (300, 300)), ((13, 21), (480, 800)),
+                                         ((16, 16, "wide"), (1920, 1080))])
 def test_mesh_solver_bit_exact_over_frames(ctx, oracle, mesh, region, monkeypatch):
     if len(mesh) == 3:
-        monkeypatch.setenv("LVK_HIP_MESH_GENERIC", "1")
+        if mesh[2] == "generic":
+            monkeypatch.setenv("LVK_HIP_MESH_GENERIC", "1")
         mesh = mesh[:2]
     cols, rows = mesh
     rng = np.random.default_rng(cols * 100 + rows)

@@ -118,6 +118,9 @@ def field_pairs(rng, n, region, frame, outliers=0.12):
     (16, 16, (480, 270), (480, 270), 1.0, 0.5),          # temporal weight changed after the constraints were generated (:229-230 vs :399-400)
     (9, 7, (320, 180), (320, 180), 2.0, 2.0),
     (17, 17, (480, 270), (480, 270), 1.0, 1.0),          # beyond the register-window device solver
+    (12, 10, (480, 270), (480, 270), 1.0, 1.0),          # nested dissection (oracle S5'): separators at rows 4 and 8, a one-row last block
+    (16, 9, (480, 270), (480, 270), 1.0, 1.0),           # ... the last row itself a separator
+    (8, 13, (320, 400), (320, 400), 1.0, 1.0),           # ... three separators, narrow mesh
 ])
 def test_oracle_mesh_is_the_least_squares_minimiser(oracle, cols, rows, region, gen_region, ts_gen, ts_now):
     rng = np.random.default_rng(cols * 31 + rows)
