@@ -109,6 +109,16 @@ struct MeshArgs
     float* out_offsets; uint8_t* out_mask; int* out_status;      // device-visible host memory
 };
 
+// wave-uniform copies (the fields of a block descriptor are read with vector loads: without this every pointer derived from them occupies
+// two VGPRs per lane instead of two SGPRs)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T* uniform(T* p)
+{
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int pair_count(const MeshArgs& a) { return a.count ? min(*a.count, a.n_pts) : a.n_pts; }
 
 // FrameTracker.cpp:233-262: the feature's cell, its barycentric weights, and its rows' contribution to N and g
@@ -212,6 +222,7 @@ struct FactorShared
     // two are spent: raw[0] is stored with zeros at x <= 3, raw[1] at x <= 2.  rinv: the reciprocal pivots.
     double raw[2][2][MS_LCOL_P], lcol[2][2][MS_LCOL_P];
     double rinv[2][2];
+    double rawhead[2][2][4];                // the first entries of the two raw pivot columns, which raw[] stores as zeros (nested dissection: the forward wavefront writes the raw columns out)
     double col[2][2][MS_COL_P];             // the two columns behind the interval's pivots as the window threads leave them (read by the chain one interval later)
     double w[MS_N_MAX + 128];               // right-hand side: g, then D^-1 L^-1 g, in place (+ slack: rows beyond n)
     double next[MS_BANDS + 1][MS_NEXT_BAND];    // phase 1: per band, the columns that enter its window when the current group is done (+ a spare slot)
@@ -277,18 +288,12 @@ __device__ __forceinline__ void chain_interval(const MeshArgs& a, FactorShared& 
     cc.b1 = readlane64(D0, 1); cc.b2 = readlane64(D0, 2);
     cc.bad = cc.bad || (c < a.n_elim && !(dc > 0.0)) || (c + 1 < a.n_elim && !(dd > 0.0));      // (a block's held-back separator pivots are formed one interval ahead and never used)
     const double rd = 1.0 / dd;
-    if (a.Rc && c < a.n_elim)
-    {
-        // the unscaled pivot columns: what a block's trailing separator window is rebuilt from after the early stop (k_mesh_solve's epilogue)
-        double* Rp = a.Rc + (size_t)c * (a.hb + 1);
-        if (lane <= a.hb) { Rp[lane] = C0; Rp[a.hb + 1 + lane] = D0; }
-        if (lane + 64 <= a.hb) { Rp[lane + 64] = C1; Rp[a.hb + 1 + lane + 64] = D1; }
-    }
     s.raw[PAR ^ 1][0][x0] = lane <= 3 ? 0.0 : C0; s.raw[PAR ^ 1][0][x0 + 80] = C1;
     s.lcol[PAR ^ 1][0][x0] = lc0; s.lcol[PAR ^ 1][0][x0 + 80] = lc1;
     s.raw[PAR ^ 1][1][x0] = lane <= 2 ? 0.0 : D0; s.raw[PAR ^ 1][1][x0 + 80] = D1;
     s.lcol[PAR ^ 1][1][x0] = lane == 0 ? 0.0 : D0 * rd; s.lcol[PAR ^ 1][1][x0 + 80] = D1 * rd;
     if (lane == 0) { s.rinv[PAR ^ 1][0] = rc; s.rinv[PAR ^ 1][1] = rd; }
+    if (lane <= 3) { s.rawhead[PAR ^ 1][0][lane] = C0; s.rawhead[PAR ^ 1][1][lane] = D0; }      // (the entries raw[] hides from the window threads: see forward_interval)
 }
 
 // The window.  An entry (column k, band offset t) is touched by pivot p iff (k - p) + t <= hb: a column at distance s from the pivot
@@ -356,6 +361,22 @@ __device__ __forceinline__ void forward_interval(const MeshArgs& a, FactorShared
     double* Lp = a.Lc + (size_t)p * (hb + 1);
     if (lane <= hb) { Lp[lane] = la0; Lp[hb + 1 + lane] = lb0; }
     if (lane + 64 <= hb) { Lp[lane + 64] = la1; Lp[hb + 1 + lane + 64] = lb1; }
+    if (a.Rc)
+    {
+        // a block of the nested dissection: the UNSCALED pivot columns too -- what its trailing separator window is rebuilt from after the
+        // early stop (k_nd_sep_assemble).  raw[] holds them with the chain's own entries zeroed; those come from rawhead[].
+        double r0 = s.raw[PAR][0][x0], q0 = s.raw[PAR][1][x0];
+        const double r1 = s.raw[PAR][0][x0 + 80], q1 = s.raw[PAR][1][x0 + 80];
+        if (lane <= 3) r0 = s.rawhead[PAR][0][lane];
+        if (lane <= 2) q0 = s.rawhead[PAR][1][lane];
+        // (addressed relative to the columns of L, behind an opaque scalar: the compiler otherwise keeps a second set of per-lane addresses
+        //  alive across the whole elimination loop, and this kernel has no register to spare -- they went to scratch)
+        long long rc_off = a.Rc - a.Lc;
+        asm volatile("" : "+s"(rc_off));
+        double* Rp = Lp + rc_off;
+        if (lane <= hb) { Rp[lane] = r0; Rp[hb + 1 + lane] = q0; }
+        if (lane + 64 <= hb) { Rp[lane + 64] = r1; Rp[hb + 1 + lane + 64] = q1; }
+    }
 }
 
 // the window's part of an interval: the pivots p = p0 + 2 H and p + 1 of the group at p0, pivot data of parity H
@@ -429,7 +450,8 @@ void k_mesh_solve(MeshArgs a)
     if (a.blocks)
     {
         const MeshBlockDev b = a.blocks[blockIdx.x];
-        a.n = b.n; a.hb = b.hb; a.nbands = b.nbands; a.n_elim = b.n_elim; a.N = b.N; a.g0 = b.g0; a.wz = b.wz; a.Lc = b.Lc; a.Rc = b.Rc; a.T = b.T;
+        a.n = uniform(b.n); a.hb = uniform(b.hb); a.nbands = uniform(b.nbands); a.n_elim = uniform(b.n_elim);
+        a.N = uniform(b.N); a.g0 = uniform(b.g0); a.wz = uniform(b.wz); a.Lc = uniform(b.Lc); a.Rc = uniform(b.Rc);
     }
     const int n = a.n, hb = a.hb;
     const int m = pair_count(a);
@@ -546,28 +568,22 @@ void k_mesh_solve(MeshArgs a)
     if (s.fail != 0) { if (tid == 0) { if (a.nd) atomicOr(a.flags, 4); else { *a.out_status = 3; *a.flags = 2; } } return; }
     for (int i = tid; i < n; i += MS_NT) a.wz[i] = s.w[i];
     if (!a.nd) { if (tid == 0) *a.flags = 0; return; }
-    if (!a.T) return;
-    // ---- a block of the nested dissection: what its pivots left of the separator x separator window.  The window itself lived in the
-    // registers of the update above and is gone; every entry is rebuilt from its original value and the columns of L and of the unscaled
-    // pivots in pivot order -- the same fused multiply-subtracts with the same operands the right-looking update applies to it.
-    __syncthreads();                                                    // the columns of L / the raw columns are in memory (this workgroup wrote them)
-    {
-        const int ns = n - n_elim, ld = hb + 1;
-        for (int e = tid; e < ns * ns; e += MS_NT)
-        {
-            const int li = e / ns, lk = e - li * ns;
-            if (lk > li) continue;
-            const int i = n_elim + li, k = n_elim + lk;
-            double acc = a.N[(size_t)k * ld + (i - k)];
-            for (int j = max(0, i - hb); j < n_elim; j++) acc = __builtin_fma(-a.Lc[(size_t)j * ld + (i - j)], a.Rc[(size_t)j * ld + (k - j)], acc);
-            a.T[(size_t)li * ns + lk] = acc;
-        }
-    }
 }
 
-// The separator system of the nested dissection: S = sum of the blocks' trailing windows, g = sum of their reduced right-hand sides, in
-// ascending block order starting from +0 (at most two blocks meet in an entry); band layout of k_mesh_solve.
-__global__ __launch_bounds__(256)
+// The separator system of the nested dissection: S = sum of what the blocks' pivots left of their separator x separator windows, g = sum of
+// their reduced right-hand sides, in ascending block order starting from +0 (at most two blocks meet in an entry); band layout of
+// k_mesh_solve.  A block's window lived in the registers of its factorisation and is gone: every entry is rebuilt here from its original
+// value and the columns of L and of the unscaled pivots in pivot order -- the same fused multiply-subtracts with the same operands the
+// right-looking update applied to it.  One thread per entry, many workgroups (a source: block << 16 | row << 8 | column of the window).
+__device__ __forceinline__ double nd_trailing_entry(const MeshBlockDev& b, int li, int lk)
+{
+    const int ld = b.hb + 1, i = b.n_elim + li, k = b.n_elim + lk;
+    double acc = b.N[(size_t)k * ld + (i - k)];
+    for (int j = max(0, i - b.hb); j < b.n_elim; j++) acc = __builtin_fma(-b.Lc[(size_t)j * ld + (i - j)], b.Rc[(size_t)j * ld + (k - j)], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(64)
 void k_nd_sep_assemble(MeshArgs a)
 {
     LVK_TRACKER_PRIORITY();
@@ -577,8 +593,8 @@ void k_nd_sep_assemble(MeshArgs a)
     {
         double v = 0.0;
         const int s0 = a.ssrc[2 * e], s1 = a.ssrc[2 * e + 1];
-        if (s0 >= 0) v = v + a.Tall[s0];
-        if (s1 >= 0) v = v + a.Tall[s1];
+        if (s0 >= 0) v = v + nd_trailing_entry(a.blocks[s0 >> 16], (s0 >> 8) & 0xff, s0 & 0xff);
+        if (s1 >= 0) v = v + nd_trailing_entry(a.blocks[s1 >> 16], (s1 >> 8) & 0xff, s1 & 0xff);
         a.N[e] = v;
     }
     else if (e < a.s_entries + a.ns)
@@ -590,6 +606,67 @@ void k_nd_sep_assemble(MeshArgs a)
         if (s1 >= 0) v = v + a.wzall[s1];
         a.g0[q] = v;
     }
+}
+
+// The same for meshes whose vertex rows are a multiple of 16 unknowns wide (8 and 16 columns: the OBS preset): one workgroup per 16 x 16 tile
+// of S.  All entries of a tile take their (at most two) contributions from the same two blocks, at consecutive rows / columns of those
+// blocks' windows -- so the 16 rows of L and the 16 raw rows the tile needs are staged in LDS once per source and every thread walks its
+// chain out of LDS (the one-thread-per-entry kernel above follows the two strided global loads of every step: 47 us for the preset's
+// 6 K entries; this one ~5 us).  Terms, operands and order are the same.
+constexpr int NT_TILE = 16, NT_JMAX = MS_HB_MAX + NT_TILE;
+__global__ __launch_bounds__(256)
+void k_nd_sep_assemble_tiled(MeshArgs a, int tiles_per_col)
+{
+    LVK_TRACKER_PRIORITY();
+    __shared__ double sL[NT_TILE][NT_JMAX + 1], sR[NT_TILE][NT_JMAX + 1];
+    if (*a.flags & 0xf) return;
+    const int tid = (int)threadIdx.x, lds = a.hb + 1;
+    const int ntiles = (a.ns / NT_TILE) * tiles_per_col;
+    if ((int)blockIdx.x >= ntiles)
+    {
+        for (int q = tid; q < a.ns; q += 256)
+        {
+            double v = 0.0;
+            const int s0 = a.gsrc[2 * q], s1 = a.gsrc[2 * q + 1];
+            if (s0 >= 0) v = v + a.wzall[s0];
+            if (s1 >= 0) v = v + a.wzall[s1];
+            a.g0[q] = v;
+        }
+        return;
+    }
+    // tile (column block tc, band block tt): separator entries (si, sk) = (16 (tc + tt) + r, 16 tc + c), r, c < 16
+    const int tc = (int)blockIdx.x / tiles_per_col, tt = (int)blockIdx.x - tc * tiles_per_col;
+    const int r = tid >> 4, c = tid & 15;
+    const int sk = NT_TILE * tc + c, si = NT_TILE * (tc + tt) + r;
+    const bool inside = si < a.ns && si - sk <= a.hb && si >= sk;
+    const int e0 = (NT_TILE * tc) * lds + NT_TILE * tt;                                  // the tile's first entry (r = c = 0) names its sources
+    double v = 0.0;
+    const bool tile_exists = NT_TILE * (tc + tt) < a.ns && NT_TILE * tt <= a.hb;
+    for (int src = 0; src < 2; src++)
+    {
+        const int code = tile_exists ? a.ssrc[2 * e0 + src] : -1;
+        if (code < 0) continue;                                                        // (uniform over the workgroup)
+        const MeshBlockDev b = a.blocks[code >> 16];
+        const int li0 = (code >> 8) & 0xff, lk0 = code & 0xff, ld = b.hb + 1;
+        const int jmin = max(0, b.n_elim + li0 - b.hb), J = b.n_elim - jmin;              // the pivots that reach the tile's first row
+        __syncthreads();
+        for (int x = tid; x < NT_TILE * J; x += 256)
+        {
+            const int jj = x >> 4, row = x & (NT_TILE - 1), j = jmin + jj;      // 16 lanes read 16 consecutive entries of one column: a 128-byte segment
+            const int oi = b.n_elim + li0 + row - j, ok = b.n_elim + lk0 + row - j;
+            sL[row][jj] = oi <= b.hb ? b.Lc[(size_t)j * ld + oi] : 0.0;
+            sR[row][jj] = ok <= b.hb ? b.Rc[(size_t)j * ld + ok] : 0.0;
+        }
+        __syncthreads();
+        if (inside)
+        {
+            const int i = b.n_elim + li0 + r, k = b.n_elim + lk0 + c;
+            double acc = b.N[(size_t)k * ld + (i - k)];
+            for (int jj = max(0, i - b.hb) - jmin; jj < J; jj++) acc = __builtin_fma(-sL[r][jj], sR[c][jj], acc);
+            v = v + acc;
+        }
+    }
+    if (inside) a.N[(size_t)sk * lds + (si - sk)] = v;
 }
 
 // phase 3 of both solvers: the solution as float (Eigen::VectorXf m_OptimizedMesh), inlier flags, offsets (FrameTracker.cpp:276-320);
@@ -642,7 +719,7 @@ void k_mesh_backsolve(MeshArgs a)
     if (nd_block)
     {
         const MeshBlockDev b = a.blocks[blockIdx.x];
-        a.n = b.n; a.hb = b.hb; a.n_elim = b.n_elim; a.wz = b.wz; a.Lc = b.Lc; xs_of = b.xs_of; nat_of = b.nat_of;
+        a.n = uniform(b.n); a.hb = uniform(b.hb); a.n_elim = uniform(b.n_elim); a.wz = uniform(b.wz); a.Lc = uniform(b.Lc); xs_of = uniform(b.xs_of); nat_of = uniform(b.nat_of);
     }
     const int n = a.n, hb = a.hb, ld = hb + 1;
     const int m = pair_count(a);
@@ -958,7 +1035,7 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
         s->nblocks = (int)blks.size(); s->ns = K * W; s->hbs = std::min(s->ns - 1, 2 * W - 1);
         bool blocks_fit = true;
         for (const Blk& b : blks)
-            blocks_fit = blocks_fit && b.hb <= MS_HB_MAX && b.n <= MS_N_MAX && b.n >= 4 && band_groups(b.hb, (b.hb + MS_TB) / MS_TB - 1) >= 1;
+            blocks_fit = blocks_fit && b.ns <= 255 && b.hb <= MS_HB_MAX && b.n <= MS_N_MAX && b.n >= 4 && band_groups(b.hb, (b.hb + MS_TB) / MS_TB - 1) >= 1;
         if (!blocks_fit) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_ARG, "mesh solver: a block of the nested dissection does not fit the register-window kernels"); }
         s->sep_generic = !(s->hbs <= MS_HB_MAX && s->ns <= MS_N_MAX && s->ns >= 4 && band_groups(s->hbs, (s->hbs + MS_TB) / MS_TB - 1) >= 1);
         if (s->sep_generic && s->hbs > MG_HB_MAX) { lvk_mesh_solver_free(s); return ctx->fail(LVK_HIP_ERR_ARG, "mesh solver: separator system too wide"); }
@@ -1048,7 +1125,7 @@ int lvk_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_w, fl
                 {
                     const int sk = tab[b.ixs + lk];                         // (the separator above comes first: sk <= si)
                     int* ss = &tab[s->ioff_ssrc + 2 * ((size_t)sk * lds + (si - sk))];
-                    ss[ss[0] < 0 ? 0 : 1] = (int)(b.T - s->off_Tall + (size_t)li * b.ns + lk);
+                    ss[ss[0] < 0 ? 0 : 1] = (bi << 16) | (li << 8) | lk;
                 }
             }
         }
@@ -1118,7 +1195,14 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
         q.N = s->d_nd + s->off_S; q.g0 = s->d_nd + s->off_gs; q.wz = s->d_nd + s->off_wzs; q.Lc = s->d_nd + s->off_Lcs; q.xs = s->d_nd + s->off_xs;
         q.ssrc = s->d_ndi + s->ioff_ssrc; q.gsrc = s->d_ndi + s->ioff_gsrc; q.s_entries = s->s_entries; q.ns = s->ns;
         q.Tall = s->d_nd + s->off_Tall; q.wzall = s->d_nd + s->off_wzall;
-        hipLaunchKernelGGL(k_nd_sep_assemble, dim3((unsigned)((s->s_entries + s->ns + 255) / 256)), dim3(256), 0, stream, q);
+        q.blocks = s->d_blocks;
+        if ((2 * s->cols) % NT_TILE == 0)
+        {
+            const int tiles_per_col = s->hbs / NT_TILE + 1;
+            hipLaunchKernelGGL(k_nd_sep_assemble_tiled, dim3((unsigned)((s->ns / NT_TILE) * tiles_per_col + 1)), dim3(256), 0, stream, q, tiles_per_col);
+        }
+        else hipLaunchKernelGGL(k_nd_sep_assemble, dim3((unsigned)((s->s_entries + s->ns + 63) / 64)), dim3(64), 0, stream, q);
+        q.blocks = nullptr;
         if (s->sep_generic)
         {
             hipLaunchKernelGGL(k_mesh_solve_generic, dim3(1), dim3(MG_NT), 0, stream, q);
