@@ -90,6 +90,7 @@ struct MeshArgs
     const int* ssrc; const int* gsrc; int s_entries, ns;      // k_nd_sep_assemble: separator band entry / unknown -> its (<= 2) sources in T / wz of the blocks
     const double* Tall; const double* wzall;
     double* xs;                             // separator solution (binary64)
+    const double* sep_wz; const double* sep_Lc; int sep_hb, fuse_sep;      // k_mesh_backsolve over the blocks: the separator system's backward substitution runs inside (fuse_sep)
     double* X;                              // solution in natural order (binary64), gathered from the blocks
     const int* sep_nat;                     // separator unknown -> natural index
     unsigned* ticket;                       // last-block-done counter of the block-parallel kernels
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(256)
 void k_nd_sep_assemble_tiled(MeshArgs a, int tiles_per_col)
 {
     LVK_TRACKER_PRIORITY();
-    __shared__ double sL[NT_TILE][NT_JMAX + 1], sR[NT_TILE][NT_JMAX + 1];
+    __shared__ double sL[NT_TILE][NT_JMAX + 2], sR[NT_TILE][NT_JMAX + 2];      // pitch 121 doubles: the 16 rows a wavefront reads at one step fall on 16 different bank pairs
     if (*a.flags & 0xf) return;
     const int tid = (int)threadIdx.x, lds = a.hb + 1;
     const int ntiles = (a.ns / NT_TILE) * tiles_per_col;
@@ -650,18 +651,33 @@ void k_nd_sep_assemble_tiled(MeshArgs a, int tiles_per_col)
         const int li0 = (code >> 8) & 0xff, lk0 = code & 0xff, ld = b.hb + 1;
         const int jmin = max(0, b.n_elim + li0 - b.hb), J = b.n_elim - jmin;              // the pivots that reach the tile's first row
         __syncthreads();
-        for (int x = tid; x < NT_TILE * J; x += 256)
+        // (all loads of the sweep in flight together: the columns were written by other compute units a moment ago and come from memory)
+        constexpr int SWEEPS = (NT_TILE * NT_JMAX + 255) / 256;
+        double vl[SWEEPS], vr[SWEEPS];
+#pragma unroll
+        for (int it = 0; it < SWEEPS; it++)
         {
-            const int jj = x >> 4, row = x & (NT_TILE - 1), j = jmin + jj;      // 16 lanes read 16 consecutive entries of one column: a 128-byte segment
+            const int x = tid + 256 * it, jj = x >> 4, row = x & (NT_TILE - 1), j = jmin + jj;      // 16 lanes read 16 consecutive entries of one column: a 128-byte segment
             const int oi = b.n_elim + li0 + row - j, ok = b.n_elim + lk0 + row - j;
-            sL[row][jj] = oi <= b.hb ? b.Lc[(size_t)j * ld + oi] : 0.0;
-            sR[row][jj] = ok <= b.hb ? b.Rc[(size_t)j * ld + ok] : 0.0;
+            const bool live = x < NT_TILE * J;
+            vl[it] = b.Lc[live && oi <= b.hb ? (size_t)j * ld + oi : 0];
+            vr[it] = b.Rc[live && ok <= b.hb ? (size_t)j * ld + ok : 0];
+            if (!(live && oi <= b.hb)) vl[it] = 0.0;
+            if (!(live && ok <= b.hb)) vr[it] = 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < SWEEPS; it++)
+        {
+            const int x = tid + 256 * it, jj = x >> 4, row = x & (NT_TILE - 1);
+            if (x < NT_TILE * J) { sL[row][jj] = vl[it]; sR[row][jj] = vr[it]; }
         }
         __syncthreads();
         if (inside)
         {
             const int i = b.n_elim + li0 + r, k = b.n_elim + lk0 + c;
             double acc = b.N[(size_t)k * ld + (i - k)];
+            // (operands of the next steps are fetched while the dependent chain of fused multiply-subtracts advances)
+#pragma unroll 8
             for (int jj = max(0, i - b.hb) - jmin; jj < J; jj++) acc = __builtin_fma(-sL[r][jj], sR[c][jj], acc);
             v = v + acc;
         }
@@ -703,6 +719,7 @@ struct BackShared
 {
     double w[MS_N_MAX + 128];               // D^-1 L^-1 g, then the solution, in place
     double lt[2][MS_CHUNK][MS_RPITCH];      // rows of L as rings, staged round by round
+    double xs[MS_N_MAX];                    // nested dissection: the separator system's solution (every block substitutes it backwards itself)
 };
 
 __global__ __launch_bounds__(MB_NT)
@@ -721,7 +738,7 @@ void k_mesh_backsolve(MeshArgs a)
         const MeshBlockDev b = a.blocks[blockIdx.x];
         a.n = uniform(b.n); a.hb = uniform(b.hb); a.n_elim = uniform(b.n_elim); a.wz = uniform(b.wz); a.Lc = uniform(b.Lc); xs_of = uniform(b.xs_of); nat_of = uniform(b.nat_of);
     }
-    const int n = a.n, hb = a.hb, ld = hb + 1;
+    const int n = a.n, hb = a.hb;
     const int m = pair_count(a);
     const int flags = *a.flags;
     __syncthreads();
@@ -733,7 +750,8 @@ void k_mesh_backsolve(MeshArgs a)
 #endif
     if (!dead)
     {
-    if (nd_block) for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < a.n_elim ? a.wz[i] : (i < n ? a.xs[xs_of[i - a.n_elim]] : 0.0);
+    if (nd_block && a.fuse_sep) { }                                  // (filled below, behind the separator system)
+    else if (nd_block) for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < a.n_elim ? a.wz[i] : (i < n ? a.xs[xs_of[i - a.n_elim]] : 0.0);
     else for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < n ? a.wz[i] : 0.0;
     __syncthreads();
 
@@ -745,7 +763,8 @@ void k_mesh_backsolve(MeshArgs a)
     // x(j), three LDS reads, three fused multiply-subtracts (an earlier version looked the band offsets up per lane: 25 instructions
     // per row, 77 us per solve; the wavefront's instruction count IS the time of this phase).  The rows run to the next multiple of 16
     // above n: the extra rows are zeros and change nothing, and every round and every block boundary is aligned.
-    {
+    auto phase2 = [&](const double* Lcp, const int n, const int hb) {
+        const int ld = hb + 1;
         const int n16 = (n + MS_CHUNK - 1) / MS_CHUNK * MS_CHUNK, nchunks = n16 / MS_CHUNK;
         const int lane = tid & 63;
         constexpr int STG = MB_NT - 64, PER = (MS_CHUNK * MS_RING + STG - 1) / STG;     // staging threads, ring slots per thread and round
@@ -761,7 +780,7 @@ void k_mesh_backsolve(MeshArgs a)
                 const int slot = sslot + (STG / MS_CHUNK) * q;
                 const int t = (int)((unsigned)(j - slot + 2 * MS_RING) % (unsigned)MS_RING), k = j - t;      // the column whose slot this is: k = j - t, k mod 192 = slot
                 const bool in = slot < MS_RING && j < n && t >= 1 && t <= hb && k >= 0;
-                reg[q] = a.Lc[in ? (size_t)k * ld + t : 0];
+                reg[q] = Lcp[in ? (size_t)k * ld + t : 0];
             }
         };
         auto commit = [&](int c, const double (&reg)[PER]) {
@@ -831,6 +850,27 @@ void k_mesh_backsolve(MeshArgs a)
             lds_barrier();
         }
         __syncthreads();
+    };
+    // nested dissection with the separator system's backward substitution inside (fuse_sep): pass 0 substitutes the separator system
+    // backwards -- every block for itself (96 rows; a kernel of its own would cost a kernel boundary on the critical chain and finish no
+    // sooner) --, pass 1 the block with the separators' values given.  One call site: phase 2 is compiled once.
+    const bool fused = nd_block && a.fuse_sep;
+    for (int pass = fused ? 0 : 1; pass < 2; pass++)
+    {
+        if (fused && pass == 0)
+        {
+            for (int i = tid; i < a.ns + 128; i += MB_NT) s.w[i] = i < a.ns ? a.sep_wz[i] : 0.0;
+            __syncthreads();
+        }
+        else if (fused)
+        {
+            for (int i = tid; i < a.ns; i += MB_NT) { s.xs[i] = s.w[i]; if (blockIdx.x == 0) a.xs[i] = s.w[i]; }
+            __syncthreads();
+            for (int i = tid; i < n + 128; i += MB_NT) s.w[i] = i < a.n_elim ? a.wz[i] : (i < n ? s.xs[xs_of[i - a.n_elim]] : 0.0);
+            __syncthreads();
+        }
+        const bool sep_pass = fused && pass == 0;
+        phase2(sep_pass ? a.sep_Lc : a.Lc, sep_pass ? a.ns : n, sep_pass ? a.sep_hb : hb);
     }
 #ifdef LVK_MESH_TIMING
     if (tid == 0) printf("mesh backsolve: %lld (100 MHz ticks)\n", wall_clock64() - tm2);
@@ -853,7 +893,7 @@ void k_mesh_backsolve(MeshArgs a)
             if (tid == 0) { *a.out_status = (flags & 8) ? 1 : ((flags & 1) ? 2 : 3); *a.flags = 0; }
             return;
         }
-        for (int q = tid; q < a.ns; q += MB_NT) a.X[a.sep_nat[q]] = a.xs[q];
+        for (int q = tid; q < a.ns; q += MB_NT) a.X[a.sep_nat[q]] = a.fuse_sep ? s.xs[q] : a.xs[q];
         __syncthreads();
         a.n = a.n_nat;
         const double* X = a.X;
@@ -1177,6 +1217,7 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
     a.region_w = region_w; a.region_h = region_h; a.ts_gen = s->ts_gen; a.ts_now = temporal_now; a.threshold = threshold;
     a.flags = s->d_flags; a.out_offsets = h_offsets; a.out_mask = h_mask; a.out_status = h_status;
     a.nd = 0; a.nblocks = 0; a.n_elim = s->n; a.n_nat = s->n; a.blocks = nullptr; a.Rc = nullptr; a.T = nullptr; a.ndst = nullptr; a.gdst = nullptr;
+    a.sep_wz = nullptr; a.sep_Lc = nullptr; a.sep_hb = 0; a.fuse_sep = 0;
     a.ssrc = nullptr; a.gsrc = nullptr; a.s_entries = 0; a.ns = 0; a.Tall = nullptr; a.wzall = nullptr; a.xs = nullptr; a.X = nullptr; a.sep_nat = nullptr; a.ticket = nullptr;
     if (n_pts > 0) hipLaunchKernelGGL(k_mesh_assemble, dim3((unsigned)((n_pts + 127) / 128)), dim3(128), 0, stream, a);
     if (s->nd)
@@ -1211,7 +1252,7 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
         else
         {
             hipLaunchKernelGGL(k_mesh_solve, dim3(1), dim3(MS_NT), 0, stream, q);
-            hipLaunchKernelGGL(k_mesh_backsolve, dim3(1), dim3(MB_NT), 0, stream, q);
+            f.fuse_sep = 1; f.sep_wz = q.wz; f.sep_Lc = q.Lc; f.sep_hb = s->hbs;      // its backward substitution: inside the blocks' kernel
         }
         hipLaunchKernelGGL(k_mesh_backsolve, dim3((unsigned)s->nblocks), dim3(MB_NT), 0, stream, f);
         LVK_HIP_CHECK(ctx, hipGetLastError());
