@@ -309,11 +309,15 @@ def main():
     # frame is two host API calls in the per-frame turnaround -- the measurement would slow what it measures by ~4 %)
     filt.set_profiling(True, stages=("remap",), every=8)
 
-    def barrier():
+    def device_sync():
+        ctx.sync()                      # lvk_hip_sync: every stream of the filter (tracking, bulk, transfers)
         torch.cuda.synchronize()
+
+    def barrier():
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     sampler = None
     if rank == 0:
@@ -333,7 +337,7 @@ def main():
         out, _ = step()
         emitted += 1 if out is not None else 0
         stamps.append(time.perf_counter())
-    torch.cuda.synchronize()
+    device_sync()
     elapsed = time.perf_counter() - t0
     wall1 = time.time()
     free_running = np.diff(np.array(stamps)) * 1e3          # host time per push in the free-running timed region
@@ -348,7 +352,7 @@ def main():
     for _ in range(n_sustained):
         out, _ = step()
         sustained_emitted += 1 if out is not None else 0
-    torch.cuda.synchronize()
+    device_sync()
     sustained_s = time.perf_counter() - ts0
     wall3 = time.time()
     sensor_samples = sampler.stop() if sampler is not None else []
@@ -359,24 +363,24 @@ def main():
     # per-step latency pass (each step synchronised) for p50 / p99 ms per frame: always 500 pushes, whatever --steps was
     lat = []
     for _ in range(500):
-        torch.cuda.synchronize()
+        device_sync()
         t = time.perf_counter()
         step()
-        torch.cuda.synchronize()
+        device_sync()
         lat.append((time.perf_counter() - t) * 1e3)
 
     # every stage's event timing in a separate free-running pass (outside the timed region: 16 event records per frame)
     filt.set_profiling(True)
     for _ in range(300):
         step()
-    torch.cuda.synchronize()
+    device_sync()
     prof_all = filt.profile()
     filt.set_profiling(False)
 
     # the same remap kernel alone on the GPU at full occupancy (the timed region runs its occupancy-capped `_co` variant next to the tracker)
     standalone_us = None
     if rank == 0 and world == 1 and args.lens != "two-pass":
-        torch.cuda.synchronize()
+        device_sync()
         meshes = filt.meshes()[1]
         srcs = frames[:8] if frames is not None else [clip.render444(i) for i in range(8)]
         dst = torch.empty_like(srcs[0])

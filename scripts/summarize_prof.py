@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 rows, cols = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2160, 3840)
 src = os.path.join(ROOT, "gpurun_out", "prof")
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("PROF_DST") or os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
