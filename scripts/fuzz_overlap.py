@@ -1,6 +1,8 @@
 """One-off fuzz: overlap-mode 4:2:0 stabilizer vs the oracle at random even frame sizes (persistent and full remap grids, both presets,
 I420 / NV12, frame delays 1..4), the GPU pushes FREE RUNNING (no synchronisation between them) with the 4:2:0 conversion pinned to the
-tracking stream, pinned to the bulk stream, or placed per push."""
+tracking stream, pinned to the bulk stream, or placed per push.  Round 3: a third of the trials feed HOST-resident planes
+(lvk_hip_stab_push_yuv420_host, with and without one frame of upload look-ahead, direct / copy sink), and the vector-field trials draw
+their motion resolution from the nested-dissection range, the register-window band range and the generic kernels' range."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,12 +24,29 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "18"))):
     frames = np.ascontiguousarray(small.repeat(2, axis=1).repeat(2, axis=2))
     delay = int(rng.integers(1, 5))
     s = oracle_lib.preset("homography" if trial % 4 else "field", predictive_samples=delay)
+    if trial % 4 == 0:
+        s.motion_width, s.motion_height = [(16, 16), (12, 10), (17, 17), (9, 14), (16, 9), (6, 20)][(trial // 4) % 6]
+    entry = ("device", "host", "host+lookahead")[(trial // 2) % 3]
+    if entry != "device": os.environ["LVK_HIP_HOST_SINK"] = ("direct", "copy")[trial % 2]
     gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_to_settings(s)); gst.set_overlap(True)
     host_planes = [oracle.egress_yuv420(f, nv12=nv12) for f in frames]
     dev_planes = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes) for planes in host_planes]
     torch.cuda.synchronize()
-    gots = [gst.apply_yuv420(dev_planes[i], timestamp=i)[0] for i in range(n)]            # free running
-    ctx.sync()
+    if entry == "device":
+        gots = [gst.apply_yuv420(dev_planes[i], timestamp=i)[0] for i in range(n)]            # free running
+        ctx.sync()
+    else:
+        hin = [gst.host_planes(rows, cols, nv12) for _ in range(n)]; hout = [gst.host_planes(rows, cols, nv12) for _ in range(n)]
+        for i in range(n):
+            for d, p in zip(hin[i], host_planes[i]): d[...] = p
+        ia = [gst.prepare_yuv420_host(p) for p in hin]; oa = [gst.prepare_yuv420_host(p) for p in hout]
+        if entry == "host+lookahead": gst.prefetch_yuv420_host_prepared(ia[0])
+        gots = []
+        for i in range(n):
+            if entry == "host+lookahead" and i + 1 < n: gst.prefetch_yuv420_host_prepared(ia[i + 1])
+            gots.append(gst.apply_yuv420_host_prepared(ia[i], i, oa[i])[0])
+        ctx.sync()
+        gots = [None if g is None else tuple(torch.from_numpy(np.array(p)) for p in g) for g in gots]
     ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
     ok = True
     for i in range(n):
@@ -35,7 +54,7 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "18"))):
         if (want is None) != (gots[i] is None): ok = False; break
         if want is not None:
             ok = ok and all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(gots[i], oracle.egress_yuv420(want, nv12=nv12)))
-    print(trial, (rows, cols), "nv12" if nv12 else "i420", "field" if trial % 4 == 0 else "homography", "delay", delay, "placement", placement or "auto", "OK" if ok else "MISMATCH", flush=True)
+    print(trial, (rows, cols), "nv12" if nv12 else "i420", "field" if trial % 4 == 0 else "homography", "delay", delay, "placement", placement or "auto", entry, (s.motion_width, s.motion_height), "OK" if ok else "MISMATCH", flush=True)
     bad += 0 if ok else 1
     ost.close(); gst.close()
 print("mismatches:", bad)
