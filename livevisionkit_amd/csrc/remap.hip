@@ -619,8 +619,9 @@ inline dim3 lvk_co_grid(lvk_hip_ctx* ctx, int dst_rows, int dst_cols)
     int& n = cus[ctx->device & 63];
     if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) n = 256;
     const unsigned full = remap_grid(dst_rows, dst_cols).x;
-    const int per_cu = ctx->co_blocks_per_cu > 0 ? ctx->co_blocks_per_cu : LVK_CO_WAVES;
-    const unsigned persistent = (unsigned)(((n * per_cu) / NUM_XCD) * NUM_XCD);
+    // co_blocks_per_cu: k > 0 = k blocks per CU, -k = one block per k CUs (a remap whose stores cross the host link does not need the chip)
+    const int per_cu = ctx->co_blocks_per_cu != 0 ? ctx->co_blocks_per_cu : LVK_CO_WAVES;
+    const unsigned persistent = (unsigned)std::max(NUM_XCD, ((per_cu > 0 ? n * per_cu : n / -per_cu) / NUM_XCD) * NUM_XCD);
     return dim3(full < persistent ? full : persistent);
 }
 

@@ -235,6 +235,7 @@ struct lvk_hip_stab
         std::chrono::steady_clock::time_point last_end{};      // when the previous host push returned
     } hostio;
     bool host_free_running_hint = false;                 // lvk_hip_stab_push_yuv420_host's own finding, for the push it wraps
+    bool host_direct_now = false;                        // the push being wrapped writes its output planes straight into host memory
     hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
     hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
     int ensure_hostio(int rows, int cols);
@@ -767,6 +768,8 @@ int lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lvk
     return LVK_HIP_OK;
 }
 
+static void rehome_stage_events(lvk_hip_ctx* ctx);
+
 void lvk_hip_stab_destroy(lvk_hip_stab* st)
 {
     if (!st) return;
@@ -786,6 +789,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     if (st->remap_stream)
     {
         (void)hipStreamSynchronize(st->remap_stream);
+        rehome_stage_events(st->ctx);
         auto& aux = st->ctx->aux_streams;
         aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
         if (st->remap_stream_owned) (void)hipStreamDestroy(st->remap_stream);
@@ -810,10 +814,21 @@ void* lvk_hip_stab_output_stream(lvk_hip_stab* st)
     return (void*)((st->overlap && st->s.stabilize_output && st->remap_stream) ? st->remap_stream : st->ctx->stream);
 }
 
+// The context's staging slots carry an event "the kernel that read this slot is done", recorded on whatever stream launched that kernel --
+// also on a bulk stream that is about to go away.  An event whose stream has been destroyed cannot be waited for any more
+// (hipEventSynchronize fails), so before a stream of this stabilizer dies the slots' events move to the context's own stream (everything
+// on the dying stream has completed: it was synchronised).
+static void rehome_stage_events(lvk_hip_ctx* ctx)
+{
+    for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventRecord(ctx->stage_done[i], ctx->stream);
+}
+
 static int stab_detach_bulk_stream(lvk_hip_stab* st)
 {
     lvk_hip_ctx* ctx = st->ctx;
     if (!st->remap_stream) return LVK_HIP_OK;
+    (void)hipStreamSynchronize(st->remap_stream);
+    rehome_stage_events(ctx);
     auto& aux = ctx->aux_streams;
     aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
     if (st->remap_stream_owned) LVK_HIP_CHECK(ctx, hipStreamDestroy(st->remap_stream));
@@ -1026,8 +1041,11 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         // 7 700 instead of 8 780 frames/s).  That only matters to a caller that runs free: one that waits for every frame (the previous
         // push ended long ago and the bulk stream is idle) gets the full grid -- the remap then has the GPU to itself (p50 latency -6 %).
         static const int pinned = [] { const char* e = std::getenv("LVK_HIP_CO_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments: blocks per CU, always
-        const bool persistent = side && (pinned > 0 || st->caller_runs_free);
-        ctx->co_blocks_per_cu = pinned;
+        const bool persistent = side && (pinned != 0 || st->caller_runs_free);
+        // a remap whose stores cross the host link (lvk_hip_stab_push_yuv420_host) is bound by the link, not by the chip: ONE block per CU
+        // for a free-running caller -- measured 2 800 frames/s against 2 560 with the 4 blocks per CU of a device-resident stream (the
+        // stores of more blocks only fill the link's write queue sooner, which stalls the tracker's kernels), 2 450 with one per two CUs
+        ctx->co_blocks_per_cu = pinned != 0 ? pinned : ((persistent && st->host_direct_now) ? 1 : 0);
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
         if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(rs, e, 0)); }
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
@@ -1519,10 +1537,11 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     }
     int prod = 0;
     tr_mark(1);
+    st->host_direct_now = direct;
     rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, &prod, out_timestamp);
     st->remap_wait = nullptr;
     st->ingest_wait[0] = st->ingest_wait[1] = nullptr;
-    st->host_free_running_hint = false;
+    st->host_free_running_hint = false; st->host_direct_now = false;
     tr_mark(2);
     // "consumed on return": the conversion (which waited for both uploads) has finished in every mode by now; the event costs nothing then
     LVK_HIP_CHECK(ctx, hipEventSynchronize(io.c_done[k]));

@@ -1,12 +1,8 @@
 #!/bin/bash
-# round-3 profiles: kernel stats + HBM traffic + SQ counters of the bench, default and vector-field preset; summaries only travel back
-R=$PWD
-mkdir -p gpurun_out/r03prof
-bash scripts/profile_gpu.sh > gpurun_out/r03prof/default.log 2>&1
-PROF_DST=$R/gpurun_out/r03prof python scripts/summarize_prof.py r03 > gpurun_out/r03prof/summ_default.log 2>&1
-cp gpurun_out/r03prof/remap_pmc_traffic.json gpurun_out/r03prof/remap_pmc_traffic_default.json
-rm -rf gpurun_out/prof
-BENCH_ARGS="--preset field" bash scripts/profile_gpu.sh > gpurun_out/r03prof/field.log 2>&1
-BENCH_ARGS="--preset field" PROF_DST=$R/gpurun_out/r03prof python scripts/summarize_prof.py r03field > gpurun_out/r03prof/summ_field.log 2>&1
-rm -rf gpurun_out/prof
-ls -la gpurun_out/r03prof
+run() { echo "== $*"; env "$@" python scripts/host_feed_probe.py 300 2>&1 | grep -v amdgpu.ids | tail -1; }
+run LOOKAHEAD=1
+run LOOKAHEAD=0
+python -m pytest tests/test_host_frames_gpu.py tests/test_remap_gpu.py -x -q 2>&1 | tail -2
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --quality-frames 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['sustained']['frames_per_s']); p=d['pcie_inclusive']; print(p.get('value'), p.get('latency_ms'), p.get('error'))"

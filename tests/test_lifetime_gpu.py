@@ -97,3 +97,26 @@ def test_first_yuv420_push_has_consumed_its_planes(ctx, oracle):
             for a, b in zip(got, oracle.egress_yuv420(want)):
                 assert np.array_equal(a.cpu().numpy(), b), i
     ost.close(); gst.close()
+
+
+def test_staging_slots_survive_the_bulk_stream_they_were_used_on(ctx, oracle):
+    """The context's staging slots remember the stream of the kernel that last read them.  A vector-field stabilizer in overlap mode stages
+    its meshes for remaps on ITS bulk stream; once it is destroyed, the next users of those slots (here: 20 plain mesh remaps, more than
+    the ring has slots) must still be able to wait for them.  (Found in round 3: hipEventSynchronize fails on an event whose stream is gone.)"""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = synth.make_clip(360, 640, 8, seed=3, jitter=1.0)
+    s = lvk.StabilizationFilterSettings.obs_preset("field", predictive_samples=2)
+    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); f.configure(s); f.set_overlap(True)
+    for i, fr in enumerate(frames):
+        f.apply(torch.from_numpy(fr).cuda(), timestamp=i)
+    ctx.sync()
+    f.close()
+    rng = np.random.default_rng(0)
+    src = synth.textured_frame(135, 240, seed=1)
+    d = torch.from_numpy(src).cuda()
+    for _ in range(20):
+        mesh = synth.random_mesh(5, 7, rng, amp=0.02)
+        got = ctx.remap_mesh(d, mesh, bg=(0, 128, 128), yuv=True)
+        ctx.sync()
+        assert np.array_equal(got.cpu().numpy(), oracle.remap_mesh(src, mesh, bg=(0, 128, 128), yuv=True))
