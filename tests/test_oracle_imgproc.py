@@ -216,3 +216,32 @@ def test_bgr_and_rgb_gray_known_answers(oracle):
     small = oracle.luma_area_resize(img, 8, 12, channel=-1)
     want = oracle.luma_area_resize(np.ascontiguousarray(g.astype(np.uint8)), 8, 12)
     assert np.array_equal(small, want)
+
+
+# ---- row a7: a second, independent statement of the tracker (tests/np_pyrlk.py, written from SURVEY App. A.3 / A.4) ------------------
+@pytest.mark.parametrize("case", ["shifted scene", "rotated texture", "small frame, 2 levels"])
+def test_pyrlk_matches_independent_numpy_restatement(oracle, case):
+    from tests import np_pyrlk
+    rng = np.random.default_rng(len(case))
+    if case == "shifted scene":
+        rows, cols = 135, 240
+        prev = _smooth_scene(rows, cols, 0, 0); nxt = _smooth_scene(rows, cols, -2.3, 1.4)
+    elif case == "rotated texture":
+        rows, cols = 120, 160
+        yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float64)
+        tex = lambda x, y: 128 + 60 * np.sin(0.21 * x + 0.07 * y) * np.cos(0.17 * y - 0.05 * x) + 30 * np.sin(0.43 * x) * np.sin(0.39 * y)
+        th = 0.02
+        xr = np.cos(th) * (xx - 80) - np.sin(th) * (yy - 60) + 80 + 0.8; yr = np.sin(th) * (xx - 80) + np.cos(th) * (yy - 60) + 60 - 0.5
+        prev = np.clip(np.rint(tex(xx, yy)), 0, 255).astype(np.uint8); nxt = np.clip(np.rint(tex(xr, yr)), 0, 255).astype(np.uint8)
+        prev[40:60, 50:90] = 200; nxt[41:61, 52:92] = 200                       # a flat rectangle: corners to track, and a flat interior (minEig)
+    else:
+        rows, cols = 44, 52                                                      # the third level would be <= the window: two levels only
+        prev = _smooth_scene(rows, cols, 0, 0); nxt = _smooth_scene(rows, cols, 0.6, -0.4)
+    pts = np.c_[rng.uniform(-8, cols + 6, 70), rng.uniform(-8, rows + 6, 70)].astype(np.float32)      # incl. points whose window leaves the frame
+    pts[:6] = [[0, 0], [cols - 1, rows - 1], [5.5, 5.5], [cols - 6.5, 5.25], [cols / 2, rows / 2], [70.25, 50.75]]
+    want, wst = oracle.pyrlk(prev, nxt, pts)
+    got, gst = np_pyrlk.calc(prev, nxt, pts)
+    assert np.array_equal(wst, gst)
+    assert 0.2 < wst.mean() < 1.0                                               # both outcomes are exercised
+    ok = wst == 1
+    assert np.array_equal(want[ok].view(np.uint32), got[ok].view(np.uint32)), np.abs(want[ok] - got[ok]).max()
