@@ -203,6 +203,43 @@ private:
     std::shared_ptr<hip::Context> m_ctx;
 };
 
+// The same wire format in PINNED HOST memory: what OBS hands the plugin (obs_source_frame planes) before FrameIngest::upload_planes and
+// after download_planes (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474).  StabilizationFilter::apply takes it directly
+// (lvk_hip_stab_push_yuv420_host): the library schedules the uploads, the conversion, the filter and the way back.
+struct HostFrame420
+{
+    uint64_t timestamp = 0;
+    bool nv12 = false;
+    int cols = 0, rows = 0;
+
+    bool empty() const { return !m_buf || cols == 0 || rows == 0; }
+    void release() { m_buf.reset(); cols = rows = 0; }
+    void create(const cv::Size& sz, bool nv12_, const std::shared_ptr<hip::Context>& ctx = nullptr)
+    {
+        LVK_HIP_ASSERT(sz.width > 0 && sz.height > 0 && sz.width % 2 == 0 && sz.height % 2 == 0);
+        if (m_buf && m_buf.use_count() == 1 && cols == sz.width && rows == sz.height && (!ctx || ctx == m_ctx)) { nv12 = nv12_; return; }
+        m_ctx = ctx ? ctx : (m_ctx ? m_ctx : hip::shared_context());
+        void* p = nullptr;
+        m_ctx->check(lvk_hip_host_malloc(m_ctx->get(), (size_t)sz.width * sz.height * 3 / 2, &p), "HostFrame420::create");
+        auto c = m_ctx;
+        m_buf = std::shared_ptr<void>(p, [c](void* q) { lvk_hip_host_free(c->get(), q); });
+        cols = sz.width; rows = sz.height; nv12 = nv12_;
+    }
+    uint8_t* y() const { return static_cast<uint8_t*>(m_buf.get()); }
+    uint8_t* u() const { return y() + (size_t)cols * rows; }
+    uint8_t* v() const { return nv12 ? u() : u() + (size_t)(cols / 2) * (rows / 2); }
+    int y_step() const { return cols; }
+    int uv_step() const { return nv12 ? cols : cols / 2; }
+    size_t bytes() const { return (size_t)cols * rows * 3 / 2; }
+    bool unique() const { return m_buf && m_buf.use_count() == 1; }
+    // an output of StabilizationFilter::apply is complete once its filter's context is idle
+    void wait() const { if (m_ctx) m_ctx->check(lvk_hip_sync(m_ctx->get()), "HostFrame420::wait"); }
+    const std::shared_ptr<hip::Context>& context() const { return m_ctx; }
+private:
+    std::shared_ptr<void> m_buf;
+    std::shared_ptr<hip::Context> m_ctx;
+};
+
 // ---------------------------------------------------------------------------------------------- Timing
 class Time
 {
@@ -536,6 +573,37 @@ public:
         sync_gpu(profile);
     }
 
+    // Frames in pinned host memory: upload_planes -> to_ocl -> filter -> to_obs -> download_planes (FrameIngest.cpp:415-474,494-602) as one
+    // push.  `input` is consumed when the call returns; `output` (released while the delay builds) is complete after output.wait() or a
+    // profiled call.  A streaming caller announces the following frame with prefetch() before applying the current one, so that the link
+    // carries frame n + 1 while frame n is tracked (what the reader thread of VideoFilter::stream does for device frames).
+    void apply(const HostFrame420& input, HostFrame420& output, const bool profile = false)
+    {
+        LVK_HIP_ASSERT(!input.empty());
+        sync_gpu(profile);
+        m_LastRows = input.rows; m_LastCols = input.cols;
+        // pinned planes are expensive to allocate: outputs come from a pool and return to it when the caller drops them
+        HostFrame420* slot = nullptr;
+        for (auto& f : m_HostPool) if (f.unique() && f.cols == input.cols && f.rows == input.rows) { slot = &f; break; }
+        if (!slot) { if (m_HostPool.size() >= 8) m_HostPool.erase(m_HostPool.begin()); m_HostPool.emplace_back(); slot = &m_HostPool.back(); }
+        slot->create({input.cols, input.rows}, input.nv12, m_Ctx);
+        HostFrame420 result = *slot;
+        int produced = 0; uint64_t ts = 0;
+        m_Ctx->check(lvk_hip_stab_push_yuv420_host(m_Stab, input.y(), input.y_step(), input.u(), input.uv_step(), input.v(), input.uv_step(), input.nv12 ? 1 : 0,
+                                                   input.rows, input.cols, input.timestamp,
+                                                   result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), &produced, &ts),
+                     "StabilizationFilter::apply(host 4:2:0)");
+        if (produced) { result.timestamp = ts; output = std::move(result); }
+        else output.release();
+        sync_gpu(profile);
+    }
+    void prefetch(const HostFrame420& next)
+    {
+        LVK_HIP_ASSERT(!next.empty());
+        m_Ctx->check(lvk_hip_stab_prefetch_yuv420_host(m_Stab, next.y(), next.y_step(), next.u(), next.uv_step(), next.v(), next.uv_step(), next.nv12 ? 1 : 0,
+                                                       next.rows, next.cols), "StabilizationFilter::prefetch");
+    }
+
 private:
     void filter(VideoFrame&& input, VideoFrame& output) override                    // StabilizationFilter.cpp:69-135
     {
@@ -591,6 +659,7 @@ private:
 
     struct HeldFrame { std::shared_ptr<void> buffer; std::shared_ptr<hip::Context> ctx; };
     int m_Device = 0;
+    std::vector<HostFrame420> m_HostPool;
     std::shared_ptr<hip::Context> m_Ctx, m_BulkCtx, m_OutCtx;      // m_OutCtx: the context (stream) output frames are produced on
     lvk_hip_stab* m_Stab = nullptr;
     bool m_Overlap = false;

@@ -231,6 +231,7 @@ struct lvk_hip_stab
         // look-ahead (lvk_hip_stab_prefetch_yuv420_host): the planes whose upload is already under way, and the slot they go to
         struct Ahead { int slot; const void* key[3]; int rows, cols, nv12; };
         std::deque<Ahead> ahead;                                // in upload order; a push consumes the oldest
+        const uint8_t* last_dst_lo = nullptr; const uint8_t* last_dst_hi = nullptr;      // luma plane of the newest download's destination
         int in_next = 0, out_next = 0, last_down = -1;       // last_down: slot of the newest download (its event orders a later direct write behind it)
         std::chrono::steady_clock::time_point last_end{};      // when the previous host push returned
     } hostio;
@@ -1270,6 +1271,13 @@ int lvk_hip_stab::flush_download(bool wait)
         return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, ds);
     };
     const auto& p = io.pending;
+    {
+        // a destination the previous download (on the other stream) may still be writing: order behind it
+        const uint8_t* lo = (const uint8_t*)p.y; const uint8_t* hi = lo + (size_t)p.ys * rows;
+        if (io.last_down >= 0 && io.last_down != j && io.down_armed[io.last_down] && io.last_dst_lo < hi && lo < io.last_dst_hi)
+            LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ds, io.down_done[io.last_down], 0));
+        io.last_dst_lo = lo; io.last_dst_hi = hi;
+    }
     const bool contiguous = p.ys == cols && p.us == ccols && (uint8_t*)p.u == (uint8_t*)p.y + (size_t)rows * cols &&
                             (nv12 || (p.vs == ccols && (uint8_t*)p.v == (uint8_t*)p.u + (size_t)crows * ccols));
     if (contiguous) LVK_HIP_CHECK(ctx, hipMemcpyAsync(p.y, o_y, (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols, hipMemcpyDeviceToHost, ds));
@@ -1494,7 +1502,9 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     {
         // its upload has been under way since the look-ahead call; look-ahead frames are pushed in the order they were announced
         const auto a = io.ahead.front();
-        LVK_HIP_REQUIRE(ctx, a.key[0] == h_y && a.key[1] == h_u && a.key[2] == (nv12 ? h_u : h_v) && a.rows == rows && a.cols == cols && a.nv12 == (nv12 ? 1 : 0));
+        if (!(a.key[0] == h_y && a.key[1] == h_u && a.key[2] == (nv12 ? h_u : h_v) && a.rows == rows && a.cols == cols && a.nv12 == (nv12 ? 1 : 0)))
+            return st->fail(LVK_HIP_ERR_ARG, "lvk_hip_stab_push_yuv420_host: another frame has been announced (lvk_hip_stab_prefetch_yuv420_host) and not pushed yet -- "
+                                             "announced frames are pushed in the order announced, and a frame pushed while announcements are outstanding must be the oldest of them");
         io.ahead.pop_front();
         k = a.slot;
     }

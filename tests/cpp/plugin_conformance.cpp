@@ -396,6 +396,68 @@ int main(int argc, char** argv)
         if (!chain.is_filter_enabled(1)) { std::printf("composite: enable_all_filters\n"); return 1; }
         std::printf("composite ok: %d frames\n", got);
     }
+    {
+        // Frames in pinned host memory (the OBS asynchronous path incl. FrameIngest's upload_planes / download_planes,
+        // Interop/FrameIngest.cpp:415-474): apply(HostFrame420) with and without look-ahead and overlap emits the bytes of apply(VideoFrame420)
+        const int hr = 360, hc = 640, count = 14;
+        auto paint = [&](uint8_t* dst, int i) {
+            for (int y = 0; y < hr; y++)
+                for (int x = 0; x < hc; x++)
+                {
+                    const int xs = x + (i % 3) * 2, ys = y + (i % 2) * 2;
+                    dst[(size_t)y * hc + x] = (uint8_t)((((xs / 16) + (ys / 16)) % 2) ? 200 : 40 + (xs * 7 + ys * 13) % 23);
+                }
+            for (int k = 0; k < hr * hc / 2; k++) dst[(size_t)hr * hc + k] = (uint8_t)(96 + (k * 5 + i) % 64);
+        };
+        lvk::StabilizationFilterSettings st;
+        st.predictive_samples = 3;
+        std::vector<std::vector<uint8_t>> want;
+        std::vector<uint64_t> want_ts;
+        {
+            lvk::StabilizationFilter filter(st);
+            std::vector<uint8_t> img((size_t)hr * hc * 3 / 2);
+            for (int i = 0; i < count; i++)
+            {
+                paint(img.data(), i);
+                lvk::VideoFrame420 in, out;
+                in.upload(img.data(), hr, hc, false, 900 + i);
+                filter.apply(in, out);
+                if (out.empty()) continue;
+                want.emplace_back(img.size()); out.download(want.back().data()); want_ts.push_back(out.timestamp);
+            }
+        }
+        if (want.size() != (size_t)count - 3) { std::printf("host frames: device path emitted %zu\n", want.size()); return 1; }
+        for (int variant = 0; variant < 3; variant++)                 // 0: synchronous, 1: look-ahead, 2: look-ahead + overlap, outputs kept
+        {
+            lvk::StabilizationFilter filter(st);
+            if (variant == 2) filter.set_overlap(true);
+            std::vector<lvk::HostFrame420> in(count), kept;
+            for (int i = 0; i < count; i++) { in[i].create({hc, hr}, false); paint(in[i].y(), i); in[i].timestamp = 900 + i; }
+            size_t got = 0;
+            for (int i = 0; i < count; i++)
+            {
+                if (variant >= 1 && i == 0) filter.prefetch(in[0]);            // announced frames are pushed in the order announced: this one first
+                if (variant >= 1 && i + 1 < count) filter.prefetch(in[i + 1]);
+                lvk::HostFrame420 out;
+                filter.apply(in[i], out, variant == 0);
+                if (out.empty()) continue;
+                if (variant == 2) { kept.push_back(out); got++; continue; }
+                out.wait();
+                if (out.timestamp != want_ts[got] || std::memcmp(out.y(), want[got].data(), out.bytes()) != 0)
+                    { std::printf("host frames: variant %d frame %zu differs\n", variant, got); return 1; }
+                got++;
+            }
+            if (variant == 2)
+            {
+                if (!kept.empty()) kept.back().wait();
+                for (size_t k = 0; k < kept.size(); k++)
+                    if (kept[k].timestamp != want_ts[k] || std::memcmp(kept[k].y(), want[k].data(), kept[k].bytes()) != 0)
+                        { std::printf("host frames: kept frame %zu differs\n", k); return 1; }
+            }
+            if (got != want.size()) { std::printf("host frames: variant %d emitted %zu\n", variant, got); return 1; }
+        }
+        std::printf("host frames ok: %zu frames x 3 variants identical to the device path\n", want.size());
+    }
     lvk::VSFilterLike vs;
     vs.configure(false, true, 0.05f, 0.05f, 5, true, false, true);
     const int rows = 360, cols = 640;

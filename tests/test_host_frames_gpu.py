@@ -123,3 +123,22 @@ def test_host_push_equals_device_push_at_4k(ctx, preset, monkeypatch):
         for k, (a, b) in enumerate(zip(got, want)):
             for pa, pb in zip(a, b):
                 assert np.array_equal(pa, pb), (preset, sink, k)
+
+
+def test_out_of_order_push_is_refused_with_a_message(ctx):
+    """Look-ahead frames are pushed in the order announced; pushing another frame first is an argument error that says so, and the
+    stream continues once the announced frame is pushed."""
+    import livevisionkit_amd as lvk
+    rows, cols = 180, 320
+    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
+    a, b, out = (f.host_planes(rows, cols) for _ in range(3))
+    for p in a + b:
+        p[...] = 90
+    pa, pb, po = (f.prepare_yuv420_host(p) for p in (a, b, out))
+    f.prefetch_yuv420_host_prepared(pb)
+    with pytest.raises(Exception, match="order announced"):
+        f.apply_yuv420_host_prepared(pa, 0, po)
+    f.apply_yuv420_host_prepared(pb, 0, po)
+    f.apply_yuv420_host_prepared(pa, 1, po)
+    ctx.sync()
+    f.close()
