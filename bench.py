@@ -300,6 +300,17 @@ def main():
             return filt.apply(corrected, timestamp=i, out=outs[i & 3])
         return filt.apply(frames[i % pool], timestamp=i, out=outs[i & 3])
 
+    # the sensor sampler (a separate process) is started BEFORE the warmup, so that nothing but the barrier sits between the warmup steps
+    # and the timed region (its start-up wait used to idle the GPU for 0.3 s right in front of the timed pushes)
+    sampler = None
+    if rank == 0:
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id) if hasattr(props, "pci_bus_id") else None
+            sampler = GpuSampler(bus)
+            time.sleep(0.3)                                  # the sampler process is up before the timed region begins
+        except Exception:
+            sampler = None
     # fill the delay (untimed, before the warmup): every timed step then emits one stabilized frame
     for _ in range(delay + 2):
         step()
@@ -319,15 +330,6 @@ def main():
             dist.barrier()
         device_sync()
 
-    sampler = None
-    if rank == 0:
-        try:
-            props = torch.cuda.get_device_properties(local_rank)
-            bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id) if hasattr(props, "pci_bus_id") else None
-            sampler = GpuSampler(bus)
-            time.sleep(0.3)                                  # the sampler process is up before the timed region begins
-        except Exception:
-            sampler = None
     barrier()
     wall0 = time.time()
     t0 = time.perf_counter()
@@ -512,6 +514,10 @@ def main():
             "ranks": rank_reports,
             "latency_ms": dict(percentiles(lat), samples=len(lat)),
             "free_running_ms": percentiles(free_running, (10, 50, 90, 99)),
+            # where the timed region goes: host time of each timed push (the first one has nothing to overlap with, pushes on which the
+            # detector runs are longer) and what is left for the final synchronisation (the last remap + lvk_hip_sync)
+            "timed_region_ms": {"pushes": [round(float(x), 4) for x in free_running[:64]],
+                                "final_sync": round(float(elapsed * 1e3 - free_running.sum()), 4), "total": round(float(elapsed * 1e3), 4)},
             "stage_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof_all.items()},
             "pcie_inclusive": pcie,
             "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked},

@@ -334,7 +334,10 @@ int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_ste
 {
     LVK_HIP_REQUIRE(ctx, d_src && d_dst && srows > 0 && scols > 0 && drows > 0 && dcols > 0);
     LVK_HIP_REQUIRE(ctx, pix_stride >= 1 && channel >= -2 && channel < pix_stride && (channel >= 0 || pix_stride >= 3));
-    LVK_HIP_REQUIRE(ctx, drows <= srows && dcols <= scols);          // the tracker only downscales (FrameTracker.cpp:117)
+    // the tracker only downscales (FrameTracker.cpp:117); cv::resize(INTER_AREA) ENLARGES with a bilinear variant that is not on this path
+    if (drows > srows || dcols > scols)
+        return ctx->fail(LVK_HIP_ERR_ARG, "frame (" + std::to_string(scols) + " x " + std::to_string(srows) + ") smaller than the detection resolution (" +
+                                          std::to_string(dcols) + " x " + std::to_string(drows) + "): INTER_AREA enlargement is not supported, lower detection_resolution");
     const dim3 block(64, 4), grid((dcols + 63) / 64, (drows + 3) / 4);
     const int isx = scols / dcols, isy = srows / drows;
     const bool exact = scols % dcols == 0 && srows % drows == 0;

@@ -129,7 +129,7 @@ def test_out_of_order_push_is_refused_with_a_message(ctx):
     """Look-ahead frames are pushed in the order announced; pushing another frame first is an argument error that says so, and the
     stream continues once the announced frame is pushed."""
     import livevisionkit_amd as lvk
-    rows, cols = 180, 320
+    rows, cols = 360, 640
     f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
     a, b, out = (f.host_planes(rows, cols) for _ in range(3))
     for p in a + b:

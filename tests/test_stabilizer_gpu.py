@@ -177,6 +177,17 @@ def test_stabilizer_field_preset_large_motion_resolution(ctx, oracle, clip, mesh
     assert _run_pair(oracle, ctx, frames[:12], oracle_lib.preset("default"), then_configure=field, overlap=mesh == (32, 32)) == 9
 
 
+def test_frame_below_the_detection_resolution_is_refused_with_a_message(ctx):
+    """FrameTracker.cpp:117 resizes to detection_resolution with INTER_AREA; this path builds the downscale only and says so."""
+    import torch
+    import livevisionkit_amd as lvk
+    gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
+    small = torch.zeros((180, 320, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception, match="smaller than the detection resolution"):
+        gst.apply(small, timestamp=0)
+    gst.close()
+
+
 def test_refused_configure_leaves_the_filter_untouched(ctx, oracle, clip):
     """A configure() the library refuses (here: a motion mesh wider than the device solver's 167 columns; also an out-of-range quality)
     returns an error and changes NOTHING: the following pushes match an oracle that never saw the call (round-2 ADVICE: the state used
@@ -342,9 +353,9 @@ def test_stabilizer_yuv420_in_out_bit_exact(ctx, oracle, clip, nv12, overlap):
     ost.close(); gst.close()
 
 
-@pytest.mark.parametrize("size,nv12", [((1080, 1920), False), ((2160, 3840), False), ((1080, 1920), True)])
+@pytest.mark.parametrize("size,nv12", [((1080, 1920), False), ((2160, 3840), False), ((1080, 1920), True), ((4320, 7680), False)])
 def test_overlap_yuv420_full_size_persistent_grid_bit_exact(ctx, oracle, size, nv12):
-    """Overlap mode at 1080p / 4K: the fused remap + 4:2:0 egress runs on the persistent grid (several strips per block, double-buffered
+    """Overlap mode at 1080p / 4K / 8K (the largest OBS canvas): the fused remap + 4:2:0 egress runs on the persistent grid (several strips per block, double-buffered
     chroma exchange), free-running next to the tracker; every emitted plane bit-identical to the oracle chain."""
     import torch
     import livevisionkit_amd as lvk
