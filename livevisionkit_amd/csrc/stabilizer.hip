@@ -1517,6 +1517,12 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     uint8_t* d_u = d_y + (size_t)rows * cols;
     uint8_t* d_v = nv12 ? d_u : d_u + (size_t)crows * ccols;
     tr_mark(0);
+    // what this call hands to the push it wraps (events to wait for, the sink hints) never outlives it, whichever way it returns
+    struct ClearHooks
+    {
+        lvk_hip_stab* s;
+        ~ClearHooks() { s->remap_wait = nullptr; s->ingest_wait[0] = s->ingest_wait[1] = nullptr; s->host_free_running_hint = false; s->host_direct_now = false; }
+    } clear_hooks{st};
     LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, io.y_is_c[k] ? io.c_done[k] : io.y_done[k], 0));           // the tracker needs the luma plane only
     st->ingest_wait[0] = io.y_is_c[k] ? nullptr : io.y_done[k]; st->ingest_wait[1] = io.c_done[k];
 
@@ -1549,9 +1555,6 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     tr_mark(1);
     st->host_direct_now = direct;
     rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, &prod, out_timestamp);
-    st->remap_wait = nullptr;
-    st->ingest_wait[0] = st->ingest_wait[1] = nullptr;
-    st->host_free_running_hint = false; st->host_direct_now = false;
     tr_mark(2);
     // "consumed on return": the conversion (which waited for both uploads) has finished in every mode by now; the event costs nothing then
     LVK_HIP_CHECK(ctx, hipEventSynchronize(io.c_done[k]));
