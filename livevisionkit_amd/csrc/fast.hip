@@ -45,13 +45,17 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int stride, int thre
     return m > threshold ? m - 1 : 0;       // cornerScore: (largest threshold at which it is still a corner)
 }
 
+// The region descriptors travel BY VALUE (kernel arguments) when there are few of them, instead of every workgroup reading them from pinned
+// host memory across the link.
+struct FastRegionList { FastRegion r[LVK_FAST_INLINE_REGIONS]; };
+
 __global__ __launch_bounds__(TW * TH)
 void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols,
-                   const FastRegion* __restrict__ regions, int segs_x,
+                   const FastRegion* __restrict__ regions, FastRegionList inl, int n_inline, int segs_x,
                    unsigned long long* __restrict__ masks, uint8_t* __restrict__ scores, int max_rh, int max_rw)
 {
     LVK_TRACKER_PRIORITY();
-    const FastRegion rg = regions[blockIdx.z];
+    const FastRegion rg = n_inline ? inl.r[blockIdx.z] : regions[blockIdx.z];
     if (!rg.active) return;
     const int lx0 = blockIdx.x * TW, ly0 = blockIdx.y * TH;
     if (lx0 >= rg.w || ly0 >= rg.h) return;
@@ -99,13 +103,13 @@ void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols
 
 // One block per region: exclusive scan of the per-segment popcounts in row-major order, then ordered scatter.
 __global__ __launch_bounds__(1024)
-void k_fast_compact(const FastRegion* __restrict__ regions, int segs_x,
+void k_fast_compact(const FastRegion* __restrict__ regions, FastRegionList inl, int n_inline, int segs_x,
                     const unsigned long long* __restrict__ masks, const uint8_t* __restrict__ scores, int max_rh, int max_rw,
                     uint32_t* __restrict__ out, int cap, int* __restrict__ counts)
 {
     LVK_TRACKER_PRIORITY();
     const int r = blockIdx.x;
-    const FastRegion rg = regions[r];
+    const FastRegion rg = n_inline ? inl.r[r] : regions[r];
     if (!rg.active) { if (threadIdx.x == 0) counts[r] = 0; return; }
     const int rsegs = (rg.w + TW - 1) / TW;
     const int nseg = rg.h * rsegs;
@@ -164,14 +168,17 @@ int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks
 // (x | y << 12 | score << 24, region-local), d_counts: nregions totals (may exceed cap; entries beyond cap are dropped).
 int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
                     const FastRegion* d_regions, int nregions, int max_rw, int max_rh,
-                    void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts)
+                    void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts, const FastRegion* host_regions)
 {
     LVK_HIP_REQUIRE(ctx, d_img && d_regions && nregions > 0 && max_rw > 0 && max_rh > 0 && max_rw < 4096 && max_rh < 4096);
     const int segs_x = (max_rw + TW - 1) / TW;
     const dim3 block(TW, TH), grid(segs_x, (max_rh + TH - 1) / TH, nregions);
-    hipLaunchKernelGGL(k_fast_detect, grid, block, 0, ctx->stream, (const uint8_t*)d_img, step, rows, cols, d_regions, segs_x,
+    FastRegionList inl{};
+    const int n_inline = (host_regions && nregions <= LVK_FAST_INLINE_REGIONS) ? nregions : 0;      // host_regions: the same descriptors, readable by the host
+    for (int i = 0; i < n_inline; i++) inl.r[i] = host_regions[i];
+    hipLaunchKernelGGL(k_fast_detect, grid, block, 0, ctx->stream, (const uint8_t*)d_img, step, rows, cols, d_regions, inl, n_inline, segs_x,
                        (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw);
-    hipLaunchKernelGGL(k_fast_compact, dim3(nregions), dim3(1024), 0, ctx->stream, d_regions, segs_x,
+    hipLaunchKernelGGL(k_fast_compact, dim3(nregions), dim3(1024), 0, ctx->stream, d_regions, inl, n_inline, segs_x,
                        (const unsigned long long*)d_masks, (const uint8_t*)d_scores, max_rh, max_rw, d_out, cap, d_counts);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;

@@ -17,7 +17,8 @@
 struct LinTabEntry { int s0, s1; float a0, a1; };   // one column/row of the INTER_LINEAR mesh->frame table
 struct Lin8Entry { int s0, s1, a0, a1; };            // 8-bit INTER_LINEAR table entry: two source indices, 11-bit coefficients
 struct AreaTabEntry { int si; float alpha; };        // one source tap of the INTER_AREA "decimate alpha" table
-struct FastRegion { int x, y, w, h, threshold, active; };   // one FAST detection region (integer ROI of the tracking frame)
+struct FastRegion { int x, y, w, h, threshold, active; };
+constexpr int LVK_FAST_INLINE_REGIONS = 8;       // up to this many region descriptors travel as kernel arguments   // one FAST detection region (integer ROI of the tracking frame)
 
 constexpr int LVK_MAX_PYR_LEVELS = 8;
 struct PyrLevel { const uint8_t* img; const short2* deriv; int rows, cols, step; };
@@ -158,7 +159,7 @@ int lvk_launch_pyramid(lvk_hip_ctx* ctx, const PyrArgs& args, bool derivs = fals
 int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks_bytes, size_t* scores_bytes);
 int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
                     const FastRegion* d_regions, int nregions, int max_rw, int max_rh,
-                    void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts);
+                    void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts, const FastRegion* host_regions = nullptr);
 
 // Pyramidal LK (pyrlk.hip)
 struct LensModel;

@@ -240,14 +240,21 @@ struct lvk_hip_stab
     hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
     hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
     int ensure_hostio(int rows, int cols);
+    int host_stream(hipStream_t& s)                          // a transfer stream, created on first use; lvk_hip_sync() covers it
+    {
+        if (s) return LVK_HIP_OK;
+        LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        ctx->aux_streams.push_back(s);
+        return LVK_HIP_OK;
+    }
     int flush_download(bool wait);
     int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
     void free_hostio();
     bool caller_free_running_now();
-    // experiments (scripts/host_feed_probe.py, scripts/host_feed_matrix.sh): LVK_HIP_HOST_UP2=0 every upload on ONE stream (default: announced frames
-    // alternate between two, see host_upload); LVK_HIP_HOST_H2D=<blocks> the uploads as copy kernels of that many workgroups instead of hipMemcpyAsync
+    // experiments (scripts/host_feed_probe.py, scripts/host_feed_matrix.sh): LVK_HIP_HOST_UP2=1 announced frames alternate between two upload streams
+    // (default: one, see host_upload); LVK_HIP_HOST_H2D=<blocks> the uploads as copy kernels of that many workgroups instead of hipMemcpyAsync
     double host_trace_acc[6] = {0, 0, 0, 0, 0, 0}; long host_trace_n = 0;      // LVK_HIP_HOST_TRACE: us inside lvk_hip_stab_push_yuv420_host, by phase
-    int host_up2 = [] { const char* e = std::getenv("LVK_HIP_HOST_UP2"); return e ? std::atoi(e) : 1; }();
+    int host_up2 = [] { const char* e = std::getenv("LVK_HIP_HOST_UP2"); return e ? std::atoi(e) : 0; }();
     int host_h2d_blocks = [] { const char* e = std::getenv("LVK_HIP_HOST_H2D"); return e ? std::atoi(e) : 0; }();
     int host_sink_mode = [] { const char* e = std::getenv("LVK_HIP_HOST_SINK"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();      // tests: direct | copy
 
@@ -534,7 +541,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         // call besides the launches is the stream synchronisation.
         pe = prof_begin(LVK_STAGE_FAST);
         if ((rc = lvk_launch_fast(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, h_regions, (int)plan.size(), fast_max_rw, fast_max_rh,
-                                  d_fast_masks, d_fast_scores, h_fast_out, fast_cap, h_fast_counts)) != LVK_HIP_OK) return rc;
+                                  d_fast_masks, d_fast_scores, h_fast_out, fast_cap, h_fast_counts, h_regions)) != LVK_HIP_OK) return rc;
         prof_end(pe);
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
         trace.mark(HostTrace::FAST_SYNC);
@@ -1161,11 +1168,14 @@ int lvk_hip_stab::ensure_hostio(int rows, int cols)
     const size_t bytes = (size_t)rows * cols + 2 * (size_t)((rows + 1) / 2) * ((cols + 1) / 2);
     for (auto& p : h.d_in) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
     for (auto& p : h.d_out) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
-    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.up, hipStreamNonBlocking));
-    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.down, hipStreamNonBlocking));
-    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.up2, hipStreamNonBlocking));
-    LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&h.down2, hipStreamNonBlocking));
-    ctx->aux_streams.push_back(h.up); ctx->aux_streams.push_back(h.down); ctx->aux_streams.push_back(h.up2); ctx->aux_streams.push_back(h.down2);
+    // The streams that exist are the streams that are used: every stream of the process is a queue the runtime maps onto its few hardware
+    // queues, and a transfer stream that lands on the hardware queue of the caller's stream stalls the tracker's kernels behind its copies
+    // (measured, 4K free running with look-ahead: 3 140-3 190 frames/s with ONE upload stream, 2 700-2 850 with two, 2 040-2 130 with a third
+    // side stream next to them).  The second upload stream (chroma of a frame pushed without look-ahead) and the download streams
+    // (LVK_HIP_HOST_SINK=copy) are made on first use.  [The mechanism was narrowed down with scripts/sdma_interference_probe.py and the timelines
+    // G-H of profiles/r03_host_feed_timeline.txt: whichever kernel comes first on the tracking stream after a look-ahead upload has started
+    // -- the downscale, the flow kernel, a 5 KB copy, even a kernel that only stores its arguments -- ends ~220 us after that upload began.]
+    { const int rcs = host_stream(h.up); if (rcs != LVK_HIP_OK) return rcs; }
     ctx->sync_hooks.emplace_back((void*)this, [this]() { return flush_download(true); });          // lvk_hip_sync() covers the transfers
     for (int i = 0; i < HostIO::K_IN; i++)
     {
@@ -1222,8 +1232,9 @@ int lvk_hip_stab::host_upload(const void* h_y, int y_step, const void* h_u, int 
     if (ahead && contiguous)
     {
         const size_t bytes = (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols;
-        // one upload stream per staging slot: hipMemcpyAsync blocks the HOST while an earlier copy of the same stream is still in flight
-        // (measured: the next frame's tracker chain was launched 90 us after the previous upload had ended)
+        // ONE upload stream.  (hipMemcpyAsync blocks the host while an earlier copy of the same stream is still in flight, which two alternating
+        // streams avoid -- LVK_HIP_HOST_UP2=1 --, but the second stream costs more than that wait: see ensure_hostio.)
+        if (host_up2 && (k & 1)) { if ((rc = host_stream(io.up2)) != LVK_HIP_OK) return rc; }
         hipStream_t us = (host_up2 && (k & 1)) ? io.up2 : io.up;
         if (host_h2d_blocks > 0 && ((uintptr_t)h_y & 15) == 0) { if ((rc = lvk_launch_copy_bytes(ctx, us, d_y, h_y, bytes, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
         else LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_y, h_y, bytes, hipMemcpyHostToDevice, us));
@@ -1265,6 +1276,7 @@ int lvk_hip_stab::flush_download(bool wait)
     else if (q != hipSuccess) return fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(q));
     const int rows = io.rows, cols = io.cols, nv12 = io.pending.nv12, crows = rows / 2, ccols = nv12 ? cols : cols / 2;
     uint8_t* o_y = (uint8_t*)io.d_out[j]; uint8_t* o_u = o_y + (size_t)rows * cols; uint8_t* o_v = nv12 ? o_u : o_u + (size_t)crows * ccols;
+    { int rcs; if ((rcs = host_stream(io.down)) != LVK_HIP_OK || (rcs = host_stream(io.down2)) != LVK_HIP_OK) return rcs; }
     hipStream_t ds = (j & 1) ? io.down2 : io.down;           // (hipMemcpyAsync blocks the host while an earlier copy of the same stream is in flight)
     auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height) -> hipError_t {
         if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, hipMemcpyDeviceToHost, ds);

@@ -29,6 +29,8 @@ torch.cuda.synchronize()
 for i in range(60):
     filt.apply_yuv420_host_prepared(ia[i % 32], i, oa[i & 3])
 ctx.sync()
+if os.environ.get("PROFILE") == "1":
+    filt.set_profiling(True)
 t0 = time.perf_counter(); stamps = []
 look = os.environ.get("LOOKAHEAD") == "1"
 if look:
@@ -43,4 +45,6 @@ dt = time.perf_counter() - t0
 import numpy as np
 d = np.diff(np.array(stamps)) * 1e3
 print("host-fed free running: %.0f frames/s, push p50 %.3f p90 %.3f ms" % (n / dt, np.percentile(d, 50), np.percentile(d, 90)))
+if os.environ.get("PROFILE") == "1":
+    print("stage us:", {k: round(1e3 * ms / max(c, 1), 1) for k, (ms, c) in filt.profile().items()})
 filt.close(); ctx.close()
