@@ -1054,7 +1054,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         static const int pinned = [] { const char* e = std::getenv("LVK_HIP_CO_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments: blocks per CU, always
         const bool persistent = side && (pinned != 0 || st->caller_runs_free);
         // a remap whose stores cross the host link (lvk_hip_stab_push_yuv420_host) is bound by the link, not by the chip: ONE block per CU
-        // for a free-running caller -- measured 2 800 frames/s against 2 560 with the 4 blocks per CU of a device-resident stream (the
+        // for a free-running caller -- measured (two upload streams at the time) 2 800 frames/s against 2 560 with the 4 blocks per CU of a device-resident stream (the
         // stores of more blocks only fill the link's write queue sooner, which stalls the tracker's kernels), 2 450 with one per two CUs
         ctx->co_blocks_per_cu = pinned != 0 ? pinned : ((persistent && st->host_direct_now) ? 1 : 0);
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
