@@ -17,8 +17,8 @@
 struct LinTabEntry { int s0, s1; float a0, a1; };   // one column/row of the INTER_LINEAR mesh->frame table
 struct Lin8Entry { int s0, s1, a0, a1; };            // 8-bit INTER_LINEAR table entry: two source indices, 11-bit coefficients
 struct AreaTabEntry { int si; float alpha; };        // one source tap of the INTER_AREA "decimate alpha" table
-struct FastRegion { int x, y, w, h, threshold, active; };
-constexpr int LVK_FAST_INLINE_REGIONS = 8;       // up to this many region descriptors travel as kernel arguments   // one FAST detection region (integer ROI of the tracking frame)
+struct FastRegion { int x, y, w, h, threshold, active; };   // one FAST detection region (integer ROI of the tracking frame)
+constexpr int LVK_FAST_INLINE_REGIONS = 8;       // up to this many region descriptors travel as kernel arguments
 
 constexpr int LVK_MAX_PYR_LEVELS = 8;
 struct PyrLevel { const uint8_t* img; const short2* deriv; int rows, cols, step; };
@@ -64,7 +64,7 @@ struct lvk_hip_ctx
     std::map<std::tuple<int, int, int>, Lin8Entry*> lin8tabs;     // 8-bit INTER_LINEAR tables (chroma upsampling)
 
     // Cached INTER_AREA tables: key = (source extent, destination extent)
-    struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; };
+    struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; int max_taps = 0; };      // max_taps: longest tap list of one destination index
     std::map<std::pair<int, int>, AreaTabDev> areatabs;
 
     int fail(int code, const std::string& msg) { last_error = msg; return code; }
@@ -145,7 +145,7 @@ int lvk_stage_consumed(lvk_hip_ctx* ctx, int slot, hipStream_t stream);
 int lvk_get_lintab(lvk_hip_ctx* ctx, int msize, int fsize, bool vertical, const LinTabEntry** d_out);
 
 // Device-resident INTER_AREA table (per destination index: [start, count) into the tap list).
-int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab);
+int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab, int* max_taps = nullptr);
 
 // Asynchronous launches on ctx->stream (device pointers).
 int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,

@@ -34,6 +34,19 @@ def test_luma_area_resize_planar(ctx, oracle):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("src_size,dst_size", [((1440, 2560), (270, 480)), ((1200, 1920), (270, 480)), ((720, 1280), (270, 480)), ((1600, 2560), (270, 480)),
+                                               ((2162, 3846), (270, 480)), ((271, 481), (270, 480)), ((600, 700), (64, 97)), ((2400, 4000), (270, 480))])
+def test_luma_area_resize_fractional_scales_planar(ctx, oracle, src_size, dst_size):
+    """Non-integer scales (resizeArea_ with its decimate-alpha tables): 1440p / 1200p / 720p canvases, barely-above-one and ragged scales, up to 8
+    taps per axis through the batched-load kernel, beyond that (2400 -> 270: 9-10 taps) through the loop kernel -- same sums in the same order."""
+    rng = np.random.default_rng(src_size[1])
+    plane = rng.integers(0, 256, src_size, dtype=np.uint8)
+    want = oracle.luma_area_resize(plane, *dst_size)
+    got = ctx.luma_area_resize(_gpu(plane), *dst_size)
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("shape", [(270, 480), (135, 240), (68, 120), (33, 47), (256, 256)])
 def test_pyr_down_and_scharr(ctx, oracle, shape):
     img = np.random.default_rng(shape[1]).integers(0, 256, shape, dtype=np.uint8)
