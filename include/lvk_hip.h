@@ -305,7 +305,8 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
  * first (the tracker starts while the chroma planes are still on the link), one copy stream per direction; the output planes are either
  * written by the remap kernel itself (a caller that waits for every frame: lowest latency) or downloaded behind it (a free-running
  * caller: highest rate) -- same pixels.  Input planes are consumed when the call returns; output planes are complete after
- * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed). */
+ * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed).  Pageable plane pointers are
+ * refused with LVK_HIP_ERR_ARG (each pointer is looked up once). */
 int  lvk_hip_stab_push_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
                                    int rows, int cols, uint64_t timestamp,
                                    void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <unordered_set>
 
 using lvkh::Feature;
 using lvkh::WarpMeshF;
@@ -240,6 +241,23 @@ struct lvk_hip_stab
     hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
     hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
     int ensure_hostio(int rows, int cols);
+    // The host entry points hand these pointers to copy engines and (output planes) to a kernel: pageable memory there is a GPU fault, not an
+    // error code.  Every plane pointer is looked up once (hipPointerGetAttributes) and remembered.
+    std::unordered_set<const void*> pinned_seen;
+    int require_pinned(const void* p, const char* what)
+    {
+        if (!p) return LVK_HIP_OK;
+        if (pinned_seen.count(p)) return LVK_HIP_OK;
+        hipPointerAttribute_t attr{};
+        const hipError_t e = hipPointerGetAttributes(&attr, p);
+        if (e != hipSuccess) (void)hipGetLastError();
+        if (e != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeDevice))
+            return fail(LVK_HIP_ERR_ARG, std::string(what) + ": the planes of the host entry points must be PINNED host memory "
+                                         "(lvk_hip_host_malloc, hipHostMalloc or hipHostRegister); this pointer is pageable memory");
+        if (pinned_seen.size() >= 4096) pinned_seen.clear();
+        pinned_seen.insert(p);
+        return LVK_HIP_OK;
+    }
     int host_stream(hipStream_t& s)                          // a transfer stream, created on first use; lvk_hip_sync() covers it
     {
         if (s) return LVK_HIP_OK;
@@ -1471,8 +1489,9 @@ int lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_s
     lvk_hip_ctx* ctx = st->ctx;
     LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
     LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
-    int rc = st->ensure_hostio(rows, cols);
-    if (rc != LVK_HIP_OK) return rc;
+    int rc;
+    for (const void* p : {h_y, h_u, nv12 ? nullptr : h_v}) if ((rc = st->require_pinned(p, "lvk_hip_stab_prefetch_yuv420_host")) != LVK_HIP_OK) return rc;
+    if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
     lvk_hip_stab::HostIO& io = st->hostio;
     // two staging slots: the frame being pushed and the one on the link -- at most two announced frames that have not been pushed yet
     LVK_HIP_REQUIRE(ctx, io.ahead.size() < (size_t)lvk_hip_stab::HostIO::K_IN);
@@ -1505,8 +1524,10 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     if (produced) *produced = 0;
     LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
     LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
-    int rc = st->ensure_hostio(rows, cols);
-    if (rc != LVK_HIP_OK) return rc;
+    int rc;
+    for (const void* p : {h_y, h_u, nv12 ? nullptr : h_v, (const void*)oh_y, (const void*)oh_u, nv12 ? nullptr : (const void*)oh_v})
+        if ((rc = st->require_pinned(p, "lvk_hip_stab_push_yuv420_host")) != LVK_HIP_OK) return rc;
+    if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
     lvk_hip_stab::HostIO& io = st->hostio;
     if ((rc = st->flush_download(false)) != LVK_HIP_OK) return rc;
     auto tr_last = std::chrono::steady_clock::now();

@@ -142,3 +142,24 @@ def test_out_of_order_push_is_refused_with_a_message(ctx):
     f.apply_yuv420_host_prepared(pa, 1, po)
     ctx.sync()
     f.close()
+
+
+def test_pageable_planes_are_refused_with_a_message(ctx):
+    """The host entry points hand their plane pointers to copy engines and to a kernel: pageable memory is an argument error, not a GPU fault."""
+    import livevisionkit_amd as lvk
+    rows, cols = 360, 640
+    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
+    good, out = f.host_planes(rows, cols), f.host_planes(rows, cols)
+    bad = tuple(np.full(p.shape, 90, np.uint8) for p in good)               # plain numpy arrays: pageable
+    for p in good:
+        p[...] = 90
+    pg, pb, po = (f.prepare_yuv420_host(p) for p in (good, bad, out))
+    with pytest.raises(Exception, match="PINNED"):
+        f.apply_yuv420_host_prepared(pb, 0, po)
+    with pytest.raises(Exception, match="PINNED"):
+        f.prefetch_yuv420_host_prepared(pb)
+    with pytest.raises(Exception, match="PINNED"):
+        f.apply_yuv420_host_prepared(pg, 0, pb)
+    f.apply_yuv420_host_prepared(pg, 0, po)
+    ctx.sync()
+    f.close()
