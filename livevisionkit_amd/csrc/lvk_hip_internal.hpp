@@ -64,7 +64,8 @@ struct lvk_hip_ctx
     std::map<std::tuple<int, int, int>, Lin8Entry*> lin8tabs;     // 8-bit INTER_LINEAR tables (chroma upsampling)
 
     // Cached INTER_AREA tables: key = (source extent, destination extent)
-    struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; int max_taps = 0; };      // max_taps: longest tap list of one destination index
+    // max_taps: longest tap list of one destination index; span64 / span4: most source samples under 64 / 4 consecutive destination indices
+    struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; int max_taps = 0, span64 = 0, span4 = 0; };
     std::map<std::pair<int, int>, AreaTabDev> areatabs;
 
     int fail(int code, const std::string& msg) { last_error = msg; return code; }
@@ -145,7 +146,7 @@ int lvk_stage_consumed(lvk_hip_ctx* ctx, int slot, hipStream_t stream);
 int lvk_get_lintab(lvk_hip_ctx* ctx, int msize, int fsize, bool vertical, const LinTabEntry** d_out);
 
 // Device-resident INTER_AREA table (per destination index: [start, count) into the tap list).
-int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab, int* max_taps = nullptr);
+int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab, int* max_taps = nullptr, int* span64 = nullptr, int* span4 = nullptr);
 
 // Asynchronous launches on ctx->stream (device pointers).
 int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
