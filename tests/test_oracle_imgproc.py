@@ -245,3 +245,46 @@ def test_pyrlk_matches_independent_numpy_restatement(oracle, case):
     assert 0.2 < wst.mean() < 1.0                                               # both outcomes are exercised
     ok = wst == 1
     assert np.array_equal(want[ok].view(np.uint32), got[ok].view(np.uint32)), np.abs(want[ok] - got[ok]).max()
+
+
+def _np_area_tab(ssize, dsize):
+    """computeResizeAreaTab, per destination index: [(source index, float32 weight)] in table order."""
+    scale = ssize / dsize
+    out = []
+    for dx in range(dsize):
+        fsx1 = dx * scale; fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1 = int(np.ceil(fsx1)); sx2 = min(int(np.floor(fsx2)), ssize - 1); sx1 = min(sx1, sx2)
+        taps = []
+        if sx1 - fsx1 > 1e-3:
+            taps.append((sx1 - 1, np.float32((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            taps.append((sx, np.float32(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            taps.append((sx2, np.float32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+        out.append(taps)
+    return out
+
+
+@pytest.mark.parametrize("src_shape,dst_shape", [((144, 256), (27, 48)), ((96, 171), (27, 48)), ((120, 192), (27, 48)), ((72, 128), (27, 48)), ((61, 97), (60, 96))])
+def test_area_resize_fractional_matches_independent_numpy_restatement(oracle, src_shape, dst_shape):
+    """resizeArea_ for non-integer scales (1440p-, 1200p-, 720p-like ratios and a barely-above-one scale), restated with whole-row float32
+    arithmetic in the table's order: horizontal pass per source row (buf += S * alpha), vertical accumulation (sum += beta * buf), round half
+    to even -- bit-identical to oracle/imgproc.cpp."""
+    f32 = np.float32
+    src = np.random.default_rng(src_shape[1]).integers(0, 256, src_shape, dtype=np.uint8)
+    xt, yt = _np_area_tab(src_shape[1], dst_shape[1]), _np_area_tab(src_shape[0], dst_shape[0])
+    kx = max(len(t) for t in xt)
+    xi = np.array([[t[min(k, len(t) - 1)][0] for k in range(kx)] for t in xt])                       # [dcols, kx]
+    xa = np.array([[t[k][1] if k < len(t) else f32(0) for k in range(kx)] for t in xt], f32)
+    want = np.zeros(dst_shape, np.uint8)
+    for dy, taps in enumerate(yt):
+        total = np.zeros(dst_shape[1], f32)
+        for sy, beta in taps:
+            row = src[sy].astype(f32)
+            buf = np.zeros(dst_shape[1], f32)
+            for k in range(kx):
+                buf = (buf + row[xi[:, k]] * xa[:, k]).astype(f32)                                   # a tap beyond the list adds v * 0
+            total = (total + beta * buf).astype(f32)
+        want[dy] = np.clip(np.rint(total), 0, 255).astype(np.uint8)
+    assert np.array_equal(oracle.luma_area_resize(src, *dst_shape), want)
