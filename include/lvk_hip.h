@@ -155,7 +155,8 @@ int  lvk_hip_mesh_solver_solve(lvk_hip_mesh_solver* solver, const float* tracked
 /* ---- a3/a4: luma + INTER_AREA downscale ---------------------------------------------------------------
  * VideoFrame::viewAsFormat(GRAY) for YUV frames (= channel 0, Data/VideoFrame.cpp:260) fused with
  * cv::resize(gray, detection_resolution, INTER_AREA) (Vision/FrameTracker.cpp:117).
- * pix_stride = bytes per source pixel (3 packed 8UC3, 1 planar); d_dst is 8UC1 drows x dcols. */
+ * pix_stride = bytes per source pixel (3 packed 8UC3, 1 planar); d_dst is 8UC1 drows x dcols.  Any pair of sizes: integer and fractional
+ * reductions, and (a frame smaller than the detection resolution) cv::resize's bilinear emulation of INTER_AREA towards a larger image. */
 int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
                              int srows, int scols, void* d_dst, int dst_step, int drows, int dcols);
 

@@ -73,6 +73,7 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
     for (auto& kv : ctx->lintabs) (void)hipFree(kv.second);
     for (auto& kv : ctx->lin8tabs) (void)hipFree(kv.second);
     for (auto& kv : ctx->areatabs) { (void)hipFree(kv.second.range); (void)hipFree(kv.second.tab); }
+    for (auto& kv : ctx->enlargetabs) (void)hipFree(kv.second);
     for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
     for (hipEvent_t e : ctx->wait_events) (void)hipEventDestroy(e);
     {

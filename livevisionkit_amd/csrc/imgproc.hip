@@ -55,6 +55,25 @@ void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, 
     dst[(long)y * dst_step + x] = out;
 }
 
+// ---- INTER_AREA towards a LARGER image (a frame smaller than the detection resolution on either axis) -----------------------------------
+// cv::resize emulates it "using some variant of bilinear interpolation": two taps per axis with AREA coefficients in 11-bit fixed point
+// (imgproc/resize.cpp: cv::hal::resize with area_mode, HResizeLinear, VResizeLinear<uchar>); the tables hold, per destination index, the
+// two source indices (the second one clamped) and the two weights -- see build_enlarge_tab and oracle/imgproc.cpp.
+__global__ __launch_bounds__(256)
+void k_area_enlarge(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
+                    uint8_t* __restrict__ dst, int dst_step, int drows, int dcols, const int4* __restrict__ xtab, const int4* __restrict__ ytab)
+{
+    LVK_TRACKER_PRIORITY();
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dcols || y >= drows) return;
+    const int4 tx = xtab[x], ty = ytab[y];
+    const uint8_t* r0 = src + (long)ty.x * src_step; const uint8_t* r1 = src + (long)ty.y * src_step;
+    const int h0 = gray_of(r0 + (long)tx.x * pix_stride, channel) * tx.z + gray_of(r0 + (long)tx.y * pix_stride, channel) * tx.w;
+    const int h1 = gray_of(r1 + (long)tx.x * pix_stride, channel) * tx.z + gray_of(r1 + (long)tx.y * pix_stride, channel) * tx.w;
+    dst[(long)y * dst_step + x] = (uint8_t)((((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2);
+}
+
 // Same arithmetic, specialised for the stabilizer's cases (4K: 8x8, 1080p: 4x4; packed 8UC3 channel 0 or planar): every
 // source row segment of a destination pixel is SX * PIX contiguous bytes = whole aligned dwords, so the SY * SX * PIX / 4
 // loads of a thread are independent and issued back to back (the generic kernel's byte loads in a runtime-bound loop
@@ -415,7 +434,50 @@ void build_area_tab(int ssize, int dsize, std::vector<int2>& range, std::vector<
     }
 }
 
+// cv::hal::resize, area_mode with ksize = 2: s = floor(d * scale), f = (d + 1) - (s + 1) * inv_scale, f = f <= 0 ? 0 : f - floor(f);
+// weights saturate_cast<short>((1 - f) * 2048), saturate_cast<short>(f * 2048); from the first index whose second tap would leave the
+// source on, the single tap S[ssize - 1] * 2048 (HResizeLinear's tail; the rows are clamped the same way, with their weights kept).
+void build_enlarge_tab(int ssize, int dsize, bool horizontal, std::vector<int4>& tab)
+{
+    const double inv = (double)dsize / ssize, scale = 1. / inv;
+    auto to_short = [](float v) -> int { const long r = lrintf(v); return (int)(r < -32768 ? -32768 : r > 32767 ? 32767 : r); };
+    tab.resize((size_t)dsize);
+    bool tail = false;
+    for (int d = 0; d < dsize; d++)
+    {
+        int s0 = (int)std::floor(d * scale);
+        float f = (float)((d + 1) - (s0 + 1) * inv);
+        f = f <= 0 ? 0.f : f - std::floor(f);
+        if (horizontal)
+        {
+            if (s0 < 0) { f = 0; s0 = 0; }
+            if (s0 + 1 >= ssize) { tail = true; if (s0 >= ssize - 1) { f = 0; s0 = ssize - 1; } }
+            const int w0 = tail ? 2048 : to_short((1.f - f) * 2048.f), w1 = tail ? 0 : to_short(f * 2048.f);
+            tab[(size_t)d] = make_int4(s0, std::min(s0 + 1, ssize - 1), w0, w1);
+        }
+        else
+            tab[(size_t)d] = make_int4(std::min(std::max(s0, 0), ssize - 1), std::min(std::max(s0 + 1, 0), ssize - 1), to_short((1.f - f) * 2048.f), to_short(f * 2048.f));
+    }
+}
+
 } // namespace
+
+static int lvk_get_enlargetab(lvk_hip_ctx* ctx, int ssize, int dsize, bool horizontal, const int4** d_tab)
+{
+    const auto key = std::make_pair(horizontal ? ssize : -ssize, dsize);
+    auto it = ctx->enlargetabs.find(key);
+    if (it == ctx->enlargetabs.end())
+    {
+        std::vector<int4> tab;
+        build_enlarge_tab(ssize, dsize, horizontal, tab);
+        int4* dev = nullptr;
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&dev, tab.size() * sizeof(int4)));
+        LVK_HIP_CHECK(ctx, hipMemcpy(dev, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice));
+        it = ctx->enlargetabs.emplace(key, dev).first;
+    }
+    *d_tab = it->second;
+    return LVK_HIP_OK;
+}
 
 int lvk_get_areatab(lvk_hip_ctx* ctx, int ssize, int dsize, const int2** d_range, const AreaTabEntry** d_tab, int* max_taps, int* span64, int* span4)
 {
@@ -453,11 +515,18 @@ int lvk_launch_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_ste
 {
     LVK_HIP_REQUIRE(ctx, d_src && d_dst && srows > 0 && scols > 0 && drows > 0 && dcols > 0);
     LVK_HIP_REQUIRE(ctx, pix_stride >= 1 && channel >= -2 && channel < pix_stride && (channel >= 0 || pix_stride >= 3));
-    // the tracker only downscales (FrameTracker.cpp:117); cv::resize(INTER_AREA) ENLARGES with a bilinear variant that is not on this path
-    if (drows > srows || dcols > scols)
-        return ctx->fail(LVK_HIP_ERR_ARG, "frame (" + std::to_string(scols) + " x " + std::to_string(srows) + ") smaller than the detection resolution (" +
-                                          std::to_string(dcols) + " x " + std::to_string(drows) + "): INTER_AREA enlargement is not supported, lower detection_resolution");
     const dim3 block(64, 4), grid((dcols + 63) / 64, (drows + 3) / 4);
+    if (drows > srows || dcols > scols)
+    {
+        // a frame smaller than the detection resolution on either axis (FrameTracker.cpp:117 resizes whatever it is given)
+        const int4 *xt, *yt;
+        int rc;
+        if ((rc = lvk_get_enlargetab(ctx, scols, dcols, true, &xt)) != LVK_HIP_OK) return rc;
+        if ((rc = lvk_get_enlargetab(ctx, srows, drows, false, &yt)) != LVK_HIP_OK) return rc;
+        hipLaunchKernelGGL(k_area_enlarge, grid, block, 0, ctx->stream, (const uint8_t*)d_src, src_step, pix_stride, channel, (uint8_t*)d_dst, dst_step, drows, dcols, xt, yt);
+        LVK_HIP_CHECK(ctx, hipGetLastError());
+        return LVK_HIP_OK;
+    }
     const int isx = scols / dcols, isy = srows / drows;
     const bool exact = scols % dcols == 0 && srows % drows == 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && (src_step & 3) == 0;

@@ -67,6 +67,8 @@ struct lvk_hip_ctx
     // max_taps: longest tap list of one destination index; span64 / span4: most source samples under 64 / 4 consecutive destination indices
     struct AreaTabDev { int2* range = nullptr; AreaTabEntry* tab = nullptr; int max_taps = 0, span64 = 0, span4 = 0; };
     std::map<std::pair<int, int>, AreaTabDev> areatabs;
+    // Cached tables of the INTER_AREA ENLARGEMENT (2 taps per destination index, 11-bit fixed point): key = (source extent, destination extent)
+    std::map<std::pair<int, int>, int4*> enlargetabs;        // per destination index: (s0, s1, w0, w1)
 
     int fail(int code, const std::string& msg) { last_error = msg; return code; }
 };

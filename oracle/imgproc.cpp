@@ -80,7 +80,48 @@ int lvko_luma_area_resize(const uint8_t* src, int src_step, int pix_stride, int 
         for (int y = 0; y < drows; y++) for (int x = 0; x < dcols; x++) dst[(size_t)y * dst_step + x] = (uint8_t)S(y, x);
         return 0;
     }
-    if (dcols > scols || drows > srows) return -2;           // the tracker only ever downscales (INTER_AREA upscale == linear; not on the path)
+    if (dcols > scols || drows > srows)
+    {
+        // A frame smaller than the detection resolution on either axis.  cv::resize: "true area interpolation is only implemented for the case
+        // (scale_x >= 1 && scale_y >= 1); in other cases it is emulated using some variant of bilinear interpolation" -- the INTER_LINEAR
+        // machinery (2 taps per axis, fixed point for 8U: INTER_RESIZE_COEF_BITS = 11) with AREA coefficients, on both axes:
+        //   sx = floor(dx * scale); fx = (dx + 1) - (sx + 1) * inv_scale; fx = fx <= 0 ? 0 : fx - floor(fx)
+        //   taps (sx, sx + 1) with weights saturate_cast<short>((1 - fx) * 2048), saturate_cast<short>(fx * 2048); past the last source column
+        //   (sx + 1 >= cols, and every dx after the first such one) the single tap S[min(sx, cols - 1)] * 2048; rows sy and sy + 1 clamped to rows - 1
+        //   HResizeLinear: int D = S[sx] * a0 + S[sx + 1] * a1;  VResizeLinear (8U): (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+        // (imgproc/resize.cpp: cv::hal::resize, HResizeLinear, VResizeLinear<uchar, int, short, FixedPtCast<...>>; restated from the published
+        // source, not part of /root/reference: parity unpinned like the other OpenCV stages.)
+        const double inv_x = (double)dcols / scols, inv_y = (double)drows / srows, sc_x = 1. / inv_x, sc_y = 1. / inv_y;
+        auto coef = [](int d, double scale, double inv, int& s0, float& f) {
+            s0 = (int)std::floor(d * scale);
+            f = (float)((d + 1) - (s0 + 1) * inv);
+            f = f <= 0 ? 0.f : f - std::floor(f);
+        };
+        auto to_short = [](float v) -> int { long r = lrintf(v); return (int)(r < -32768 ? -32768 : r > 32767 ? 32767 : r); };
+        std::vector<int> xofs(dcols), xa0(dcols), xa1(dcols);
+        int xmax = dcols;
+        for (int dx = 0; dx < dcols; dx++)
+        {
+            int sx; float fx; coef(dx, sc_x, inv_x, sx, fx);
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx + 1 >= scols) { xmax = std::min(xmax, dx); if (sx >= scols - 1) { fx = 0; sx = scols - 1; } }
+            xofs[dx] = sx; xa0[dx] = to_short((1.f - fx) * 2048.f); xa1[dx] = to_short(fx * 2048.f);
+        }
+        for (int dy = 0; dy < drows; dy++)
+        {
+            int sy; float fy; coef(dy, sc_y, inv_y, sy, fy);
+            const int b0 = to_short((1.f - fy) * 2048.f), b1 = to_short(fy * 2048.f);
+            const int y0 = std::min(std::max(sy, 0), srows - 1), y1 = std::min(std::max(sy + 1, 0), srows - 1);
+            for (int dx = 0; dx < dcols; dx++)
+            {
+                int r0, r1;
+                if (dx < xmax) { r0 = S(y0, xofs[dx]) * xa0[dx] + S(y0, xofs[dx] + 1) * xa1[dx]; r1 = S(y1, xofs[dx]) * xa0[dx] + S(y1, xofs[dx] + 1) * xa1[dx]; }
+                else { r0 = S(y0, xofs[dx]) * 2048; r1 = S(y1, xofs[dx]) * 2048; }
+                dst[(size_t)dy * dst_step + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+        return 0;
+    }
     const double scale_x = (double)scols / dcols, scale_y = (double)srows / drows;
     const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
     const bool fast = std::fabs(scale_x - iscale_x) < 2.220446049250313e-16 && std::fabs(scale_y - iscale_y) < 2.220446049250313e-16;

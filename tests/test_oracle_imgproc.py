@@ -288,3 +288,33 @@ def test_area_resize_fractional_matches_independent_numpy_restatement(oracle, sr
             total = (total + beta * buf).astype(f32)
         want[dy] = np.clip(np.rint(total), 0, 255).astype(np.uint8)
     assert np.array_equal(oracle.luma_area_resize(src, *dst_shape), want)
+
+
+def _np_enlarge_axis(ssize, dsize, horizontal):
+    """cv::hal::resize with area_mode and ksize = 2 (the INTER_AREA "enlargement" of imgproc/resize.cpp), one axis: (s0, s1, w0, w1) per index."""
+    f32 = np.float32
+    inv = dsize / ssize; scale = 1.0 / inv
+    s0 = np.floor(np.arange(dsize) * scale).astype(np.int64)
+    f = ((np.arange(dsize) + 1) - (s0 + 1) * inv).astype(f32)
+    f = np.where(f <= 0, f32(0), f - np.floor(f)).astype(f32)
+    w0 = np.clip(np.rint((f32(1) - f) * f32(2048)), -32768, 32767).astype(np.int64)
+    w1 = np.clip(np.rint(f * f32(2048)), -32768, 32767).astype(np.int64)
+    if horizontal:
+        tail = np.maximum.accumulate(s0 + 1 >= ssize)                 # from the first index whose second tap leaves the source: S[last] * 2048
+        w0 = np.where(tail, 2048, w0); w1 = np.where(tail, 0, w1)
+    return np.clip(s0, 0, ssize - 1), np.clip(s0 + 1, 0, ssize - 1), w0, w1
+
+
+@pytest.mark.parametrize("src_shape,dst_shape", [((180, 320), (270, 480)), ((135, 240), (270, 480)), ((200, 300), (270, 480)), ((400, 300), (270, 480)),
+                                                 ((100, 640), (270, 480)), ((269, 479), (270, 480)), ((7, 5), (33, 47))])
+def test_area_resize_enlargement_matches_independent_numpy_restatement(oracle, src_shape, dst_shape):
+    """A frame smaller than the detection resolution on either axis (FrameTracker.cpp:117 resizes whatever it gets): cv::resize's bilinear
+    emulation of INTER_AREA -- 2 taps per axis, 11-bit fixed point -- restated with whole-image integer arithmetic.  2x enlargement replicates."""
+    src = np.random.default_rng(src_shape[0] * 7 + src_shape[1]).integers(0, 256, src_shape, dtype=np.uint8).astype(np.int64)
+    x0, x1, a0, a1 = _np_enlarge_axis(src_shape[1], dst_shape[1], True)
+    y0, y1, b0, b1 = _np_enlarge_axis(src_shape[0], dst_shape[0], False)
+    h = src[:, x0] * a0[None, :] + src[:, x1] * a1[None, :]                          # HResizeLinear, every source row
+    want = ((((b0[:, None] * (h[y0] >> 4)) >> 16) + ((b1[:, None] * (h[y1] >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(oracle.luma_area_resize(src.astype(np.uint8), *dst_shape), want)
+    if src_shape == (135, 240):
+        assert np.array_equal(want, src.astype(np.uint8).repeat(2, 0).repeat(2, 1))

@@ -177,15 +177,40 @@ def test_stabilizer_field_preset_large_motion_resolution(ctx, oracle, clip, mesh
     assert _run_pair(oracle, ctx, frames[:12], oracle_lib.preset("default"), then_configure=field, overlap=mesh == (32, 32)) == 9
 
 
-def test_frame_below_the_detection_resolution_is_refused_with_a_message(ctx):
-    """FrameTracker.cpp:117 resizes to detection_resolution with INTER_AREA; this path builds the downscale only and says so."""
+@pytest.mark.parametrize("size", [(180, 320), (300, 400)])
+def test_frames_below_the_detection_resolution_bit_exact(ctx, oracle, size):
+    """FrameTracker.cpp:117 resizes whatever it is given to detection_resolution: a frame SMALLER than 480 x 270 on one or both axes goes through
+    cv::resize's bilinear emulation of INTER_AREA (k_area_enlarge); the stream matches the oracle frame by frame, packed and 4:2:0."""
     import torch
     import livevisionkit_amd as lvk
-    gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
-    small = torch.zeros((180, 320, 3), dtype=torch.uint8, device="cuda")
-    with pytest.raises(Exception, match="smaller than the detection resolution"):
-        gst.apply(small, timestamp=0)
-    gst.close()
+    rows, cols = size
+    frames, _ = synth.make_clip(rows, cols, 12, seed=rows, jitter=0.6)
+    s = oracle_lib.preset("homography", predictive_samples=2, min_scene_quality=0.3, min_tracking_quality=0.2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    ost2 = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    gst2 = lvk.StabilizationFilter(_to_settings(s), context=ctx); gst2.set_overlap(True)
+    emitted = tracked = 0
+    for i, f in enumerate(frames):
+        want, _ = ost.push(f, ts=i)
+        got, _ = gst.apply(torch.from_numpy(f).cuda(), timestamp=i)
+        ctx.sync()
+        assert (want is None) == (got is None), i
+        assert np.array_equal(gst.features(), ost.features()), i
+        tracked = max(tracked, len(ost.features()))
+        if want is not None:
+            assert np.array_equal(got.cpu().numpy(), want), i
+            emitted += 1
+        planes = oracle.egress_yuv420(f)
+        want2, _ = ost2.push(oracle.ingest_yuv420(*planes), ts=i)
+        got2, _ = gst2.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)
+        ctx.sync()
+        if want2 is not None:
+            for a, b in zip(got2, oracle.egress_yuv420(want2)):
+                assert np.array_equal(a.cpu().numpy(), b), i
+    assert emitted == 10 and tracked > 80
+    for x in (ost, ost2, gst, gst2):
+        x.close()
 
 
 def test_refused_configure_leaves_the_filter_untouched(ctx, oracle, clip):

@@ -47,6 +47,19 @@ def test_luma_area_resize_fractional_scales_planar(ctx, oracle, src_size, dst_si
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("src_size,dst_size", [((180, 320), (270, 480)), ((135, 240), (270, 480)), ((200, 300), (270, 480)), ((400, 300), (270, 480)),
+                                               ((100, 640), (270, 480)), ((269, 479), (270, 480)), ((7, 5), (33, 47))])
+@pytest.mark.parametrize("packed", [False, True])
+def test_luma_area_resize_enlargement(ctx, oracle, src_size, dst_size, packed):
+    """INTER_AREA towards a larger image on one or both axes (cv::resize's bilinear emulation): k_area_enlarge against the oracle."""
+    rng = np.random.default_rng(src_size[0] + 3)
+    frame = rng.integers(0, 256, src_size + ((3,) if packed else ()), dtype=np.uint8)
+    want = oracle.luma_area_resize(frame, *dst_size)
+    got = ctx.luma_area_resize(_gpu(frame), *dst_size)
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("shape", [(270, 480), (135, 240), (68, 120), (33, 47), (256, 256)])
 def test_pyr_down_and_scharr(ctx, oracle, shape):
     img = np.random.default_rng(shape[1]).integers(0, 256, shape, dtype=np.uint8)
