@@ -58,7 +58,7 @@ void k_area_fast(const uint8_t* __restrict__ src, int src_step, int pix_stride, 
 // ---- INTER_AREA towards a LARGER image (a frame smaller than the detection resolution on either axis) -----------------------------------
 // cv::resize emulates it "using some variant of bilinear interpolation": two taps per axis with AREA coefficients in 11-bit fixed point
 // (imgproc/resize.cpp: cv::hal::resize with area_mode, HResizeLinear, VResizeLinear<uchar>); the tables hold, per destination index, the
-// two source indices (the second one clamped) and the two weights -- see build_enlarge_tab and oracle/imgproc.cpp.
+// two source indices (the second one clamped) and the two weights -- see build_enlarge_tab.
 __global__ __launch_bounds__(256)
 void k_area_enlarge(const uint8_t* __restrict__ src, int src_step, int pix_stride, int channel,
                     uint8_t* __restrict__ dst, int dst_step, int drows, int dcols, const int4* __restrict__ xtab, const int4* __restrict__ ytab)
