@@ -152,7 +152,7 @@ def test_fused_stabilizer_tracks_like_the_two_pass_chain(oracle):
     """End to end on a lens-distorted shaky clip: the fused filter's per-frame motion meshes stay close to those of the
     reference chain (LC remap, then the plain filter), and its output is the same picture."""
     from tests import oracle_lib
-    rows, cols, n = 180, 320, 12
+    rows, cols, n = 270, 480, 12        # (at 180 x 320 this test used to pass on two filters that tracked nothing: the oracle refused to enlarge the tracking frame)
     frames, _ = synth.make_clip(rows, cols, n, seed=5)
     params = LENS(rows, cols)
     corrected_of_raw = oracle.lens_undistort_points(params, rows, cols, 1.0, 1.0, _grid(rows, cols).reshape(-1, 2)).reshape(rows, cols, 2)
@@ -160,18 +160,24 @@ def test_fused_stabilizer_tracks_like_the_two_pass_chain(oracle):
     off, _ = oracle.lens_offset_map(params, rows, cols)
     s = oracle_lib.preset("homography", predictive_samples=3)
     two = oracle_lib.OracleStabilizer(oracle, s); one = oracle_lib.OracleStabilizer(oracle, s)
-    one.set_lens(params)
-    produced = 0
+    one.set_lens(params)                 # (restarts the filter: m_SceneQuality = 1, StabilizationFilter.cpp:138-143)
+    two.restart()                        # the same quality-assurance state for the chain it is compared with
+    produced = moving = 0
     for i in range(n):
         a, _ = two.push(oracle.remap_map(raw[i], off, bg=(0, 0, 0)), ts=i)
         b, _ = one.push(raw[i], ts=i)
         assert (a is None) == (b is None)
         ma, _ = two.meshes(); mb, _ = one.meshes()
-        assert np.abs(ma - mb).max() < 2e-3, i                  # normalised offsets: < 0.7 px at this width
+        # (a frame on which one of the two trackers falls below min_tracking_quality has its motion zeroed by the quality assurance: compared
+        #  are the frames on which both delivered one)
+        both = bool(np.abs(ma).max() > 0 and np.abs(mb).max() > 0)
+        moving += both
+        if both:
+            assert np.abs(ma - mb).max() < 2e-3, i              # normalised offsets: < 1 px at this width
         if a is not None:
             produced += 1
             assert synth.psnr(a[16:-16, 16:-16], b[16:-16, 16:-16]) > 27.0, i
-    assert produced == n - 3
+    assert produced == n - 3 and moving >= 4                 # both filters really tracked (the trust factor leaves zero after ~7 frames)
     two.close(); one.close()
 
 
