@@ -23,7 +23,8 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "18"))):
     small, _ = synth.make_clip(rows // 2, cols // 2, n, seed=trial + 100, jitter=1.0)
     frames = np.ascontiguousarray(small.repeat(2, axis=1).repeat(2, axis=2))
     delay = int(rng.integers(1, 5))
-    s = oracle_lib.preset("homography" if trial % 4 else "field", predictive_samples=delay)
+    # relaxed quality assurance: the trust factor leaves zero after ~5 frames, so the emitted planes depend on what the tracker found
+    s = oracle_lib.preset("homography" if trial % 4 else "field", predictive_samples=delay, min_scene_quality=0.3, min_tracking_quality=0.2)
     if trial % 4 == 0:
         s.motion_width, s.motion_height = [(16, 16), (12, 10), (17, 17), (9, 14), (16, 9), (6, 20)][(trial // 4) % 6]
     entry = ("device", "host", "host+lookahead")[(trial // 2) % 3]

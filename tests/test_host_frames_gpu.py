@@ -26,7 +26,7 @@ def test_host_push_matches_the_oracle(ctx, oracle, monkeypatch, sink, nv12):
         monkeypatch.setenv("LVK_HIP_HOST_SINK", sink)
     rows, cols, n = 540, 960, 14
     frames, _ = synth.make_clip(rows, cols, n, seed=31, jitter=1.0)
-    so = oracle_lib.preset("homography", predictive_samples=3)
+    so = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)      # (the trust factor leaves zero: real homographies)
     ost = oracle_lib.OracleStabilizer(oracle, so)
     gst = lvk.StabilizationFilter(_settings(lvk, so), context=ctx)
     gst.set_overlap(True)
@@ -65,7 +65,7 @@ def test_host_push_equals_device_push_at_4k(ctx, preset, monkeypatch):
     clip = clipgen.Clip(rows, cols, n, device="cuda")
     planes = [clip.render_i420(i) for i in range(n)]
     torch.cuda.synchronize()
-    s = lvk.StabilizationFilterSettings.obs_preset(preset, predictive_samples=4)
+    s = lvk.StabilizationFilterSettings.obs_preset(preset, strict=False, predictive_samples=4)       # relaxed QA: the outputs depend on the tracker
 
     def device_run():
         f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); f.configure(s); f.set_overlap(True)

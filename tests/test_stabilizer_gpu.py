@@ -385,10 +385,11 @@ def test_overlap_yuv420_full_size_persistent_grid_bit_exact(ctx, oracle, size, n
     import torch
     import livevisionkit_amd as lvk
     rows, cols = size
-    n = 7
+    n = 9
     small, _ = synth.make_clip(rows // 4, cols // 4, n, seed=rows + 1, jitter=1.0)
     frames = np.ascontiguousarray(small.repeat(4, axis=1).repeat(4, axis=2))
-    s = oracle_lib.preset("homography", predictive_samples=2)
+    # relaxed quality assurance: the trust factor leaves zero at the fifth frame, the later remaps apply a real homography
+    s = oracle_lib.preset("homography", predictive_samples=2, min_scene_quality=0.3, min_tracking_quality=0.2)
     ost = oracle_lib.OracleStabilizer(oracle, s)
     gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
     gst.set_overlap(True)
@@ -402,7 +403,7 @@ def test_overlap_yuv420_full_size_persistent_grid_bit_exact(ctx, oracle, size, n
         if want is not None:
             wants.append(oracle.egress_yuv420(want, nv12=nv12)); gots.append(got)
     ctx.sync()
-    assert len(wants) == n - 2
+    assert len(wants) == n - 2 and ost.stats().trust > 0.1
     for i, (w, g) in enumerate(zip(wants, gots)):
         for a, b in zip(g, w):
             assert np.array_equal(a.cpu().numpy(), b), (size, i)
