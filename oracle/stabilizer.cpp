@@ -11,6 +11,8 @@
 #include "parallel.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <deque>
@@ -285,7 +287,12 @@ struct Tracker
         prev.swap(cur); std::swap(prev_w, cur_w); std::swap(prev_h, cur_h);
         cur_w = s.detection_width; cur_h = s.detection_height;
         cur.resize((size_t)cur_w * cur_h);
-        lvko_luma_area_resize(frame, step, pix_stride, luma_channel, rows, cols, cur.data(), cur_w, cur_h, cur_w);
+        if (lvko_luma_area_resize(frame, step, pix_stride, luma_channel, rows, cols, cur.data(), cur_w, cur_h, cur_w) != 0)
+        {
+            // (a refused resize used to leave the tracking frame empty and the filter silently tracking nothing: a test ran on that for two rounds)
+            std::fprintf(stderr, "lvk oracle: the tracking-frame resize refused a %d x %d frame\n", cols, rows);
+            std::abort();
+        }
         last_detected = last_matched = 0; last_distribution = 0.0f; last_estimator = 0;
         if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return false; }
 
