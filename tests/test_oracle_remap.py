@@ -63,27 +63,39 @@ def test_oracle_matches_independent_numpy_restatement_homography(oracle, yuv):
         assert (d == 0).mean() > 0.9995
 
 
-def test_mesh_map_matches_numpy_bilinear(oracle):
+@pytest.mark.parametrize("mesh_shape,size", [((5, 7), (45, 80)), ((2, 2), (37, 53)), ((16, 16), (270, 480)), ((17, 9), (33, 200)), ((3, 31), (64, 48))])
+def test_mesh_map_matches_numpy_bilinear(oracle, mesh_shape, size):
+    """WarpMesh::apply's dense map (WarpMesh.cpp:190-191: cv::resize of the CV_32FC2 offsets, then * frame size): the float INTER_LINEAR machinery
+    (imgproc/resize.cpp: fx = (float)((dx + 0.5) * scale - 0.5), taps (sx, sx + 1) with weights (1 - fx, fx), S[sx] * 1 past the last column,
+    rows clipped individually) restated with whole-array float32 arithmetic in the same order -- bit-identical to the oracle."""
+    f32 = np.float32
     rng = np.random.default_rng(11)
-    mesh = synth.random_mesh(5, 7, rng)
-    rows, cols = 45, 80
+    mesh = synth.random_mesh(mesh_shape[0], mesh_shape[1], rng)
+    rows, cols = size
     m = oracle.mesh_to_map(mesh, rows, cols)
-    # independent evaluation of cv::resize(INTER_LINEAR) semantics in float64, then compared loosely
+
     def axis(msize, fsize, vertical):
-        d = np.arange(fsize)
-        f = ((d + 0.5) * (msize / fsize) - 0.5).astype(np.float32)
-        s = np.floor(f).astype(np.int64); fr = (f - s).astype(np.float64)
+        scale = 1.0 / (fsize / msize)
+        f = ((np.arange(fsize) + 0.5) * scale - 0.5).astype(f32)
+        s = np.floor(f).astype(np.int64); f = (f - s.astype(f32)).astype(f32)
         if vertical:
-            return np.clip(s, 0, msize - 1), np.clip(s + 1, 0, msize - 1), fr
-        lo = s < 0; fr[lo] = 0; s[lo] = 0
-        hi = s >= msize - 1; fr[hi] = 0; s[hi] = msize - 1
-        return s, np.minimum(s + 1, msize - 1), fr
-    x0, x1, fx = axis(7, cols, False); y0, y1, fy = axis(5, rows, True)
-    M = mesh.astype(np.float64)
-    top = M[y0][:, x0] * (1 - fx)[None, :, None] + M[y0][:, x1] * fx[None, :, None]
-    bot = M[y1][:, x0] * (1 - fx)[None, :, None] + M[y1][:, x1] * fx[None, :, None]
-    ref = (top * (1 - fy)[:, None, None] + bot * fy[:, None, None]) * np.array([cols, rows])
-    assert np.abs(m - ref).max() < 1e-4
+            return np.clip(s, 0, msize - 1), np.clip(s + 1, 0, msize - 1), (f32(1) - f).astype(f32), f
+        lo = s < 0; f[lo] = 0; s[lo] = 0
+        single = s + 1 >= msize
+        s = np.minimum(s, msize - 1)
+        return s, np.where(single, s, s + 1), np.where(single, f32(1), f32(1) - f).astype(f32), np.where(single, f32(0), f).astype(f32), single
+    x0, x1, a0, a1, single = axis(mesh_shape[1], cols, False)
+    y0, y1, b0, b1 = axis(mesh_shape[0], rows, True)
+    M = mesh.astype(f32)
+
+    def hresize(rows_of):
+        two = (rows_of[:, x0] * a0[None, :, None]).astype(f32) + (rows_of[:, x1] * a1[None, :, None]).astype(f32)
+        one = (rows_of[:, x0] * f32(1)).astype(f32)
+        return np.where(single[None, :, None], one, two.astype(f32)).astype(f32)
+    h0, h1 = hresize(M[y0]), hresize(M[y1])
+    v = ((h0 * b0[:, None, None]).astype(f32) + (h1 * b1[:, None, None]).astype(f32)).astype(f32)
+    want = (v * np.array([cols, rows], f32)).astype(f32)
+    assert np.array_equal(m, want)
 
 
 def test_oracle_mesh_remap_equals_map_remap(oracle):
