@@ -318,3 +318,51 @@ def test_area_resize_enlargement_matches_independent_numpy_restatement(oracle, s
     assert np.array_equal(oracle.luma_area_resize(src.astype(np.uint8), *dst_shape), want)
     if src_shape == (135, 240):
         assert np.array_equal(want, src.astype(np.uint8).repeat(2, 0).repeat(2, 1))
+
+
+def _np_linear8_axis(ssize, dsize, vertical):
+    """cv::resize 8U INTER_LINEAR, one axis: taps and 11-bit weights (imgproc/resize.cpp; the rows are clipped individually, the columns fold the
+    tail into a single tap of weight 2048)."""
+    f32 = np.float32
+    scale = 1.0 / (dsize / ssize)
+    f = ((np.arange(dsize) + 0.5) * scale - 0.5).astype(f32)
+    s = np.floor(f).astype(np.int64); f = (f - s.astype(f32)).astype(f32)
+    if vertical:
+        return np.clip(s, 0, ssize - 1), np.clip(s + 1, 0, ssize - 1), np.rint((f32(1) - f) * f32(2048)).astype(np.int64), np.rint(f * f32(2048)).astype(np.int64)
+    lo = s < 0; f[lo] = 0; s[lo] = 0
+    single = s + 1 >= ssize
+    s = np.minimum(s, ssize - 1)
+    return (s, np.where(single, s, s + 1), np.where(single, 2048, np.rint((f32(1) - f) * f32(2048)).astype(np.int64)),
+            np.where(single, 0, np.rint(f * f32(2048)).astype(np.int64)))
+
+
+@pytest.mark.parametrize("shape", [(36, 48), (270, 480), (38, 50), (2, 2)])
+@pytest.mark.parametrize("nv12", [False, True])
+def test_yuv420_conversions_match_independent_numpy_restatement(oracle, shape, nv12):
+    """FrameIngest's conversions either side of the filter (Interop/FrameIngest.cpp:494-602): chroma planes enlarged 2x with cv::resize(8U,
+    INTER_LINEAR) -- fixed point, phases .25 / .75 --, merged with luma; back: split, 2 x 2 area mean (a + b + c + d + 2) >> 2.  Whole-plane
+    integer arithmetic, bit-identical to oracle/ingest.cpp, I420 and NV12."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows + cols)
+    y = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    u = rng.integers(0, 256, (rows // 2, cols // 2), dtype=np.uint8); v = rng.integers(0, 256, (rows // 2, cols // 2), dtype=np.uint8)
+    x0, x1, a0, a1 = _np_linear8_axis(cols // 2, cols, False)
+    y0, y1, b0, b1 = _np_linear8_axis(rows // 2, rows, True)
+
+    def enlarge(p):
+        p = p.astype(np.int64)
+        h = p[:, x0] * a0[None, :] + p[:, x1] * a1[None, :]
+        return ((((b0[:, None] * (h[y0] >> 4)) >> 16) + ((b1[:, None] * (h[y1] >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    want = np.stack([y, enlarge(u), enlarge(v)], -1)
+    got = oracle.ingest_yuv420(y, np.stack([u, v], -1)) if nv12 else oracle.ingest_yuv420(y, u, v)
+    assert np.array_equal(got, want)
+    # and back
+    frame = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    f = frame.astype(np.int64)
+    mean = lambda c: ((f[0::2, 0::2, c] + f[0::2, 1::2, c] + f[1::2, 0::2, c] + f[1::2, 1::2, c] + 2) >> 2).astype(np.uint8)
+    planes = oracle.egress_yuv420(frame, nv12=nv12)
+    assert np.array_equal(planes[0], frame[..., 0])
+    if nv12:
+        assert np.array_equal(planes[1][..., 0], mean(1)) and np.array_equal(planes[1][..., 1], mean(2))
+    else:
+        assert np.array_equal(planes[1], mean(1)) and np.array_equal(planes[2], mean(2))
