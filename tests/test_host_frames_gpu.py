@@ -163,3 +163,43 @@ def test_pageable_planes_are_refused_with_a_message(ctx):
     f.apply_yuv420_host_prepared(pg, 0, po)
     ctx.sync()
     f.close()
+
+
+def test_host_and_device_pushes_mixed_in_one_stream(ctx):
+    """lvk_hip.h: the host entry point shares the frame queue with lvk_hip_stab_push_yuv420, 'the two may be mixed'.  Even frames through the
+    host entry (pinned planes in and out), odd frames through the device entry, free running; every emitted frame equals the all-device run."""
+    import torch
+    import livevisionkit_amd as lvk
+    rows, cols, n = 720, 1280, 18
+    clip = clipgen.Clip(rows, cols, n, device="cuda")
+    planes = [clip.render_i420(i) for i in range(n)]
+    torch.cuda.synchronize()
+    s = lvk.StabilizationFilterSettings.obs_preset("homography", strict=False, predictive_samples=3)
+
+    def run(mixed):
+        f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); f.configure(s); f.set_overlap(True)
+        hin = [f.host_planes(rows, cols) for _ in range(n)]; hout = [f.host_planes(rows, cols) for _ in range(n)]
+        for i in range(n):
+            for d, p in zip(hin[i], planes[i]):
+                d[...] = p.cpu().numpy()
+        dout = [tuple(torch.empty_like(p) for p in planes[0]) for _ in range(n)]
+        emitted = []
+        for i in range(n):
+            if mixed and i % 2 == 0:
+                got, _ = f.apply_yuv420_host_prepared(f.prepare_yuv420_host(hin[i]), i, f.prepare_yuv420_host(hout[i]))
+                emitted.append(None if got is None else ("host", i))
+            else:
+                got, _ = f.apply_yuv420(planes[i], timestamp=i, out=dout[i])
+                emitted.append(None if got is None else ("dev", i))
+        ctx.sync()
+        outs = [None if e is None else ([np.array(p) for p in hout[e[1]]] if e[0] == "host" else [p.cpu().numpy() for p in dout[e[1]]]) for e in emitted]
+        f.close()
+        return outs
+
+    a, b = run(False), run(True)
+    assert sum(o is not None for o in a) == n - 3
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert (x is None) == (y is None), i
+        if x is not None:
+            for p, q in zip(x, y):
+                assert np.array_equal(p, q), i
