@@ -294,7 +294,8 @@ int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int ro
  * frames the filter queues live in an internal pool; a warped frame leaves through one kernel that remaps and writes the planes.
  * Input planes are consumed when the call returns; output planes are complete after lvk_hip_sync().  A filter is fed EITHER
  * through this call OR through lvk_hip_stab_push -- switching needs lvk_hip_stab_restart() (the two own their queued frames
- * differently). */
+ * differently).  When rows / cols CHANGE in the middle of a stream, tracker and path smoother carry on (as in the reference) and the frames still
+ * queued at the old size are dropped: *produced stays 0 until the delay has built up again. */
 int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
                               int rows, int cols, uint64_t timestamp,
                               void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,

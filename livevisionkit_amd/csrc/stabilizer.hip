@@ -1335,7 +1335,11 @@ int lvk_hip_stab::ensure_pool(int rows, int cols)
         // new geometry: queued pool frames of the old size stay valid until they are emitted, so only grow lazily
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
-        LVK_HIP_REQUIRE(ctx, queue.empty() || pool_all.empty());          // mixed-size YUV420 streams need a restart() in between
+        // A resolution change in the middle of a 4:2:0 stream: the frames still queued live in pool slots of the old geometry, and the
+        // caller's output planes have the new one -- they are DROPPED (the delay builds up again, `produced` stays 0 for predictive_samples
+        // pushes); tracker and path smoother carry on, as in the reference, which would also still emit those frames at their old size
+        // (StabilizationFilter.cpp:118-131 keeps whole VideoFrames in its queue).
+        if (!queue.empty() && !pool_all.empty()) { queue.clear(); pending_release = nullptr; pending_slot = -1; }
         free_pool();
         pool_rows = rows; pool_cols = cols;
         LVK_HIP_CHECK(ctx, hipMalloc(&pool_out, (size_t)rows * cols * 3));

@@ -464,9 +464,11 @@ class OracleStabilizer:
             pr = np.ascontiguousarray(params, np.float64).reshape(9)
             self.L.lvko_stab_set_lens(self.h, _p(pr, _f64p))
 
-    def push(self, frame, ts=0, nthreads=8, fmt=4):
+    def push(self, frame, ts=0, nthreads=8, fmt=4, out=None):
+        """out: a buffer for the emitted frame when it may be LARGER than the pushed one (a stream whose frame size changes: the queue
+        holds whole frames; the caller crops the buffer to the emitted frame's size, which it knows from the timestamp)."""
         frame = np.ascontiguousarray(frame, np.uint8)
-        out = np.zeros_like(frame)
+        out = np.zeros_like(frame) if out is None else out
         ots = _c.c_uint64(0)
         self.L.lvko_stab_push_fmt.restype = _c.c_int
         self.L.lvko_stab_push_fmt.argtypes = [_c.c_void_p, _u8p, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _u8p, _c.c_int,

@@ -459,3 +459,36 @@ def test_mixing_push_flavours_needs_a_restart(ctx):
     f.restart()
     f.apply(packed)
     ctx.sync(); f.close()
+
+
+def test_yuv420_resolution_change_mid_stream(ctx, oracle):
+    """A 4:2:0 stream whose frame size changes (an OBS source that is resized; VSFilter.cpp does not restart its filter): tracker and path
+    smoother carry on, the frames still queued at the old size are dropped (the reference would still emit them at their old size -- its queue
+    holds whole VideoFrames), and every frame emitted afterwards equals the oracle's frame of the same timestamp."""
+    import torch
+    import livevisionkit_amd as lvk
+    a, _ = synth.make_clip(360, 640, 10, seed=31, jitter=1.0)
+    b, _ = synth.make_clip(270, 480, 12, seed=31, jitter=1.0)
+    frames = list(a) + list(b)
+    s = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx); gst.set_overlap(True)
+    want, got = {}, {}
+    for i, f in enumerate(frames):
+        planes = oracle.egress_yuv420(f)
+        big = np.zeros((360, 640, 3), np.uint8)                                  # the oracle may emit a frame of the OLD size
+        w, wts = ost.push(oracle.ingest_yuv420(*planes), ts=i, out=big)
+        if w is not None:
+            r, c = (360, 640) if wts < 10 else (270, 480)
+            want[wts] = oracle.egress_yuv420(np.ascontiguousarray(big[:r, :c]))
+        g, gts = gst.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)
+        ctx.sync()
+        if g is not None:
+            got[gts] = [p.cpu().numpy() for p in g]
+        assert np.array_equal(gst.features(), ost.features()), i
+    assert sorted(want) == list(range(0, 19))                                   # the oracle emits every frame, old sizes included
+    assert sorted(got) == list(range(0, 7)) + list(range(10, 19))               # 7, 8, 9 were queued at the old size when it changed
+    for ts, planes in got.items():
+        for p, q in zip(planes, want[ts]):
+            assert p.shape == q.shape and np.array_equal(p, q), ts
+    ost.close(); gst.close()
