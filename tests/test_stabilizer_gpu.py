@@ -461,7 +461,8 @@ def test_mixing_push_flavours_needs_a_restart(ctx):
     ctx.sync(); f.close()
 
 
-def test_yuv420_resolution_change_mid_stream(ctx, oracle):
+@pytest.mark.parametrize("entry", ["device", "host"])
+def test_yuv420_resolution_change_mid_stream(ctx, oracle, entry):
     """A 4:2:0 stream whose frame size changes (an OBS source that is resized; VSFilter.cpp does not restart its filter): tracker and path
     smoother carry on, the frames still queued at the old size are dropped (the reference would still emit them at their old size -- its queue
     holds whole VideoFrames), and every frame emitted afterwards equals the oracle's frame of the same timestamp."""
@@ -481,10 +482,19 @@ def test_yuv420_resolution_change_mid_stream(ctx, oracle):
         if w is not None:
             r, c = (360, 640) if wts < 10 else (270, 480)
             want[wts] = oracle.egress_yuv420(np.ascontiguousarray(big[:r, :c]))
-        g, gts = gst.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)
-        ctx.sync()
-        if g is not None:
-            got[gts] = [p.cpu().numpy() for p in g]
+        if entry == "device":
+            g, gts = gst.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)
+            ctx.sync()
+            if g is not None:
+                got[gts] = [p.cpu().numpy() for p in g]
+        else:
+            hin, hout = gst.host_planes(*f.shape[:2]), gst.host_planes(*f.shape[:2])
+            for d, p in zip(hin, planes):
+                d[...] = p
+            g, gts = gst.apply_yuv420_host_prepared(gst.prepare_yuv420_host(hin), i, gst.prepare_yuv420_host(hout))
+            ctx.sync()
+            if g is not None:
+                got[gst._ots.value] = [np.array(p) for p in hout]
         assert np.array_equal(gst.features(), ost.features()), i
     assert sorted(want) == list(range(0, 19))                                   # the oracle emits every frame, old sizes included
     assert sorted(got) == list(range(0, 7)) + list(range(10, 19))               # 7, 8, 9 were queued at the old size when it changed
