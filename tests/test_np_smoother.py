@@ -76,3 +76,12 @@ def test_restart_clears_the_path(oracle):
         if out is not None:
             assert np.array_equal(correction, corr), i
     ost.close()
+
+
+def test_gaussian_kernel_convention_against_scipy():
+    """cv::getGaussianKernel(n, sigma): samples exp(-x^2 / (2 sigma^2)) centred on (n - 1) / 2, normalised to 1 -- scipy.signal.windows.gaussian is
+    the same window up to the normalisation (a third party's centre / sigma convention)."""
+    from scipy.signal.windows import gaussian
+    for n, sigma in ((21, 1.75), (7, 0.6), (9, 3.25), (2, 1.0)):
+        w = gaussian(n, std=sigma); w = w / w.sum()
+        assert np.abs(np_smoother.gaussian_kernel_f32(n, sigma).astype(np.float64) - w).max() < 1e-7
