@@ -6,6 +6,9 @@
 //   pyrDown / Scharr derivatives                  inside cv::SparsePyrLKOpticalFlow::calc, Vision/FrameTracker.cpp:140-146
 //   cv::FastFeatureDetector(TYPE_9_16, nms=true)  Vision/FeatureDetector.cpp:38-41,130-134
 // Everything here is integer arithmetic except the non-integer INTER_AREA path (binary32, no contraction).
+// Pinning (no OpenCV binary or source in this image): independent numpy restatements of every function (tests/test_oracle_imgproc.py, tests/np_pyrlk.py),
+// and third-party fixtures where the image holds an implementation -- FAST-9/16 against scikit-image's segment test (keypoints and scores equal,
+// tests/test_fast_third_party.py), the integer box mean and the bilinear alignment against scikit-image (tests/test_resize_third_party.py).
 #include "lvk_oracle.h"
 #include "parallel.h"
 
