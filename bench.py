@@ -12,7 +12,11 @@ Workload (config.workload): one 3840x2160 I420 stream per GPU, planes resident i
 cut at frame 300, ground-truth homographies and the jitter-free render); OBS "Homography" preset (tracking 480x270, 2x1 regions, 2x2
 mesh), predictive_samples = 10, auto-crop 5 %.  Beside `value`: latency (always >= 500 synchronised pushes), the live roofline of the remap
 (always >= 64 HIP-event samples inside / right after the timed region), the PCIe-inclusive rate, the picture quality against the ideal
-render for the GPU and for the CPU oracle, and the oracle timed on the host cores."""
+render for the GPU and for the CPU oracle, the oracle timed on the host cores, the reference's own remap kernel (compiled for this chip)
+timed on the same frame, short legs of the other BASELINE configurations, and K concurrent streams on this one GPU.
+
+`--gpus N` with N > 1 launched plainly (no torch.distributed.run around it) spawns its N ranks itself; whichever way it was launched, the
+line's `n_gpus` is the number of ranks that timed, and the run fails (exit code 3) when that is not --gpus."""
 import argparse
 import json
 import os
@@ -137,14 +141,47 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="keep the output remap on the tracking stream")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work of the oracle baseline")
     ap.add_argument("--quality-frames", type=int, default=90, help="frames of the picture-quality pass (GPU and oracle vs the ideal render); 0 = skip")
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="K independent streams (filters, HIP streams, clips, host threads) on every GPU: `value` is the aggregate over all of them. "
+                         "One 4K60 stream occupies < 1 %% of the GPU -- streams per device is the scaling that matters to a deployment")
+    ap.add_argument("--input", default=None, help="raw 4:2:0 file (I420, or NV12 with --format nv12) of --cols x --rows frames instead of the synthetic clip "
+                                                  "(the reference's harness reads a clip: Modules/VideoEditor/VideoProcessor.cpp:148-230)")
+    ap.add_argument("--write-input", default=None, help="write the first --pool frames of the synthetic clip to this file (raw I420 / NV12) and exit")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (1080p, lens-fused, field preset)")
+    ap.add_argument("--no-reference-kernel", action="store_true", help="skip timing the reference's compiled remap kernel (oracle/_ref) on the same frame")
+    ap.add_argument("--no-multi-stream", action="store_true", help="skip the extra leg with 4 concurrent streams on this GPU")
     return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` launched plainly: run the N ranks through torch.distributed.run ourselves (the way the driver launches N > 1),
+    check the one line they print against --gpus, and pass it on.  A multi-GPU run can then not silently degrade to one rank."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stdout.write(p.stdout)
+        raise SystemExit(p.returncode if p.returncode else 3)
+    r = json.loads(lines[0])
+    if r.get("n_gpus") != args.gpus or len(r.get("ranks", [])) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {r.get('n_gpus')} rank(s) timed\n")
+        raise SystemExit(3)
+    print(lines[0], flush=True)
+    return r
 
 
 def percentiles(x, ps=(50, 99)):
     return {"p%d" % p: float(np.percentile(x, p)) for p in ps}
 
 
-def cpu_baseline(oracle, clip, preset_name, nthreads, budget_s, fmt, lens_params, delay):
+def cpu_baseline(oracle, rig, preset_name, nthreads, budget_s, fmt, lens_params, delay):
     """The CPU oracle (a port: CPU restatement of the reference, oracle/lvk_oracle.h) timed on the host cores on a bounded sample of the
     same workload: ingest -> filter -> egress of consecutive frames of the same clip, every stage row / point-parallel."""
     from tests import oracle_lib
@@ -158,7 +195,9 @@ def cpu_baseline(oracle, clip, preset_name, nthreads, budget_s, fmt, lens_params
     oracle.set_num_threads(nthreads)
 
     def source(i):
-        f = clip.render444(i).cpu().numpy()
+        if rig.clip is None:                                 # --input: the file's own planes
+            return tuple(np.ascontiguousarray(q) for q in rig.file_planes(i))
+        f = rig.clip.render444(i).cpu().numpy()
         return oracle.egress_yuv420(f, nv12=nv12) if yuv420 else f
 
     def one(i, src):
@@ -223,19 +262,272 @@ def quality_pass(lvk, ctx, oracle, clip, preset_name, nframes, nthreads):
     return out
 
 
+class Rig:
+    """One stream: a context on a HIP stream of its own, a filter, its frames resident in HBM, and step() = one push in steady state."""
+
+    def __init__(self, lvk, local_rank, device, seed, rows, cols, preset, fmt, lens, overlap, pool, input_path=None, cut=True, pingpong=False):
+        import torch
+        from tests import clipgen
+        self.lvk, self.rows, self.cols, self.fmt, self.lens, self.preset, self.seed = lvk, rows, cols, fmt, lens, preset, seed
+        # the filter works on its own (non-blocking) stream: the process default stream would implicitly serialise with every
+        # blocking stream of the process
+        self.stream = torch.cuda.Stream(device)
+        self.ctx = lvk.Context(local_rank, stream=self.stream)
+        self.settings = lvk.StabilizationFilterSettings.obs_preset(preset)
+        # the OBS plugin's flow (VSFilter.cpp:255-293): a default-constructed filter that is then configured with the preset --
+        # constructing the "field" preset directly would keep FrameTracker's constructor-time 256x256 mesh constraints (reference quirk)
+        self.filt = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=self.ctx)
+        self.filt.configure(self.settings)
+        if overlap:
+            self.filt.set_overlap(True)          # remap of frame n-N on a second stream, concurrent with the tracking of frame n+1
+        self.delay = self.filt.frame_delay()
+        self.lens_params = (0.8 * cols, 0.8 * cols, cols / 2, rows / 2, -0.12, 0.03, 0.0, 0.0, 0.0)
+        self.lens_map = self.lens_bufs = None
+        if lens == "fused":
+            self.filt.set_lens(self.lens_params)
+        elif lens == "two-pass":
+            if fmt != "packed":
+                raise SystemExit("--lens two-pass needs --format packed")
+            self.lens_map, _ = self.ctx.lens_map(self.lens_params, rows, cols)
+        self.yuv420 = fmt != "packed"
+        self.nv12 = fmt == "nv12"
+        self.pingpong = pingpong
+        self.file = None
+        t_gen = time.perf_counter()
+        if input_path is not None:
+            # a clip from a file: raw I420 (Y, U, V planes back to back) or NV12 (Y, interleaved UV) frames, uploaded once
+            if not self.yuv420:
+                raise SystemExit("--input holds 4:2:0 frames: use --format i420 or nv12")
+            fbytes = rows * cols * 3 // 2
+            nfile = os.path.getsize(input_path) // fbytes
+            if nfile < 2 * self.delay + 4:
+                raise SystemExit(f"--input: {nfile} frames of {cols}x{rows} in {input_path}, need at least {2 * self.delay + 4}")
+            pool = min(pool, nfile)
+            self.file = np.memmap(input_path, dtype=np.uint8, mode="r", shape=(nfile, fbytes))
+            self.clip = None
+            planes = [tuple(torch.from_numpy(np.ascontiguousarray(q)).to(device) for q in self.file_planes(i)) for i in range(pool)]
+        else:
+            pool = max(pool, 2 * self.delay + 4)
+            # ---- the synthetic stream, rendered on the GPU and kept resident in HBM (4K I420: 12.4 MB per frame, 7.5 GB for 600 poses)
+            self.clip = clipgen.Clip(rows, cols, pool, seed=seed, device=device, cut_at=(pool // 2) if cut else None)
+            planes = [self.clip.render_i420(i, nv12=self.nv12) for i in range(pool)] if self.yuv420 else None
+        self.pool = pool
+        if self.yuv420:
+            self.planes = planes
+            self.frames = None
+            self.outs = [tuple(torch.empty_like(q) for q in planes[0]) for _ in range(4)]
+            self.planes_args = [self.filt.prepare_yuv420(q) for q in planes]          # addresses / pitches marshalled once, outside the timed region
+            self.outs_args = [self.filt.prepare_yuv420(o) for o in self.outs]
+        else:
+            self.frames = [self.clip.render444(i) for i in range(pool)]
+            self.outs = [torch.empty_like(self.frames[0]) for _ in range(4)]
+        if self.lens_map is not None:
+            self.lens_bufs = [torch.empty_like(self.frames[0]) for _ in range(self.delay + 4)]       # corrected frames stay borrowed for `delay` pushes
+        torch.cuda.synchronize()
+        self.t_gen = time.perf_counter() - t_gen
+        self.step_no = 0
+
+    def file_planes(self, i):
+        """numpy planes of frame i of the --input file."""
+        rows, cols = self.rows, self.cols
+        f = self.file[i % self.file.shape[0]]
+        y = f[:rows * cols].reshape(rows, cols)
+        if self.nv12:
+            return y, f[rows * cols:].reshape(rows // 2, cols // 2, 2)
+        q = rows * cols // 4
+        return y, f[rows * cols:rows * cols + q].reshape(rows // 2, cols // 2), f[rows * cols + q:].reshape(rows // 2, cols // 2)
+
+    def index(self, i):
+        if not self.pingpong:
+            return i % self.pool
+        period = 2 * self.pool - 2                           # forward, then backward: continuous motion without a wrap-around jump
+        k = i % period
+        return k if k < self.pool else period - k
+
+    def step(self):
+        i = self.step_no; self.step_no += 1
+        k = self.index(i)
+        if self.yuv420:
+            return self.filt.apply_yuv420_prepared(self.planes_args[k], i, self.outs_args[i & 3])
+        if self.lens_map is not None:
+            corrected = self.ctx.remap_map(self.frames[k], self.lens_map, bg=(0, 0, 0), out=self.lens_bufs[i % len(self.lens_bufs)])     # LCFilter::filter
+            return self.filt.apply(corrected, timestamp=i, out=self.outs[i & 3])
+        return self.filt.apply(self.frames[k], timestamp=i, out=self.outs[i & 3])
+
+    def sync(self):
+        self.ctx.sync()                      # lvk_hip_sync: every stream of the filter (tracking, bulk, transfers)
+
+    def close(self):
+        self.filt.close(); self.ctx.close()
+
+
+def run_region(rigs, n, device_sync, local_rank):
+    """n free-running pushes on every rig (one host thread per rig beyond the first), bracketed by device-wide synchronisations.
+    Returns (seconds, frames emitted by all rigs, host time stamps of rig 0's pushes)."""
+    import threading
+    import torch
+    if len(rigs) == 1:
+        rig = rigs[0]
+        t0 = time.perf_counter()
+        emitted = 0
+        stamps = [t0]
+        for _ in range(n):
+            out, _ = rig.step()
+            emitted += 1 if out is not None else 0
+            stamps.append(time.perf_counter())
+        device_sync()
+        return time.perf_counter() - t0, emitted, stamps
+    gate = threading.Barrier(len(rigs) + 1)
+    res = [None] * len(rigs)
+
+    def worker(k):
+        torch.cuda.set_device(local_rank)              # the current device is per host thread
+        rig = rigs[k]
+        gate.wait()
+        e, st = 0, [time.perf_counter()]
+        try:
+            for _ in range(n):
+                out, _ = rig.step()
+                e += 1 if out is not None else 0
+                st.append(time.perf_counter())
+            res[k] = (e, st, None)
+        except Exception as ex:                        # reported by the main thread
+            res[k] = (e, st, ex)
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(rigs))]
+    for t in threads:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    for r in res:
+        if r[2] is not None:
+            raise r[2]
+    return elapsed, sum(r[0] for r in res), res[0][1]
+
+
+def latency_pass(rigs, n, local_rank):
+    """n synchronised pushes (sync, push, sync) per rig, all rigs at once: per-rig lists of milliseconds."""
+    import threading
+    import torch
+
+    def one(rig, out):
+        for _ in range(n):
+            rig.sync()
+            t = time.perf_counter()
+            rig.step()
+            rig.sync()
+            out.append((time.perf_counter() - t) * 1e3)
+    lats = [[] for _ in rigs]
+    if len(rigs) == 1:
+        one(rigs[0], lats[0])
+        return lats
+
+    def worker(k):
+        torch.cuda.set_device(local_rank)
+        one(rigs[k], lats[k])
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(rigs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return lats
+
+
+def config_leg(lvk, local_rank, device, rows, cols, preset, lens, label, seed, steps=400):
+    """A short leg of another BASELINE configuration (outside `value`): same generator, 48 poses played forward and backward, I420 planes
+    resident in HBM, overlap on; free-running rate over `steps` pushes, p50 / p99 of 150 synchronised pushes, live remap time."""
+    import torch
+    rig = Rig(lvk, local_rank, device, seed, rows, cols, preset, "i420", lens, True, 48, cut=False, pingpong=True)
+    try:
+        for _ in range(rig.delay + 2 + 60):
+            rig.step()
+        rig.filt.set_profiling(True, stages=("remap",), every=4)
+        rig.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rig.step()
+        rig.sync()
+        dt = time.perf_counter() - t0
+        prof = rig.filt.profile()
+        rig.filt.set_profiling(False)
+        lat = latency_pass([rig], 150, local_rank)[0]
+        st = rig.filt.stats()
+        rms, rn = prof["remap"]
+        return {"workload": label, "value": steps / dt, "unit": "frames/s", "steps": steps, "p50_ms": float(np.percentile(lat, 50)),
+                "p99_ms": float(np.percentile(lat, 99)), "remap_us": (rms / rn * 1e3) if rn else None, "trust": float(st.trust), "features": int(st.n_tracked)}
+    finally:
+        rig.close()
+
+
+def reference_kernel_leg(rig):
+    """The REFERENCE's own remap kernel -- FSR.cl's easu_remap_homography compiled for gfx950 from the reference tree (oracle/_ref/fsr_yuv.hsaco,
+    recipe oracle/Makefile `ref`) and launched the way lvk::remap launches it (Functions/Image.cpp:133-146, 8 x 8 work-groups of
+    OpenCL/Kernels.cpp:49-71) -- timed with HIP events on one frame of the workload with the warp that stabilizes it, next to the product's
+    kernel on the same frame, same matrix, same stream; and whether the two outputs are identical."""
+    import torch
+    from tests import ref_cl
+    if not ref_cl.available():
+        return {"error": "oracle/_ref/*.hsaco not present (built by __graft_entry__.build() where /root/reference exists)"}
+    ref = ref_cl.RefKernels()
+    rows, cols = rig.rows, rig.cols
+    if rig.clip is not None:
+        src = rig.clip.render444(7)
+        H = np.linalg.inv(rig.clip.matrix(7)) @ rig.clip.matrix(7, smooth=True)          # stabilized pixel -> source pixel of frame 7
+    else:
+        src = rig.ctx.ingest_yuv420(*rig.planes[7])
+        th, z = np.deg2rad(0.15), 1.002
+        c, si = np.cos(th) * z, np.sin(th) * z
+        H = np.array([[c, -si, 0.004 * cols], [si, c, -0.003 * cols], [0, 0, 1.0]])
+    H = H / H[2, 2]
+    bg = (105, 212, 235)
+    out_r = torch.zeros_like(src); out_g = torch.zeros_like(src)
+    torch.cuda.synchronize(); rig.sync()
+
+    def timed(fn, n):
+        with torch.cuda.stream(rig.stream):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(rig.stream)
+            for _ in range(n):
+                fn()
+            e1.record(rig.stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    t_ref = timed(lambda: ref.remap_homography(src, H, bg=bg, yuv=True, out=out_r), 10)
+    t_hip = timed(lambda: rig.ctx.remap_homography(src, H, bg=bg, yuv=True, out=out_g), 40)
+    same = bool(torch.equal(out_r, out_g))
+    b = 6 * rows * cols
+    return {"kernel": "easu_remap_homography (LiveVisionKit/Functions/OpenCL/Sources/FSR.cl, -D YUV_INPUT) compiled for gfx950 by oracle/Makefile `ref`",
+            "launch": "Functions/Image.cpp:133-146 argument list, 8x8 work-groups (OpenCL/Kernels.cpp:49-71)", "frame": f"{cols}x{rows} packed YUV444 in / out ({b} B)",
+            "avg_launch_us": t_ref, "launches": 10, "hbm_frac": b / (t_ref * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "product_kernel": "k_remap_homography<yuv> (same frame, same matrix, same stream, alone on the GPU)", "product_avg_launch_us": t_hip,
+            "product_hbm_frac": b / (t_hip * 1e-6) / 1e9 / HBM_PEAK_GBS, "speedup": t_ref / t_hip, "outputs_bit_equal": same}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        # never a silent degradation: the ranks that run are the ranks that were asked for
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
+    K = max(1, args.streams_per_gpu)
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if os.environ.get("LVK_BENCH_SHARE_GPU") == "1":         # functional test of the N > 1 path on a box with fewer GPUs than ranks
+    share = os.environ.get("LVK_BENCH_SHARE_GPU") == "1"       # functional test of the N > 1 path on a box with fewer GPUs than ranks
+    if world > torch.cuda.device_count() and not share:
+        raise SystemExit(f"bench.py: --gpus {world} but {torch.cuda.device_count()} GPU(s) visible (LVK_BENCH_SHARE_GPU=1 maps the ranks onto them for a functional test)")
+    if share:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -246,59 +538,28 @@ def main():
     import livevisionkit_amd as lvk
     from tests import clipgen
     numa_cpus = lvk.shard.bind_to_gpu_numa(local_rank) if os.environ.get("LVK_BENCH_NUMA", "1") != "0" else []
-    # the filter works on its own (non-blocking) stream: the process default stream would implicitly serialise with every
-    # blocking stream of the process
-    work_stream = torch.cuda.Stream(device)
-    ctx = lvk.Context(local_rank, stream=work_stream)
-    settings = lvk.StabilizationFilterSettings.obs_preset(args.preset)
-    # the OBS plugin's flow (VSFilter.cpp:255-293): a default-constructed filter that is then configured with the preset --
-    # constructing the "field" preset directly would keep FrameTracker's constructor-time 256x256 mesh constraints (reference quirk)
-    filt = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
-    filt.configure(settings)
-    if not args.no_overlap:
-        filt.set_overlap(True)          # remap of frame n-N on a second stream, concurrent with the tracking of frame n+1
-    delay = filt.frame_delay()
-
     rows, cols = args.rows, args.cols
-    lens_params = (0.8 * cols, 0.8 * cols, cols / 2, rows / 2, -0.12, 0.03, 0.0, 0.0, 0.0)
-    lens_map = lens_bufs = None
-    if args.lens == "fused":
-        filt.set_lens(lens_params)
-    elif args.lens == "two-pass":
-        if args.format != "packed":
-            raise SystemExit("--lens two-pass needs --format packed")
-        lens_map, _ = ctx.lens_map(lens_params, rows, cols)
-    pool = max(args.pool, 2 * delay + 4)
-    yuv420 = args.format != "packed"
-    nv12 = args.format == "nv12"
-
-    # ---- the synthetic stream, rendered on the GPU and kept resident in HBM (4K I420: 12.4 MB per frame, 7.5 GB for 600 poses)
-    t_gen = time.perf_counter()
-    clip = clipgen.Clip(rows, cols, pool, seed=0x4C564B31 + rank, device=device, cut_at=pool // 2)
-    if yuv420:
-        planes = [clip.render_i420(i, nv12=nv12) for i in range(pool)]
-        frames = None
-        outs = [tuple(torch.empty_like(p) for p in planes[0]) for _ in range(4)]
-        planes_args = [filt.prepare_yuv420(p) for p in planes]          # addresses / pitches marshalled once, outside the timed region
-        outs_args = [filt.prepare_yuv420(o) for o in outs]
-    else:
-        frames = [clip.render444(i) for i in range(pool)]
-        outs = [torch.empty_like(frames[0]) for _ in range(4)]
-    if lens_map is not None:
-        lens_bufs = [torch.empty_like(frames[0]) for _ in range(delay + 4)]       # corrected frames stay borrowed for `delay` pushes
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
-
-    step_no = [0]
+    seed0 = 0x4C564B31 + rank * K
+    pool_k = args.pool if K == 1 else max(48, min(args.pool, 600 // K))      # K clips share the HBM budget of one
+    rigs = [Rig(lvk, local_rank, device, seed0 + k, rows, cols, args.preset, args.format, args.lens, not args.no_overlap,
+                pool_k, input_path=args.input) for k in range(K)]
+    rig = rigs[0]
+    filt, ctx, clip, delay, pool = rig.filt, rig.ctx, rig.clip, rig.delay, rig.pool
+    settings, lens_params = rig.settings, rig.lens_params
+    yuv420, nv12 = rig.yuv420, rig.nv12
+    t_gen = sum(r.t_gen for r in rigs)
+    if args.write_input:
+        if not yuv420 or clip is None:
+            raise SystemExit("--write-input writes the synthetic clip's 4:2:0 planes")
+        with open(args.write_input, "wb") as f:
+            for q in rig.planes:
+                for plane in q:
+                    f.write(plane.cpu().numpy().tobytes())
+        print(json.dumps({"written": args.write_input, "frames": pool, "rows": rows, "cols": cols, "format": args.format}), flush=True)
+        return None
 
     def step():
-        i = step_no[0]; step_no[0] += 1
-        if yuv420:
-            return filt.apply_yuv420_prepared(planes_args[i % pool], i, outs_args[i & 3])
-        if lens_map is not None:
-            corrected = ctx.remap_map(frames[i % pool], lens_map, bg=(0, 0, 0), out=lens_bufs[i % len(lens_bufs)])     # LCFilter::filter
-            return filt.apply(corrected, timestamp=i, out=outs[i & 3])
-        return filt.apply(frames[i % pool], timestamp=i, out=outs[i & 3])
+        return rig.step()
 
     # the sensor sampler (a separate process) is started BEFORE the warmup, so that nothing but the barrier sits between the warmup steps
     # and the timed region (its start-up wait used to idle the GPU for 0.3 s right in front of the timed pushes)
@@ -312,16 +573,21 @@ def main():
         except Exception:
             sampler = None
     # fill the delay (untimed, before the warmup): every timed step then emits one stabilized frame
-    for _ in range(delay + 2):
-        step()
-    for _ in range(args.warmup):
-        step()
+    for r in rigs:
+        for _ in range(delay + 2):
+            r.step()
+    if K == 1:
+        for _ in range(args.warmup):
+            step()
+    else:
+        run_region(rigs, args.warmup, lambda: None, local_rank)
     # live HIP-event timing of the dominant kernel inside the timed region: that stage only, and one launch in eight (an event pair per
     # frame is two host API calls in the per-frame turnaround -- the measurement would slow what it measures by ~4 %)
     filt.set_profiling(True, stages=("remap",), every=8)
 
     def device_sync():
-        ctx.sync()                      # lvk_hip_sync: every stream of the filter (tracking, bulk, transfers)
+        for r in rigs:
+            r.sync()
         torch.cuda.synchronize()
 
     def barrier():
@@ -332,44 +598,32 @@ def main():
 
     barrier()
     wall0 = time.time()
-    t0 = time.perf_counter()
-    emitted = 0
-    stamps = [t0]
-    for _ in range(args.steps):
-        out, _ = step()
-        emitted += 1 if out is not None else 0
-        stamps.append(time.perf_counter())
-    device_sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, emitted, stamps = run_region(rigs, args.steps, device_sync, local_rank)
     wall1 = time.time()
-    free_running = np.diff(np.array(stamps)) * 1e3          # host time per push in the free-running timed region
+    free_running = np.diff(np.array(stamps)) * 1e3          # host time per push of stream 0 in the free-running timed region
     barrier()
     # SUSTAINED rate ("steady state, >= 600 frames"): the same free-running loop kept going for at least 600 more
     # pushes right behind the timed region -- a --steps 20 timed region is 2.6 ms, of which the pipeline fill after the barrier and the
     # un-overlapped last remap are 6-8 %.  Outside `value` (the contract times exactly --steps), reported beside it; it also gives the
     # roofline its >= 64 event samples of the remap whatever --steps was.
     n_sustained = max(600, 64 * 8 - args.steps)
-    ts0 = time.perf_counter(); wall2 = time.time()
-    sustained_emitted = 0
-    for _ in range(n_sustained):
-        out, _ = step()
-        sustained_emitted += 1 if out is not None else 0
-    device_sync()
-    sustained_s = time.perf_counter() - ts0
+    wall2 = time.time()
+    sustained_s, sustained_emitted, _ = run_region(rigs, n_sustained, device_sync, local_rank)
     wall3 = time.time()
     sensor_samples = sampler.stop() if sampler is not None else []
     prof = filt.profile()
     filt.set_profiling(False)
     stats = filt.stats()
+    import zlib
+    last_out = rig.outs[(rig.step_no - 1) & 3]
+    out_crc = 0
+    for q in (last_out if isinstance(last_out, tuple) else (last_out,)):
+        out_crc = zlib.crc32(q.cpu().numpy().tobytes(), out_crc)
 
     # per-step latency pass (each step synchronised) for p50 / p99 ms per frame: always 500 pushes, whatever --steps was
-    lat = []
-    for _ in range(500):
-        device_sync()
-        t = time.perf_counter()
-        step()
-        device_sync()
-        lat.append((time.perf_counter() - t) * 1e3)
+    # (K > 1: every stream at once, one host thread each -- the latency a stream sees next to its K - 1 neighbours)
+    lats = latency_pass(rigs, 500 if K == 1 else 200, local_rank)
+    lat = lats[0]
 
     # every stage's event timing in a separate free-running pass (outside the timed region: 16 event records per frame)
     filt.set_profiling(True)
@@ -381,21 +635,21 @@ def main():
 
     # the same remap kernel alone on the GPU at full occupancy (the timed region runs its occupancy-capped `_co` variant next to the tracker)
     standalone_us = None
-    if rank == 0 and world == 1 and args.lens != "two-pass":
+    if rank == 0 and world == 1 and K == 1 and args.lens != "two-pass" and clip is not None:
         device_sync()
         meshes = filt.meshes()[1]
-        srcs = frames[:8] if frames is not None else [clip.render444(i) for i in range(8)]
+        srcs = rig.frames[:8] if rig.frames is not None else [clip.render444(i) for i in range(8)]
         dst = torch.empty_like(srcs[0])
         torch.cuda.synchronize()                                 # the frames are rendered on torch's stream, the remap runs on the filter's
         bgc = tuple(int(v) for v in settings.background)
-        with torch.cuda.stream(work_stream):
+        with torch.cuda.stream(rig.stream):
             for _ in range(3):
                 ctx.warpmesh_apply(srcs[0], meshes, bg=bgc, yuv=True, out=dst)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(work_stream)
+            e0.record(rig.stream)
             for i in range(40):
                 ctx.warpmesh_apply(srcs[i % len(srcs)], meshes, bg=bgc, yuv=True, out=dst)
-            e1.record(work_stream)
+            e1.record(rig.stream)
         torch.cuda.synchronize()
         standalone_us = e0.elapsed_time(e1) / 40 * 1e3
         del srcs, dst
@@ -405,13 +659,13 @@ def main():
     # filter's output stream (lvk_hip_stab_output_stream), no host synchronisation inside the loop.  The push itself orders the bulk
     # stream behind the uploads the tracking stream waits for (no explicit wait on the output stream here).
     pcie = None
-    if rank == 0 and world == 1 and yuv420 and not args.no_pcie and not args.no_overlap:
+    if rank == 0 and world == 1 and K == 1 and yuv420 and not args.no_pcie and not args.no_overlap:
         try:
             nsteps = 1000
             hpool = min(pool, 48)
             host_in = [filt.host_planes(rows, cols, nv12) for _ in range(hpool)]            # pinned, contiguous I420 / NV12 frames (the OBS layout)
             for k in range(hpool):
-                for dst, p in zip(host_in[k], planes[k]):
+                for dst, p in zip(host_in[k], rig.planes[k]):
                     dst[...] = p.cpu().numpy()
             host_out = [filt.host_planes(rows, cols, nv12) for _ in range(4)]
             in_args = [filt.prepare_yuv420_host(p) for p in host_in]
@@ -426,22 +680,22 @@ def main():
                         filt.prefetch_yuv420_host_prepared(in_args[(i + 1) % hpool])
                     filt.apply_yuv420_host_prepared(in_args[i % hpool], i, out_args[i & 3])
             torch.cuda.synchronize(); ctx.sync()
-            run(100, step_no[0]); step_no[0] += 100
+            run(100, rig.step_no); rig.step_no += 100
             ctx.sync()
             tp = time.perf_counter()
-            run(nsteps, step_no[0]); step_no[0] += nsteps
+            run(nsteps, rig.step_no); rig.step_no += nsteps
             ctx.sync()
             dtp = time.perf_counter() - tp
             mb = rows * cols * 1.5 / 1e6
             # per-frame latency with the transfers inside (BASELINE's p99 ms/frame for host-resident frames): push the host planes, wait
             # for the emitted host planes -- one frame at a time
             lat_pcie = []
-            for i in range(step_no[0], step_no[0] + 500):
+            for i in range(rig.step_no, rig.step_no + 500):
                 tl = time.perf_counter()
                 filt.apply_yuv420_host_prepared(in_args[i % hpool], i, out_args[i & 3])
                 ctx.sync()
                 lat_pcie.append((time.perf_counter() - tl) * 1e3)
-            step_no[0] += 500
+            rig.step_no += 500
             pcie = {"value": nsteps / dtp, "unit": "frames/s", "host_to_device_MB_per_frame": mb, "device_to_host_MB_per_frame": mb,
                     "GBps_each_way": nsteps / dtp * mb / 1e3,
                     "link_ceiling": "profiles/r03_pcie_probe.txt: 55 GB/s one way; both ways at once 46.8 GB/s each with a copy engine per direction (3760 frames/s), "
@@ -456,13 +710,58 @@ def main():
         except Exception as e:          # the extra pass must never break the contract line
             pcie = {"error": repr(e)}
 
+    # ---- beside the headline (rank 0 of a 1-GPU run, outside `value`): the reference's own kernel on this chip, the other BASELINE
+    # configurations, K streams on this GPU
+    extras = rank == 0 and world == 1 and K == 1
+    reference_kernel = None
+    if extras and not args.no_reference_kernel:
+        try:
+            reference_kernel = reference_kernel_leg(rig)
+        except Exception as e:
+            reference_kernel = {"error": repr(e)}
+    configs = None
+    if extras and not args.no_configs and args.input is None:
+        configs = []
+        for (r_, c_, preset_, lens_, label_) in (
+                (1080, 1920, "homography", "off", "1920x1080 I420, OBS 'homography' preset (BASELINE configs 2 / 4, per-GPU leg)"),
+                (2160, 3840, "homography", "fused", "3840x2160 I420, lens correction fused into the remap (BASELINE config 5, per-GPU leg)"),
+                (2160, 3840, "field", "off", "3840x2160 I420, OBS 'vector field' preset (16x16 mesh)")):
+            try:
+                configs.append(config_leg(lvk, local_rank, device, r_, c_, preset_, lens_, label_, seed0 + 101))
+            except Exception as e:
+                configs.append({"workload": label_, "error": repr(e)})
+    multi_stream = None
+    if extras and not args.no_multi_stream and args.input is None and yuv420:
+        try:
+            Km = 4
+            mr = [Rig(lvk, local_rank, device, seed0 + 200 + k, rows, cols, args.preset, args.format, args.lens, not args.no_overlap, 48,
+                      cut=False, pingpong=True) for k in range(Km)]
+            for r in mr:
+                for _ in range(r.delay + 2):
+                    r.step()
+            run_region(mr, 100, lambda: None, local_rank)
+            for r in mr:
+                r.sync()
+            dtm, em, _ = run_region(mr, 600, lambda: [r.sync() for r in mr], local_rank)
+            lm = latency_pass(mr, 150, local_rank)
+            multi_stream = {"streams": Km, "value": em / dtm, "unit": "frames/s", "pushes_per_stream": 600,
+                            "per_stream_latency_ms": [dict(percentiles(x), samples=len(x)) for x in lm],
+                            "note": f"{Km} independent filters (own HIP streams, own clips, one host thread each) on this ONE GPU, free-running aggregate, then "
+                                    "every stream pushing synchronised frames at once; `bench.py --streams-per-gpu K` makes it the headline"}
+            for r in mr:
+                r.close()
+        except Exception as e:
+            multi_stream = {"error": repr(e)}
+
     elapsed_max, total_frames = lvk.shard.reduce_timing(elapsed, emitted)
     sustained_max, sustained_frames = lvk.shard.reduce_timing(sustained_s, sustained_emitted)
     rank_reports = lvk.shard.gather_rank_reports({
-        "rank": rank, "device": local_rank, "clip_seed": 0x4C564B31 + rank, "frames": emitted, "elapsed_s": elapsed, "frames_per_s": emitted / elapsed,
-        "sustained_frames_per_s": sustained_emitted / sustained_s, "numa_cpus": (f"{numa_cpus[0]}-{numa_cpus[-1]} ({len(numa_cpus)})" if numa_cpus else "unbound")})
+        "rank": rank, "device": local_rank, "clip_seed": seed0, "streams": K, "frames": emitted, "elapsed_s": elapsed, "frames_per_s": emitted / elapsed,
+        "sustained_frames_per_s": sustained_emitted / sustained_s, "numa_cpus": (f"{numa_cpus[0]}-{numa_cpus[-1]} ({len(numa_cpus)})" if numa_cpus else "unbound"),
+        "stream_latency_ms": [dict(percentiles(x), samples=len(x)) for x in lats] if K > 1 else None})
 
     result = None
+    rc = 0
     if rank == 0:
         remap_ms, remap_n = prof["remap"]
         remap_s = remap_ms / remap_n * 1e-3 if remap_n else None
@@ -483,12 +782,26 @@ def main():
                 traffic = None
         valu_per_px = (counters or {}).get("valu_per_px", 534.0 if fused_420 else 531.0)      # rocprofv3 SQ_INSTS_VALU * 64 / pixels
         valu_rate = valu_per_px * rows * cols / remap_s if remap_s else None
+        stage_us = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof_all.items()}
+        # the HBM-bound kernels beside the remap (north star: "HBM GB/s on the remap and pyramid kernels against the chip's peak"): the luma
+        # downscale that feeds the pyramid and the 4:2:0 -> 4:4:4 conversion, from the live HIP-event times of the all-stages pass
+        secondary = []
+        det = settings.detection_width * settings.detection_height
+        for kname, stage, b, what in (
+                ("k_area_fast_dw / k_area_general* (luma INTER_AREA downscale to the tracking resolution)", "downscale", rows * cols + det, "W H luma read + the tracking frame written"),
+                ("k_pyr_fused3 (pyramid levels 1-3 in one launch)", "pyramid", det + det // 4 + det // 16 + det // 64, "level 0 read + levels 1-3 written (172 KB: launch latency, not bandwidth)"),
+                ("k_ingest_yuv420_x2 (4:2:0 planes -> packed 4:4:4)", "ingest", (9 * rows * cols) // 2 if yuv420 else 0, "1.5 W H read + 3 W H written")):
+            us = stage_us.get(stage, 0.0)
+            if us > 0 and b > 0:
+                secondary.append({"kernel": kname, "bound": "hbm", "algorithmic_bytes_per_launch": b, "bytes": what, "avg_launch_us": us,
+                                  "achieved": b / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        n_ranks = len(rank_reports)
         result = {
-            "metric": "stabilized frames/sec (one 4K YUV420 stream per GPU, steady state)" if yuv420 else
+            "metric": ("stabilized frames/sec (one 4K YUV420 stream per GPU, steady state)" if K == 1 else f"stabilized frames/sec ({K} concurrent 4K YUV420 streams per GPU, steady state)") if yuv420 else
                       "stabilized frames/sec (one 4K packed-YUV444 stream per GPU, steady state)",
             "value": total_frames / elapsed_max,
             "unit": "frames/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,                               # the ranks that timed
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
@@ -496,15 +809,16 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.input is None else f"file {os.path.basename(args.input)} ({pool} frames resident in HBM, cycled)",
             "config": {"workload": (f"{cols}x{rows} {args.format.upper()} (YUV 4:2:0) stream per GPU, planes resident in HBM, ingest -> lvk::StabilizationFilter -> egress, "
                                     if yuv420 else f"{cols}x{rows} packed YUV444 8UC3 stream per GPU (lvk::StabilizationFilter boundary format), ")
                                    + f"OBS '{args.preset}' preset, tracking 480x270, predictive_samples={delay}, crop 5%"
-                                   + ("" if args.lens == "off" else f", lens correction {args.lens} (fx=fy=0.8W, k1=-0.12, k2=0.03)"),
-                       "clip": f"SURVEY 8d generator: {pool} distinct poses (smooth pan + AR(1) jitter: 0.4 % W translation, 0.15 deg, 0.2 % zoom), scene cut at frame {pool // 2}, "
-                               f"cycled; rendered on the GPU in {t_gen:.1f} s",
-                       "parallelism": f"{world} independent stream(s), one per GPU, no collective (gloo barrier only)",
-                       "frames_in_hbm": pool, "host_cpus_bound": len(numa_cpus)},
+                                   + ("" if args.lens == "off" else f", lens correction {args.lens} (fx=fy=0.8W, k1=-0.12, k2=0.03)")
+                                   + ("" if K == 1 else f"; {K} such streams per GPU, one host thread each"),
+                       "clip": (f"SURVEY 8d generator: {pool} distinct poses (smooth pan + AR(1) jitter: 0.4 % W translation, 0.15 deg, 0.2 % zoom), scene cut at frame {pool // 2}, "
+                                f"cycled; rendered on the GPU in {t_gen:.1f} s") if args.input is None else f"{args.input}: {pool} frames, cycled",
+                       "parallelism": f"{n_ranks} rank(s), one per GPU, {K} independent stream(s) each, no collective (gloo barrier only)",
+                       "streams_per_gpu": K, "frames_in_hbm": pool * K, "host_cpus_bound": len(numa_cpus)},
             "sustained": {"frames": int(sustained_frames), "frames_per_s": sustained_frames / sustained_max, "ms_per_frame": sustained_max / n_sustained * 1e3,
                           "note": "the free-running loop continued for >= 600 pushes right after the timed region (SURVEY 8d's steady state); "
                                   "whole job, max over ranks; not `value`"},
@@ -518,9 +832,9 @@ def main():
             # detector runs are longer) and what is left for the final synchronisation (the last remap + lvk_hip_sync)
             "timed_region_ms": {"pushes": [round(float(x), 4) for x in free_running[:64]],
                                 "final_sync": round(float(elapsed * 1e3 - free_running.sum()), 4), "total": round(float(elapsed * 1e3), 4)},
-            "stage_us": {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in prof_all.items()},
+            "stage_us": stage_us,
             "pcie_inclusive": pcie,
-            "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked},
+            "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked, "last_output_crc32": out_crc},
             "roofline": {"kernel": ("k_remap_homography" if args.preset == "homography" else "k_remap_mesh") + ("_lens" if args.lens == "fused" else "")
                                    + (("_420<nv12>" if nv12 else "_420<i420>") if fused_420 else ("<yuv>" if args.no_overlap else "_co<yuv>")),
                          # The HBM figures are what the contract asks for (algorithmic bytes / launch duration against 8 TB/s).  The
@@ -541,8 +855,12 @@ def main():
                          "standalone_us": standalone_us,
                          "standalone_frac": (6 * rows * cols / (standalone_us * 1e-6)) / 1e9 / HBM_PEAK_GBS if standalone_us else None,
                          "standalone_valu_frac_spec": ((counters or {}).get("valu_per_px_packed", 531.0) * rows * cols / (standalone_us * 1e-6)) / VALU_PEAK_SPEC if standalone_us else None},
+            "roofline_secondary": secondary,
+            "reference_kernel": reference_kernel,
+            "configs": configs,
+            "multi_stream": multi_stream,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and K == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
             oracle = oracle_lib.load()
             # one thread per PHYSICAL core of the CPUs this process may run on (the NUMA node of the GPU when bound: 64 cores / 128 SMT threads on
@@ -550,21 +868,27 @@ def main():
             # are memory-bound and the SMT siblings only add contention.
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             nthreads = max(1, min(ncpu // 2 if ncpu >= 16 else ncpu, 64))
-            fps, dt, done = cpu_baseline(oracle, clip, args.preset, nthreads, args.cpu_budget, args.format,
+            fps, dt, done = cpu_baseline(oracle, rig, args.preset, nthreads, args.cpu_budget, args.format,
                                          lens_params if args.lens == "fused" else None, delay)
             result["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": nthreads, "kind": "port",
                                       "sample": f"{done} consecutive steady-state frames of the same clip and settings ({dt:.1f} s of CPU work; oracle = CPU "
                                                 f"restatement of the reference; 4:2:0 conversion, tracking-frame downscale, optical flow and remap "
                                                 f"row / point-parallel over {nthreads} threads)"}
-            if args.quality_frames > 0 and args.lens == "off":
+            if args.quality_frames > 0 and args.lens == "off" and clip is not None:
                 try:
                     result["quality"] = quality_pass(lvk, ctx, oracle, clip, args.preset, max(args.quality_frames, 4 * delay + 2), nthreads)
                 except Exception as e:
                     result["quality"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
-    filt.close()
+        if n_ranks != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but {n_ranks} rank(s) reported\n")
+            rc = 3
+    for r in rigs:
+        r.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
     return result
 
 

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <functional>
@@ -63,8 +64,17 @@ public:
             lvk::context::assert_handler("LiveVisionKit.hpp", "Context", std::string("lvk_hip_ctx_create_on_stream: ") + lvk_hip_last_error(nullptr));
     }
     ~Context() { lvk_hip_ctx_destroy(m_ctx); }
+    // The C-ABI's rule is "one context is driven by one host thread at a time" (lvk_hip.h).  Objects of this facade may SHARE a context
+    // across threads (two filters constructed on one context, a frame handed to another thread): every facade call that drives a
+    // context holds its mutex for the duration of the call.  Recursive: facade calls nest (a filter's apply creates frames).
+    std::recursive_mutex& mutex() const { return m_mutex; }
     // everything enqueued so far on `producer` happens before what this context enqueues from now on (GPU-side, no host wait)
-    void wait_for(const Context& producer) const { if (producer.m_ctx != m_ctx) check(lvk_hip_ctx_wait(m_ctx, producer.m_ctx), "Context::wait_for"); }
+    void wait_for(const Context& producer) const
+    {
+        if (producer.m_ctx == m_ctx) return;
+        std::scoped_lock lock(m_mutex, producer.m_mutex);         // both, deadlock-free whatever the order two threads name them in
+        check(lvk_hip_ctx_wait(m_ctx, producer.m_ctx), "Context::wait_for");
+    }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     lvk_hip_ctx* get() const { return m_ctx; }
@@ -74,7 +84,9 @@ public:
     }
 private:
     lvk_hip_ctx* m_ctx = nullptr;
+    mutable std::recursive_mutex m_mutex;
 };
+using ContextLock = std::lock_guard<std::recursive_mutex>;
 inline std::shared_ptr<Context> shared_context(int device = 0)
 {
     static thread_local std::weak_ptr<Context> cached;
@@ -132,11 +144,13 @@ struct VideoFrame
     void upload(const uint8_t* host, int rows_, int cols_, Format fmt, uint64_t ts, const std::shared_ptr<hip::Context>& ctx = nullptr)
     {
         create({cols_, rows_}, CV_8UC3, ctx);
+        hip::ContextLock lock(m_ctx->mutex());
         m_ctx->check(lvk_hip_upload(m_ctx->get(), m_buf.get(), host, step * (size_t)rows), "VideoFrame::upload");
         format = fmt; timestamp = ts;
     }
     void download(uint8_t* host) const
     {
+        hip::ContextLock lock(m_ctx->mutex());
         m_ctx->check(lvk_hip_download(m_ctx->get(), host, m_buf.get(), step * (size_t)rows), "VideoFrame::download");
         m_ctx->check(lvk_hip_sync(m_ctx->get()), "VideoFrame::download");
     }
@@ -147,6 +161,7 @@ struct VideoFrame
         VideoFrame c;
         if (empty()) return c;
         c.create(size(), CV_8UC3, m_ctx);
+        hip::ContextLock lock(m_ctx->mutex());
         m_ctx->check(lvk_hip_upscale(m_ctx->get(), m_buf.get(), (int)step, rows, cols, c.m_buf.get(), (int)c.step, rows, cols, 1), "VideoFrame::clone");
         c.timestamp = timestamp; c.format = format;
         return c;
@@ -189,11 +204,13 @@ struct VideoFrame420
     void upload(const uint8_t* host, int rows_, int cols_, bool nv12_, uint64_t ts, const std::shared_ptr<hip::Context>& ctx = nullptr)
     {
         create({cols_, rows_}, nv12_, ctx);
+        hip::ContextLock lock(m_ctx->mutex());
         m_ctx->check(lvk_hip_upload(m_ctx->get(), m_buf.get(), host, (size_t)cols * rows * 3 / 2), "VideoFrame420::upload");
         timestamp = ts;
     }
     void download(uint8_t* host) const
     {
+        hip::ContextLock lock(m_ctx->mutex());
         m_ctx->check(lvk_hip_download(m_ctx->get(), host, m_buf.get(), (size_t)cols * rows * 3 / 2), "VideoFrame420::download");
         m_ctx->check(lvk_hip_sync(m_ctx->get()), "VideoFrame420::download");
     }
@@ -233,7 +250,7 @@ struct HostFrame420
     size_t bytes() const { return (size_t)cols * rows * 3 / 2; }
     bool unique() const { return m_buf && m_buf.use_count() == 1; }
     // an output of StabilizationFilter::apply is complete once its filter's context is idle
-    void wait() const { if (m_ctx) m_ctx->check(lvk_hip_sync(m_ctx->get()), "HostFrame420::wait"); }
+    void wait() const { if (m_ctx) { hip::ContextLock lock(m_ctx->mutex()); m_ctx->check(lvk_hip_sync(m_ctx->get()), "HostFrame420::wait"); } }
     const std::shared_ptr<hip::Context>& context() const { return m_ctx; }
 private:
     std::shared_ptr<void> m_buf;
@@ -437,10 +454,17 @@ public:
             Frame read_frame;
             while (input.read(read_frame))
             {
-                if (!read_frame.has_known_format()) read_frame.format = VideoFrame::BGR;          // "assume the input frame is BGR"
+                // VideoFilter.cpp:81-85: "Assume the input frame is BGR" (what cv::VideoCapture decodes to) and stamp it with the stream
+                // position -- both ALWAYS overwritten.  A capture that delivers frames in another 3-channel format (a raw YUV reader)
+                // says so through stream_keeps_frame_format(true); the timestamp is the stream position either way.
+                if (!m_StreamKeepsFormat || !read_frame.has_known_format()) read_frame.format = VideoFrame::BGR;
                 const double stream_position = std::max(0.0, input.get(cv::CAP_PROP_POS_MSEC));
-                if (read_frame.timestamp == 0) read_frame.timestamp = static_cast<uint64_t>(stream_position * 1.0e6);    // ms -> ns
-                if (read_frame.context()) read_frame.context()->check(lvk_hip_sync(read_frame.context()->get()), "VideoFilter::stream");
+                read_frame.timestamp = static_cast<uint64_t>(stream_position * 1.0e6);              // Time::Milliseconds(..).nanoseconds()
+                if (read_frame.context())
+                {
+                    hip::ContextLock lock(read_frame.context()->mutex());
+                    read_frame.context()->check(lvk_hip_sync(read_frame.context()->get()), "VideoFilter::stream");
+                }
                 if (!input_queue.push(std::move(read_frame))) break;
                 read_frame = Frame();
             }
@@ -470,6 +494,8 @@ public:
         input_thread.join();
         filter_thread.join();
     }
+    // (no reference counterpart) stream(): keep the format a capture has set on its frames instead of assuming BGR
+    void stream_keeps_frame_format(const bool keep) { m_StreamKeepsFormat = keep; }
     void set_timing_samples(const size_t samples) { LVK_HIP_ASSERT(samples >= 1); m_FrameTimer.set_history_size(samples); }
     const Stopwatch& timings() const { return m_FrameTimer; }
 
@@ -479,6 +505,7 @@ protected:
 private:
     Stopwatch m_FrameTimer;
     const std::string m_Alias;
+    bool m_StreamKeepsFormat = false;
 };
 typedef VideoFilter IdentityFilter;
 
@@ -500,12 +527,13 @@ public:
     {
         configure(settings);
     }
-    ~StabilizationFilter() override { lvk_hip_stab_destroy(m_Stab); }
+    ~StabilizationFilter() override { hip::ContextLock lock(m_Ctx->mutex()); lvk_hip_stab_destroy(m_Stab); }
     StabilizationFilter(const StabilizationFilter&) = delete;
     StabilizationFilter& operator=(const StabilizationFilter&) = delete;
 
     void configure(const StabilizationFilterSettings& settings) override          // StabilizationFilter.cpp:42-65
     {
+        hip::ContextLock lock(m_Ctx->mutex());
         const lvk_stab_settings pod = to_pod(settings);
         if (!m_Stab) m_Ctx->check(lvk_hip_stab_create(m_Ctx->get(), &pod, &m_Stab), "StabilizationFilter::configure");
         else m_Ctx->check(lvk_hip_stab_configure(m_Stab, &pod), "StabilizationFilter::configure");
@@ -515,15 +543,16 @@ public:
         refresh_output_context();
     }
 
-    void restart() { m_Ctx->check(lvk_hip_stab_restart(m_Stab), "restart"); m_Held.clear(); }
-    bool ready() const { return lvk_hip_stab_ready(m_Stab) != 0; }
-    void reset_context() { m_Ctx->check(lvk_hip_stab_reset_context(m_Stab), "reset_context"); }
-    void draw_trackers() { m_Ctx->check(lvk_hip_stab_draw_trackers(m_Stab), "draw_trackers"); }          // StabilizationFilter.cpp:163-175
-    void draw_motion_mesh() { m_Ctx->check(lvk_hip_stab_draw_motion_mesh(m_Stab), "draw_motion_mesh"); }    // StabilizationFilter.cpp:179-188
-    size_t frame_delay() const { return (size_t)lvk_hip_stab_frame_delay(m_Stab); }
+    void restart() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_restart(m_Stab), "restart"); m_Held.clear(); }
+    bool ready() const { hip::ContextLock lock(m_Ctx->mutex()); return lvk_hip_stab_ready(m_Stab) != 0; }
+    void reset_context() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_reset_context(m_Stab), "reset_context"); }
+    void draw_trackers() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_draw_trackers(m_Stab), "draw_trackers"); }          // StabilizationFilter.cpp:163-175
+    void draw_motion_mesh() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_draw_motion_mesh(m_Stab), "draw_motion_mesh"); }    // StabilizationFilter.cpp:179-188
+    size_t frame_delay() const { hip::ContextLock lock(m_Ctx->mutex()); return (size_t)lvk_hip_stab_frame_delay(m_Stab); }
     cv::Rect stable_region() const
     {
         int r[4] = {0, 0, 0, 0};
+        hip::ContextLock lock(m_Ctx->mutex());
         lvk_hip_stab_stable_region(m_Stab, m_LastRows, m_LastCols, r);
         return {r[0], r[1], r[2], r[3]};
     }
@@ -536,6 +565,7 @@ public:
     void set_overlap(const bool enable)
     {
         // the bulk stream belongs to a context of the facade, so that output frames stay valid after the filter is gone
+        hip::ContextLock lock(m_Ctx->mutex());
         if (enable && !m_BulkCtx) m_BulkCtx = std::make_shared<hip::Context>(m_Device);
         m_Ctx->check(lvk_hip_stab_set_bulk_context(m_Stab, enable ? m_BulkCtx->get() : nullptr), "set_overlap");
         m_Overlap = enable;
@@ -546,9 +576,10 @@ public:
     void set_lens(const CameraParameters& p)
     {
         const lvk_camera_params c{p.fx, p.fy, p.cx, p.cy, p.k1, p.k2, p.p1, p.p2, p.k3};
+        hip::ContextLock lock(m_Ctx->mutex());
         m_Ctx->check(lvk_hip_stab_set_lens(m_Stab, &c), "set_lens"); m_Held.clear();
     }
-    void clear_lens() { m_Ctx->check(lvk_hip_stab_set_lens(m_Stab, nullptr), "clear_lens"); m_Held.clear(); }
+    void clear_lens() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_set_lens(m_Stab, nullptr), "clear_lens"); m_Held.clear(); }
 
     // The OBS asynchronous path in one call (VisionFilter.cpp:151-212 = to_ocl -> filter -> to_obs): 4:2:0 planes in, 4:2:0 planes out.
     // `output` is released while the delay builds, exactly like the packed overload.
@@ -556,9 +587,10 @@ public:
     void apply(const VideoFrame420& input, VideoFrame420& output, const bool profile = false)
     {
         LVK_HIP_ASSERT(!input.empty());
+        if (input.context() != m_Ctx) m_Ctx->wait_for(*input.context());      // (takes both contexts' locks: before ours is held)
+        hip::ContextLock lock(m_Ctx->mutex());
         sync_gpu(profile);
         m_LastRows = input.rows; m_LastCols = input.cols;
-        if (input.context() != m_Ctx) m_Ctx->wait_for(*input.context());
         VideoFrame420 result;
         result.create({input.cols, input.rows}, input.nv12, m_OutCtx);
         int produced = 0; uint64_t ts = 0;
@@ -566,11 +598,11 @@ public:
                                               input.rows, input.cols, input.timestamp,
                                               result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), &produced, &ts),
                      "StabilizationFilter::apply(4:2:0)");
-        // the planes are consumed when the push returns only in overlap mode; otherwise their conversion is merely enqueued on our stream
-        if (!m_Overlap && input.context() != m_Ctx) input.context()->wait_for(*m_Ctx);
         if (produced) { result.timestamp = ts; output = std::move(result); }
         else output.release();
         sync_gpu(profile);
+        // the planes are consumed when the push returns only in overlap mode; otherwise their conversion is merely enqueued on our stream
+        if (!m_Overlap && input.context() != m_Ctx) input.context()->wait_for(*m_Ctx);
     }
 
     // Frames in pinned host memory: upload_planes -> to_ocl -> filter -> to_obs -> download_planes (FrameIngest.cpp:415-474,494-602) as one
@@ -580,6 +612,7 @@ public:
     void apply(const HostFrame420& input, HostFrame420& output, const bool profile = false)
     {
         LVK_HIP_ASSERT(!input.empty());
+        hip::ContextLock lock(m_Ctx->mutex());
         sync_gpu(profile);
         m_LastRows = input.rows; m_LastCols = input.cols;
         // pinned planes are expensive to allocate: outputs come from a pool and return to it when the caller drops them
@@ -600,9 +633,13 @@ public:
     void prefetch(const HostFrame420& next)
     {
         LVK_HIP_ASSERT(!next.empty());
+        hip::ContextLock lock(m_Ctx->mutex());
         m_Ctx->check(lvk_hip_stab_prefetch_yuv420_host(m_Stab, next.y(), next.y_step(), next.u(), next.uv_step(), next.v(), next.uv_step(), next.nv12 ? 1 : 0,
                                                        next.rows, next.cols), "StabilizationFilter::prefetch");
     }
+
+    // a frame was announced and will not be applied (the source ended, seeked or switched buffers)
+    void cancel_prefetch() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_prefetch_cancel(m_Stab), "StabilizationFilter::cancel_prefetch"); }
 
 private:
     void filter(VideoFrame&& input, VideoFrame& output) override                    // StabilizationFilter.cpp:69-135
@@ -613,6 +650,9 @@ private:
         VideoFrame in = std::move(input);                  // input and output may alias the same object (VSFilter.cpp:358,363)
         // the frame was written on its own context's stream (an upload, an upstream filter): order our stream behind it
         if (in.context() && in.context() != m_Ctx) m_Ctx->wait_for(*in.context());
+        std::shared_ptr<hip::Context> give_back;           // owner of a released frame that must still wait for our last read of it
+        {
+        hip::ContextLock lock(m_Ctx->mutex());
         VideoFrame result;
         result.create(in.size(), CV_8UC3, m_OutCtx);       // pooled: the reference's dst.create is a no-op in steady state (Image.cpp:116)
         int produced = 0; uint64_t ts = 0; const void* released = nullptr;
@@ -625,14 +665,16 @@ private:
                 {
                     // hand the buffer back to its owner: its context's stream must not reuse it before our last read (the remap just
                     // enqueued) has run.  In overlap mode the library reports a frame only after that remap has finished.
-                    if (!m_Overlap && it->ctx && it->ctx != m_Ctx) it->ctx->wait_for(*m_Ctx);
+                    if (!m_Overlap && it->ctx && it->ctx != m_Ctx) give_back = it->ctx;
                     m_Held.erase(it);
                     break;
                 }
         if (produced) { result.timestamp = ts; result.format = in.format; output = std::move(result); }
         else output.release();
+        }
+        if (give_back) give_back->wait_for(*m_Ctx);        // (both contexts' locks: ours is no longer held)
     }
-    void sync_gpu(bool trigger) override { if (trigger) m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); }
+    void sync_gpu(bool trigger) override { if (trigger) { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); } }
     void refresh_output_context()
     {
         // outputs are produced on the bulk stream while overlap is on and the output is being stabilized (lvk_hip_stab_output_stream)
@@ -667,6 +709,102 @@ private:
     int m_LastRows = 0, m_LastCols = 0;
 };
 
+// ---------------------------------------------------------------------------------------------- file input
+// A raw 4:2:0 clip as a cv::VideoCapture: the reference's harness streams a FILE through its filters (VideoFilter::stream,
+// Filters/VideoFilter.cpp:62-209; the CLI opens a cv::VideoCapture on a path, Modules/VideoEditor/VideoProcessor.cpp:148-230).  Frames of
+// a fixed size back to back, I420 (Y, U, V planes) or NV12 (Y, interleaved UV); `fps` gives CAP_PROP_POS_MSEC (frame k: k * 1000 / fps),
+// which stream() turns into the frame's timestamp.  Delivered as
+//   * BGR (default) -- what cv::VideoCapture decodes to and what stream() assumes (VideoFilter.cpp:81-82): the conversion is OpenCV 4.8's
+//     8-bit YUV420 -> BGR (ITU-R BT.601, 20-bit fixed point, nearest chroma; imgproc/src/color_yuv.simd.hpp) on the host, as a decoder's;
+//   * YUV -- packed 4:4:4 through the library's own 4:2:0 ingest (lvk_hip_ingest_yuv420 = the plugin's I4XXIngest / NV12Ingest::to_ocl),
+//     with VideoFilter::stream_keeps_frame_format(true) on the filter;
+// and as the raw planes in pinned host memory (read(HostFrame420&)) for StabilizationFilter::apply(const HostFrame420&, ..).
+#ifndef LVK_WITH_OPENCV                                          // (with the real cv::VideoCapture the file is opened through OpenCV's backends)
+class RawYuvCapture : public cv::VideoCapture
+{
+public:
+    enum class Deliver { BGR, YUV };
+    RawYuvCapture(const std::string& path, const int cols, const int rows, const double fps, const bool nv12 = false,
+                  const Deliver deliver = Deliver::BGR, const std::shared_ptr<hip::Context>& ctx = nullptr)
+        : m_Cols(cols), m_Rows(rows), m_Fps(fps), m_NV12(nv12), m_Deliver(deliver), m_Ctx(ctx)
+    {
+        LVK_HIP_ASSERT(cols > 0 && rows > 0 && cols % 2 == 0 && rows % 2 == 0 && fps > 0.0);
+        m_File = std::fopen(path.c_str(), "rb");
+    }
+    ~RawYuvCapture() override { if (m_File) std::fclose(m_File); }
+    RawYuvCapture(const RawYuvCapture&) = delete;
+    RawYuvCapture& operator=(const RawYuvCapture&) = delete;
+
+    bool isOpened() const override { return m_File != nullptr; }
+    double get(int prop) const override { return (prop == cv::CAP_PROP_POS_MSEC && m_Index > 0) ? (double)(m_Index - 1) * 1000.0 / m_Fps : 0.0; }
+    size_t frames_read() const { return m_Index; }
+    size_t frame_bytes() const { return (size_t)m_Cols * m_Rows * 3 / 2; }
+
+    bool read(HostFrame420& frame)                              // the planes as stored, in pinned host memory
+    {
+        if (!m_File) return false;
+        frame.create({m_Cols, m_Rows}, m_NV12, m_Ctx);
+        if (std::fread(frame.y(), 1, frame_bytes(), m_File) != frame_bytes()) return false;
+        frame.timestamp = (uint64_t)((double)m_Index * 1000.0 / m_Fps * 1.0e6);
+        m_Index++;
+        return true;
+    }
+
+    bool read(VideoFrame& frame) override                       // packed 8UC3
+    {
+        if (!read(m_Stage)) return false;
+        if (m_Deliver == Deliver::BGR)
+        {
+            m_Packed.resize((size_t)m_Cols * m_Rows * 3);
+            to_bgr(m_Stage, m_Packed.data());
+            frame.upload(m_Packed.data(), m_Rows, m_Cols, VideoFrame::BGR, m_Stage.timestamp, m_Ctx);
+            // (upload enqueues a copy out of m_Packed: complete before the next read overwrites it)
+            hip::ContextLock lock(frame.context()->mutex());
+            frame.context()->check(lvk_hip_sync(frame.context()->get()), "RawYuvCapture::read");
+            return true;
+        }
+        frame.create({m_Cols, m_Rows}, CV_8UC3, m_Ctx);
+        const auto& ctx = frame.context();
+        m_Planes.create({m_Cols, m_Rows}, m_NV12, ctx);
+        hip::ContextLock lock(ctx->mutex());
+        ctx->check(lvk_hip_upload(ctx->get(), m_Planes.y(), m_Stage.y(), frame_bytes()), "RawYuvCapture::read");
+        ctx->check(lvk_hip_ingest_yuv420(ctx->get(), m_Planes.y(), m_Planes.y_step(), m_Planes.u(), m_Planes.uv_step(), m_Planes.v(), m_Planes.uv_step(),
+                                         m_NV12 ? 1 : 0, m_Rows, m_Cols, frame.device_ptr(), (int)frame.step), "RawYuvCapture::read");
+        ctx->check(lvk_hip_sync(ctx->get()), "RawYuvCapture::read");                   // the staging planes are reused by the next read
+        frame.format = VideoFrame::YUV; frame.timestamp = m_Stage.timestamp;
+        return true;
+    }
+
+private:
+    static uint8_t sat8(const int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+    void to_bgr(const HostFrame420& f, uint8_t* dst) const
+    {
+        constexpr int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SHIFT = 20;
+        const uint8_t* yp = f.y(); const uint8_t* up = f.u(); const uint8_t* vp = f.v();
+        const int cstep = f.uv_step(), cpix = m_NV12 ? 2 : 1;
+        for (int y = 0; y < m_Rows; y++)
+            for (int x = 0; x < m_Cols; x++)
+            {
+                const size_t ci = (size_t)(y / 2) * cstep + (size_t)(x / 2) * cpix;
+                const int u = (int)up[ci] - 128, v = (int)(m_NV12 ? up[ci + 1] : vp[ci]) - 128;
+                const int yy = std::max(0, (int)yp[(size_t)y * m_Cols + x] - 16) * CY;
+                uint8_t* p = dst + ((size_t)y * m_Cols + x) * 3;
+                p[0] = sat8((yy + (1 << (SHIFT - 1)) + CUB * u) >> SHIFT);
+                p[1] = sat8((yy + (1 << (SHIFT - 1)) + CVG * v + CUG * u) >> SHIFT);
+                p[2] = sat8((yy + (1 << (SHIFT - 1)) + CVR * v) >> SHIFT);
+            }
+    }
+
+    int m_Cols, m_Rows; double m_Fps; bool m_NV12; Deliver m_Deliver;
+    std::shared_ptr<hip::Context> m_Ctx;
+    std::FILE* m_File = nullptr;
+    size_t m_Index = 0;
+    HostFrame420 m_Stage;
+    VideoFrame420 m_Planes;
+    std::vector<uint8_t> m_Packed;
+};
+#endif
+
 // ---------------------------------------------------------------------------------------------- Functions/Image.hpp, Filters/ScalingFilter.hpp
 // lvk::upscale (Image.cpp:155-202): EASU upsampling to `size`; size == src.size() copies.
 inline void upscale(const VideoFrame& src, VideoFrame& dst, const cv::Size& size, const bool yuv = true)
@@ -676,6 +814,7 @@ inline void upscale(const VideoFrame& src, VideoFrame& dst, const cv::Size& size
     const auto& ctx = src.context();
     VideoFrame out;                                        // dst may be the object src refers to
     out.create(size, CV_8UC3, ctx);
+    hip::ContextLock lock(ctx->mutex());
     ctx->check(lvk_hip_upscale(ctx->get(), src.device_ptr(), (int)src.step, src.rows, src.cols,
                                out.device_ptr(), (int)out.step, out.rows, out.cols, yuv ? 1 : 0), "upscale");
     out.timestamp = src.timestamp; out.format = src.format;
@@ -691,6 +830,7 @@ inline void sharpen(const VideoFrame& src, VideoFrame& dst, const float sharpnes
     const auto& ctx = src.context();
     VideoFrame out;
     out.create(src.size(), CV_8UC3, ctx);
+    hip::ContextLock lock(ctx->mutex());
     ctx->check(lvk_hip_sharpen(ctx->get(), src.device_ptr(), (int)src.step, src.rows, src.cols, out.device_ptr(), (int)out.step, sharpness), "sharpen");
     out.timestamp = src.timestamp; out.format = src.format;
     dst = std::move(out);
@@ -729,7 +869,7 @@ private:
         lvk::sharpen(scaled, output, m_Settings.sharpness);
         output.timestamp = in.timestamp;
     }
-    void sync_gpu(bool trigger) override { if (trigger && m_Ctx) m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); }
+    void sync_gpu(bool trigger) override { if (trigger && m_Ctx) { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_sync(m_Ctx->get()), "sync_gpu"); } }
     std::shared_ptr<hip::Context> m_Ctx;
 };
 

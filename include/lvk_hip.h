@@ -304,11 +304,13 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
 /* The same path for frames that live in HOST memory -- FrameIngest::upload_planes -> to_ocl -> filter -> to_obs -> download_planes
  * (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602): h_* / oh_* are planes in PINNED host memory (lvk_hip_host_malloc,
  * hipHostMalloc or hipHostRegister; contiguous planes, the OBS layout, travel as one copy).  The library schedules the transfers: luma
- * first (the tracker starts while the chroma planes are still on the link), one copy stream per direction; the output planes are either
- * written by the remap kernel itself (a caller that waits for every frame: lowest latency) or downloaded behind it (a free-running
- * caller: highest rate) -- same pixels.  Input planes are consumed when the call returns; output planes are complete after
- * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed).  Pageable plane pointers are
- * refused with LVK_HIP_ERR_ARG (each pointer is looked up once). */
+ * first (the tracker starts while the chroma planes are still on the link), one upload stream; the output planes are written by the
+ * remap kernel ITSELF, straight into the pinned host planes (zero copy; the download route -- remap to device planes, then a D2H copy --
+ * is kept behind LVK_HIP_HOST_SINK=copy for comparison: the runtime performs that copy with a blit kernel that is slower for every
+ * caller measured) -- same pixels.  Input planes are consumed when the call returns; output planes are complete after
+ * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed).  Pageable plane
+ * pointers are refused with LVK_HIP_ERR_ARG: both ends of every plane are looked up on every call (an address that was pinned once may
+ * have been freed and handed out again as pageable memory). */
 int  lvk_hip_stab_push_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
                                    int rows, int cols, uint64_t timestamp,
                                    void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
@@ -319,6 +321,10 @@ int  lvk_hip_stab_push_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_st
  * order announced, at most two outstanding; the planes stay the caller's until their push returns. */
 int  lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step,
                                        int nv12, int rows, int cols);
+/* Forget the frames that were announced and not pushed (a caller that stops, seeks or switches buffers after announcing frame n + 1 --
+ * VideoFilter::stream's reader thread ending on a failed read, Filters/VideoFilter.cpp:77-103).  Returns once their uploads no longer
+ * read the caller's planes.  lvk_hip_stab_restart() implies it. */
+int  lvk_hip_stab_prefetch_cancel(lvk_hip_stab* stab);
 int  lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr);      /* pinned, device-visible host memory */
 int  lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr);
 

@@ -43,6 +43,7 @@ static int ctx_create_impl(int device, bool own_stream, void* stream, lvk_hip_ct
 
     auto* ctx = new lvk_hip_ctx();
     ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
     if (!own_stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
     else
     {
@@ -77,10 +78,14 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
     for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
     for (hipEvent_t e : ctx->wait_events) (void)hipEventDestroy(e);
     {
+        // (under the registry lock: a lvk_hip_free of one of these blocks through another context, on another thread, either finds this
+        //  context alive and its pool intact, or no owner at all)
         std::lock_guard<std::mutex> glock(g_owner_mutex);
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
         for (auto& kv : ctx->pool_sizes) g_block_owner.erase(kv.first);      // blocks still out there are plain device memory from now on
+        for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+        ctx->pool_free.clear(); ctx->pool_cached.clear(); ctx->pool_sizes.clear(); ctx->pool_cached_bytes = 0;
     }
-    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -90,6 +95,7 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx)
 int lvk_hip_sync(lvk_hip_ctx* ctx)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(ctx);
     for (auto& hook : ctx->sync_hooks) { const int rc = hook.second(); if (rc != LVK_HIP_OK) return rc; }
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (hipStream_t s : ctx->aux_streams) LVK_HIP_CHECK(ctx, hipStreamSynchronize(s));
@@ -133,27 +139,35 @@ int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr)
     if (!d_ptr) return LVK_HIP_OK;
     lvk_hip_ctx* caller = ctx;
     {
-        // a block of another (live) context goes back to ITS pool
-        std::lock_guard<std::mutex> glock(g_owner_mutex);
+        // A block of another (live) context goes back to ITS pool.  The owner registry stays locked until the block sits in that pool: the
+        // owner cannot be destroyed (lvk_hip_ctx_destroy takes the same lock to strike its blocks) between the look-up and the insertion.
+        // Lock order everywhere: g_owner_mutex, then a context's pool_mutex.
+        std::unique_lock<std::mutex> glock(g_owner_mutex);
         auto o = g_block_owner.find(d_ptr);
-        if (o != g_block_owner.end()) ctx = o->second;
-    }
-    {
-        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-        auto it = ctx->pool_sizes.find(d_ptr);
-        if (it != ctx->pool_sizes.end() && ctx->pool_cached.count(d_ptr))
-            return caller->fail(LVK_HIP_ERR_ARG, "lvk_hip_free: block freed twice");
-        if (it != ctx->pool_sizes.end() && ctx->pool_cached_bytes + it->second <= lvk_hip_ctx::kPoolMaxCachedBytes)
+        lvk_hip_ctx* owner = o != g_block_owner.end() ? o->second : ctx;
+        if (owner != caller)
         {
-            ctx->pool_free.emplace(it->second, d_ptr);
-            ctx->pool_cached.insert(d_ptr);
-            ctx->pool_cached_bytes += it->second;
+            // "work that still uses the block must be on this context's stream" (lvk_hip.h): the owner hands the block out again in ITS stream
+            // order, so what the CALLER's stream still has in flight is waited for first (hipFree, where this path used to end, synchronised
+            // implicitly).  An idle stream costs a query.
+            glock.unlock();
+            if (hipStreamQuery(caller->stream) != hipSuccess) { (void)hipGetLastError(); LVK_HIP_CHECK(caller, hipStreamSynchronize(caller->stream)); }
+            glock.lock();
+            o = g_block_owner.find(d_ptr);                                 // the owner may have gone meanwhile: then it is plain device memory
+            owner = o != g_block_owner.end() ? o->second : caller;
+        }
+        std::lock_guard<std::mutex> lock(owner->pool_mutex);
+        auto it = owner->pool_sizes.find(d_ptr);
+        if (it != owner->pool_sizes.end() && owner->pool_cached.count(d_ptr))
+            return caller->fail(LVK_HIP_ERR_ARG, "lvk_hip_free: block freed twice");
+        if (it != owner->pool_sizes.end() && owner->pool_cached_bytes + it->second <= lvk_hip_ctx::kPoolMaxCachedBytes)
+        {
+            owner->pool_free.emplace(it->second, d_ptr);
+            owner->pool_cached.insert(d_ptr);
+            owner->pool_cached_bytes += it->second;
             return LVK_HIP_OK;
         }
-        if (it != ctx->pool_sizes.end()) ctx->pool_sizes.erase(it);
-    }
-    {
-        std::lock_guard<std::mutex> glock(g_owner_mutex);
+        if (it != owner->pool_sizes.end()) owner->pool_sizes.erase(it);
         g_block_owner.erase(d_ptr);
     }
     LVK_HIP_CHECK(caller, hipFree(d_ptr));
@@ -163,11 +177,9 @@ int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr)
 int lvk_hip_trim(lvk_hip_ctx* ctx)
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
+    std::lock_guard<std::mutex> glock(g_owner_mutex);
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-    {
-        std::lock_guard<std::mutex> glock(g_owner_mutex);
-        for (auto& kv : ctx->pool_free) g_block_owner.erase(kv.second);
-    }
+    for (auto& kv : ctx->pool_free) g_block_owner.erase(kv.second);
     for (auto& kv : ctx->pool_free) { ctx->pool_sizes.erase(kv.second); (void)hipFree(kv.second); }
     ctx->pool_free.clear();
     ctx->pool_cached.clear();

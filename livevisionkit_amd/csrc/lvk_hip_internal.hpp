@@ -28,6 +28,7 @@ struct lvk_hip_ctx
 {
     int co_blocks_per_cu = 0;               // persistent remap grid of the overlap mode: blocks per CU for the next launch (0: the default)
     int device = 0;
+    int cu_count = 0;                   // compute units of the device (persistent-grid sizing of the remap)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string last_error;
@@ -71,6 +72,22 @@ struct lvk_hip_ctx
     std::map<std::pair<int, int>, int4*> enlargetabs;        // per destination index: (s0, s1, w0, w1)
 
     int fail(int code, const std::string& msg) { last_error = msg; return code; }
+};
+
+// The current device is a per-thread setting of the HIP runtime, and events / streams / allocations are made on it: an entry point that may
+// be called from any host thread (one filter per source, each on whatever thread the host gives it -- VisionFilter.cpp:157-162) makes its
+// context's device current for the duration of the call and puts the caller's back.  One hipGetDevice (a thread-local read) when they match.
+struct lvk_device_guard
+{
+    int prev = -1; bool switched = false;
+    explicit lvk_device_guard(const lvk_hip_ctx* ctx)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~lvk_device_guard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    lvk_device_guard(const lvk_device_guard&) = delete;
+    lvk_device_guard& operator=(const lvk_device_guard&) = delete;
 };
 
 #define LVK_HIP_CHECK(ctx, expr)                                                                      \

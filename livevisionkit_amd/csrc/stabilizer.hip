@@ -26,7 +26,6 @@
 #include <cstring>
 #include <deque>
 #include <functional>
-#include <unordered_set>
 
 using lvkh::Feature;
 using lvkh::WarpMeshF;
@@ -242,21 +241,35 @@ struct lvk_hip_stab
     hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
     int ensure_hostio(int rows, int cols);
     // The host entry points hand these pointers to copy engines and (output planes) to a kernel: pageable memory there is a GPU fault, not an
-    // error code.  Every plane pointer is looked up once (hipPointerGetAttributes) and remembered.
-    std::unordered_set<const void*> pinned_seen;
-    int require_pinned(const void* p, const char* what)
+    // error code.  Looked up on EVERY call (hipPointerGetAttributes: ~1 us) -- an address that was pinned once may be pageable memory the next
+    // time it is seen (hipHostFree / hipHostUnregister, then malloc) -- and at BOTH ends of the byte range, so that a plane that runs past
+    // its registration is refused too.
+    int require_pinned(const void* p, size_t bytes, const char* what)
     {
-        if (!p) return LVK_HIP_OK;
-        if (pinned_seen.count(p)) return LVK_HIP_OK;
-        hipPointerAttribute_t attr{};
-        const hipError_t e = hipPointerGetAttributes(&attr, p);
-        if (e != hipSuccess) (void)hipGetLastError();
-        if (e != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeDevice))
-            return fail(LVK_HIP_ERR_ARG, std::string(what) + ": the planes of the host entry points must be PINNED host memory "
-                                         "(lvk_hip_host_malloc, hipHostMalloc or hipHostRegister); this pointer is pageable memory");
-        if (pinned_seen.size() >= 4096) pinned_seen.clear();
-        pinned_seen.insert(p);
+        if (!p || bytes == 0) return LVK_HIP_OK;
+        for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + (bytes - 1)})
+        {
+            hipPointerAttribute_t attr{};
+            const hipError_t e = hipPointerGetAttributes(&attr, q);
+            if (e != hipSuccess) (void)hipGetLastError();
+            if (e != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeDevice))
+                return fail(LVK_HIP_ERR_ARG, std::string(what) + ": the planes of the host entry points must be PINNED host memory "
+                                             "(lvk_hip_host_malloc, hipHostMalloc or hipHostRegister) over their whole extent; this pointer is pageable memory");
+        }
         return LVK_HIP_OK;
+    }
+    // the planes of one 4:2:0 frame: one range when they are contiguous (the OBS layout), else plane by plane
+    int require_pinned_planes(const void* y, int y_step, const void* u, int u_step, const void* v, int v_step, int nv12, int rows, int cols, const char* what)
+    {
+        if (!y) return LVK_HIP_OK;
+        const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;
+        const size_t yb = (size_t)y_step * (rows - 1) + cols, ub = (size_t)u_step * (crows - 1) + ccols, vb = nv12 ? 0 : (size_t)v_step * (crows - 1) + ccols;
+        const uint8_t* ye = (const uint8_t*)y + yb; const uint8_t* ue = (const uint8_t*)u + ub;
+        if (y_step == cols && u_step == ccols && (const uint8_t*)u == ye && (nv12 || (v_step == ccols && (const uint8_t*)v == ue)))
+            return require_pinned(y, yb + ub + vb, what);
+        int rc;
+        if ((rc = require_pinned(y, yb, what)) != LVK_HIP_OK || (rc = require_pinned(u, ub, what)) != LVK_HIP_OK) return rc;
+        return nv12 ? LVK_HIP_OK : require_pinned(v, vb, what);
     }
     int host_stream(hipStream_t& s)                          // a transfer stream, created on first use; lvk_hip_sync() covers it
     {
@@ -266,6 +279,7 @@ struct lvk_hip_stab
         return LVK_HIP_OK;
     }
     int flush_download(bool wait);
+    int cancel_lookahead();
     int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
     void free_hostio();
     bool caller_free_running_now();
@@ -782,6 +796,7 @@ int lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lvk
 {
     if (!ctx) return LVK_HIP_ERR_ARG;
     LVK_HIP_REQUIRE(ctx, settings && out);
+    lvk_device_guard device_guard(ctx);
     *out = nullptr;
     auto* st = new lvk_hip_stab();
     st->ctx = ctx;
@@ -802,6 +817,7 @@ static void rehome_stage_events(lvk_hip_ctx* ctx);
 void lvk_hip_stab_destroy(lvk_hip_stab* st)
 {
     if (!st) return;
+    lvk_device_guard device_guard(st->ctx);
     (void)hipStreamSynchronize(st->ctx->stream);
     st->trace.dump();
     if (st->trace.on && st->host_trace_n)
@@ -858,6 +874,14 @@ static int stab_detach_bulk_stream(lvk_hip_stab* st)
     if (!st->remap_stream) return LVK_HIP_OK;
     (void)hipStreamSynchronize(st->remap_stream);
     rehome_stage_events(ctx);
+    // Events of this stabilizer that were recorded on the stream that goes away: everything on it has completed, so nothing has to wait for
+    // them any more -- and an event whose stream has been destroyed must not be waited for at all.  The per-slot "remap has read this pool
+    // slot" events are disarmed; the events a later push waits on unconditionally (remap_done of a pending release, ingest_done) are
+    // re-recorded on the context's own stream.
+    std::fill(st->slot_read_armed.begin(), st->slot_read_armed.end(), (char)0);
+    for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventRecord(st->remap_done[i], ctx->stream);
+    if (st->ingest_done) (void)hipEventRecord(st->ingest_done, ctx->stream);
+    st->remap_wait = nullptr;
     auto& aux = ctx->aux_streams;
     aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
     if (st->remap_stream_owned) LVK_HIP_CHECK(ctx, hipStreamDestroy(st->remap_stream));
@@ -909,6 +933,7 @@ static int stab_set_overlap(lvk_hip_stab* st, bool enable, lvk_hip_ctx* bulk)
 int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     return stab_set_overlap(st, enable != 0, nullptr);
 }
 
@@ -917,6 +942,7 @@ int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
 int lvk_hip_stab_set_bulk_context(lvk_hip_stab* st, lvk_hip_ctx* bulk)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     return stab_set_overlap(st, bulk != nullptr, bulk);
 }
 
@@ -926,6 +952,7 @@ int lvk_hip_stab_set_bulk_context(lvk_hip_stab* st, lvk_hip_ctx* bulk)
 int lvk_hip_stab_set_profiling(lvk_hip_stab* st, int enable)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     const int rc = st->prof_collect();
     st->profiling = enable != 0;
     st->prof_mask = enable == 1 ? ~0u : ((unsigned)enable & 0xffffu) >> 1;   // 1: every stage; otherwise (1 << (stage + 1)) bits
@@ -946,6 +973,7 @@ int lvk_hip_stab_get_profile(lvk_hip_stab* st, double total_ms[LVK_STAGE_COUNT],
 int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     LVK_HIP_REQUIRE(st->ctx, settings);
     st->finish_post();
     return st->configure(*settings);
@@ -966,6 +994,7 @@ static void overlay_colours(int format, double red[3], double green[3], double b
 int lvk_hip_stab_draw_trackers(lvk_hip_stab* st)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());                                           // StreamBuffer::newest: !is_empty()
     st->finish_post();
     const QueuedFrame& f = st->queue.back();
@@ -984,6 +1013,7 @@ int lvk_hip_stab_draw_trackers(lvk_hip_stab* st)
 int lvk_hip_stab_draw_motion_mesh(lvk_hip_stab* st)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());
     const QueuedFrame& f = st->queue.back();
     double r[3], g[3], b[3];
@@ -1006,8 +1036,14 @@ int lvk_hip_stab_set_lens(lvk_hip_stab* st, const lvk_camera_params* params)
 int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::restart (StabilizationFilter.cpp:139-144)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     // the queue's frames go back to their owners: nothing on the bulk stream may still be reading them
     if (st->remap_stream) LVK_HIP_CHECK(st->ctx, hipStreamSynchronize(st->remap_stream));
+    // host entry points: the emitted frame whose download has not been handed to the copy engine yet still goes out (*produced was
+    // reported); frames that were announced and never pushed are forgotten -- a restart is where a caller seeks or switches sources, and a
+    // stale announcement would otherwise refuse every later push ("another frame has been announced") or, matched by pointer identity,
+    // feed a reused buffer's pre-restart upload to the tracker
+    { int hrc; if ((hrc = st->flush_download(true)) != LVK_HIP_OK || (hrc = st->cancel_lookahead()) != LVK_HIP_OK) return hrc; }
     st->scene_quality = 1.0f;
     st->queue.clear(); st->queue_kind = 0;
     st->pending_release = nullptr; st->pending_slot = -1;
@@ -1019,6 +1055,7 @@ int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::rest
 int lvk_hip_stab_reset_context(lvk_hip_stab* st)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     st->reset_context();
     return LVK_HIP_OK;
 }
@@ -1185,6 +1222,9 @@ int lvk_hip_stab::ensure_hostio(int rows, int cols)
     if (h.rows == rows && h.cols == cols && h.up) return LVK_HIP_OK;
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
+    // (LVK_HIP_HOST_SINK=copy: the last emitted frame of the old size may not have been handed to the copy engine yet -- it was reported as
+    //  produced, so it goes out before its staging planes are freed)
+    { const int frc = flush_download(true); if (frc != LVK_HIP_OK) return frc; }
     free_hostio();
     const size_t bytes = (size_t)rows * cols + 2 * (size_t)((rows + 1) / 2) * ((cols + 1) / 2);
     for (auto& p : h.d_in) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
@@ -1326,6 +1366,17 @@ int lvk_hip_stab::flush_download(bool wait)
     return LVK_HIP_OK;
 }
 
+// Announced frames that will not be pushed (the caller stopped, seeked or restarted): their uploads are waited for -- the staging slots are
+// rewritten by the next upload on the same stream anyway, but the caller's planes must not be read after this returns -- and forgotten.
+int lvk_hip_stab::cancel_lookahead()
+{
+    HostIO& io = hostio;
+    for (hipStream_t us : {io.up, io.up2}) if (us) LVK_HIP_CHECK(ctx, hipStreamSynchronize(us));
+    io.ahead.clear();
+    for (hipEvent_t& e : ingest_wait) e = nullptr;
+    return LVK_HIP_OK;
+}
+
 int lvk_hip_stab::ensure_pool(int rows, int cols)
 {
     const size_t want = (size_t)s.predictive_samples + 4;
@@ -1368,6 +1419,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
                       void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     st->trace.begin();
     st->prof_tick++;
     if (st->queue.empty()) st->queue_kind = 0;
@@ -1393,6 +1445,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
                              int* produced, uint64_t* out_timestamp)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     lvk_hip_ctx* ctx = st->ctx;
     st->trace.begin();
     st->prof_tick++;
@@ -1490,11 +1543,12 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
 int lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     lvk_hip_ctx* ctx = st->ctx;
     LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
     LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
     int rc;
-    for (const void* p : {h_y, h_u, nv12 ? nullptr : h_v}) if ((rc = st->require_pinned(p, "lvk_hip_stab_prefetch_yuv420_host")) != LVK_HIP_OK) return rc;
+    if ((rc = st->require_pinned_planes(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, "lvk_hip_stab_prefetch_yuv420_host")) != LVK_HIP_OK) return rc;
     if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
     lvk_hip_stab::HostIO& io = st->hostio;
     // two staging slots: the frame being pushed and the one on the link -- at most two announced frames that have not been pushed yet
@@ -1503,6 +1557,15 @@ int lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_s
     if ((rc = st->host_upload(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, k, true)) != LVK_HIP_OK) return rc;
     io.ahead.push_back({k, {h_y, h_u, nv12 ? h_u : h_v}, rows, cols, nv12 ? 1 : 0});
     return LVK_HIP_OK;
+}
+
+// Forget the announced frames that have not been pushed (lvk_hip_stab_restart does the same): for a caller that announced frame n + 1 and
+// then stops, seeks or switches to other buffers.  Returns once the uploads no longer read the caller's planes.
+int lvk_hip_stab_prefetch_cancel(lvk_hip_stab* st)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
+    return st->cancel_lookahead();
 }
 
 // Host-resident frames: FrameIngest::upload_planes -> to_ocl -> StabilizationFilter::filter -> to_obs -> download_planes in one call
@@ -1524,13 +1587,18 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
                                   int* produced, uint64_t* out_timestamp)
 {
     if (!st) return LVK_HIP_ERR_ARG;
+    lvk_device_guard device_guard(st->ctx);
     lvk_hip_ctx* ctx = st->ctx;
     if (produced) *produced = 0;
     LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
     LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
     int rc;
-    for (const void* p : {h_y, h_u, nv12 ? nullptr : h_v, (const void*)oh_y, (const void*)oh_u, nv12 ? nullptr : (const void*)oh_v})
-        if ((rc = st->require_pinned(p, "lvk_hip_stab_push_yuv420_host")) != LVK_HIP_OK) return rc;
+    if ((rc = st->require_pinned_planes(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, "lvk_hip_stab_push_yuv420_host")) != LVK_HIP_OK) return rc;
+    if (oh_y && oh_u && (nv12 || oh_v))
+    {
+        LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
+        if ((rc = st->require_pinned_planes(oh_y, oy_step, oh_u, ou_step, oh_v, ov_step, nv12, rows, cols, "lvk_hip_stab_push_yuv420_host (output)")) != LVK_HIP_OK) return rc;
+    }
     if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
     lvk_hip_stab::HostIO& io = st->hostio;
     if ((rc = st->flush_download(false)) != LVK_HIP_OK) return rc;

@@ -218,6 +218,10 @@ class StabilizationFilter:
         if rc != 0:
             self.ctx._check(rc)
 
+    def prefetch_cancel(self):
+        """lvk_hip_stab_prefetch_cancel: forget the announced frames that have not been pushed."""
+        self.ctx._check(self.lib.lvk_hip_stab_prefetch_cancel(self.handle))
+
     def apply_yuv420_host_prepared(self, src, timestamp, dst):
         """lvk_hip_stab_push_yuv420_host: pinned host planes in, pinned host planes out (complete after Context.sync())."""
         produced = self._produced; ots = self._ots

@@ -20,7 +20,10 @@ def main():
     rng = np.random.default_rng(0)
     H = synth.random_homography(rows, cols, rng, strength=0.5)
     mesh = synth.random_mesh(16, 16, rng, amp=0.01)
+    # the fused remap + 4:2:0 egress kernel of the default stream (k_remap_homography_420): a 2 x 2 mesh of small corner offsets
+    mesh2 = np.array([[[0.004, -0.003], [-0.002, 0.004]], [[0.003, 0.002], [-0.004, -0.002]]], np.float32)
     for name, fn in [("homography", lambda s: ctx.remap_homography(s, H, yuv=True, out=out)),
+                     ("homography_420", lambda s: ctx.warpmesh_apply_yuv420(s, mesh2)),
                      ("mesh16", lambda s: ctx.remap_mesh(s, mesh, yuv=True, out=out))]:
         for s in srcs[:3]:
             fn(s)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lvk/LiveVisionKit.hpp"
@@ -156,7 +157,7 @@ int run_golden(const char* clip_path, int n, int rows, int cols, const char* out
         const std::vector<uint8_t>& clip; int n, rows, cols, i = 0;
         ClipCapture(const std::vector<uint8_t>& c, int n_, int r, int co) : clip(c), n(n_), rows(r), cols(co) {}
         bool isOpened() const override { return true; }
-        double get(int) const override { return 0.0; }
+        double get(int) const override { return (double)(i - 1); }          // frame k sits at k ms: stream() stamps it k * 1e6 ns (VideoFilter.cpp:84-85)
         bool read(lvk::VideoFrame& f) override
         {
             if (i >= n) return false;
@@ -169,10 +170,11 @@ int run_golden(const char* clip_path, int n, int rows, int cols, const char* out
     {
         lvk::StabilizationFilter filter;
         filter.configure(golden_settings(name));
+        filter.stream_keeps_frame_format(true);                 // the golden clip is packed YUV (the reference's reader would call it BGR)
         ClipCapture cap(clip, n, rows, cols);
         int emitted = 0; bool ok = true;
         filter.stream(cap, [&](lvk::Frame& frame) {
-            ok = ok && frame.timestamp == (uint64_t)(1000 + emitted);
+            ok = ok && frame.timestamp == (uint64_t)emitted * 1000000ull && frame.format == lvk::VideoFrame::YUV;
             frame.download(host.data());
             std::fwrite(host.data(), 1, host.size(), out);
             emitted++;
@@ -233,6 +235,169 @@ int run_chain_race_check()
         for (size_t k = 0; k < a.size(); k++) if (a[k] != b[k]) { std::printf("chain: frame %zu differs between the synchronous and the free-running chain (overlap %d)\n", k, (int)overlap); return 1; }
     }
     std::printf("chain ok: free-running == synchronous, with and without overlap\n");
+    return 0;
+}
+
+// Concurrent filter instances in one process: the plugin holds one StabilizationFilter per source and runs each on whatever thread OBS
+// gives it (VSFilter.hpp:54, Interop/VisionFilter.cpp:157-162; SURVEY 8b: "re-entrant per instance, no shared mutable globals").  Two
+// filters on two std::threads, different clips and presets, free-running with overlap on: each stream's emitted bytes must equal its own
+// single-threaded run -- with a context per filter, and with BOTH filters on ONE shared hip::Context.
+int run_two_threads_check()
+{
+    const int rows = 360, cols = 640, n = 40;
+    auto paint = [&](std::vector<uint8_t>& img, int stream, int i) {
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++)
+            {
+                uint8_t* p = &img[((size_t)y * cols + x) * 3];
+                const int xs = x + (stream ? 3 : 2) * (i % 4) + stream * 17, ys = y + (i % 3) + stream * 5, cell = stream ? 18 : 13;
+                p[0] = (uint8_t)((((xs / cell) + (ys / cell)) % 2) ? 200 - 20 * stream : 35 + (xs * 5 + ys * (9 + 2 * stream)) % 31);
+                p[1] = (uint8_t)(100 + (x >> 3) + 9 * stream); p[2] = (uint8_t)(90 + (y >> 2));
+            }
+    };
+    auto settings_of = [](int stream) {
+        lvk::StabilizationFilterSettings st;
+        st.predictive_samples = 3 + stream; st.detection_resolution = {480, 270};
+        st.min_scene_quality = 0.4f; st.min_tracking_quality = 0.2f;
+        if (stream == 0) { st.track_local_motions = false; st.motion_resolution = {2, 2}; st.detection_regions = {2, 1}; st.acceptance_threshold = 3.0f; }
+        else { st.track_local_motions = true; st.motion_resolution = {16, 16}; st.detection_regions = {2, 2}; st.acceptance_threshold = 10.0f; }
+        return st;
+    };
+    using Outputs = std::vector<std::vector<uint8_t>>;
+    auto run_stream = [&](int stream, const std::shared_ptr<lvk::hip::Context>& ctx, Outputs& outs) {
+        std::unique_ptr<lvk::StabilizationFilter> filter;
+        if (ctx) filter = std::make_unique<lvk::StabilizationFilter>(lvk::StabilizationFilterSettings{}, ctx);
+        else filter = std::make_unique<lvk::StabilizationFilter>();
+        filter->configure(settings_of(stream));
+        filter->set_overlap(true);
+        std::vector<uint8_t> img((size_t)rows * cols * 3);
+        std::vector<lvk::Frame> kept;
+        for (int i = 0; i < n; i++)
+        {
+            paint(img, stream, i);
+            lvk::Frame frame;
+            frame.upload(img.data(), rows, cols, lvk::VideoFrame::YUV, 100 * stream + i, ctx);
+            filter->apply(std::move(frame), frame);                   // free-running: nothing waits for the GPU inside the loop
+            if (!frame.empty()) kept.push_back(std::move(frame));
+        }
+        for (auto& f : kept) { outs.emplace_back((size_t)rows * cols * 3); f.download(outs.back().data()); }
+    };
+    Outputs want[2];
+    for (int s = 0; s < 2; s++) run_stream(s, nullptr, want[s]);
+    if (want[0].size() != (size_t)n - 3 || want[1].size() != (size_t)n - 4) { std::printf("threads: reference runs emitted %zu / %zu\n", want[0].size(), want[1].size()); return 1; }
+    if (want[0][10] == want[1][10]) { std::printf("threads: the two streams are not distinct\n"); return 1; }
+    for (int shared = 0; shared < 2; shared++)
+        for (int round = 0; round < 2; round++)
+        {
+            Outputs got[2];
+            std::shared_ptr<lvk::hip::Context> ctx = shared ? std::make_shared<lvk::hip::Context>() : nullptr;
+            std::thread t0([&] { run_stream(0, ctx, got[0]); });
+            std::thread t1([&] { run_stream(1, ctx, got[1]); });
+            t0.join(); t1.join();
+            for (int s = 0; s < 2; s++)
+            {
+                if (got[s].size() != want[s].size()) { std::printf("threads: stream %d emitted %zu frames (shared %d)\n", s, got[s].size(), shared); return 1; }
+                for (size_t k = 0; k < got[s].size(); k++)
+                    if (got[s][k] != want[s][k]) { std::printf("threads: stream %d frame %zu differs from its single-threaded run (shared context %d, round %d)\n", s, k, shared, round); return 1; }
+            }
+        }
+    std::printf("threads ok: 2 filters on 2 threads == their single-threaded runs, own contexts and one shared context\n");
+    return 0;
+}
+
+// A clip FILE through VideoFilter::stream (the reference's harness: VideoProcessor.cpp:148-230 opens a cv::VideoCapture on a path and
+// streams it): lvk::RawYuvCapture on a raw I420 file.  Delivered as YUV the emitted frames must equal apply() on the same frames ingested
+// by lvk_hip_ingest_yuv420, stamped with the stream position; delivered as BGR (the reference's assumption) the run must complete with BGR
+// frames; read(HostFrame420&) feeds the host entry point and must emit the planes of the device 4:2:0 path.
+int run_file_input_check(const char* dir)
+{
+    const int rows = 360, cols = 640, n = 18; const double fps = 50.0;
+    const std::string path = std::string(dir) + "/clip_i420.yuv";
+    std::vector<std::vector<uint8_t>> frames(n, std::vector<uint8_t>((size_t)rows * cols * 3 / 2));
+    {
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f) { std::printf("file input: cannot write %s\n", path.c_str()); return 1; }
+        for (int i = 0; i < n; i++)
+        {
+            uint8_t* d = frames[i].data();
+            for (int y = 0; y < rows; y++)
+                for (int x = 0; x < cols; x++)
+                {
+                    const int xs = x + 2 * (i % 3), ys = y + (i % 2);
+                    d[(size_t)y * cols + x] = (uint8_t)((((xs / 15) + (ys / 15)) % 2) ? 190 : 45 + (xs * 3 + ys * 7) % 37);
+                }
+            for (int k = 0; k < rows * cols / 2; k++) d[(size_t)rows * cols + k] = (uint8_t)(100 + (k * 3 + i) % 50);
+            std::fwrite(d, 1, frames[i].size(), f);
+        }
+        std::fclose(f);
+    }
+    lvk::StabilizationFilterSettings st; st.predictive_samples = 4;
+    // expected: apply() on the frames ingested by the library's own 4:2:0 -> 4:4:4 conversion
+    std::vector<std::vector<uint8_t>> want;
+    {
+        lvk::StabilizationFilter filter(st);
+        for (int i = 0; i < n; i++)
+        {
+            lvk::VideoFrame420 planes; planes.upload(frames[i].data(), rows, cols, false, i);
+            lvk::Frame frame; frame.create({cols, rows}, CV_8UC3, planes.context());
+            planes.context()->check(lvk_hip_ingest_yuv420(planes.context()->get(), planes.y(), planes.y_step(), planes.u(), planes.uv_step(), planes.v(), planes.uv_step(), 0,
+                                                          rows, cols, frame.device_ptr(), (int)frame.step), "file input");
+            frame.format = lvk::VideoFrame::YUV; frame.timestamp = i;
+            filter.apply(std::move(frame), frame);
+            if (frame.empty()) continue;
+            want.emplace_back((size_t)rows * cols * 3); frame.download(want.back().data());
+        }
+    }
+    {
+        lvk::StabilizationFilter filter(st);
+        filter.stream_keeps_frame_format(true);
+        lvk::RawYuvCapture cap(path, cols, rows, fps, false, lvk::RawYuvCapture::Deliver::YUV);
+        if (!cap.isOpened()) { std::printf("file input: capture not opened\n"); return 1; }
+        size_t k = 0; bool ok = true;
+        std::vector<uint8_t> host((size_t)rows * cols * 3);
+        filter.stream(cap, [&](lvk::Frame& frame) {
+            const uint64_t ts = (uint64_t)((double)k * 1000.0 / fps * 1.0e6);           // frame k of the file: k / fps seconds
+            frame.download(host.data());
+            ok = ok && k < want.size() && frame.timestamp == ts && frame.format == lvk::VideoFrame::YUV && host == want[k];
+            k++;
+            return false;
+        });
+        if (!ok || k != want.size() || cap.frames_read() != (size_t)n) { std::printf("file input: YUV stream differs (%zu of %zu frames)\n", k, want.size()); return 1; }
+    }
+    {
+        lvk::StabilizationFilter filter(st);                            // the reference's reader: frames assumed BGR
+        lvk::RawYuvCapture cap(path, cols, rows, fps);
+        size_t k = 0; bool ok = true;
+        filter.stream(cap, [&](lvk::Frame& frame) { ok = ok && frame.format == lvk::VideoFrame::BGR && frame.cols == cols; k++; return false; });
+        if (!ok || k != (size_t)n - 4) { std::printf("file input: BGR stream emitted %zu frames\n", k); return 1; }
+    }
+    {
+        // the raw planes into the host entry point against the device 4:2:0 overload
+        std::vector<std::vector<uint8_t>> want420;
+        {
+            lvk::StabilizationFilter filter(st);
+            for (int i = 0; i < n; i++)
+            {
+                lvk::VideoFrame420 in, out; in.upload(frames[i].data(), rows, cols, false, i);
+                filter.apply(in, out);
+                if (out.empty()) continue;
+                want420.emplace_back(frames[i].size()); out.download(want420.back().data());
+            }
+        }
+        lvk::StabilizationFilter filter(st);
+        lvk::RawYuvCapture cap(path, cols, rows, fps);
+        lvk::HostFrame420 in; size_t k = 0;
+        while (cap.read(in))
+        {
+            lvk::HostFrame420 out;
+            filter.apply(in, out, true);
+            if (out.empty()) continue;
+            if (k >= want420.size() || std::memcmp(out.y(), want420[k].data(), out.bytes()) != 0) { std::printf("file input: host frame %zu differs\n", k); return 1; }
+            k++;
+        }
+        if (k != want420.size()) { std::printf("file input: host path emitted %zu\n", k); return 1; }
+    }
+    std::printf("file input ok: %zu frames through stream() == apply(), BGR delivery runs, host planes == device planes\n", want.size());
     return 0;
 }
 
@@ -298,6 +463,7 @@ int main(int argc, char** argv)
 #ifdef RUN_ON_GPU
     if (argc >= 7 && std::string(argv[1]) == "--golden") return run_golden(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
     if (argc >= 7 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5], std::atoi(argv[6]));
+    if (argc >= 3 && std::string(argv[1]) == "--threads-and-files") return (run_two_threads_check() != 0 || run_file_input_check(argv[2]) != 0) ? 1 : 0;
     if (run_chain_race_check() != 0) return 1;
     {
         // VideoFilter::stream (Filters/VideoFilter.cpp:62-209; CLI use Modules/VideoEditor/VideoProcessor.cpp:148-230): reader thread ->

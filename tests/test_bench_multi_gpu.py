@@ -35,3 +35,64 @@ def test_bench_two_ranks_on_a_shared_gpu():
     assert abs(r["ms_per_step"] - slowest / 20 * 1e3) <= 0.02 * r["ms_per_step"]
     assert r["sustained"]["frames"] >= 1200
     print("\n[bench --gpus 2 on a shared GPU] value %.0f frames/s; per rank: %s" % (r["value"], [(x["device"], x["numa_cpus"], round(x["frames_per_s"])) for x in ranks]))
+
+
+def _run_bench(extra, env=None, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-pcie", "--no-configs",
+           "--no-reference-kernel", "--no-multi-stream", "--rows", "1080", "--cols", "1920", "--pool", "64"] + extra
+    return subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks_when_launched_plainly():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it (the way the driver launches --gpus 1) must not silently run one rank:
+    it spawns its two ranks itself and prints ONE line with n_gpus 2 and two streams."""
+    p = _run_bench(["--gpus", "2"], env={"LVK_BENCH_SHARE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and len(r["ranks"]) == 2 and r["ranks"][0]["clip_seed"] != r["ranks"][1]["clip_seed"]
+    assert all(x["frames"] == 20 for x in r["ranks"])
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    """More ranks asked for than GPUs present (and no sharing flag), or a launcher whose WORLD_SIZE disagrees with --gpus: a non-zero exit, no line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = _run_bench(["--gpus", str(n)])
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout[-1000:]
+    p = _run_bench(["--gpus", "2"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_streams_per_gpu():
+    """K concurrent streams on one GPU (one host thread, one filter, one clip each): aggregate value over all of them, per-stream latency."""
+    p = _run_bench(["--streams-per-gpu", "3"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["config"]["streams_per_gpu"] == 3
+    rk = r["ranks"][0]
+    assert rk["frames"] == 60 and rk["streams"] == 3 and len(rk["stream_latency_ms"]) == 3
+    assert abs(r["value"] - 60 / rk["elapsed_s"]) <= 0.02 * r["value"]
+    assert r["sustained"]["frames"] >= 1800
+    print("\n[bench --streams-per-gpu 3, 1080p] value %.0f frames/s, per-stream p99 ms: %s" % (r["value"], [round(x["p99"], 3) for x in rk["stream_latency_ms"]]))
+
+
+@pytest.mark.gpu
+def test_bench_reads_a_clip_file(tmp_path):
+    """--input: the synthetic clip written to a raw I420 file and read back gives the run the generator gives (same tracker state, same last
+    output frame) -- the file path feeds the same frames."""
+    path = str(tmp_path / "clip.yuv")
+    p = _run_bench(["--write-input", path])
+    assert p.returncode == 0 and os.path.getsize(path) == 64 * 1920 * 1080 * 3 // 2, p.stderr[-2000:]
+    a = _run_bench([])
+    b = _run_bench(["--input", path])
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1500:], b.stderr[-1500:])
+    ra = json.loads([ln for ln in a.stdout.splitlines() if ln.startswith("{")][0])
+    rb = json.loads([ln for ln in b.stdout.splitlines() if ln.startswith("{")][0])
+    assert rb["data"].startswith("file clip.yuv") and ra["data"] == "synthetic"
+    assert ra["tracking"] == rb["tracking"] and ra["tracking"]["features"] > 100

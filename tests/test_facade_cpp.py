@@ -37,6 +37,17 @@ def test_plugin_call_sites_run_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_filters_on_two_threads_and_a_clip_file(tmp_path):
+    """Per-instance re-entrancy (VSFilter.hpp:54, VisionFilter.cpp:157-162): two filters on two host threads, own contexts and one shared
+    context, each stream's bytes equal to its single-threaded run; and a raw I420 FILE through VideoFilter::stream (lvk::RawYuvCapture; the
+    reference's harness streams a file, VideoProcessor.cpp:148-230)."""
+    exe = _build(tmp_path, ["-DRUN_ON_GPU", "-O1", "-pthread"])
+    out = subprocess.check_output([exe, "--threads-and-files", str(tmp_path)], timeout=600).decode()
+    assert "threads ok: 2 filters on 2 threads" in out
+    assert "file input ok:" in out
+
+
+@pytest.mark.gpu
 def test_facade_emits_the_golden_frames(tmp_path):
     """Pixels through the C++ API the plugin links against: lvk::StabilizationFilter::apply on the golden clip, both presets, must give
     the frames of tests/golden/stabilizer.npz (sha-256 per emitted frame; the same vectors pin the oracle and the C-ABI)."""
