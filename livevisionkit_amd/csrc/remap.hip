@@ -122,13 +122,9 @@ __device__ __forceinline__ float4 make_tap(uint32_t lo_bytes)
     return make_float4(p.x, p.y, p.z, luma<YUV>(p));
 }
 
-// One output pixel: its three 8-bit channels, each in a register of its own.  (They used to travel as 0x00ZZYYXX: packed at the end of the
-// filter, taken apart again by the 4:2:0 sink -- 5 to 7 instructions per pixel that produce nothing.)
-struct Px3 { uint32_t c0, c1, c2; };
-
-// FSR.cl:181-318 on the 12 taps  b c / e f g h / i j k l / n o  (order of the array below).
+// FSR.cl:181-318 on the 12 taps  b c / e f g h / i j k l / n o  (order of the array below).  Returns 0x00ZZYYXX.
 enum { TB, TC, TE, TF, TG, TH_, TI, TJ, TK, TL, TN, TO };
-__device__ __forceinline__ Px3 easu_core(const float4 t[12], float ppx, float ppy)
+__device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, float ppy)
 {
     // FSR.cl:244-249
     float len = 0.0f, dirx = 0.0f, diry = 0.0f;
@@ -186,13 +182,15 @@ __device__ __forceinline__ Px3 easu_core(const float4 t[12], float ppx, float pp
     const float px = clamp3_(aC.x * rW, mi4.x, ma4.x);
     const float py = clamp3_(aC.y * rW, mi4.y, ma4.y);
     const float pz = clamp3_(aC.z * rW, mi4.z, ma4.z);
-    // convert_uchar3(x * 255): x lies between two of the taps' channels, i.e. in [0, 1], so the truncated product is 0 .. 255 as it is
-    return Px3{(uint32_t)(int)(px * 255.0f), (uint32_t)(int)(py * 255.0f), (uint32_t)(int)(pz * 255.0f)};
+    const uint32_t ux = (uint32_t)(int)(px * 255.0f) & 0xffu;
+    const uint32_t uy = (uint32_t)(int)(py * 255.0f) & 0xffu;
+    const uint32_t uz = (uint32_t)(int)(pz * 255.0f) & 0xffu;
+    return ux | (uy << 8) | (uz << 16);
 }
 
 // EASU with the 12 taps gathered straight from global memory (8 + 16 + 16 + 8 byte loads like FSR.cl:196-202).
 template <bool YUV>
-__device__ __forceinline__ Px3 easu_gather(const uint8_t* __restrict__ src, int step, int sx, int sy, float ppx, float ppy)
+__device__ __forceinline__ uint32_t easu_gather(const uint8_t* __restrict__ src, int step, int sx, int sy, float ppx, float ppy)
 {
     const uint8_t* r0p = src + (long)(sy - 1) * step + 3 * sx;      // b, c
     const uint8_t* r1p = r0p + step - 3;                            // e, f, g, h
@@ -331,40 +329,32 @@ constexpr int NUM_XCD = 8;
 // Output pixels are written once and not read again by this GPU for N frames: streaming (non-temporal) stores keep them from sitting
 // dirty in the L2s that the tracker's kernels release at every kernel boundary (+1 % frames/s, -2 % latency next to the tracker)
 #define LVK_STREAM_STORE(ptr, v) __builtin_nontemporal_store((uint32_t)(v), (ptr))
+__device__ __forceinline__ void store_pixels(uint8_t* __restrict__ drow, int x0, int npx, const uint32_t px[PXT], bool aligned)
+{
+    if (npx == PXT && aligned)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);      // 4 packed pixels = 12 bytes = 3 dwords
+        LVK_STREAM_STORE(d + 0, px[0] | (px[1] << 24));
+        LVK_STREAM_STORE(d + 1, (px[1] >> 8) | (px[2] << 16));
+        LVK_STREAM_STORE(d + 2, (px[2] >> 16) | (px[3] << 8));
+    }
+    else
+        for (int p = 0; p < npx; p++)
+        {
+            uint8_t* d = drow + 3 * (x0 + p);
+            d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16);
+        }
+}
 
-// Where a thread's PXT output pixels go.  A sink has an accumulator the pixels are folded into as they are produced -- in the layout they
-// are stored in, three registers for the four pixels -- and a store().  PackedSink: the packed 8UC3 frame (three aligned dwords per thread).
+// Where a thread's PXT output pixels go.  PackedSink: the packed 8UC3 frame (three aligned dwords per thread).
 struct PackedSink
 {
     uint8_t* __restrict__ dst; int dst_step;
-    struct Acc
-    {
-        uint32_t d[3] = {0u, 0u, 0u};                                 // the 12 bytes of 4 packed pixels, little endian
-        __device__ __forceinline__ void add(int p, const Px3& v)      // p is a constant after unrolling: every shift below is an immediate
-        {
-            const uint32_t c[3] = {v.c0, v.c1, v.c2};
-#pragma unroll
-            for (int k = 0; k < 3; k++) { const int byte = 3 * p + k; d[byte >> 2] |= c[k] << (8 * (byte & 3)); }
-        }
-        __device__ __forceinline__ uint32_t byte(int i) const { return (d[i >> 2] >> (8 * (i & 3))) & 0xffu; }
-    };
-    __device__ __forceinline__ void store(int x0, int y, int npx, const Acc& a, bool active, int /*parity*/) const
+    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active, int /*parity*/) const
     {
         if (!active) return;
         uint8_t* drow = dst + (long)y * dst_step;
-        if (npx == PXT && ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0))
-        {
-            uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);      // 4 packed pixels = 12 bytes = 3 dwords
-            LVK_STREAM_STORE(d + 0, a.d[0]);
-            LVK_STREAM_STORE(d + 1, a.d[1]);
-            LVK_STREAM_STORE(d + 2, a.d[2]);
-        }
-        else
-        {
-            uint8_t* d = drow + 3 * x0;
-#pragma unroll
-            for (int i = 0; i < 3 * PXT; i++) if (i < 3 * npx) d[i] = (uint8_t)a.byte(i);
-        }
+        store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
     }
 };
 
@@ -375,29 +365,21 @@ template <bool NV12>
 struct Sink420
 {
     uint8_t* __restrict__ yp; int y_step; uint8_t* __restrict__ up; int u_step; uint8_t* __restrict__ vp; int v_step;
-    struct Acc
-    {
-        // the four luma bytes; (U, V) as two 16-bit sums per word: u0 + u1 | u2 + u3 and v0 + v1 | v2 + v3 (horizontal pairs pre-added)
-        uint32_t yy = 0u, uu = 0u, vv = 0u;
-        __device__ __forceinline__ void add(int p, const Px3& v)
-        {
-            yy |= v.c0 << (8 * p);
-            uu += v.c1 << (16 * (p >> 1));
-            vv += v.c2 << (16 * (p >> 1));
-        }
-    };
-    __device__ __forceinline__ void store(int x0, int y, int npx, const Acc& acc, bool active, int parity) const
+    __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active, int parity) const
     {
         // two buffers, alternating per strip of a block: a wave that is already writing the next strip's sums cannot overwrite what a
         // slower wave of the block still has to read for this one (the one barrier per strip orders everything else)
         __shared__ uint2 s_uv2[2][256];
         uint2* s_uv = s_uv2[parity & 1];
         const int t = (int)threadIdx.x;
-        s_uv[t] = make_uint2(acc.uu, acc.vv);
+        // (U, V) of the four pixels, two 16-bit sums per word: u0 + u1 | u2 + u3 and v0 + v1 | v2 + v3 (horizontal pairs pre-added)
+        const uint32_t u01 = ((px[0] >> 8) & 0xffu) + ((px[1] >> 8) & 0xffu), u23 = ((px[2] >> 8) & 0xffu) + ((px[3] >> 8) & 0xffu);
+        const uint32_t v01 = ((px[0] >> 16) & 0xffu) + ((px[1] >> 16) & 0xffu), v23 = ((px[2] >> 16) & 0xffu) + ((px[3] >> 16) & 0xffu);
+        s_uv[t] = make_uint2(u01 | (u23 << 16), v01 | (v23 << 16));
         if (active)
         {
             uint8_t* yr = yp + (long)y * y_step + x0;
-            const uint32_t yy = acc.yy;
+            const uint32_t yy = (px[0] & 0xffu) | ((px[1] & 0xffu) << 8) | ((px[2] & 0xffu) << 16) | ((px[3] & 0xffu) << 24);
             if (npx == PXT && ((reinterpret_cast<uintptr_t>(yr) & 3u) == 0)) LVK_STREAM_STORE(reinterpret_cast<uint32_t*>(yr), yy);
             else for (int p = 0; p < npx; p++) yr[p] = (uint8_t)(yy >> (8 * p));
         }
@@ -434,10 +416,11 @@ __device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src,
     const int y = sy_ * STRIP_H + (int)(threadIdx.x >> 6);
     const bool active = strip < nstrips && x0 < dst_cols && y < dst_rows;
     const int npx = active ? min(PXT, dst_cols - x0) : 0;
-    typename Sink::Acc acc;
+    uint32_t px[PXT];
 #pragma unroll
     for (int p = 0; p < PXT; p++)
     {
+        px[p] = 0;
         if (p < npx)
         {
             float subx, suby;
@@ -452,14 +435,14 @@ __device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src,
                 if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)
                 {
                     const uint8_t* s = src + (long)sy * src_step + 3 * sx;
-                    acc.add(p, Px3{(uint32_t)s[0], (uint32_t)s[1], (uint32_t)s[2]});
+                    px[p] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
                 }
-                else acc.add(p, Px3{bg & 0xffu, (bg >> 8) & 0xffu, (bg >> 16) & 0xffu});
+                else px[p] = bg;
             }
-            else acc.add(p, easu_gather<YUV>(src, src_step, sx, sy, ppx, ppy));
+            else px[p] = easu_gather<YUV>(src, src_step, sx, sy, ppx, ppy);
         }
     }
-    sink.store(x0, y, npx, acc, active, parity);
+    sink.store(x0, y, npx, px, active, parity);
 }
 
 template <bool YUV, class Coord, class Sink>

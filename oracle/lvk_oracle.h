@@ -95,6 +95,11 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
                const float* prev_pts, int n, float* next_pts, uint8_t* status,
                int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
 
+/* the tracker with OpenCV's binary32 window sums instead of the specification's exact ones (lanes 1 / 4 / 8 / 16; pairs: v_dotprod pre-sums):
+ * only there to measure the distance between the two (tests/test_pyrlk_float_order.py) */
+int lvko_pyrlk_float(const uint8_t* prev, int prev_step, const uint8_t* next, int next_step, int rows, int cols,
+                     const float* prev_pts, int n, float* next_pts, uint8_t* status,
+                     int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold, int lanes, int pairs);
 int lvko_pyramid_levels(int rows, int cols, int max_level, int win_w, int win_h, int* out_rows, int* out_cols);
 
 

@@ -68,14 +68,54 @@ std::vector<Level> build_pyramid(const uint8_t* img, int step, int rows, int col
 
 inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
+// How a window sum of int products is formed.
+//   lanes == 0: the SPECIFICATION -- exact integer sum, converted to binary32 once (what the HIP kernel computes).
+//   lanes >= 1: the way OpenCV 4.8's LKTrackerInvoker forms it (video/src/lkpyramid.cpp), kept to MEASURE how far the specification is from
+//               it: binary32 accumulation in window row-major order.  lanes == 1 is the scalar loop (`iA11 += (float)(ixval * ixval)`).
+//               lanes = 4 / 8 / 16 model the SIMD loops: per window row, full groups of (pairs ? 2 : 1) * lanes elements are added lane-wise
+//               into `lanes` binary32 accumulators -- with pairs, adjacent products are first summed exactly in int32, as v_dotprod does for
+//               the int16 operands (the universal-intrinsic loop: v_int16x8, 8 elements per step, 4 float lanes) --, the rest of the row goes
+//               to a scalar binary32 accumulator in order; the result is scalar + (lane 0 + lane 1 + ...), as v_reduce_sum adds them.
+struct WinSum
+{
+    int lanes, pairs;
+    long long exact = 0;
+    float scalar = 0.f, lane[16] = {0.f};
+    int row_fill = 0; long long pending = 0; int pending_n = 0;
+    WinSum(int lanes_, int pairs_) : lanes(lanes_), pairs(pairs_) {}
+    // one window row of products, in order
+    void add_row(const long long* prod, int n)
+    {
+        if (lanes == 0) { for (int i = 0; i < n; i++) exact += prod[i]; return; }
+        if (lanes == 1) { for (int i = 0; i < n; i++) scalar += (float)prod[i]; return; }
+        const int per = pairs ? 2 : 1, group = per * lanes;
+        int i = 0;
+        for (; i + group <= n; i += group)
+            for (int l = 0; l < lanes; l++)
+            {
+                long long v = prod[i + per * l];
+                if (pairs) v += prod[i + per * l + 1];
+                lane[l] += (float)v;
+            }
+        for (; i < n; i++) scalar += (float)prod[i];
+    }
+    float total(float scale) const
+    {
+        if (lanes == 0) return (float)exact * scale;
+        float r = 0.f;
+        if (lanes > 1) { for (int l = 0; l < lanes; l++) r += lane[l]; }
+        return (scalar + r) * scale;
+    }
+};
+
 } // namespace
 
-extern "C" {
+namespace {
 
 // Returns the number of pyramid levels used minus one (the effective maxLevel), or < 0 on error.
-int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next_step, int rows, int cols,
+int pyrlk_impl(const uint8_t* prev, int prev_step, const uint8_t* next, int next_step, int rows, int cols,
                const float* prev_pts, int n, float* next_pts, uint8_t* status,
-               int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold)
+               int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold, int acc_lanes, int acc_pairs)
 {
     if (!prev || !next || n < 0) return -1;
     // SparsePyrLKOpticalFlowImpl: criteria clamp, epsilon squared
@@ -99,6 +139,7 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
         // the points are independent of each other (OpenCV runs this loop under parallel_for_ as well)
         lvko_parallel_for(n, 16, [&](int pt0, int pt1) {
         std::vector<int> Iw((size_t)win_w * win_h), Ixw((size_t)win_w * win_h), Iyw((size_t)win_w * win_h);
+        std::vector<long long> r0((size_t)win_w), r1((size_t)win_w), r2((size_t)win_w);
         for (int pt = pt0; pt < pt1; pt++)
         {
             float px = prev_pts[2 * pt] * (float)(1. / (1 << level));
@@ -121,8 +162,9 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
             int iw10 = (int)lrintf((1.f - a) * b * (1 << W_BITS));
             int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-            long long sA11 = 0, sA12 = 0, sA22 = 0;
+            WinSum sA11(acc_lanes, acc_pairs), sA12(acc_lanes, acc_pairs), sA22(acc_lanes, acc_pairs);
             for (int y = 0; y < win_h; y++)
+            {
                 for (int x = 0; x < win_w; x++)
                 {
                     const int yy = ipy + y, xx = ipx + x;
@@ -132,11 +174,13 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
                     Iw[(size_t)y * win_w + x] = (int16_t)ival;
                     Ixw[(size_t)y * win_w + x] = (int16_t)ixval;
                     Iyw[(size_t)y * win_w + x] = (int16_t)iyval;
-                    sA11 += (long long)ixval * ixval;
-                    sA12 += (long long)ixval * iyval;
-                    sA22 += (long long)iyval * iyval;
+                    r0[(size_t)x] = (long long)ixval * ixval;
+                    r1[(size_t)x] = (long long)ixval * iyval;
+                    r2[(size_t)x] = (long long)iyval * iyval;
                 }
-            const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+                sA11.add_row(r0.data(), win_w); sA12.add_row(r1.data(), win_w); sA22.add_row(r2.data(), win_w);
+            }
+            const float A11 = sA11.total(FLT_SCALE), A12 = sA12.total(FLT_SCALE), A22 = sA22.total(FLT_SCALE);
             float D = A11 * A22 - A12 * A12;
             const float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win_w * win_h);
             if (minEig < (float)min_eig_threshold || D < 1.1920928955078125e-07f /* FLT_EPSILON */)
@@ -160,17 +204,20 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
                 iw01 = (int)lrintf(a * (1.f - b) * (1 << W_BITS));
                 iw10 = (int)lrintf((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-                long long sb1 = 0, sb2 = 0;
+                WinSum sb1(acc_lanes, acc_pairs), sb2(acc_lanes, acc_pairs);
                 for (int y = 0; y < win_h; y++)
+                {
                     for (int x = 0; x < win_w; x++)
                     {
                         const int yy = iny + y, xx = inx + x;
                         const int diff = descale(J.at(yy, xx) * iw00 + J.at(yy, xx + 1) * iw01 + J.at(yy + 1, xx) * iw10 + J.at(yy + 1, xx + 1) * iw11, W_BITS - 5)
                                          - Iw[(size_t)y * win_w + x];
-                        sb1 += (long long)diff * Ixw[(size_t)y * win_w + x];
-                        sb2 += (long long)diff * Iyw[(size_t)y * win_w + x];
+                        r0[(size_t)x] = (long long)diff * Ixw[(size_t)y * win_w + x];
+                        r1[(size_t)x] = (long long)diff * Iyw[(size_t)y * win_w + x];
                     }
-                const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+                    sb1.add_row(r0.data(), win_w); sb2.add_row(r1.data(), win_w);
+                }
+                const float b1 = sb1.total(FLT_SCALE), b2 = sb2.total(FLT_SCALE);
                 const float dx = (A12 * b2 - A22 * b1) * D;
                 const float dy = (A12 * b1 - A11 * b2) * D;
                 nx += dx; ny += dy;
@@ -187,6 +234,30 @@ int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next
         });
     }
     return top;
+}
+
+} // namespace
+
+extern "C" {
+
+// The specification (exact integer window sums).
+int lvko_pyrlk(const uint8_t* prev, int prev_step, const uint8_t* next, int next_step, int rows, int cols,
+               const float* prev_pts, int n, float* next_pts, uint8_t* status,
+               int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold)
+{
+    return pyrlk_impl(prev, prev_step, next, next_step, rows, cols, prev_pts, n, next_pts, status, win_w, win_h, max_level, max_count, epsilon,
+                      min_eig_threshold, 0, 0);
+}
+
+// The same tracker with OpenCV's binary32 window sums (see WinSum): lanes = 1 scalar loop, 4 / 8 / 16 SIMD lane counts; pairs != 0: adjacent
+// products pre-added exactly (v_dotprod).  NOT the specification -- tests/test_pyrlk_float_order.py measures the distance between the two.
+int lvko_pyrlk_float(const uint8_t* prev, int prev_step, const uint8_t* next, int next_step, int rows, int cols,
+                     const float* prev_pts, int n, float* next_pts, uint8_t* status,
+                     int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold, int lanes, int pairs)
+{
+    if (!(lanes == 1 || lanes == 4 || lanes == 8 || lanes == 16)) return -1;
+    return pyrlk_impl(prev, prev_step, next, next_step, rows, cols, prev_pts, n, next_pts, status, win_w, win_h, max_level, max_count, epsilon,
+                      min_eig_threshold, lanes, pairs ? 1 : 0);
 }
 
 // Level geometry helper for tests: writes rows/cols of each level, returns the level count.

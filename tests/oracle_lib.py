@@ -55,6 +55,8 @@ class Oracle:
         L.lvko_pyrlk.restype = _i
         L.lvko_pyrlk.argtypes = [_u8p, _i, _u8p, _i, _i, _i, _f32p, _i, _f32p, _u8p, _i, _i, _i, _i, _c.c_double, _c.c_double]
         L.lvko_pyramid_levels.restype = _i
+        L.lvko_pyrlk_float.restype = _i
+        L.lvko_pyrlk_float.argtypes = [_u8p, _i, _u8p, _i, _i, _i, _f32p, _i, _f32p, _u8p, _i, _i, _i, _i, _c.c_double, _c.c_double, _i, _i]
         L.lvko_pyramid_levels.argtypes = [_i, _i, _i, _i, _i, _i32p, _i32p]
 
     def set_num_threads(self, n):
@@ -153,6 +155,18 @@ class Oracle:
         lv = self.lib.lvko_pyrlk(_p(prev, _u8p), prev.strides[0], _p(nxt, _u8p), nxt.strides[0], prev.shape[0], prev.shape[1],
                                  _p(pts, _f32p), len(pts), _p(out, _f32p), _p(st, _u8p), win[0], win[1], max_level, max_count,
                                  float(epsilon), float(min_eig))
+        assert lv >= 0
+        return out, st
+
+    def pyrlk_float(self, prev, nxt, pts, lanes, pairs, win=(11, 11), max_level=3, max_count=5, epsilon=0.01, min_eig=1e-4):
+        """The tracker with OpenCV's binary32 window sums (lanes 1 / 4 / 8 / 16, pairs = v_dotprod pre-sums) instead of the specification's
+        exact integer sums -- only to measure the distance between the two."""
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(pts); st = np.zeros(len(pts), np.uint8)
+        lv = self.lib.lvko_pyrlk_float(_p(prev, _u8p), prev.strides[0], _p(nxt, _u8p), nxt.strides[0], prev.shape[0], prev.shape[1],
+                                       _p(pts, _f32p), len(pts), _p(out, _f32p), _p(st, _u8p), win[0], win[1], max_level, max_count,
+                                       float(epsilon), float(min_eig), int(lanes), int(pairs))
         assert lv >= 0
         return out, st
 

@@ -82,6 +82,11 @@ class RefKernels:
         return self.funcs[k]
 
     def _launch(self, fn, gx, gy, bx, by, args):
+        self._prepare(fn, gx, gy, bx, by, args)()
+
+    def _prepare(self, fn, gx, gy, bx, by, args):
+        """The launch with its argument block marshalled ONCE: returns a callable that only calls hipModuleLaunchKernel on torch's current
+        stream (a timing loop then measures the kernel, not the ctypes marshalling of its arguments)."""
         import torch
         holders = []
         for a in args:
@@ -92,9 +97,12 @@ class RefKernels:
             else:
                 holders.append(a)
         ptrs = (_c.c_void_p * len(holders))(*[_c.cast(_c.pointer(h), _c.c_void_p) for h in holders])
-        stream = _c.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = self.hip.hipModuleLaunchKernel(fn, gx, gy, 1, bx, by, 1, 0, stream, ptrs, None)
-        assert rc == 0, f"hipModuleLaunchKernel = {rc}"
+        launch = self.hip.hipModuleLaunchKernel
+
+        def go(_keep=(holders, ptrs)):
+            rc = launch(fn, gx, gy, 1, bx, by, 1, 0, _c.c_void_p(torch.cuda.current_stream().cuda_stream), ptrs, None)
+            assert rc == 0, f"hipModuleLaunchKernel = {rc}"
+        return go
 
     @staticmethod
     def _groups(cols, rows):
@@ -109,8 +117,9 @@ class RefKernels:
         return _B4((_c.c_uint8 * 4)(int(bg[0]), int(bg[1]), int(bg[2]), 0))
 
     # ---- FSR.cl ---------------------------------------------------------------------------------------------------
-    def remap_homography(self, src, H, bg=(255, 0, 255), yuv=True, dst_size=None, offset=(0, 0), out=None):
-        """easu_remap_homography as lvk::remap(src, dst, H, bg, inverted = true) launches it; H = dst -> src, row major."""
+    def remap_homography(self, src, H, bg=(255, 0, 255), yuv=True, dst_size=None, offset=(0, 0), out=None, prepared=False):
+        """easu_remap_homography as lvk::remap(src, dst, H, bg, inverted = true) launches it; H = dst -> src, row major.
+        prepared=True: returns (launch callable, out) instead of launching."""
         import torch
         rows, cols = src.shape[:2]
         drows, dcols = dst_size if dst_size is not None else (rows, cols)
@@ -119,10 +128,13 @@ class RefKernels:
         Hd = np.asarray(H, np.float64).reshape(3, 3)
         r = [_F4((_c.c_float * 4)(float(np.float32(Hd[i, 0])), float(np.float32(Hd[i, 1])), float(np.float32(Hd[i, 2])), 0.0)) for i in range(3)]
         gx, gy = self._groups(dcols, drows)
-        self._launch(self._fn("yuv" if yuv else "bgr", "easu_remap_homography"), gx, gy, 8, 8, [
+        go = self._prepare(self._fn("yuv" if yuv else "bgr", "easu_remap_homography"), gx, gy, 8, 8, [
             self._ptr(src), src.stride(0), 0, rows, cols,
             self._ptr(out), out.stride(0), 0, _I4((_c.c_int * 4)(offset[0], offset[1], dcols, drows)),
             r[0], r[1], r[2], self._bg(bg)])
+        if prepared:
+            return go, out
+        go()
         return out
 
     def remap_map(self, src, offsets, bg=(255, 0, 255), yuv=True, out=None):

@@ -54,8 +54,49 @@ def static_rows(cols, rows, region, temporal, local, mutate=None):
     return out
 
 
-def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched, threshold):
-    """estimate_local_motions (:200-321) with np.linalg.lstsq in place of Eigen::LeastSquaresConjugateGradient."""
+def eigen_lscg(A, b, x0):
+    """Eigen 3.4 LeastSquaresConjugateGradient<SparseMatrix<float>>::solveWithGuess(b, x0) with its defaults, restated from
+    Eigen/src/IterativeLinearSolvers/LeastSquareConjugateGradient.h (the library is absent: unpinned): binary32 throughout,
+    LeastSquareDiagonalPreconditioner (1 / squared column norm), tolerance = epsilon<float> on ||A'(b - A x)|| / ||A' b||, at most
+    2 * cols iterations.  Returns (x, iterations, final relative normal-residual).  (Dense binary32 products here: the sparse products of
+    the library sum the same terms in another order -- a 1e-7 relative effect, against the 1e-5 distances measured below.)"""
+    A = A.astype(f32); b = b.astype(f32); x = x0.astype(f32).copy()
+    n = A.shape[1]
+    tol = np.finfo(f32).eps; max_iters = 2 * n
+    col2 = (A * A).sum(axis=0, dtype=f32)
+    invdiag = np.where(col2 > 0, f32(1) / col2, f32(1)).astype(f32)
+    residual = (b - A @ x).astype(f32)
+    normal = (A.T @ residual).astype(f32)
+    rhs2 = f32(np.dot(A.T @ b, A.T @ b))
+    if rhs2 == 0:
+        return np.zeros(n, f32), 0, 0.0
+    threshold = f32(tol * tol * rhs2)
+    res2 = f32(np.dot(normal, normal))
+    if res2 < threshold:
+        return x, 0, float(np.sqrt(res2 / rhs2))
+    p = (invdiag * normal).astype(f32)
+    abs_new = f32(np.dot(normal, p))
+    i = 0
+    while i < max_iters:
+        tmp = (A @ p).astype(f32)
+        alpha = f32(abs_new / f32(np.dot(tmp, tmp)))
+        x = (x + alpha * p).astype(f32)
+        residual = (residual - alpha * tmp).astype(f32)
+        normal = (A.T @ residual).astype(f32)
+        res2 = f32(np.dot(normal, normal))
+        if res2 < threshold:
+            break
+        z = (invdiag * normal).astype(f32)
+        abs_old = abs_new
+        abs_new = f32(np.dot(normal, z))
+        p = (z + f32(abs_new / abs_old) * p).astype(f32)
+        i += 1
+    return x, i, float(np.sqrt(res2 / rhs2))
+
+
+def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched, threshold, solver="lstsq", info=None):
+    """estimate_local_motions (:200-321); solver "lstsq": np.linalg.lstsq (binary64 SVD) in place of Eigen::LeastSquaresConjugateGradient,
+    "lscg": the restated Eigen solver itself, warm-started from prev_mesh (:274-276)."""
     kw, kh = key_size(cols, rows, region)
     n = 2 * cols * rows
     m = len(static) + 2 * len(tracked)
@@ -83,7 +124,13 @@ def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, ma
                 A[at, ids[q] + comp] += float(w[q])
             b[at] = float(dst); at += 1
         feats.append((ids, w))
-    x = np.linalg.lstsq(A, b, rcond=None)[0]
+    if solver == "lscg":
+        # the reference's operands are binary32: A's triplets and b are floats (:221-222)
+        x, iters, rel = eigen_lscg(A, b, np.asarray(prev_mesh, f32))
+        if info is not None:
+            info.append((iters, rel))
+    else:
+        x = np.linalg.lstsq(A, b, rcond=None)[0]
     mesh = x.astype(f32)                                                    # Eigen::VectorXf m_OptimizedMesh
     inl = np.zeros(len(tracked), np.uint8)
     for k, ((ids, w), (dx, dy)) in enumerate(zip(feats, matched)):          # :279-310
@@ -166,4 +213,31 @@ def test_the_lstsq_check_would_catch_a_wrong_similarity_row(oracle, mutate):
     bad = solve_frame(cols, rows, static_rows(cols, rows, region, 1.0, 20.0, mutate=mutate), region, 1.0, np.zeros(512, f32), a, b, 10.0)[2]
     assert np.abs(off_o.astype(np.float64).reshape(rows, cols, 2) - good).max() <= 1e-5
     assert np.abs(off_o.astype(np.float64).reshape(rows, cols, 2) - bad).max() > 1e-4
+    ref.close()
+
+
+@pytest.mark.parametrize("cols,rows,region", [(16, 16, (480, 270)), (9, 7, (320, 180))])
+def test_distance_to_where_eigens_lscg_stops(oracle, cols, rows, region):
+    """The reference does not compute the minimiser: it runs Eigen's LSCG in binary32 from the previous mesh (FrameTracker.cpp:274-276) and
+    takes whatever the iteration has reached after at most 2 n steps.  eigen_lscg restates that solver; each side feeds ITS OWN previous
+    solution into the temporal rows and the warm start, as two real filters would.  Measured (16 x 16 preset, 8 frames): the iteration
+    meets its epsilon<float> tolerance after 159-173 of its 1024 allowed steps (relative normal residual 1e-7) and ends within 2.0e-6
+    (normalised; 0.001 px at 480 px) of the specification's exact minimiser -- inside SURVEY 8c's 1e-5; 9 x 7: 65 steps, 8.6e-7."""
+    rng = np.random.default_rng(cols * 7 + rows)
+    static = static_rows(cols, rows, region, 1.0, 20.0)
+    ref = oracle_lib.OracleMeshSolver(oracle, cols, rows, gen_region=region, temporal=1.0, local=20.0)
+    prev = np.zeros(2 * cols * rows, f32)
+    info = []
+    worst = 0.0
+    for frame in range(8):
+        a, b = field_pairs(rng, 700 - 40 * frame, region, frame % 5)
+        rc, inl_o, off_o = ref.solve(a, b, region=region, temporal=1.0, threshold=10.0)
+        assert rc == 0
+        prev, inl_c, off_c = solve_frame(cols, rows, static, region, 1.0, prev, a, b, 10.0, solver="lscg", info=info)
+        d = np.abs(off_o.astype(np.float64).reshape(rows, cols, 2) - off_c).max()
+        worst = max(worst, d)
+        assert d <= 1e-5, (frame, d, info[-1])
+        assert (inl_o != inl_c).mean() <= 0.005
+    print("\n[a10 lscg] %dx%d: max |offset difference| product specification vs restated Eigen LSCG %.2e (normalised) = %.4f px; "
+          "iterations / final relative normal residual per frame: %s" % (cols, rows, worst, worst * region[0], [(i, float("%.1e" % r)) for i, r in info]))
     ref.close()
