@@ -17,7 +17,11 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     m = re.search(r"(k_[a-z_0-9]+(?:<[a-z0-9, ]+>)?)", name)
-    return m.group(1) if m else None
+    if m:
+        return m.group(1)
+    if "easu_remap" in name:                                   # the REFERENCE's kernel (oracle/_ref/fsr_yuv.hsaco), launched by bench.py's reference_kernel leg
+        return "reference:" + name.split("(")[0].strip().replace(".kd", "")
+    return None
 
 
 # ---- kernel-trace --stats
