@@ -348,6 +348,10 @@ void* lvk_hip_stab_output_stream(lvk_hip_stab* stab);
 
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
 /* last frame motion (after the trust factor) and last applied correction; each motion_height x motion_width x 2 floats */
+/* Frames on which FeatureDetector::detect ran FAST so far (Vision/FeatureDetector.cpp:125-157), by where the corners went through the
+ * suppression grid: on the device inside the tracker's chain of kernels, or in the host loop (grids beyond 4096 cells, detection regions off
+ * the pixel grid, LVK_HIP_HOST_GRID=1).  Same features either way; a tap for tests and tuning. */
+int  lvk_hip_stab_detector_frames(const lvk_hip_stab* stab, long long* on_device, long long* on_host);
 int  lvk_hip_stab_get_meshes(const lvk_hip_stab* stab, float* motion, float* correction, int cap_floats);
 /* FrameTracker::features(): (x, y, response, age) per tracked feature; returns the total count */
 int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int cap);

@@ -154,6 +154,214 @@ void k_fast_compact(const FastRegion* __restrict__ regions, FastRegionList inl, 
     if (threadIdx.x == 0) counts[r] = s_base;
 }
 
+
+// ---- the suppression grid on the device --------------------------------------------------------------------------------------------
+// FeatureDetector::detect runs every raw corner, region after region in row-major order, through a grid with one slot per cell
+// (Vision/FeatureDetector.cpp:138-157): an empty cell takes the corner (appended to the feature list), a cell that holds a DETECTED
+// feature keeps the stronger of the two in place (strictly greater response: the earlier corner wins a tie), a cell that holds a
+// PROPAGATED feature never changes.  Closed form of what that loop leaves behind: the new features are, for every cell without a
+// propagated feature that receives at least one corner, the corner of maximal score (earliest on ties), listed in the order of the
+// cells' FIRST corners.  One workgroup computes that straight from k_fast_detect's ballots -- no ordered corner list is materialised, no
+// host round trip splits the frame's chain of kernels -- and appends the new points to the list the optical-flow kernel reads:
+//   1. exclusive scan of the per-word popcounts (words in region / row / segment order) -> the sequence number of every corner;
+//   2. per corner: atomicMin of the sequence number and atomicMax of (score << 24 | ~sequence) on its cell (LDS);
+//   3. per corner again: a corner that IS its cell's first one opens a list position (scan of those counts per word); the winner of
+//      the cell is looked up by its sequence number (binary search over the scan, k-th set bit of the word);
+//   4. SpatialMap::distribution_quality (Data/SpatialMap.tpp:589-625) over propagated + new cells, the two early-outs of
+//      FrameTracker::track (Vision/FrameTracker.cpp:127-131) and the homography / similarity choice (:170) for the kernels that follow.
+struct FastInsertArgs
+{
+    const uint16_t* col_of; const uint32_t* row_base; const uint8_t* bucket;      // device tables of the grid (FeatureGridH)
+    const uint32_t* occ;                  // cells that hold a propagated feature, one bit each (device-visible host memory)
+    int capacity, small_grid, n_held, min_samples; float uniformity, homography_threshold;
+    float2* pts;                          // the optical flow's point list: new points go to pts[n_held ...]
+    uint32_t* new_kp;                     // x | y << 12 | score << 24 (frame coordinates) of the new features, list order
+    int* result;                          // [0] new features, [1] points to track (0: early out), [2] quality (float bits), [3] full homography, [4] corners
+    int* d_n; int* d_full;                // [1] and [3] again in device memory, for the kernels of the chain
+    int* counts;                          // raw corner count per region
+};
+
+constexpr int INS_NT = 1024, INS_MAX_WORDS = 4096, INS_MAX_CELLS = 4096;
+
+__global__ __launch_bounds__(INS_NT)
+void k_fast_insert(FastRegionList inl, int nregions, int segs_x, const unsigned long long* __restrict__ masks, const uint8_t* __restrict__ scores,
+                   int max_rh, int max_rw, FastInsertArgs a)
+{
+    LVK_TRACKER_PRIORITY();
+    __shared__ uint32_t s_first[INS_MAX_CELLS], s_best[INS_MAX_CELLS];
+    __shared__ int s_wbase[INS_MAX_WORDS + 1];
+    __shared__ unsigned short s_fbase[INS_MAX_WORDS];
+    __shared__ uint32_t s_occ[INS_MAX_CELLS / 32];
+    __shared__ int s_wave[INS_NT / 64], s_carry, s_woff[LVK_FAST_INLINE_REGIONS + 1], s_bucket[16], s_used;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (int i = t; i < a.capacity; i += INS_NT) { s_first[i] = 0xFFFFFFFFu; s_best[i] = 0u; }
+    for (int i = t; i < (a.capacity + 31) / 32; i += INS_NT) s_occ[i] = a.occ[i];
+    if (t < 16) s_bucket[t] = 0;
+    if (t == 0)
+    {
+        int off = 0;
+        for (int r = 0; r < nregions; r++) { s_woff[r] = off; if (inl.r[r].active) off += inl.r[r].h * ((inl.r[r].w + TW - 1) / TW); }
+        s_woff[nregions] = off; s_carry = 0; s_used = 0;
+    }
+    __syncthreads();
+    const int nwords = s_woff[nregions];
+    // word w of the flattened order -> (region, row, segment) and the ballot word itself
+    auto word_at = [&](int w, int& r, int& ly, int& sg) -> unsigned long long {
+        r = 0;
+        while (r + 1 < nregions && w >= s_woff[r + 1]) r++;
+        while (!inl.r[r].active) r++;                                        // (an inactive region owns no words: skip to the owner)
+        const int rsegs = (inl.r[r].w + TW - 1) / TW, k = w - s_woff[r];
+        ly = k / rsegs; sg = k - ly * rsegs;
+        return masks[((long)r * max_rh + ly) * segs_x + sg];
+    };
+
+    // 1. sequence numbers: exclusive scan of the popcounts
+    for (int chunk = 0; chunk < nwords; chunk += INS_NT)
+    {
+        const int w = chunk + t;
+        int r, ly, sg;
+        const int cnt = w < nwords ? __popcll(word_at(w, r, ly, sg)) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int q = 0; q < wave; q++) wave_off += s_wave[q];
+        if (w < nwords) s_wbase[w] = s_carry + wave_off + incl - cnt;
+        __syncthreads();
+        if (t == INS_NT - 1) s_carry = s_carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (t == 0) s_wbase[nwords] = s_carry;
+    __syncthreads();
+    const int total = s_wbase[nwords];
+    if (t < nregions) a.counts[t] = inl.r[t].active ? s_wbase[s_woff[t + 1]] - s_wbase[s_woff[t]] : 0;
+
+    // 2. first corner and strongest corner of every cell
+    for (int w = t; w < nwords; w += INS_NT)
+    {
+        int r, ly, sg;
+        unsigned long long m = word_at(w, r, ly, sg);
+        uint32_t seq = (uint32_t)s_wbase[w];
+        const int gy = inl.r[r].y + ly;
+        while (m)
+        {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int lx = sg * TW + bit;
+            const uint32_t ci = a.row_base[gy] + a.col_of[inl.r[r].x + lx];
+            if (!((s_occ[ci >> 5] >> (ci & 31)) & 1u))
+            {
+                const uint32_t sc = scores[((long)r * max_rh + ly) * max_rw + lx];
+                atomicMin(&s_first[ci], seq);
+                atomicMax(&s_best[ci], (sc << 24) | (0xFFFFFFu - seq));
+            }
+            seq++;
+        }
+    }
+    __syncthreads();
+
+    // 3. list positions: corners that are their cell's first one, in sequence order
+    s_carry = 0;                                       // (every thread read `total` above; the barrier below orders this store)
+    __syncthreads();
+    for (int chunk = 0; chunk < nwords; chunk += INS_NT)
+    {
+        const int w = chunk + t;
+        int cnt = 0;
+        if (w < nwords)
+        {
+            int r, ly, sg;
+            unsigned long long m = word_at(w, r, ly, sg);
+            uint32_t seq = (uint32_t)s_wbase[w];
+            const int gy = inl.r[r].y + ly;
+            while (m)
+            {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t ci = a.row_base[gy] + a.col_of[inl.r[r].x + sg * TW + bit];
+                cnt += s_first[ci] == seq ? 1 : 0;     // (an occupied cell keeps first = ~0, which is no sequence number)
+                seq++;
+            }
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int q = 0; q < wave; q++) wave_off += s_wave[q];
+        if (w < nwords) s_fbase[w] = (unsigned short)(s_carry + wave_off + incl - cnt);
+        __syncthreads();
+        if (t == INS_NT - 1) s_carry = s_carry + wave_off + incl;
+        __syncthreads();
+    }
+    const int n_new = s_carry;
+    for (int w = t; w < nwords; w += INS_NT)
+    {
+        int r, ly, sg;
+        unsigned long long m = word_at(w, r, ly, sg);
+        uint32_t seq = (uint32_t)s_wbase[w];
+        int pos = s_fbase[w];
+        const int gy = inl.r[r].y + ly;
+        while (m)
+        {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int gx = inl.r[r].x + sg * TW + bit;
+            const uint32_t ci = a.row_base[gy] + a.col_of[gx];
+            if (s_first[ci] == seq)
+            {
+                const uint32_t key = s_best[ci], sb = 0xFFFFFFu - (key & 0xFFFFFFu);
+                int bx = gx, by = gy;
+                if (sb != seq)
+                {
+                    // the strongest corner of the cell is a later one: find its word (largest wb with wbase[wb] <= sb), then its bit
+                    int lo = 0, hi = nwords - 1;
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((uint32_t)s_wbase[mid] <= sb) lo = mid; else hi = mid - 1; }
+                    int r2, ly2, sg2;
+                    unsigned long long m2 = word_at(lo, r2, ly2, sg2);
+                    for (int k = (int)sb - s_wbase[lo]; k > 0; k--) m2 &= m2 - 1;
+                    bx = inl.r[r2].x + sg2 * TW + (__ffsll((long long)m2) - 1); by = inl.r[r2].y + ly2;
+                }
+                a.pts[a.n_held + pos] = make_float2((float)bx, (float)by);
+                a.new_kp[pos] = (uint32_t)bx | ((uint32_t)by << 12) | (key & 0xFF000000u);
+                pos++;
+            }
+            seq++;
+        }
+    }
+
+    // 4. distribution quality over the occupied cells, the early-outs and the model choice
+    int used = 0;
+    for (int ci = t; ci < a.capacity; ci += INS_NT)
+        if (((s_occ[ci >> 5] >> (ci & 31)) & 1u) || s_first[ci] != 0xFFFFFFFFu) { used++; if (!a.small_grid) atomicAdd(&s_bucket[a.bucket[ci]], 1); }
+    if (used) atomicAdd(&s_used, used);
+    __syncthreads();
+    if (t == 0)
+    {
+        const int m_used = s_used;
+        float q = 1.0f;
+        if (m_used != 0)
+        {
+            if (a.small_grid) q = (float)m_used / (float)a.capacity;
+            else
+            {
+                const int ideal = (int)((float)m_used / 16.0f);
+                int excess = 0;
+                for (int b = 0; b < 16; b++) excess += max(s_bucket[b] - ideal, 0);
+                q = 1.0f - ((float)excess / (float)(m_used - ideal));
+            }
+        }
+        const int n_total = a.n_held + n_new;
+        const int n_eff = (n_total < a.min_samples || q < a.uniformity) ? 0 : n_total;
+        const int full = q > a.homography_threshold ? 1 : 0;
+        a.result[0] = n_new; a.result[1] = n_eff; a.result[2] = __float_as_int(q); a.result[3] = full; a.result[4] = total;
+        *a.d_n = n_eff; *a.d_full = full;
+    }
+}
+
 } // namespace
 
 int lvk_fast_workspace_bytes(int nregions, int max_rw, int max_rh, size_t* masks_bytes, size_t* scores_bytes)
@@ -183,6 +391,32 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
+
+
+// Detection + the suppression grid on the device (see k_fast_insert): same detect kernel, then ONE workgroup that leaves the new features
+// behind the held ones in `pts` and the counts / flags the rest of the chain reads.  Regions travel as kernel arguments (<= 8).
+int lvk_launch_fast_insert(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, const FastRegion* host_regions, int nregions,
+                           int max_rw, int max_rh, void* d_masks, void* d_scores, const FastInsertDesc& d)
+{
+    LVK_HIP_REQUIRE(ctx, d_img && host_regions && nregions > 0 && nregions <= LVK_FAST_INLINE_REGIONS && max_rw > 0 && max_rh > 0 && max_rw < 4096 && max_rh < 4096);
+    LVK_HIP_REQUIRE(ctx, d.capacity > 0 && d.capacity <= INS_MAX_CELLS && d.pts && d.new_kp && d.result && d.d_n && d.d_full && d.counts && d.occ);
+    const int segs_x = (max_rw + TW - 1) / TW;
+    int nwords = 0;
+    FastRegionList inl{};
+    for (int i = 0; i < nregions; i++) { inl.r[i] = host_regions[i]; if (inl.r[i].active) nwords += inl.r[i].h * ((inl.r[i].w + TW - 1) / TW); }
+    LVK_HIP_REQUIRE(ctx, nwords <= INS_MAX_WORDS);
+    const dim3 block(TW, TH), grid(segs_x, (max_rh + TH - 1) / TH, nregions);
+    hipLaunchKernelGGL(k_fast_detect, grid, block, 0, ctx->stream, (const uint8_t*)d_img, step, rows, cols, (const FastRegion*)nullptr, inl, nregions, segs_x,
+                       (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw);
+    const FastInsertArgs a{d.col_of, d.row_base, d.bucket, d.occ, d.capacity, d.small_grid ? 1 : 0, d.n_held, d.min_samples, d.uniformity, d.homography_threshold,
+                           d.pts, d.new_kp, d.result, d.d_n, d.d_full, d.counts};
+    hipLaunchKernelGGL(k_fast_insert, dim3(1), dim3(INS_NT), 0, ctx->stream, inl, nregions, segs_x, (const unsigned long long*)d_masks, (const uint8_t*)d_scores,
+                       max_rh, max_rw, a);
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_fast_insert_limits(int* max_cells, int* max_words) { *max_cells = INS_MAX_CELLS; *max_words = INS_MAX_WORDS; return TW; }
 
 extern "C" {
 

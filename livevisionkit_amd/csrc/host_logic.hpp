@@ -277,9 +277,54 @@ public:
             if (cell < 0) { cell = (long)held.size(); m_used++; m_used_cells.push_back((uint32_t)(&cell - m_cells.data())); held.push_back(f); }
             else if (f.response > held[(size_t)cell].response && held[(size_t)cell].age <= 0) held[(size_t)cell] = f;
         }
-        const size_t n = (size_t)count;
+        feedback(z, (size_t)count);
+    }
+
+    // FeatureDetector.cpp:160-163: the region's threshold follows its raw corner count towards the target (m_target - 150 wraps for small
+    // targets exactly as the reference's size_t arithmetic does)
+    void feedback(Zone& z, size_t n) const
+    {
         if (n > m_target + 150) z.threshold = std::min(z.threshold + 5, 250);
         else if (n < m_target - 150) z.threshold = z.threshold > 10 ? std::max(z.threshold - 5, 10) : std::min(z.threshold + 5, 10);
+    }
+
+    // ---- the suppression grid on the DEVICE (fast.hip k_fast_insert): on a frame on which the detector runs the corners go through the
+    // grid inside the tracker's chain of kernels instead of on the host between two halves of it.  What the kernel needs from here: the
+    // tables below, which cells hold a propagated feature (those never change: FeatureDetector.cpp:150 `class_id <= 0`), and the held
+    // points; what comes back: the new features in list order.
+    static constexpr int kDeviceMaxCells = 4096;
+    size_t used_cells() const { return m_used; }
+    int grid_cols() const { return m_gc; }
+    int grid_rows() const { return m_gr; }
+    const std::vector<uint16_t>& col_table() const { return m_col_of; }
+    const std::vector<uint32_t>& row_base_table() const { return m_row_base; }
+    const std::vector<uint8_t>& bucket_table() const { return m_bucket; }
+    bool device_insert_ok() const
+    {
+        if (capacity() > (size_t)kDeviceMaxCells || m_w >= 4096 || m_h >= 4096 || m_mutable_marked) return false;
+        for (const Zone& z : zones)          // corners at whole pixels inside the frame: the cell of a corner comes from the integer tables
+            if (!(z.x == std::floor(z.x) && z.y == std::floor(z.y) && z.x >= 0.0f && z.y >= 0.0f && cv_round(z.x) + cv_round(z.w) <= m_w && cv_round(z.y) + cv_round(z.h) <= m_h)) return false;
+        return true;
+    }
+    void occupancy(uint32_t* bits) const     // one bit per cell that holds a propagated feature; (capacity + 31) / 32 words
+    {
+        std::fill(bits, bits + (capacity() + 31) / 32, 0u);
+        for (uint32_t c : m_used_cells) bits[c >> 5] |= 1u << (c & 31);
+    }
+    // End of detect() when the kernel has run the corners through the grid: kp = the new features in list order (frame coordinates,
+    // x | y << 12 | score << 24), raw = every zone's raw corner count.  Same hand-over as absorb() x zones + finish().
+    float finish_device(std::vector<Feature>& out, const uint32_t* kp, int n_new, const int* raw, int cap)
+    {
+        for (size_t i = 0; i < zones.size(); i++)
+            if (zones[i].ran) feedback(zones[i], (size_t)std::min(raw[i], cap));
+        for (int k = 0; k < n_new; k++)
+        {
+            const unsigned xi = kp[k] & 0xFFFu, yi = (kp[k] >> 12) & 0xFFFu;
+            const uint32_t ci = m_row_base[yi] + m_col_of[xi];
+            m_cells[ci] = (long)held.size(); m_used++; m_used_cells.push_back(ci);
+            held.push_back(Feature{(float)xi, (float)yi, (float)(kp[k] >> 24), 0});
+        }
+        return finish(out);
     }
 
     // End of detect(): hand the surviving features over, compute the distribution quality, clear the grid.
@@ -304,8 +349,9 @@ public:
                 cell = (long)held.size(); m_used++; m_used_cells.push_back((uint32_t)(&cell - m_cells.data()));
                 zones[quot(f.y, m_zh, m_izh) * (size_t)m_zc + quot(f.x, m_zw, m_izw)].load++;
                 held.push_back(f);
+                if (f.age <= 0) m_mutable_marked = true;           // (never for tracked features: their age was just raised)
             }
-            else if (f.response > held[(size_t)cell].response && f.age >= held[(size_t)cell].age) held[(size_t)cell] = f;
+            else if (f.response > held[(size_t)cell].response && f.age >= held[(size_t)cell].age) { held[(size_t)cell] = f; if (f.age <= 0) m_mutable_marked = true; }
         }
     }
 
@@ -334,7 +380,7 @@ private:
     void clear_cells()
     {
         for (uint32_t c : m_used_cells) m_cells[c] = -1;
-        m_used_cells.clear(); m_used = 0;
+        m_used_cells.clear(); m_used = 0; m_mutable_marked = false;
     }
 
     float quality() const                    // SpatialMap::distribution_quality
@@ -360,6 +406,7 @@ private:
     std::vector<uint32_t> m_row_base;        // m_row_of[y] * m_gc
     size_t m_used = 0, m_min_load = 0, m_target = 0;
     bool m_force = false;
+    bool m_mutable_marked = false;           // a marked cell holds a feature of age <= 0 (a stronger corner would replace it in place)
 };
 
 // ------------------------------------------------------------------------------------------------ local motion (vector field)

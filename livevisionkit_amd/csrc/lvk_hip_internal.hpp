@@ -181,13 +181,26 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
                     const FastRegion* d_regions, int nregions, int max_rw, int max_rh,
                     void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts, const FastRegion* host_regions = nullptr);
 
+// ... with the suppression grid on the device (k_fast_insert): the new features land behind the held ones in `pts`
+struct FastInsertDesc
+{
+    const uint16_t* col_of; const uint32_t* row_base; const uint8_t* bucket;      // device copies of FeatureGridH's tables
+    const uint32_t* occ;                   // device-visible host memory: one bit per cell that holds a propagated feature
+    int capacity; bool small_grid; int n_held, min_samples; float uniformity, homography_threshold;
+    float2* pts; uint32_t* new_kp; int* result; int* d_n; int* d_full; int* counts;
+};
+int lvk_launch_fast_insert(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, const FastRegion* host_regions, int nregions,
+                           int max_rw, int max_rh, void* d_masks, void* d_scores, const FastInsertDesc& d);
+int lvk_fast_insert_limits(int* max_cells, int* max_words);      // returns the ballot word width (pixels)
+
 // Pyramidal LK (pyrlk.hip)
 struct LensModel;
 int lvk_pyramid_geometry(int rows, int cols, int max_level, int win_w, int win_h, int* lrows, int* lcols);
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
                      float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig,
                      float2* d_prev_copy = nullptr,      // pts may be device-visible host memory; d_prev_copy receives a device copy
-                     const LensModel* lens = nullptr, double lens_sx = 0.0, double lens_sy = 0.0, float2* d_und = nullptr);
+                     const LensModel* lens = nullptr, double lens_sx = 0.0, double lens_sy = 0.0, float2* d_und = nullptr,
+                     const int* d_n = nullptr);         // d_n: the point count lives on the device (n = the launch's upper bound)
                      // lens + d_und: the flow kernel also writes the lens-corrected (previous | matched) positions, 2 n entries (fused lens mode)
 
 // Image pyramid + Scharr derivative images of one tracking frame, resident in HBM.
@@ -204,19 +217,22 @@ struct DevicePyramid
 // Robust global motion (motion.hip)
 size_t lvk_ransac_workspace_bytes(int n);
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
-                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n = nullptr);
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n = nullptr,
+                      const int* d_full = nullptr);      // d_full: the model choice lives on the device (full_homography ignored)
 // fast_filter (Functions/Container.tpp:97-121) of the optical-flow result on the GPU: compacts (prev, matched) by `status` into
 // (d_p1, d_p2) in exactly the order the host's back-to-front swap-erase produces, writes the count to d_count, and mirrors the raw
 // matched points / status flags into device-visible host memory for the host's own bookkeeping.
 int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
                              float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
-                             const float2* d_und = nullptr, float region_w = 0.0f, float region_h = 0.0f);   // d_und: lens-corrected (prev | matched), see k_match_compact
-// both in two kernels (the hypotheses kernel compacts the flow result itself): same results; n <= 1024 pairs
-constexpr int LVK_COMPACT_RANSAC_MAX = 1024;
+                             const float2* d_und = nullptr, float region_w = 0.0f, float region_h = 0.0f,   // d_und: lens-corrected (prev | matched), see k_match_compact
+                             const int* d_n_raw = nullptr);                                                    // the raw count lives on the device (n: upper bound)
+// both in two kernels (the hypotheses kernel compacts the flow result itself): same results; n <= 2048 pairs
+constexpr int LVK_COMPACT_RANSAC_MAX = 2048;
 int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
                               float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
                               const float2* d_und, float region_wf, float region_hf,
-                              double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask);
+                              double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask,
+                              const int* d_n_raw = nullptr, const int* d_full = nullptr);
 
 struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)

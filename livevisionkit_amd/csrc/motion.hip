@@ -226,15 +226,15 @@ __device__ bool model_from_sample(bool full, const float2* __restrict__ p1, cons
 // element if it was kept, or else whatever was moved into it when IT was a hole (rank i < j, i.e. the content of position n - i) -- a
 // chain that ends at a kept tail element.
 constexpr int CMP_CAP = 4096;
-// One block of CMP_NT threads over n <= 4 CMP_NT pairs: fills s_keep (the effective status flags) and s_above (per element, the number
+// One block of CMP_NT threads over n <= EPT CMP_NT pairs: fills s_keep (the effective status flags) and s_above (per element, the number
 // of dropped elements with a higher index) and returns m.  mirror: also copy the raw flow result to device-visible host memory.
-template <int CMP_NT>
+template <int CMP_NT, int EPT = 4>
 __device__ __forceinline__ int compact_plan(const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
                                             const float2* __restrict__ und, float region_w, float region_h,
                                             unsigned short* s_above, uint8_t* s_keep, int* s_wave, bool mirror,
                                             float2* __restrict__ host_matched, uint8_t* __restrict__ host_status)
 {
-    static_assert(CMP_NT == 1024 || CMP_NT == 256, "4 elements per thread: 4096 or 1024 pairs");
+    static_assert(CMP_NT == 1024 || CMP_NT == 256, "EPT elements per thread: 4096 / 1024 pairs at 4, 2048 at 8 x 256");
     const int t = threadIdx.x;
     for (int i = t; i < n; i += CMP_NT)
     {
@@ -250,12 +250,12 @@ __device__ __forceinline__ int compact_plan(const float2* __restrict__ matched, 
         if (mirror) { host_status[i] = k; host_matched[i] = matched[i]; }
     }
     __syncthreads();
-    // exclusive prefix count of dropped elements over the reversed index j = n - 1 - i; thread t owns j = 4t .. 4t + 3
-    int loc[4], sum = 0;
+    // exclusive prefix count of dropped elements over the reversed index j = n - 1 - i; thread t owns j = EPT t .. EPT t + EPT - 1
+    int loc[EPT], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < EPT; q++)
     {
-        const int j = 4 * t + q;
+        const int j = EPT * t + q;
         loc[q] = sum;
         sum += (j < n && !s_keep[n - 1 - j]) ? 1 : 0;
     }
@@ -269,9 +269,9 @@ __device__ __forceinline__ int compact_plan(const float2* __restrict__ matched, 
     for (int w = 0; w < CMP_NT / 64; w++) { const int v = s_wave[w]; total += v; if (w < (t >> 6)) base += v; }
     const int excl = base + inc - sum;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < EPT; q++)
     {
-        const int j = 4 * t + q;
+        const int j = EPT * t + q;
         if (j < n) s_above[n - 1 - j] = (unsigned short)(excl + loc[q]);
     }
     __syncthreads();
@@ -294,6 +294,9 @@ struct CompactArgs
 {
     const float2* prev; const float2* matched; const uint8_t* status; const float2* und; float region_w, region_h;
     float2* p1; float2* p2; int* count; int* host_count; float2* host_matched; uint8_t* host_status;
+    // the number of tracked points / the model choice when they were decided on the device (fast.hip k_fast_insert): n and `full` of the
+    // launch are then only upper bound / placeholder
+    const int* n_raw_dev; const int* full_dev;
 };
 
 // FUSED: fast_filter runs inside this kernel -- every block derives the compacted pairs straight into its LDS copy (the staging sweep
@@ -311,13 +314,16 @@ void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict
     __shared__ int s_ok;
     __shared__ long long s_scratch[NT / 64];
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
+    if (ca.full_dev) full = *ca.full_dev;                   // the model choice was made on the device (fast.hip k_fast_insert)
     if (FUSED)
     {
-        __shared__ unsigned short s_above[FUSED ? 4 * NT : 1];
-        __shared__ uint8_t s_keep[FUSED ? 4 * NT : 1];
+        constexpr int EPT = LVK_COMPACT_RANSAC_MAX / NT;
+        __shared__ unsigned short s_above[FUSED ? EPT * NT : 1];
+        __shared__ uint8_t s_keep[FUSED ? EPT * NT : 1];
         __shared__ int s_wave[NT / 64];
         const bool first = blockIdx.x == 0;
-        const int m = compact_plan<NT>(ca.matched, ca.status, n, ca.und, ca.region_w, ca.region_h, s_above, s_keep, s_wave, first, ca.host_matched, ca.host_status);
+        if (ca.n_raw_dev) n = min(max(*ca.n_raw_dev, 0), n);
+        const int m = compact_plan<NT, EPT>(ca.matched, ca.status, n, ca.und, ca.region_w, ca.region_h, s_above, s_keep, s_wave, first, ca.host_matched, ca.host_status);
         const float2* pair_prev = ca.und ? ca.und : ca.prev;
         const float2* pair_next = ca.und ? ca.und + n : ca.matched;
         for (int i = threadIdx.x; i < m; i += NT)
@@ -627,7 +633,7 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
 template <bool STAGED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3)))
 void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
-                       double cx, double cy, double sc,
+                       const int* __restrict__ full_dev, double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
                        uint8_t* __restrict__ gmask_a, uint8_t* __restrict__ gmask_b,
                        double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
@@ -641,6 +647,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     __shared__ uint8_t s_mask[2][STAGED ? LDS_POINTS : 1];
     const int lane = threadIdx.x;
     if (n_dev) n = max(min(*n_dev, n), 0);
+    if (full_dev) full = *full_dev;
     if (STAGED)
     {
         for (int i = lane; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
@@ -731,10 +738,11 @@ __global__ __launch_bounds__(CMP_NT)
 void k_match_compact(const float2* __restrict__ prev, const float2* __restrict__ matched, const uint8_t* __restrict__ status, int n,
                      float2* __restrict__ p1, float2* __restrict__ p2, int* __restrict__ count, int* __restrict__ host_count,
                      float2* __restrict__ host_matched, uint8_t* __restrict__ host_status,
-                     const float2* __restrict__ und, float region_w, float region_h)
+                     const float2* __restrict__ und, float region_w, float region_h, const int* __restrict__ n_raw_dev)
 {
     LVK_TL(2);
     LVK_TRACKER_PRIORITY();
+    if (n_raw_dev) n = min(max(*n_raw_dev, 0), n);          // the point count was decided on the device: n is the launch's upper bound
     __shared__ unsigned short s_above[CMP_CAP];            // number of dropped elements with a higher index
     __shared__ uint8_t s_keep[CMP_CAP];
     __shared__ int s_wave[CMP_NT / 64];
@@ -761,8 +769,9 @@ size_t lvk_ransac_workspace_bytes(int n)
 
 // d_p1/d_p2: n pairs; d_ws: lvk_ransac_workspace_bytes(n); outputs d_H (9 doubles), d_ninl, d_mask (n bytes).
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
-                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n)
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n, const int* d_full)
 {
+    CompactArgs ca{}; ca.full_dev = d_full;
     LVK_HIP_REQUIRE(ctx, d_p1 && d_p2 && d_ws && d_H && d_ninl && d_mask && (d_n || n >= (full_homography ? 4 : 2)));
     double* hyp_H = (double*)d_ws;
     long long* hyp_score = (long long*)(hyp_H + K_HYPOTHESES * 9);
@@ -771,14 +780,14 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     const double t2 = threshold * threshold;
     if (n <= LDS_POINTS)
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, CompactArgs{});
-        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0,
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
+        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     else
     {
-        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, CompactArgs{});
-        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0,
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
+        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     LVK_HIP_CHECK(ctx, hipGetLastError());
@@ -787,37 +796,40 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
 
 int lvk_launch_match_compact(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
                              float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
-                             const float2* d_und, float region_w, float region_h)
+                             const float2* d_und, float region_w, float region_h, const int* d_n_raw)
 {
     LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n >= 0 && n <= CMP_CAP);
     if (n <= 1024)
         hipLaunchKernelGGL(k_match_compact<256>, dim3(1), dim3(256), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
-                           d_und, region_w, region_h);
+                           d_und, region_w, region_h, d_n_raw);
     else
         hipLaunchKernelGGL(k_match_compact<1024>, dim3(1), dim3(1024), 0, ctx->stream, d_prev, d_matched, d_status, n, d_p1, d_p2, d_count, h_count, h_matched, h_status,
-                           d_und, region_w, region_h);
+                           d_und, region_w, region_h, d_n_raw);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
 
 // fast_filter + RANSAC in two kernels instead of three: the hypotheses kernel compacts the flow result itself (see k_ransac_hypotheses,
-// FUSED).  Same arguments and results as lvk_launch_match_compact followed by lvk_launch_ransac(.., d_count); n <= 1024 pairs.
+// FUSED).  Same arguments and results as lvk_launch_match_compact followed by lvk_launch_ransac(.., d_count); n <= LVK_COMPACT_RANSAC_MAX pairs.
+// d_n_raw / d_full: the number of tracked points and the model choice live on the device (n = upper bound, full_homography ignored).
 int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const float2* d_matched, const uint8_t* d_status, int n,
                               float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
                               const float2* d_und, float region_wf, float region_hf,
-                              double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask)
+                              double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask,
+                              const int* d_n_raw, const int* d_full)
 {
-    LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n > 0 && n <= 4 * NT && n <= LDS_POINTS);
+    static_assert(LVK_COMPACT_RANSAC_MAX % NT == 0 && LVK_COMPACT_RANSAC_MAX <= LDS_POINTS, "the fused variant compacts into its LDS copy");
+    LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n > 0 && n <= LVK_COMPACT_RANSAC_MAX);
     LVK_HIP_REQUIRE(ctx, d_ws && d_H && d_ninl && d_mask);
     double* hyp_H = (double*)d_ws;
     long long* hyp_score = (long long*)(hyp_H + K_HYPOTHESES * 9);
     uint8_t* mask_a = (uint8_t*)(hyp_score + K_HYPOTHESES);
     uint8_t* mask_b = mask_a + (((size_t)n + 255) & ~(size_t)255);
     const double t2 = threshold * threshold;
-    const CompactArgs ca{d_prev, d_matched, d_status, d_und, region_wf, region_hf, d_p1, d_p2, d_count, h_count, h_matched, h_status};
+    const CompactArgs ca{d_prev, d_matched, d_status, d_und, region_wf, region_hf, d_p1, d_p2, d_count, h_count, h_matched, h_status, d_n_raw, d_full};
     hipLaunchKernelGGL((k_ransac_hypotheses<true, true>), dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, (const float2*)nullptr, (const float2*)nullptr, n, (const int*)nullptr,
                        t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
-    hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, (const float2*)d_p1, (const float2*)d_p2, n, (const int*)d_count, t2, full_homography ? 1 : 0,
+    hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, (const float2*)d_p1, (const float2*)d_p2, n, (const int*)d_count, t2, full_homography ? 1 : 0, d_full,
                        region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;

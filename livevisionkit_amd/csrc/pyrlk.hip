@@ -258,7 +258,9 @@ __device__ __forceinline__ void stage_one_window(uint8_t* __restrict__ tb, const
 // (the tracker's window is always 11 x 11: FrameTracker.cpp:33); 0: the window of the arguments.
 // LENS (fused lens mode): the feature's block also writes the lens-corrected positions of its point pair -- (previous | matched), what
 // the motion is estimated from -- instead of a kernel of its own between the flow and the motion estimate.
-struct LensPointArgs { LensModelD model; double sx, sy; float2* und; };
+// n_dev: the number of points when it is decided on the device (the detector's suppression grid runs inside the chain, fast.hip): the grid is
+// launched for the largest possible count and workgroups beyond *n_dev leave at once
+struct LensPointArgs { LensModelD model; double sx, sy; float2* und; const int* n_dev; };
 template <int WIN, bool LENS>
 __global__ __launch_bounds__(64 * LVK_MAX_PYR_LEVELS)
 void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, float2* __restrict__ prev_copy, int n,
@@ -271,6 +273,7 @@ void k_pyrlk(PyrArgs prev, PyrArgs next, const float2* __restrict__ prev_pts, fl
     const int level_bytes = WIN ? (int)lvk_pyrlk_part_offset(WIN, WIN) : level_bytes_arg;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int pt = blockIdx.x;                                                // grid = n
+    if (la.n_dev) { n = *la.n_dev; if (pt >= n) return; }                      // (workgroup-uniform: before any barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = win_w + 1, th = win_h + 1, area = win_w * win_h, tarea = tw * th;
     const int jw = tw + 2 * LK_MARGIN, jh = th + 2 * LK_MARGIN;               // next-frame window incl. search margin
@@ -482,7 +485,7 @@ size_t lvk_pyrlk_lds_bytes(int win_w, int win_h, int nlevels)
 
 int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next, const float2* d_prev_pts, int n,
                      float2* d_next_pts, uint8_t* d_status, int win_w, int win_h, int max_count, double epsilon, double min_eig, float2* d_prev_copy,
-                     const LensModel* lens, double lens_sx, double lens_sy, float2* d_und)
+                     const LensModel* lens, double lens_sx, double lens_sy, float2* d_und, const int* d_n)
 {
     LVK_HIP_REQUIRE(ctx, prev.nlevels >= 1 && prev.nlevels == next.nlevels && prev.nlevels <= LVK_MAX_PYR_LEVELS);
     LVK_HIP_REQUIRE(ctx, win_w >= 3 && win_h >= 3 && win_w <= 31 && win_h <= 31);
@@ -495,6 +498,7 @@ int lvk_launch_pyrlk(lvk_hip_ctx* ctx, const PyrArgs& prev, const PyrArgs& next,
     LensPointArgs la{};
     const bool with_lens = lens != nullptr && d_und != nullptr;
     if (with_lens) { for (int i = 0; i < 17; i++) la.model.d[i] = lens->d[i]; la.sx = lens_sx; la.sy = lens_sy; la.und = d_und; }
+    la.n_dev = d_n;
     auto launch = [&](auto kernel) -> int {
         if (lds > 48 * 1024)
             LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -91,6 +91,13 @@ struct lvk_hip_stab
     float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr; uint8_t* d_status = nullptr;      // d_p1: 2 * cap_features pairs (p1 | p2)
     void* d_ransac_ws = nullptr;
     int* d_count = nullptr;                    // number of matches after the GPU-side fast_filter
+    // the suppression grid on the device (fast.hip k_fast_insert): the grid's tables, the point count / model choice the chain's kernels read,
+    // and (pinned) which cells hold propagated features, the new features and the kernel's verdicts
+    uint16_t* d_grid_col = nullptr; uint32_t* d_grid_row = nullptr; uint8_t* d_grid_bucket = nullptr;
+    int* d_n_points = nullptr; int* d_full = nullptr;
+    uint32_t* h_occ = nullptr; uint32_t* h_new_kp = nullptr; int* h_insert = nullptr;
+    bool device_grid = [] { const char* e = std::getenv("LVK_HIP_HOST_GRID"); return !(e && e[0] == '1'); }();      // LVK_HIP_HOST_GRID=1: the host loop (A/B, tests)
+    long device_grid_frames = 0, host_grid_frames = 0;
     float2* d_und = nullptr;                   // fused lens mode, chained path: lens-corrected (previous | matched) positions
     // pinned host mirrors
     uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
@@ -340,10 +347,12 @@ int lvk_hip_stab::alloc_pyramids()
 
 void lvk_hip_stab::free_tracker_buffers()
 {
-    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und, d_mesh_scratch};
+    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und, d_mesh_scratch,
+                   d_grid_col, d_grid_row, d_grid_bucket, d_n_points, d_full};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count};
+    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count, h_occ, h_new_kp, h_insert};
     for (void* p : host) if (p) (void)hipHostFree(p);
+    d_grid_col = nullptr; d_grid_row = nullptr; d_grid_bucket = nullptr; d_n_points = d_full = nullptr; h_occ = h_new_kp = nullptr; h_insert = nullptr;
     d_fast_masks = d_fast_scores = nullptr;
     d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr; d_und = nullptr; d_mesh_scratch = nullptr;
     h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = nullptr; h_status = nullptr;
@@ -387,6 +396,21 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_und, 2 * n * sizeof(float2), hipHostMallocDefault));
     LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_count, sizeof(int), hipHostMallocDefault));
+    // the suppression grid's tables for k_fast_insert (constant per configuration)
+    {
+        const auto& col = grid.col_table(); const auto& row = grid.row_base_table(); const auto& bucket = grid.bucket_table();
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_grid_col, std::max<size_t>(col.size(), 1) * sizeof(uint16_t)));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_grid_row, std::max<size_t>(row.size(), 1) * sizeof(uint32_t)));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_grid_bucket, std::max<size_t>(bucket.size(), 1)));
+        LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_col, col.data(), col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_row, row.data(), row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_bucket, bucket.data(), bucket.size(), hipMemcpyHostToDevice));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_n_points, sizeof(int)));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_full, sizeof(int)));
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_occ, ((grid.capacity() + 31) / 32 + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_new_kp, std::max<size_t>(grid.capacity(), 1) * sizeof(uint32_t), hipHostMallocDefault));
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_insert, 8 * sizeof(int), hipHostMallocDefault));
+    }
     return LVK_HIP_OK;
 }
 
@@ -566,6 +590,33 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     grid.plan(plan);
     bool any = false;
     for (size_t i = 0; i < plan.size(); i++) { h_regions[i] = plan[i]; any = any || plan[i].active; }
+    // On a frame on which the detector runs, the corners go through the suppression grid ON THE DEVICE, inside the chain (k_fast_insert): the
+    // new features land behind the held ones in the flow kernel's point list, and the kernels that follow take the point count and the
+    // model choice from device memory -- one chain and one synchronisation per frame, like a frame without detection.  The host loop stays
+    // for what the kernel does not cover (huge grids, regions off the pixel grid, more points than the on-device fast_filter takes).
+    int ins_words = 0;
+    for (const FastRegion& r : plan) if (r.active) ins_words += r.h * ((r.w + 63) / 64);
+    int ins_max_cells = 0, ins_max_words = 0;
+    (void)lvk_fast_insert_limits(&ins_max_cells, &ins_max_words);
+    const size_t n_held = grid.held.size();
+    const size_t n_bound = std::min(cap_features, n_held + (grid.capacity() - grid.used_cells()));      // every free cell takes at most one corner
+    const bool dev_insert = any && device_grid && grid.device_insert_ok() && (int)plan.size() <= LVK_FAST_INLINE_REGIONS && ins_words <= ins_max_words &&
+                            (int)grid.capacity() <= ins_max_cells && n_bound >= 1 && n_bound <= 4096;
+    float distribution = 0.0f;
+    if (dev_insert)
+    {
+        for (size_t i = 0; i < n_held; i++) h_pts[i] = make_float2(grid.held[i].x, grid.held[i].y);
+        grid.occupancy(h_occ);
+        const FastInsertDesc d{d_grid_col, d_grid_row, d_grid_bucket, h_occ, (int)grid.capacity(), grid.grid_cols() <= 4 || grid.grid_rows() <= 4, (int)n_held,
+                               s.min_motion_samples, s.uniformity_threshold, HOMOGRAPHY_DISTRIBUTION_THRESHOLD, h_pts, h_new_kp, h_insert, d_n_points, d_full, h_fast_counts};
+        pe = prof_begin(LVK_STAGE_FAST);
+        if ((rc = lvk_launch_fast_insert(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, h_regions, (int)plan.size(), fast_max_rw, fast_max_rh,
+                                         d_fast_masks, d_fast_scores, d)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+        device_grid_frames++;
+    }
+    else
+    {
     if (any)
     {
         // The small per-frame parameter / result blocks live in pinned, device-visible host memory: the kernels read the
@@ -577,19 +628,24 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         prof_end(pe);
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
         trace.mark(HostTrace::FAST_SYNC);
+        host_grid_frames++;
     }
     for (size_t i = 0; i < plan.size(); i++)
         if (plan[i].active) grid.absorb(i, h_fast_out + i * (size_t)fast_cap, std::min(h_fast_counts[i], fast_cap));
-    const float distribution = grid.finish(tracked);
+    distribution = grid.finish(tracked);
     last_distribution = distribution; last_detected = (int)tracked.size();
     if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return leave_early(); }
     if (tracked.size() > cap_features) return fail(LVK_HIP_ERR_RUNTIME, "feature count exceeds the suppression grid capacity");
+    }
 
     trace.mark(HostTrace::GRID);
     // ---- sparse optical flow prev -> cur
-    const int n = (int)tracked.size();
-    for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
-    const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;
+    // (device grid: n is the upper bound the kernels are launched for; they read the count itself from d_n_points)
+    int n = dev_insert ? (int)n_bound : (int)tracked.size();
+    if (!dev_insert) for (int i = 0; i < n; i++) h_pts[i] = make_float2(tracked[i].x, tracked[i].y);
+    const int* dn = dev_insert ? d_n_points : nullptr;
+    const int* dfull = dev_insert ? d_full : nullptr;
+    const bool full = distribution > HOMOGRAPHY_DISTRIBUTION_THRESHOLD;         // (device grid: decided by the kernel, d_full)
     // Global-motion mode without a lens model: the whole chain optical flow -> fast_filter -> RANSAC runs on the GPU without a
     // host round trip in between (the flow kernel reads the points from pinned host memory, k_match_compact reproduces the host's
     // swap-erase order); the host synchronises once and then repeats the cheap bookkeeping on its own copies.
@@ -601,10 +657,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         // fused lens mode: the motion is estimated between lens-corrected positions (what the reference chain LC -> VS tracks); the flow
         // kernel writes them itself (d_und: previous | matched)
         if ((rc = lvk_launch_pyrlk(ctx, P.args, C.args, h_pts, n, d_matched, d_status, LK_WIN, LK_WIN, LK_ITERS, LK_EPS, LK_MIN_EIG, d_pts,
-                                   lens ? &lens_model : nullptr, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h, lens ? d_und : nullptr)) != LVK_HIP_OK) return rc;
+                                   lens ? &lens_model : nullptr, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h, lens ? d_und : nullptr, dn)) != LVK_HIP_OK) return rc;
         const bool fused_compact = !field && n <= LVK_COMPACT_RANSAC_MAX;        // the RANSAC's first kernel compacts the flow result itself
         if (!fused_compact && (rc = lvk_launch_match_compact(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
-                                                             lens ? d_und : nullptr, (float)cur_w, (float)cur_h)) != LVK_HIP_OK) return rc;
+                                                             lens ? d_und : nullptr, (float)cur_w, (float)cur_h, dn)) != LVK_HIP_OK) return rc;
         prof_end(pe);
         pe = prof_begin(LVK_STAGE_MOTION);
         if (field)
@@ -617,9 +673,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         {
             if ((rc = lvk_launch_compact_ransac(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
                                                 lens ? d_und : nullptr, (float)cur_w, (float)cur_h,
-                                                s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask)) != LVK_HIP_OK) return rc;
+                                                s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, dn, dfull)) != LVK_HIP_OK) return rc;
         }
-        else if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count)) != LVK_HIP_OK) return rc;
+        else if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count, dfull)) != LVK_HIP_OK) return rc;
         prof_end(pe);
     }
     else
@@ -660,6 +716,22 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     trace.mark(HostTrace::LK_SYNC);
 
+    if (dev_insert)
+    {
+        // what the host loop would have left behind: thresholds, the feature list (held + new), the distribution quality -- recomputed here
+        // from the new features and held against the kernel's own figure
+        const int n_new = h_insert[0];
+        float q_dev; std::memcpy(&q_dev, &h_insert[2], sizeof(float));
+        if (n_new < 0 || (size_t)n_new > grid.capacity()) return fail(LVK_HIP_ERR_RUNTIME, "device suppression grid returned an impossible count");
+        distribution = grid.finish_device(tracked, h_new_kp, n_new, h_fast_counts, fast_cap);
+        last_distribution = distribution; last_detected = (int)tracked.size();
+        if (distribution != q_dev || tracked.size() != n_held + (size_t)n_new)
+            return fail(LVK_HIP_ERR_RUNTIME, "device suppression grid disagrees with the host's bookkeeping");
+        // FrameTracker.cpp:127-131 (the kernels of the chain saw a point count of zero and did nothing)
+        if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return LVK_HIP_OK; }
+        if (tracked.size() > cap_features) return fail(LVK_HIP_ERR_RUNTIME, "feature count exceeds the suppression grid capacity");
+        n = (int)tracked.size();
+    }
     if (chained)
     {
         // everything the remap launch needs is in the pinned result block; the list bookkeeping follows in finish_post()
@@ -1711,6 +1783,15 @@ int lvk_hip_stab_get_stats(const lvk_hip_stab* st, lvk_stab_stats* o)
     o->n_tracked = (int)st->tracked.size(); o->frame_delay = st->s.predictive_samples;
     o->smoothing_factor = st->smoother.smoothing_factor();
     for (int i = 0; i < 9; i++) o->homography[i] = st->last_H[i];
+    return LVK_HIP_OK;
+}
+
+// How many frames ran the detector so far, and where their corners went through the suppression grid: inside the chain on the device
+// (k_fast_insert) or in the host loop between two halves of it (grids / regions the kernel does not cover, LVK_HIP_HOST_GRID=1).
+int lvk_hip_stab_detector_frames(const lvk_hip_stab* st, long long* on_device, long long* on_host)
+{
+    if (!st || !on_device || !on_host) return LVK_HIP_ERR_ARG;
+    *on_device = st->device_grid_frames; *on_host = st->host_grid_frames;
     return LVK_HIP_OK;
 }
 

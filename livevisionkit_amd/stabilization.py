@@ -255,6 +255,12 @@ class StabilizationFilter:
         self.ctx._check(self.lib.lvk_hip_stab_get_stats(self.handle, _c.byref(st)))
         return st
 
+    def detector_frames(self):
+        """(frames whose corners went through the suppression grid on the device, frames that took the host loop)."""
+        a = _c.c_longlong(0); b = _c.c_longlong(0)
+        self.ctx._check(self.lib.lvk_hip_stab_detector_frames(self.handle, _c.byref(a), _c.byref(b)))
+        return a.value, b.value
+
     def meshes(self):
         n = self._settings.motion_width * self._settings.motion_height * 2
         a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)

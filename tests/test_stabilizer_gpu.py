@@ -502,3 +502,53 @@ def test_yuv420_resolution_change_mid_stream(ctx, oracle, entry):
         for p, q in zip(planes, want[ts]):
             assert p.shape == q.shape and np.array_equal(p, q), ts
     ost.close(); gst.close()
+
+
+def _tie_clip(rows, cols, n):
+    """A checkerboard of flat squares under a slow drift: hundreds of corners with IDENTICAL scores, several to a suppression-grid cell --
+    the grid keeps the FIRST of the strongest ones (FeatureDetector.cpp:150 `>`), so the order the corners are met in decides."""
+    frames = []
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    for i in range(n):
+        f = np.zeros((rows, cols, 3), np.uint8)
+        sx, sy = xx + 2 * i, yy + (i % 3)
+        f[..., 0] = np.where(((sx // 9) + (sy // 7)) % 2 == 1, 200, 40) + ((sx // 45 + sy // 35) % 3) * 8
+        f[..., 1] = 128; f[..., 2] = 120
+        frames.append(f)
+    return frames
+
+
+@pytest.mark.parametrize("preset", ["homography", "field"])
+def test_suppression_grid_on_the_device(ctx, oracle, clip, preset, monkeypatch):
+    """Frames on which the detector runs put their corners through the suppression grid INSIDE the chain (k_fast_insert): no host loop, no
+    second synchronisation.  The feature list (positions, responses, ages, ORDER), the counts and the distribution quality must equal the
+    oracle's and the host loop's (LVK_HIP_HOST_GRID=1) frame by frame -- on the jittering clip, on a clip full of equal-score corners,
+    through a restart, and with the relaxed and strict quality thresholds (early-outs decided by the kernel)."""
+    import torch
+    import livevisionkit_amd as lvk
+    for frames, over in ((clip[0], dict(min_scene_quality=0.4, min_tracking_quality=0.2)), (_tie_clip(360, 640, 16), dict()),
+                         (clip[0][:12], dict(uniformity_threshold=0.95, min_motion_samples=75))):          # the last: distribution < threshold, nothing tracked
+        so = oracle_lib.preset(preset, predictive_samples=2, **over)
+        ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(so)
+        gdev = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gdev.configure(_to_settings(so))
+        monkeypatch.setenv("LVK_HIP_HOST_GRID", "1")
+        ghost = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); ghost.configure(_to_settings(so))
+        monkeypatch.delenv("LVK_HIP_HOST_GRID")
+        for i, f in enumerate(frames):
+            if i == 9:
+                ost.restart(); gdev.restart(); ghost.restart()
+            d = torch.from_numpy(f).cuda()
+            ost.push(f, ts=i); gdev.apply(d, timestamp=i); ghost.apply(d.clone(), timestamp=i)
+            ctx.sync()
+            s0, s1, s2 = ost.stats(), gdev.stats(), ghost.stats()
+            for k in ("n_detected", "n_matched", "n_tracked", "distribution", "tracking_stability", "trust"):
+                assert getattr(s0, k) == getattr(s1, k) == getattr(s2, k), (preset, i, k, getattr(s0, k), getattr(s1, k), getattr(s2, k))
+            f0, f1, f2 = ost.features(), gdev.features(), ghost.features()
+            assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32)), (preset, i)
+            assert np.array_equal(f0.view(np.uint32), f2.view(np.uint32)), (preset, i)
+            assert np.array_equal(ost.meshes()[0].view(np.uint32), gdev.meshes()[0].view(np.uint32)), (preset, i)
+        dev, host = gdev.detector_frames()
+        assert dev >= 3 and host == 0, (preset, dev, host)
+        dev, host = ghost.detector_frames()
+        assert dev == 0 and host >= 3, (preset, dev, host)
+        ost.close(); gdev.close(); ghost.close()
