@@ -49,10 +49,17 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int stride, int thre
 // host memory across the link.
 struct FastRegionList { FastRegion r[LVK_FAST_INLINE_REGIONS]; };
 
+// The suppression grid's per-cell reduction, done by the detector itself when `cells.first` is given (see k_fast_insert below): every kept
+// corner folds its position key -- (region, row, column) packed in the order FeatureDetector::detect meets the corners in -- into its
+// cell's "first corner" (atomicMin) and "strongest corner, earliest on ties" (atomicMax of score << 24 | ~key) slots in global memory.
+// best: score << 56 | ~key << 32 | x | y << 12 | score << 24 -- the order is decided by the upper half (score, then the EARLIER key), the lower
+// half is the winner's feature record riding along
+struct FastCells { const uint16_t* col_of; const uint32_t* row_base; uint32_t* first; unsigned long long* best; int* region_count; };
+
 __global__ __launch_bounds__(TW * TH)
 void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols,
                    const FastRegion* __restrict__ regions, FastRegionList inl, int n_inline, int segs_x,
-                   unsigned long long* __restrict__ masks, uint8_t* __restrict__ scores, int max_rh, int max_rw)
+                   unsigned long long* __restrict__ masks, uint8_t* __restrict__ scores, int max_rh, int max_rw, FastCells cells)
 {
     LVK_TRACKER_PRIORITY();
     const FastRegion rg = n_inline ? inl.r[blockIdx.z] : regions[blockIdx.z];
@@ -71,6 +78,14 @@ void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols
         const int gx = min(max(rg.x + lx0 - AP + tx, 0), cols - 1);
         const int gy = min(max(rg.y + ly0 - AP + ty, 0), rows - 1);
         s_img[ty][tx] = img[(long)gy * step + gx];
+    }
+    // (suppression grid on the device: the cell coordinates of this tile's 64 columns and 8 rows, fetched with the tile -- no round trip of
+    //  their own later, when a kept corner looks its cell up)
+    __shared__ uint32_t s_cell_col[TW], s_cell_row[TH];
+    if (cells.first)
+    {
+        if (tid < TW) s_cell_col[tid] = cells.col_of[min(rg.x + lx0 + tid, cols - 1)];
+        else if (tid < TW + TH) s_cell_row[tid - TW] = cells.row_base[min(rg.y + ly0 + tid - TW, rows - 1)];
     }
     __syncthreads();
 
@@ -97,7 +112,16 @@ void k_fast_detect(const uint8_t* __restrict__ img, int step, int rows, int cols
     if (ly < rg.h)
     {
         if (threadIdx.x == 0) masks[((long)blockIdx.z * max_rh + ly) * segs_x + blockIdx.x] = mask;
+        if (threadIdx.x == 0 && cells.first && mask) atomicAdd(&cells.region_count[blockIdx.z], __popcll(mask));      // raw corners of the region
         if (keep) scores[((long)blockIdx.z * max_rh + ly) * max_rw + lx] = (uint8_t)s;
+        if (keep && cells.first)
+        {
+            const uint32_t ci = s_cell_row[threadIdx.y] + s_cell_col[threadIdx.x];
+            const uint32_t key = (uint32_t)(((int)blockIdx.z * max_rh + ly) * max_rw + lx);
+            atomicMin(&cells.first[ci], key);
+            const uint32_t rec = (uint32_t)(rg.x + lx) | ((uint32_t)(rg.y + ly) << 12) | ((uint32_t)s << 24);
+            atomicMax(&cells.best[ci], ((unsigned long long)(((uint32_t)s << 24) | (0xFFFFFFu - key)) << 32) | rec);
+        }
     }
 }
 
@@ -161,187 +185,132 @@ void k_fast_compact(const FastRegion* __restrict__ regions, FastRegionList inl, 
 // feature keeps the stronger of the two in place (strictly greater response: the earlier corner wins a tie), a cell that holds a
 // PROPAGATED feature never changes.  Closed form of what that loop leaves behind: the new features are, for every cell without a
 // propagated feature that receives at least one corner, the corner of maximal score (earliest on ties), listed in the order of the
-// cells' FIRST corners.  One workgroup computes that straight from k_fast_detect's ballots -- no ordered corner list is materialised, no
-// host round trip splits the frame's chain of kernels -- and appends the new points to the list the optical-flow kernel reads:
-//   1. exclusive scan of the per-word popcounts (words in region / row / segment order) -> the sequence number of every corner;
-//   2. per corner: atomicMin of the sequence number and atomicMax of (score << 24 | ~sequence) on its cell (LDS);
-//   3. per corner again: a corner that IS its cell's first one opens a list position (scan of those counts per word); the winner of
-//      the cell is looked up by its sequence number (binary search over the scan, k-th set bit of the word);
-//   4. SpatialMap::distribution_quality (Data/SpatialMap.tpp:589-625) over propagated + new cells, the two early-outs of
-//      FrameTracker::track (Vision/FrameTracker.cpp:127-131) and the homography / similarity choice (:170) for the kernels that follow.
+// cells' FIRST corners.  "Earlier" is the order of (region, row, column) -- a position key, no sequence numbers needed:
+//   * k_fast_detect folds every kept corner into its cell's two slots (above): the per-corner work runs on the detector's own ~540
+//     workgroups, one corner per lane, no dependent memory round trips in a serial loop (a first version that walked the ballots in ONE
+//     workgroup spent 35-90 us on exactly those, next to a remap that keeps every memory pipe busy);
+//   * k_fast_insert (one workgroup) ranks the cells by their first corner -- a bitmap over the position keys in LDS and a prefix popcount --,
+//     appends the winners to the list the optical-flow kernel reads, evaluates SpatialMap::distribution_quality (Data/SpatialMap.tpp:589-625)
+//     over propagated + new cells, the two early-outs of FrameTracker::track (Vision/FrameTracker.cpp:127-131) and the homography /
+//     similarity choice (:170) for the kernels that follow, and clears the slots for the next frame.
 struct FastInsertArgs
 {
-    const uint16_t* col_of; const uint32_t* row_base; const uint8_t* bucket;      // device tables of the grid (FeatureGridH)
-    const uint32_t* occ;                  // cells that hold a propagated feature, one bit each (device-visible host memory)
+    const uint8_t* bucket;                // device table of the grid (FeatureGridH): distribution bucket of every cell
+    uint32_t* first; unsigned long long* best;      // the per-cell slots k_fast_detect filled (device memory; left cleared)
+    int* region_count;                    // raw corners per region, summed by k_fast_detect (device memory; left cleared)
     int capacity, small_grid, n_held, min_samples; float uniformity, homography_threshold;
+    int nkeys;                            // position keys: nregions * max_rh * max_rw
     float2* pts;                          // the optical flow's point list: new points go to pts[n_held ...]
     uint32_t* new_kp;                     // x | y << 12 | score << 24 (frame coordinates) of the new features, list order
     int* result;                          // [0] new features, [1] points to track (0: early out), [2] quality (float bits), [3] full homography, [4] corners
     int* d_n; int* d_full;                // [1] and [3] again in device memory, for the kernels of the chain
     int* counts;                          // raw corner count per region
+    uint32_t occ[128];                    // cells that hold a propagated feature, one bit each (by value: no read across the host link)
+    int occ_bucket[16];                   // ... and how many of them lie in each distribution bucket
 };
 
-constexpr int INS_NT = 1024, INS_MAX_WORDS = 4096, INS_MAX_CELLS = 4096;
+// 1024 threads x <= 48 VGPRs: four wavefronts per SIMD fit into the 192 VGPRs the persistent remap grid of the overlap mode leaves free, and
+// the SIMDs have four of this kernel's (prioritised) waves to issue from -- next to the remap a lone wave issues an instruction every 5-10
+// cycles, and the kernel is a few thousand instructions of bookkeeping, not arithmetic.
+constexpr int INS_NT = 1024, INS_MAX_CELLS = 4096, INS_CPT = INS_MAX_CELLS / INS_NT, INS_MAX_KEYS = 1 << 18;
+
+// LDS (dynamic): bitmap over the position keys (nkeys / 32 words) + exclusive prefix popcount per bitmap word (u16)
+__host__ __device__ inline size_t ins_lds_bytes(int nkeys) { const size_t words = ((size_t)nkeys + 31) / 32; return words * 4 + ((words + 1) & ~(size_t)1) * 2; }
 
 __global__ __launch_bounds__(INS_NT)
-void k_fast_insert(FastRegionList inl, int nregions, int segs_x, const unsigned long long* __restrict__ masks, const uint8_t* __restrict__ scores,
-                   int max_rh, int max_rw, FastInsertArgs a)
+void k_fast_insert(int nregions, FastInsertArgs a)
 {
     LVK_TRACKER_PRIORITY();
-    __shared__ uint32_t s_first[INS_MAX_CELLS], s_best[INS_MAX_CELLS];
-    __shared__ int s_wbase[INS_MAX_WORDS + 1];
-    __shared__ unsigned short s_fbase[INS_MAX_WORDS];
+#ifdef LVK_INS_TIMING
+    long long tk[8]; int ntk = 0;
+#define INS_MARK() do { tk[ntk++] = wall_clock64(); } while (0)
+#else
+#define INS_MARK() do { } while (0)
+#endif
+    INS_MARK();
+    extern __shared__ __attribute__((aligned(16))) uint8_t ins_smem[];
+    const int bwords = (a.nkeys + 31) / 32;
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(ins_smem);
+    unsigned short* s_pre = reinterpret_cast<unsigned short*>(s_bits + bwords);
+    __shared__ int s_wave[INS_NT / 64], s_bucket[16], s_count[LVK_FAST_INLINE_REGIONS];
     __shared__ uint32_t s_occ[INS_MAX_CELLS / 32];
-    __shared__ int s_wave[INS_NT / 64], s_carry, s_woff[LVK_FAST_INLINE_REGIONS + 1], s_bucket[16], s_used;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    for (int i = t; i < a.capacity; i += INS_NT) { s_first[i] = 0xFFFFFFFFu; s_best[i] = 0u; }
-    for (int i = t; i < (a.capacity + 31) / 32; i += INS_NT) s_occ[i] = a.occ[i];
-    if (t < 16) s_bucket[t] = 0;
+    // everything this thread needs from global memory, all loads in flight together: next to a remap that keeps the memory pipes busy a
+    // dependent round trip costs microseconds, and this kernel has exactly one
+    uint32_t f[INS_CPT]; unsigned long long bk[INS_CPT]; uint32_t bu[INS_CPT];
+#pragma unroll
+    for (int k = 0; k < INS_CPT; k++)
+    {
+        const int ci = t + k * INS_NT;
+        f[k] = ci < a.capacity ? a.first[ci] : 0xFFFFFFFFu;
+        bk[k] = ci < a.capacity ? a.best[ci] : 0ull;
+        bu[k] = ci < a.capacity ? a.bucket[ci] : 0u;
+    }
+    const int my_count = t < nregions ? a.region_count[t] : 0;
+#pragma unroll 1
+    for (int i = t; i < bwords; i += INS_NT) s_bits[i] = 0u;
+    if (t < INS_MAX_CELLS / 32) s_occ[t] = a.occ[t];
+    if (t < LVK_FAST_INLINE_REGIONS) s_count[t] = my_count;
+    if (t < nregions && my_count) a.region_count[t] = 0;
+    if (t < 16) s_bucket[t] = a.occ_bucket[t];
+    __syncthreads();
+    INS_MARK();
+
+    // the cells that received a corner and hold no propagated feature: their first corner's key into the bitmap; slots cleared for the next
+    // frame.  The distribution buckets of the PROPAGATED cells come counted from the host (it marked them); only the new cells are counted
+    // here (a few hundred LDS atomics instead of the thousand that cost the first version 4 us)
+#pragma unroll
+    for (int k = 0; k < INS_CPT; k++)
+    {
+        const int ci = t + k * INS_NT;
+        if (ci < a.capacity && f[k] != 0xFFFFFFFFu)
+        {
+            a.first[ci] = 0xFFFFFFFFu; a.best[ci] = 0ull;
+            if ((s_occ[ci >> 5] >> (ci & 31)) & 1u) f[k] = 0xFFFFFFFFu;      // a propagated feature: whatever the detector found there is ignored
+            else { atomicOr(&s_bits[f[k] >> 5], 1u << (f[k] & 31)); atomicAdd(&s_bucket[bu[k] & 15u], 1); }
+        }
+    }
+    __syncthreads();
+    INS_MARK();
+    // exclusive prefix popcount over the bitmap words: consecutive words per thread, one wave scan, one barrier
+    const int wpt = (bwords + INS_NT - 1) / INS_NT, wb0 = t * wpt, wb1 = min(wb0 + wpt, bwords);
+    int mine = 0;
+#pragma unroll 1
+    for (int w = wb0; w < wb1; w++) mine += __popc(s_bits[w]);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, n_new = 0;
+#pragma unroll 2
+    for (int q = 0; q < INS_NT / 64; q++) { const int u = s_wave[q]; n_new += u; if (q < wave) base += u; }      // (not all 16 at once: the kernel has 48 VGPRs)
+    int run = base + incl - mine;
+#pragma unroll 1
+    for (int w = wb0; w < wb1; w++) { s_pre[w] = (unsigned short)run; run += __popc(s_bits[w]); }
+    __syncthreads();
+    INS_MARK();
+
+    // the winners, in the order of their cells' first corners: the record rode along in the lower half of the slot
+#pragma unroll
+    for (int k = 0; k < INS_CPT; k++)
+        if (f[k] != 0xFFFFFFFFu)
+        {
+            const uint32_t w = f[k] >> 5, bit = f[k] & 31;
+            const int pos = (int)s_pre[w] + __popc(s_bits[w] & ((1u << bit) - 1u));
+            const uint32_t rec = (uint32_t)bk[k];
+            a.pts[a.n_held + pos] = make_float2((float)(rec & 0xFFFu), (float)((rec >> 12) & 0xFFFu));
+            a.new_kp[pos] = rec;
+        }
+    INS_MARK();
+
+    // distribution quality over the occupied cells, the early-outs and the model choice
+    if (t < nregions) a.counts[t] = s_count[t];
     if (t == 0)
     {
-        int off = 0;
-        for (int r = 0; r < nregions; r++) { s_woff[r] = off; if (inl.r[r].active) off += inl.r[r].h * ((inl.r[r].w + TW - 1) / TW); }
-        s_woff[nregions] = off; s_carry = 0; s_used = 0;
-    }
-    __syncthreads();
-    const int nwords = s_woff[nregions];
-    // word w of the flattened order -> (region, row, segment) and the ballot word itself
-    auto word_at = [&](int w, int& r, int& ly, int& sg) -> unsigned long long {
-        r = 0;
-        while (r + 1 < nregions && w >= s_woff[r + 1]) r++;
-        while (!inl.r[r].active) r++;                                        // (an inactive region owns no words: skip to the owner)
-        const int rsegs = (inl.r[r].w + TW - 1) / TW, k = w - s_woff[r];
-        ly = k / rsegs; sg = k - ly * rsegs;
-        return masks[((long)r * max_rh + ly) * segs_x + sg];
-    };
-
-    // 1. sequence numbers: exclusive scan of the popcounts
-    for (int chunk = 0; chunk < nwords; chunk += INS_NT)
-    {
-        const int w = chunk + t;
-        int r, ly, sg;
-        const int cnt = w < nwords ? __popcll(word_at(w, r, ly, sg)) : 0;
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int wave_off = 0;
-        for (int q = 0; q < wave; q++) wave_off += s_wave[q];
-        if (w < nwords) s_wbase[w] = s_carry + wave_off + incl - cnt;
-        __syncthreads();
-        if (t == INS_NT - 1) s_carry = s_carry + wave_off + incl;
-        __syncthreads();
-    }
-    if (t == 0) s_wbase[nwords] = s_carry;
-    __syncthreads();
-    const int total = s_wbase[nwords];
-    if (t < nregions) a.counts[t] = inl.r[t].active ? s_wbase[s_woff[t + 1]] - s_wbase[s_woff[t]] : 0;
-
-    // 2. first corner and strongest corner of every cell
-    for (int w = t; w < nwords; w += INS_NT)
-    {
-        int r, ly, sg;
-        unsigned long long m = word_at(w, r, ly, sg);
-        uint32_t seq = (uint32_t)s_wbase[w];
-        const int gy = inl.r[r].y + ly;
-        while (m)
-        {
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int lx = sg * TW + bit;
-            const uint32_t ci = a.row_base[gy] + a.col_of[inl.r[r].x + lx];
-            if (!((s_occ[ci >> 5] >> (ci & 31)) & 1u))
-            {
-                const uint32_t sc = scores[((long)r * max_rh + ly) * max_rw + lx];
-                atomicMin(&s_first[ci], seq);
-                atomicMax(&s_best[ci], (sc << 24) | (0xFFFFFFu - seq));
-            }
-            seq++;
-        }
-    }
-    __syncthreads();
-
-    // 3. list positions: corners that are their cell's first one, in sequence order
-    s_carry = 0;                                       // (every thread read `total` above; the barrier below orders this store)
-    __syncthreads();
-    for (int chunk = 0; chunk < nwords; chunk += INS_NT)
-    {
-        const int w = chunk + t;
-        int cnt = 0;
-        if (w < nwords)
-        {
-            int r, ly, sg;
-            unsigned long long m = word_at(w, r, ly, sg);
-            uint32_t seq = (uint32_t)s_wbase[w];
-            const int gy = inl.r[r].y + ly;
-            while (m)
-            {
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const uint32_t ci = a.row_base[gy] + a.col_of[inl.r[r].x + sg * TW + bit];
-                cnt += s_first[ci] == seq ? 1 : 0;     // (an occupied cell keeps first = ~0, which is no sequence number)
-                seq++;
-            }
-        }
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int wave_off = 0;
-        for (int q = 0; q < wave; q++) wave_off += s_wave[q];
-        if (w < nwords) s_fbase[w] = (unsigned short)(s_carry + wave_off + incl - cnt);
-        __syncthreads();
-        if (t == INS_NT - 1) s_carry = s_carry + wave_off + incl;
-        __syncthreads();
-    }
-    const int n_new = s_carry;
-    for (int w = t; w < nwords; w += INS_NT)
-    {
-        int r, ly, sg;
-        unsigned long long m = word_at(w, r, ly, sg);
-        uint32_t seq = (uint32_t)s_wbase[w];
-        int pos = s_fbase[w];
-        const int gy = inl.r[r].y + ly;
-        while (m)
-        {
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int gx = inl.r[r].x + sg * TW + bit;
-            const uint32_t ci = a.row_base[gy] + a.col_of[gx];
-            if (s_first[ci] == seq)
-            {
-                const uint32_t key = s_best[ci], sb = 0xFFFFFFu - (key & 0xFFFFFFu);
-                int bx = gx, by = gy;
-                if (sb != seq)
-                {
-                    // the strongest corner of the cell is a later one: find its word (largest wb with wbase[wb] <= sb), then its bit
-                    int lo = 0, hi = nwords - 1;
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((uint32_t)s_wbase[mid] <= sb) lo = mid; else hi = mid - 1; }
-                    int r2, ly2, sg2;
-                    unsigned long long m2 = word_at(lo, r2, ly2, sg2);
-                    for (int k = (int)sb - s_wbase[lo]; k > 0; k--) m2 &= m2 - 1;
-                    bx = inl.r[r2].x + sg2 * TW + (__ffsll((long long)m2) - 1); by = inl.r[r2].y + ly2;
-                }
-                a.pts[a.n_held + pos] = make_float2((float)bx, (float)by);
-                a.new_kp[pos] = (uint32_t)bx | ((uint32_t)by << 12) | (key & 0xFF000000u);
-                pos++;
-            }
-            seq++;
-        }
-    }
-
-    // 4. distribution quality over the occupied cells, the early-outs and the model choice
-    int used = 0;
-    for (int ci = t; ci < a.capacity; ci += INS_NT)
-        if (((s_occ[ci >> 5] >> (ci & 31)) & 1u) || s_first[ci] != 0xFFFFFFFFu) { used++; if (!a.small_grid) atomicAdd(&s_bucket[a.bucket[ci]], 1); }
-    if (used) atomicAdd(&s_used, used);
-    __syncthreads();
-    if (t == 0)
-    {
-        const int m_used = s_used;
+        int m_used = 0;
+        for (int b = 0; b < 16; b++) m_used += s_bucket[b];
         float q = 1.0f;
         if (m_used != 0)
         {
@@ -354,12 +323,19 @@ void k_fast_insert(FastRegionList inl, int nregions, int segs_x, const unsigned 
                 q = 1.0f - ((float)excess / (float)(m_used - ideal));
             }
         }
+        int total = 0;
+        for (int r = 0; r < nregions; r++) total += s_count[r];
         const int n_total = a.n_held + n_new;
         const int n_eff = (n_total < a.min_samples || q < a.uniformity) ? 0 : n_total;
         const int full = q > a.homography_threshold ? 1 : 0;
         a.result[0] = n_new; a.result[1] = n_eff; a.result[2] = __float_as_int(q); a.result[3] = full; a.result[4] = total;
         *a.d_n = n_eff; *a.d_full = full;
     }
+#ifdef LVK_INS_TIMING
+    INS_MARK();
+    if (t == 0) printf("k_fast_insert (100 MHz ticks): loads+init %lld, slots+buckets %lld, prefix %lld, winners %lld, verdict %lld | new %d\n",
+                       tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], n_new);
+#endif
 }
 
 } // namespace
@@ -385,7 +361,7 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
     const int n_inline = (host_regions && nregions <= LVK_FAST_INLINE_REGIONS) ? nregions : 0;      // host_regions: the same descriptors, readable by the host
     for (int i = 0; i < n_inline; i++) inl.r[i] = host_regions[i];
     hipLaunchKernelGGL(k_fast_detect, grid, block, 0, ctx->stream, (const uint8_t*)d_img, step, rows, cols, d_regions, inl, n_inline, segs_x,
-                       (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw);
+                       (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw, FastCells{});
     hipLaunchKernelGGL(k_fast_compact, dim3(nregions), dim3(1024), 0, ctx->stream, d_regions, inl, n_inline, segs_x,
                        (const unsigned long long*)d_masks, (const uint8_t*)d_scores, max_rh, max_rw, d_out, cap, d_counts);
     LVK_HIP_CHECK(ctx, hipGetLastError());
@@ -393,30 +369,48 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
 }
 
 
-// Detection + the suppression grid on the device (see k_fast_insert): same detect kernel, then ONE workgroup that leaves the new features
-// behind the held ones in `pts` and the counts / flags the rest of the chain reads.  Regions travel as kernel arguments (<= 8).
+// Detection + the suppression grid on the device (see k_fast_insert): the detect kernel folds the corners into the per-cell slots, ONE
+// workgroup leaves the new features behind the held ones in `pts` and the counts / flags the rest of the chain reads.  Regions travel as
+// kernel arguments (<= 8).
 int lvk_launch_fast_insert(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, const FastRegion* host_regions, int nregions,
                            int max_rw, int max_rh, void* d_masks, void* d_scores, const FastInsertDesc& d)
 {
-    LVK_HIP_REQUIRE(ctx, d_img && host_regions && nregions > 0 && nregions <= LVK_FAST_INLINE_REGIONS && max_rw > 0 && max_rh > 0 && max_rw < 4096 && max_rh < 4096);
-    LVK_HIP_REQUIRE(ctx, d.capacity > 0 && d.capacity <= INS_MAX_CELLS && d.pts && d.new_kp && d.result && d.d_n && d.d_full && d.counts && d.occ);
+    LVK_HIP_REQUIRE(ctx, d_img && host_regions && nregions > 0 && nregions <= LVK_FAST_INLINE_REGIONS && max_rw > 0 && max_rh > 0);
+    LVK_HIP_REQUIRE(ctx, lvk_fast_insert_fits(d.capacity, nregions, max_rw, max_rh, cols, rows));
+    LVK_HIP_REQUIRE(ctx, d.pts && d.new_kp && d.result && d.d_n && d.d_full && d.counts && d.occ && d.cell_first && d.cell_best && d.region_count && d.occ_bucket && d.col_of && d.row_base && d.bucket);
     const int segs_x = (max_rw + TW - 1) / TW;
-    int nwords = 0;
     FastRegionList inl{};
-    for (int i = 0; i < nregions; i++) { inl.r[i] = host_regions[i]; if (inl.r[i].active) nwords += inl.r[i].h * ((inl.r[i].w + TW - 1) / TW); }
-    LVK_HIP_REQUIRE(ctx, nwords <= INS_MAX_WORDS);
+    for (int i = 0; i < nregions; i++) inl.r[i] = host_regions[i];
+    const int nkeys = nregions * max_rh * max_rw;
+    const size_t lds = ins_lds_bytes(nkeys);
+    if (lds > 48 * 1024)
+        LVK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_insert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 block(TW, TH), grid(segs_x, (max_rh + TH - 1) / TH, nregions);
     hipLaunchKernelGGL(k_fast_detect, grid, block, 0, ctx->stream, (const uint8_t*)d_img, step, rows, cols, (const FastRegion*)nullptr, inl, nregions, segs_x,
-                       (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw);
-    const FastInsertArgs a{d.col_of, d.row_base, d.bucket, d.occ, d.capacity, d.small_grid ? 1 : 0, d.n_held, d.min_samples, d.uniformity, d.homography_threshold,
-                           d.pts, d.new_kp, d.result, d.d_n, d.d_full, d.counts};
-    hipLaunchKernelGGL(k_fast_insert, dim3(1), dim3(INS_NT), 0, ctx->stream, inl, nregions, segs_x, (const unsigned long long*)d_masks, (const uint8_t*)d_scores,
-                       max_rh, max_rw, a);
+                       (unsigned long long*)d_masks, (uint8_t*)d_scores, max_rh, max_rw, FastCells{d.col_of, d.row_base, d.cell_first, (unsigned long long*)d.cell_best, d.region_count});
+    FastInsertArgs a{d.bucket, d.cell_first, (unsigned long long*)d.cell_best, d.region_count, d.capacity, d.small_grid ? 1 : 0, d.n_held, d.min_samples, d.uniformity, d.homography_threshold, nkeys,
+                     d.pts, d.new_kp, d.result, d.d_n, d.d_full, d.counts, {}, {}};
+    for (int i = 0; i < (d.capacity + 31) / 32; i++) a.occ[i] = d.occ[i];
+    for (int i = 0; i < 16; i++) a.occ_bucket[i] = d.occ_bucket[i];
+    hipLaunchKernelGGL(k_fast_insert, dim3(1), dim3(INS_NT), lds, ctx->stream, nregions, a);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }
 
-int lvk_fast_insert_limits(int* max_cells, int* max_words) { *max_cells = INS_MAX_CELLS; *max_words = INS_MAX_WORDS; return TW; }
+// what the kernels cover, for the caller's choice between them and the host loop; and the initial state of the per-cell slots
+bool lvk_fast_insert_fits(int cells, int nregions, int max_rw, int max_rh, int cols, int rows)
+{
+    if (!(cells > 0 && cells <= INS_MAX_CELLS && nregions > 0 && nregions <= LVK_FAST_INLINE_REGIONS && cols < 4096 && rows < 4096 && max_rw < 4096 && max_rh < 4096)) return false;
+    const long nkeys = (long)nregions * max_rh * max_rw;
+    return nkeys <= INS_MAX_KEYS && ins_lds_bytes((int)nkeys) <= 60 * 1024;
+}
+int lvk_fast_cells_reset(lvk_hip_ctx* ctx, uint32_t* d_first, void* d_best, int cells, int* d_region_count)
+{
+    LVK_HIP_CHECK(ctx, hipMemsetAsync(d_region_count, 0, LVK_FAST_INLINE_REGIONS * sizeof(int), ctx->stream));
+    LVK_HIP_CHECK(ctx, hipMemsetAsync(d_first, 0xFF, (size_t)cells * sizeof(uint32_t), ctx->stream));
+    LVK_HIP_CHECK(ctx, hipMemsetAsync(d_best, 0, (size_t)cells * sizeof(unsigned long long), ctx->stream));
+    return LVK_HIP_OK;
+}
 
 extern "C" {
 

@@ -306,10 +306,11 @@ public:
             if (!(z.x == std::floor(z.x) && z.y == std::floor(z.y) && z.x >= 0.0f && z.y >= 0.0f && cv_round(z.x) + cv_round(z.w) <= m_w && cv_round(z.y) + cv_round(z.h) <= m_h)) return false;
         return true;
     }
-    void occupancy(uint32_t* bits) const     // one bit per cell that holds a propagated feature; (capacity + 31) / 32 words
+    void occupancy(uint32_t* bits, int bucket_counts[16]) const     // one bit per cell that holds a propagated feature ((capacity + 31) / 32 words), and their number per distribution bucket
     {
         std::fill(bits, bits + (capacity() + 31) / 32, 0u);
-        for (uint32_t c : m_used_cells) bits[c >> 5] |= 1u << (c & 31);
+        std::fill(bucket_counts, bucket_counts + 16, 0);
+        for (uint32_t c : m_used_cells) { bits[c >> 5] |= 1u << (c & 31); bucket_counts[m_bucket[c] & 15]++; }
     }
     // End of detect() when the kernel has run the corners through the grid: kp = the new features in list order (frame coordinates,
     // x | y << 12 | score << 24), raw = every zone's raw corner count.  Same hand-over as absorb() x zones + finish().

@@ -181,17 +181,20 @@ int lvk_launch_fast(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int
                     const FastRegion* d_regions, int nregions, int max_rw, int max_rh,
                     void* d_masks, void* d_scores, uint32_t* d_out, int cap, int* d_counts, const FastRegion* host_regions = nullptr);
 
-// ... with the suppression grid on the device (k_fast_insert): the new features land behind the held ones in `pts`
+// ... with the suppression grid on the device (k_fast_detect's per-cell slots + k_fast_insert): the new features land behind the held ones in `pts`
 struct FastInsertDesc
 {
     const uint16_t* col_of; const uint32_t* row_base; const uint8_t* bucket;      // device copies of FeatureGridH's tables
-    const uint32_t* occ;                   // device-visible host memory: one bit per cell that holds a propagated feature
+    uint32_t* cell_first; void* cell_best /* 8 bytes per cell */; int* region_count;                 // device: one slot pair per cell, one counter per region (lvk_fast_cells_reset once; the kernels leave them cleared)
+    const uint32_t* occ;                   // host memory: one bit per cell that holds a propagated feature (travels as a kernel argument)
+    const int* occ_bucket;                 // host memory: 16 counts, the propagated cells per distribution bucket
     int capacity; bool small_grid; int n_held, min_samples; float uniformity, homography_threshold;
     float2* pts; uint32_t* new_kp; int* result; int* d_n; int* d_full; int* counts;
 };
 int lvk_launch_fast_insert(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, const FastRegion* host_regions, int nregions,
                            int max_rw, int max_rh, void* d_masks, void* d_scores, const FastInsertDesc& d);
-int lvk_fast_insert_limits(int* max_cells, int* max_words);      // returns the ballot word width (pixels)
+bool lvk_fast_insert_fits(int cells, int nregions, int max_rw, int max_rh, int cols, int rows);      // what the kernels cover (else: the host loop)
+int lvk_fast_cells_reset(lvk_hip_ctx* ctx, uint32_t* d_first, void* d_best, int cells, int* d_region_count /* LVK_FAST_INLINE_REGIONS ints */);
 
 // Pyramidal LK (pyrlk.hip)
 struct LensModel;

@@ -94,6 +94,7 @@ struct lvk_hip_stab
     // the suppression grid on the device (fast.hip k_fast_insert): the grid's tables, the point count / model choice the chain's kernels read,
     // and (pinned) which cells hold propagated features, the new features and the kernel's verdicts
     uint16_t* d_grid_col = nullptr; uint32_t* d_grid_row = nullptr; uint8_t* d_grid_bucket = nullptr;
+    uint32_t* d_cell_first = nullptr; void* d_cell_best = nullptr; int* d_region_count = nullptr;      // per-cell slots / per-region counters the detector folds its corners into
     int* d_n_points = nullptr; int* d_full = nullptr;
     uint32_t* h_occ = nullptr; uint32_t* h_new_kp = nullptr; int* h_insert = nullptr;
     bool device_grid = [] { const char* e = std::getenv("LVK_HIP_HOST_GRID"); return !(e && e[0] == '1'); }();      // LVK_HIP_HOST_GRID=1: the host loop (A/B, tests)
@@ -348,11 +349,11 @@ int lvk_hip_stab::alloc_pyramids()
 void lvk_hip_stab::free_tracker_buffers()
 {
     void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und, d_mesh_scratch,
-                   d_grid_col, d_grid_row, d_grid_bucket, d_n_points, d_full};
+                   d_grid_col, d_grid_row, d_grid_bucket, d_n_points, d_full, d_cell_first, d_cell_best, d_region_count};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count, h_occ, h_new_kp, h_insert};
     for (void* p : host) if (p) (void)hipHostFree(p);
-    d_grid_col = nullptr; d_grid_row = nullptr; d_grid_bucket = nullptr; d_n_points = d_full = nullptr; h_occ = h_new_kp = nullptr; h_insert = nullptr;
+    d_grid_col = nullptr; d_grid_row = nullptr; d_grid_bucket = nullptr; d_n_points = d_full = nullptr; d_cell_first = nullptr; d_cell_best = nullptr; d_region_count = nullptr; h_occ = h_new_kp = nullptr; h_insert = nullptr;
     d_fast_masks = d_fast_scores = nullptr;
     d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr; d_und = nullptr; d_mesh_scratch = nullptr;
     h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = nullptr; h_status = nullptr;
@@ -405,6 +406,10 @@ int lvk_hip_stab::alloc_tracker_buffers()
         LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_col, col.data(), col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_row, row.data(), row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_bucket, bucket.data(), bucket.size(), hipMemcpyHostToDevice));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_cell_first, std::max<size_t>(grid.capacity(), 1) * sizeof(uint32_t)));
+        LVK_HIP_CHECK(ctx, hipMalloc(&d_cell_best, std::max<size_t>(grid.capacity(), 1) * sizeof(unsigned long long)));
+        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_region_count, LVK_FAST_INLINE_REGIONS * sizeof(int)));
+        { const int crc = lvk_fast_cells_reset(ctx, d_cell_first, d_cell_best, (int)std::max<size_t>(grid.capacity(), 1), d_region_count); if (crc != LVK_HIP_OK) return crc; }
         LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_n_points, sizeof(int)));
         LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_full, sizeof(int)));
         LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_occ, ((grid.capacity() + 31) / 32 + 1) * sizeof(uint32_t), hipHostMallocDefault));
@@ -594,20 +599,17 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // new features land behind the held ones in the flow kernel's point list, and the kernels that follow take the point count and the
     // model choice from device memory -- one chain and one synchronisation per frame, like a frame without detection.  The host loop stays
     // for what the kernel does not cover (huge grids, regions off the pixel grid, more points than the on-device fast_filter takes).
-    int ins_words = 0;
-    for (const FastRegion& r : plan) if (r.active) ins_words += r.h * ((r.w + 63) / 64);
-    int ins_max_cells = 0, ins_max_words = 0;
-    (void)lvk_fast_insert_limits(&ins_max_cells, &ins_max_words);
     const size_t n_held = grid.held.size();
     const size_t n_bound = std::min(cap_features, n_held + (grid.capacity() - grid.used_cells()));      // every free cell takes at most one corner
-    const bool dev_insert = any && device_grid && grid.device_insert_ok() && (int)plan.size() <= LVK_FAST_INLINE_REGIONS && ins_words <= ins_max_words &&
-                            (int)grid.capacity() <= ins_max_cells && n_bound >= 1 && n_bound <= 4096;
+    const bool dev_insert = any && device_grid && grid.device_insert_ok() && (int)plan.size() <= LVK_FAST_INLINE_REGIONS &&
+                            lvk_fast_insert_fits((int)grid.capacity(), (int)plan.size(), fast_max_rw, fast_max_rh, cur_w, cur_h) && n_bound >= 1 && n_bound <= 4096;
     float distribution = 0.0f;
     if (dev_insert)
     {
         for (size_t i = 0; i < n_held; i++) h_pts[i] = make_float2(grid.held[i].x, grid.held[i].y);
-        grid.occupancy(h_occ);
-        const FastInsertDesc d{d_grid_col, d_grid_row, d_grid_bucket, h_occ, (int)grid.capacity(), grid.grid_cols() <= 4 || grid.grid_rows() <= 4, (int)n_held,
+        int occ_bucket[16];
+        grid.occupancy(h_occ, occ_bucket);
+        const FastInsertDesc d{d_grid_col, d_grid_row, d_grid_bucket, d_cell_first, d_cell_best, d_region_count, h_occ, occ_bucket, (int)grid.capacity(), grid.grid_cols() <= 4 || grid.grid_rows() <= 4, (int)n_held,
                                s.min_motion_samples, s.uniformity_threshold, HOMOGRAPHY_DISTRIBUTION_THRESHOLD, h_pts, h_new_kp, h_insert, d_n_points, d_full, h_fast_counts};
         pe = prof_begin(LVK_STAGE_FAST);
         if ((rc = lvk_launch_fast_insert(ctx, C.args.lv[0].img, C.args.lv[0].step, cur_h, cur_w, h_regions, (int)plan.size(), fast_max_rw, fast_max_rh,

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r04_3
 rm -rf $OUT; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
+timeout 1500 python -m pytest tests/test_stabilizer_gpu.py tests/test_long_run_gpu.py tests/test_config5_gpu.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
 tail -25 $OUT/pytest.log
 for i in 1 2; do
   for which in host dev; do

@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "livevisionkit_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 MESH_FLAGS = ["-mllvm", "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]      # as csrc/Makefile
-VGPR_BUDGET = {r"k_remap_\w+": 80, r"k_easu_scale": 80, r"k_ransac_finalize": 168, r"k_mesh_backsolve(?!_generic)": 168, r"k_pyrlk": 96, r"k_mesh_solve(?!_generic)": 256}
+VGPR_BUDGET = {r"k_fast_insert": 48, r"k_remap_\w+": 80, r"k_easu_scale": 80, r"k_ransac_finalize": 168, r"k_mesh_backsolve(?!_generic)": 168, r"k_pyrlk": 96, r"k_mesh_solve(?!_generic)": 256}
 
 
 def _kernels(unit):
