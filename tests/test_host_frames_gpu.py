@@ -144,6 +144,42 @@ def test_out_of_order_push_is_refused_with_a_message(ctx):
     f.close()
 
 
+def test_announced_frames_are_forgotten_on_restart_and_cancel(ctx):
+    """A caller that announced frame n + 1 and then restarts, seeks or switches buffers: restart() and lvk_hip_stab_prefetch_cancel
+    forget the announcement -- later pushes with other pointers go through (they used to be refused until the stale pointers were pushed), and
+    a REUSED buffer pushed after the restart carries its new content, not the upload started before it."""
+    import livevisionkit_amd as lvk
+    rows, cols = 360, 640
+    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings.obs_preset("homography", predictive_samples=1), context=ctx)
+    a, b, o0, o1 = (f.host_planes(rows, cols) for _ in range(4))
+    rng = np.random.default_rng(3)
+    tex = rng.integers(0, 255, (rows, cols), dtype=np.uint8)
+    for p, val in ((a, 60), (b, 200)):
+        p[0][...] = val; p[1][...] = 110; p[2][...] = 140
+    pa, pb, p0, p1 = (f.prepare_yuv420_host(p) for p in (a, b, o0, o1))
+    f.apply_yuv420_host_prepared(pa, 0, p0)
+    f.prefetch_yuv420_host_prepared(pb)                     # announced, never pushed
+    f.restart()
+    f.apply_yuv420_host_prepared(pa, 1, p0)                 # other pointers than the announced ones: fine after a restart
+    f.prefetch_yuv420_host_prepared(pb)
+    f.prefetch_cancel()
+    f.apply_yuv420_host_prepared(pa, 2, p0)                 # ... and after a cancel
+    ctx.sync()
+    # the reused-buffer case: announce b, restart, rewrite b, push b -- the emitted frame (delay 1, identity motion on flat frames) is the NEW b
+    f.restart()
+    f.prefetch_yuv420_host_prepared(pb)
+    f.restart()
+    b[0][...] = tex
+    out, ts = f.apply_yuv420_host_prepared(pb, 10, p0)
+    assert out is None
+    out, ts = f.apply_yuv420_host_prepared(pa, 11, p1)
+    ctx.sync()
+    assert out is not None and ts == 10
+    inner = (slice(40, rows - 40), slice(40, cols - 40))
+    assert np.array_equal(o1[0][inner], tex[inner]), "the frame pushed after the restart carries the pre-restart upload"
+    f.close()
+
+
 def test_pageable_planes_are_refused_with_a_message(ctx):
     """The host entry points hand their plane pointers to copy engines and to a kernel: pageable memory is an argument error, not a GPU fault."""
     import livevisionkit_amd as lvk

@@ -40,3 +40,24 @@ def test_no_scratch_and_vgpr_budgets(unit):
         for pat, budget in VGPR_BUDGET.items():
             if re.search(pat, name):
                 assert vgprs <= budget, f"{name}: {vgprs} VGPRs (budget {budget})"
+
+
+def test_remap_instruction_ceiling():
+    """The remap is bound by how many VALU instructions it issues per pixel: 498.9 per pixel measured (rocprofv3
+    SQ_INSTS_VALU, profiles/r04_sq_counters_per_kernel.txt) = 2 124 static VALU instructions per 4-pixel thread of k_remap_homography_420
+    (both paths of every branch counted).  This keeps a refactor from quietly adding to it, and holds the two round-4 savings in place: EASU's
+    saturate as the `clamp` modifier of the multiply that feeds it (no v_min_f32 / v_max_f32 pair with 1.0 / 0 behind it) and the final clamp
+    between the centre taps' minimum and maximum as one v_med3_f32."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, "remap.hip")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(\S*k_remap_homography_420\S*):[^\n]*\n(.*?)\.Lfunc_end", out.stdout, re.S | re.M)}
+    assert len(bodies) == 2, list(bodies)                                  # <false> (I420) and <true> (NV12)
+    for name, body in bodies.items():
+        ops = [ln.split()[0] for ln in body.splitlines() if ln.strip() and not ln.strip().startswith((";", ".", "//")) and not ln.strip().endswith(":")]
+        valu = [o for o in ops if o.startswith("v_")]
+        assert len(valu) <= 2140, f"{name}: {len(valu)} static VALU instructions (ceiling 2 140; round 3: 2 200)"
+        clamped = [ln for ln in body.splitlines() if re.search(r"v_mul_f32_e64 .* clamp", ln)]
+        assert len(clamped) >= 32, f"{name}: {len(clamped)} clamped multiplies (8 per pixel expected)"
+        assert sum(1 for o in valu if o.startswith("v_med3_f32")) >= 12, name
+        assert not re.search(r"v_min_f32_e32 v\d+, 1\.0,", body), f"{name}: a saturate compiled to v_min 1.0 / v_max 0 again"
