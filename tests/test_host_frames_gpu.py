@@ -150,7 +150,7 @@ def test_announced_frames_are_forgotten_on_restart_and_cancel(ctx):
     a REUSED buffer pushed after the restart carries its new content, not the upload started before it."""
     import livevisionkit_amd as lvk
     rows, cols = 360, 640
-    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings.obs_preset("homography", predictive_samples=1), context=ctx)
+    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings.obs_preset("homography", predictive_samples=1, apply_crop=False), context=ctx)
     a, b, o0, o1 = (f.host_planes(rows, cols) for _ in range(4))
     rng = np.random.default_rng(3)
     tex = rng.integers(0, 255, (rows, cols), dtype=np.uint8)
@@ -176,7 +176,10 @@ def test_announced_frames_are_forgotten_on_restart_and_cancel(ctx):
     ctx.sync()
     assert out is not None and ts == 10
     inner = (slice(40, rows - 40), slice(40, cols - 40))
-    assert np.array_equal(o1[0][inner], tex[inner]), "the frame pushed after the restart carries the pre-restart upload"
+    got = o1[0][inner].astype(int)
+    # (identity warp: the resampler returns the centre pixel up to its x 255 truncation -- a stale upload would be the flat 200 of before)
+    assert np.abs(got - tex[inner].astype(int)).max() <= 2, "the frame pushed after the restart carries the pre-restart upload"
+    assert np.abs(got - 200).mean() > 30
     f.close()
 
 
