@@ -152,8 +152,8 @@ def test_announced_frames_are_forgotten_on_restart_and_cancel(ctx):
     rows, cols = 360, 640
     f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings.obs_preset("homography", predictive_samples=1, apply_crop=False), context=ctx)
     a, b, o0, o1 = (f.host_planes(rows, cols) for _ in range(4))
-    rng = np.random.default_rng(3)
-    tex = rng.integers(0, 255, (rows, cols), dtype=np.uint8)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    tex = np.rint(128 + 60 * np.sin(xx / 37.0) + 40 * np.cos(yy / 23.0)).astype(np.uint8)      # smooth: an identity warp returns it (edge-adaptive filter)
     for p, val in ((a, 60), (b, 200)):
         p[0][...] = val; p[1][...] = 110; p[2][...] = 140
     pa, pb, p0, p1 = (f.prepare_yuv420_host(p) for p in (a, b, o0, o1))
@@ -178,7 +178,7 @@ def test_announced_frames_are_forgotten_on_restart_and_cancel(ctx):
     inner = (slice(40, rows - 40), slice(40, cols - 40))
     got = o1[0][inner].astype(int)
     # (identity warp: the resampler returns the centre pixel up to its x 255 truncation -- a stale upload would be the flat 200 of before)
-    assert np.abs(got - tex[inner].astype(int)).max() <= 2, "the frame pushed after the restart carries the pre-restart upload"
+    assert np.abs(got - tex[inner].astype(int)).max() <= 3, "the frame pushed after the restart carries the pre-restart upload"
     assert np.abs(got - 200).mean() > 30
     f.close()
 
