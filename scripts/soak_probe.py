@@ -55,6 +55,7 @@ def host_run(count):
     for i in range(count):
         if i == count // 2:
             ctx.sync(); f.restart()
+            f.prefetch_yuv420_host_prepared(ia[i % 64])       # restart() forgets the announced frames (round 4): announce this one again
         if i == count // 3:
             ctx.sync()
             f.configure(lvk.StabilizationFilterSettings.obs_preset("field")); f.configure(lvk.StabilizationFilterSettings.obs_preset("homography"))
