@@ -309,10 +309,10 @@ int run_two_threads_check()
 // streams it): lvk::RawYuvCapture on a raw I420 file.  Delivered as YUV the emitted frames must equal apply() on the same frames ingested
 // by lvk_hip_ingest_yuv420, stamped with the stream position; delivered as BGR (the reference's assumption) the run must complete with BGR
 // frames; read(HostFrame420&) feeds the host entry point and must emit the planes of the device 4:2:0 path.
-int run_file_input_check(const char* dir)
+static int run_file_input_case(const char* dir, const bool nv12)
 {
     const int rows = 360, cols = 640, n = 18; const double fps = 50.0;
-    const std::string path = std::string(dir) + "/clip_i420.yuv";
+    const std::string path = std::string(dir) + (nv12 ? "/clip_nv12.yuv" : "/clip_i420.yuv");
     std::vector<std::vector<uint8_t>> frames(n, std::vector<uint8_t>((size_t)rows * cols * 3 / 2));
     {
         FILE* f = std::fopen(path.c_str(), "wb");
@@ -338,9 +338,9 @@ int run_file_input_check(const char* dir)
         lvk::StabilizationFilter filter(st);
         for (int i = 0; i < n; i++)
         {
-            lvk::VideoFrame420 planes; planes.upload(frames[i].data(), rows, cols, false, i);
+            lvk::VideoFrame420 planes; planes.upload(frames[i].data(), rows, cols, nv12, i);
             lvk::Frame frame; frame.create({cols, rows}, CV_8UC3, planes.context());
-            planes.context()->check(lvk_hip_ingest_yuv420(planes.context()->get(), planes.y(), planes.y_step(), planes.u(), planes.uv_step(), planes.v(), planes.uv_step(), 0,
+            planes.context()->check(lvk_hip_ingest_yuv420(planes.context()->get(), planes.y(), planes.y_step(), planes.u(), planes.uv_step(), planes.v(), planes.uv_step(), nv12 ? 1 : 0,
                                                           rows, cols, frame.device_ptr(), (int)frame.step), "file input");
             frame.format = lvk::VideoFrame::YUV; frame.timestamp = i;
             filter.apply(std::move(frame), frame);
@@ -351,7 +351,7 @@ int run_file_input_check(const char* dir)
     {
         lvk::StabilizationFilter filter(st);
         filter.stream_keeps_frame_format(true);
-        lvk::RawYuvCapture cap(path, cols, rows, fps, false, lvk::RawYuvCapture::Deliver::YUV);
+        lvk::RawYuvCapture cap(path, cols, rows, fps, nv12, lvk::RawYuvCapture::Deliver::YUV);
         if (!cap.isOpened()) { std::printf("file input: capture not opened\n"); return 1; }
         size_t k = 0; bool ok = true;
         std::vector<uint8_t> host((size_t)rows * cols * 3);
@@ -366,7 +366,7 @@ int run_file_input_check(const char* dir)
     }
     {
         lvk::StabilizationFilter filter(st);                            // the reference's reader: frames assumed BGR
-        lvk::RawYuvCapture cap(path, cols, rows, fps);
+        lvk::RawYuvCapture cap(path, cols, rows, fps, nv12);
         size_t k = 0; bool ok = true;
         filter.stream(cap, [&](lvk::Frame& frame) { ok = ok && frame.format == lvk::VideoFrame::BGR && frame.cols == cols; k++; return false; });
         if (!ok || k != (size_t)n - 4) { std::printf("file input: BGR stream emitted %zu frames\n", k); return 1; }
@@ -378,14 +378,14 @@ int run_file_input_check(const char* dir)
             lvk::StabilizationFilter filter(st);
             for (int i = 0; i < n; i++)
             {
-                lvk::VideoFrame420 in, out; in.upload(frames[i].data(), rows, cols, false, i);
+                lvk::VideoFrame420 in, out; in.upload(frames[i].data(), rows, cols, nv12, i);
                 filter.apply(in, out);
                 if (out.empty()) continue;
                 want420.emplace_back(frames[i].size()); out.download(want420.back().data());
             }
         }
         lvk::StabilizationFilter filter(st);
-        lvk::RawYuvCapture cap(path, cols, rows, fps);
+        lvk::RawYuvCapture cap(path, cols, rows, fps, nv12);
         lvk::HostFrame420 in; size_t k = 0;
         while (cap.read(in))
         {
@@ -397,8 +397,13 @@ int run_file_input_check(const char* dir)
         }
         if (k != want420.size()) { std::printf("file input: host path emitted %zu\n", k); return 1; }
     }
-    std::printf("file input ok: %zu frames through stream() == apply(), BGR delivery runs, host planes == device planes\n", want.size());
+    std::printf("file input ok (%s): %zu frames through stream() == apply(), BGR delivery runs, host planes == device planes\n", nv12 ? "NV12" : "I420", want.size());
     return 0;
+}
+
+int run_file_input_check(const char* dir)
+{
+    return (run_file_input_case(dir, false) != 0 || run_file_input_case(dir, true) != 0) ? 1 : 0;
 }
 
 // --bench <rows> <cols> <frames> <clip.i420> <distinct>: steady-state frames/s through lvk::StabilizationFilter::apply with the frames resident in HBM

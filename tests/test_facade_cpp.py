@@ -39,12 +39,12 @@ def test_plugin_call_sites_run_on_gpu(tmp_path):
 @pytest.mark.gpu
 def test_two_filters_on_two_threads_and_a_clip_file(tmp_path):
     """Per-instance re-entrancy (VSFilter.hpp:54, VisionFilter.cpp:157-162): two filters on two host threads, own contexts and one shared
-    context, each stream's bytes equal to its single-threaded run; and a raw I420 FILE through VideoFilter::stream (lvk::RawYuvCapture; the
+    context, each stream's bytes equal to its single-threaded run; and a raw I420 / NV12 FILE through VideoFilter::stream (lvk::RawYuvCapture; the
     reference's harness streams a file, VideoProcessor.cpp:148-230)."""
     exe = _build(tmp_path, ["-DRUN_ON_GPU", "-O1", "-pthread"])
     out = subprocess.check_output([exe, "--threads-and-files", str(tmp_path)], timeout=600).decode()
     assert "threads ok: 2 filters on 2 threads" in out
-    assert "file input ok:" in out
+    assert "file input ok (I420):" in out and "file input ok (NV12):" in out
 
 
 @pytest.mark.gpu
