@@ -137,6 +137,7 @@ def parse():
     ap.add_argument("--lens", default="off", choices=["off", "fused", "two-pass"],
                     help="BASELINE config 5: lens-correction pre-warp (profile of SURVEY.md section 8d) fused into the stabilizing remap, "
                          "or as the reference chain's separate LC pass (two-pass; --format packed only)")
+    ap.add_argument("--no-lookahead", action="store_true", help="skip the extra pass in which every frame is announced one push ahead")
     ap.add_argument("--no-pcie", action="store_true", help="skip the extra (untimed-for-`value`) pass with host-resident frames")
     ap.add_argument("--no-overlap", action="store_true", help="keep the output remap on the tracking stream")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work of the oracle baseline")
@@ -344,10 +345,15 @@ class Rig:
         k = i % period
         return k if k < self.pool else period - k
 
-    def step(self):
+    announce_always = bool(os.environ.get("LVK_BENCH_ANNOUNCE"))          # experiments: every push of every region announces its successor
+
+    def step(self, announce=False):
+        announce = announce or self.announce_always
         i = self.step_no; self.step_no += 1
         k = self.index(i)
         if self.yuv420:
+            if announce:                # the next frame is resident already: lvk_hip_stab_prefetch_yuv420, then the push of this one
+                self.filt.prefetch_yuv420_prepared(self.planes_args[self.index(i + 1)])
             return self.filt.apply_yuv420_prepared(self.planes_args[k], i, self.outs_args[i & 3])
         if self.lens_map is not None:
             corrected = self.ctx.remap_map(self.frames[k], self.lens_map, bg=(0, 0, 0), out=self.lens_bufs[i % len(self.lens_bufs)])     # LCFilter::filter
@@ -645,6 +651,33 @@ def main():
     prof_all = filt.profile()
     filt.set_profiling(False)
 
+    # the same stream by a caller that knows its next frame (VideoFilter::stream's reader thread is one ahead; a transcoder): frame i + 1 is
+    # announced before frame i is pushed (lvk_hip_stab_prefetch_yuv420), its downscale + pyramid run behind frame i's chain.  Beside `value`.
+    lookahead = None
+    if rank == 0 and world == 1 and K == 1 and yuv420 and not args.no_lookahead:
+        try:
+            device_sync()
+            for _ in range(100):
+                rig.step(announce=True)
+            device_sync()
+            hits0 = filt.lookahead_frames()
+            tl = time.perf_counter()
+            for _ in range(1000):
+                rig.step(announce=True)
+            device_sync()
+            dtl = time.perf_counter() - tl
+            hits = filt.lookahead_frames() - hits0
+            lat_la = []
+            for _ in range(300):
+                rig.sync(); t_ = time.perf_counter(); rig.step(announce=True); rig.sync(); lat_la.append((time.perf_counter() - t_) * 1e3)
+            filt.prefetch_cancel()
+            lookahead = {"frames_per_s": 1000 / dtl, "frames": 1000, "pushes_that_found_their_pyramid_built": int(hits),
+                         "latency_ms": dict(percentiles(lat_la), samples=len(lat_la)),
+                         "note": "free-running, frame i + 1 announced (lvk_hip_stab_prefetch_yuv420) before frame i is pushed; same pixels "
+                                 "(tests/test_stabilizer_gpu.py::test_device_lookahead_same_frames); not `value`, whose caller knows one frame at a time"}
+        except Exception as e:          # the extra pass must never break the contract line
+            lookahead = {"error": repr(e)}
+
     # the same remap kernel alone on the GPU at full occupancy (the timed region runs its occupancy-capped `_co` variant next to the tracker)
     standalone_us = None
     if rank == 0 and world == 1 and K == 1 and args.lens != "two-pass" and clip is not None:
@@ -846,6 +879,7 @@ def main():
                                 "final_sync": round(float(elapsed * 1e3 - free_running.sum()), 4), "total": round(float(elapsed * 1e3), 4)},
             "stage_us": stage_us,
             "pcie_inclusive": pcie,
+            "lookahead": lookahead,
             "tracking": {"stability": stats.tracking_stability, "trust": stats.trust, "features": stats.n_tracked, "last_output_crc32": out_crc},
             "roofline": {"kernel": ("k_remap_homography" if args.preset == "homography" else "k_remap_mesh") + ("_lens" if args.lens == "fused" else "")
                                    + (("_420<nv12>" if nv12 else "_420<i420>") if fused_420 else ("<yuv>" if args.no_overlap else "_co<yuv>")),

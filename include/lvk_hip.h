@@ -325,6 +325,18 @@ int  lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* stab, const void* h_y, int 
  * VideoFilter::stream's reader thread ending on a failed read, Filters/VideoFilter.cpp:77-103).  Returns once their uploads no longer
  * read the caller's planes.  lvk_hip_stab_restart() implies it. */
 int  lvk_hip_stab_prefetch_cancel(lvk_hip_stab* stab);
+/* Look-ahead for DEVICE-resident frames, for callers that hold the next frame already (VideoFilter::stream's reader thread runs ahead of
+ * its filter thread, Filters/VideoFilter.cpp:62-209; a transcoder whose clip is resident): announce frame n + 1, then push frame n.  The
+ * push puts the luma downscale and the pyramid of frame n + 1 on the tracking stream behind its own chain, where the GPU runs them during
+ * the host's turn, and the push of frame n + 1 starts at the optical flow.  Only the luma is read ahead (Y plane; channel 0 / the grey
+ * value of a packed frame); it must not change between the announcement and the return of the push that carries it.  The announcement
+ * holds for the very next push only; a push that carries other planes or another geometry, or that does not track, works as if nothing
+ * had been announced.  Same pixels either way.  lvk_hip_stab_prefetch_cancel / lvk_hip_stab_restart forget it.
+ * lvk_hip_stab_lookahead_frames: the pushes so far that found their pyramid built. */
+int  lvk_hip_stab_prefetch(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, int format);
+int  lvk_hip_stab_prefetch_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step,
+                                  int nv12, int rows, int cols);
+long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* stab);
 int  lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr);      /* pinned, device-visible host memory */
 int  lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr);
 

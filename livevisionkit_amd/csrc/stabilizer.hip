@@ -288,6 +288,16 @@ struct lvk_hip_stab
     }
     int flush_download(bool wait);
     int cancel_lookahead();
+    // ---- look-ahead for DEVICE-resident frames (lvk_hip_stab_prefetch / _yuv420): the luma of the frame the next push will carry.  Its
+    // downscale and pyramid are put on the tracking stream BEHIND this push's chain (into the pyramid that becomes `cur` at the next push), where
+    // the GPU runs them during the host's turn between two chains; the next push then starts at the optical flow.
+    struct LumaAhead { const void* luma = nullptr; int step = 0, pix = 0, channel = 0, rows = 0, cols = 0;
+                       bool same(const void* l, int st, int px, int ch, int r, int c) const { return luma && luma == l && step == st && pix == px && channel == ch && rows == r && cols == c; } };
+    LumaAhead ahead_announced;                 // announced, not yet on the stream (cleared by the push that follows, whatever it does with it)
+    LumaAhead ahead_built;                     // what pyr[cur ^ 1] holds already
+    unsigned long long push_seq = 0, ahead_built_for = 0;      // a built pyramid is only good for the very next push
+    long lookahead_frames = 0;
+    void forget_device_lookahead() { ahead_announced = LumaAhead(); ahead_built = LumaAhead(); ahead_built_for = 0; }
     int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
     void free_hostio();
     bool caller_free_running_now();
@@ -343,6 +353,7 @@ int lvk_hip_stab::alloc_pyramids()
     if ((rc = pyr[0].allocate(ctx, s.detection_height, s.detection_width, LK_LEVELS, LK_WIN, LK_WIN)) != LVK_HIP_OK) return rc;
     if ((rc = pyr[1].allocate(ctx, s.detection_height, s.detection_width, LK_LEVELS, LK_WIN, LK_WIN)) != LVK_HIP_OK) return rc;
     pyr_w = s.detection_width; pyr_h = s.detection_height;
+    forget_device_lookahead();
     return LVK_HIP_OK;
 }
 
@@ -428,6 +439,7 @@ void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameT
     initialized = false;
     if (mesh_dev) (void)lvk_mesh_solver_reset(mesh_dev, ctx->stream);
     post_n = -1;
+    forget_device_lookahead();
 }
 
 void lvk_hip_stab::finish_post()
@@ -573,12 +585,21 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     cur_w = s.detection_width; cur_h = s.detection_height;
     DevicePyramid& C = pyr[cur];
     DevicePyramid& P = pyr[cur ^ 1];
-    int pe = prof_begin(LVK_STAGE_DOWNSCALE);
-    if ((rc = lvk_launch_luma_area_resize(ctx, luma, luma_step, luma_pix, luma_channel, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
-    prof_end(pe);
-    pe = prof_begin(LVK_STAGE_PYRAMID);
-    if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
-    prof_end(pe);
+    int pe = 0;
+    // (look-ahead: this frame's downscale and pyramid were put behind the previous push's chain -- same planes, same geometry, announced for
+    //  exactly this push --, so `C` holds them already, in stream order)
+    const bool built_ahead = ahead_built_for == push_seq && ahead_built.same(luma, luma_step, luma_pix, luma_channel, f.rows, f.cols) && pyr_w == cur_w && pyr_h == cur_h;
+    ahead_built = LumaAhead(); ahead_built_for = 0;
+    if (built_ahead) lookahead_frames++;
+    else
+    {
+        pe = prof_begin(LVK_STAGE_DOWNSCALE);
+        if ((rc = lvk_launch_luma_area_resize(ctx, luma, luma_step, luma_pix, luma_channel, f.rows, f.cols, const_cast<uint8_t*>(C.args.lv[0].img), C.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+        pe = prof_begin(LVK_STAGE_PYRAMID);
+        if ((rc = C.build(ctx)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+    }
     trace.mark(HostTrace::DOWN_PYR_LAUNCH);
     // The previous frame's list bookkeeping (fast_filter, ageing, the suppression grid's re-seed) runs HERE, in the shadow of the two kernels
     // just launched: the next kernel of this frame (optical flow) cannot start before they are done anyway, while at the end of the
@@ -702,13 +723,28 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         //  slowed-down chain --: an announced host frame, whose planes have arrived, is converted there; 3 320 against 3 215 frames/s, and the
         //  pushes on which the detector runs no longer stand out: p90 0.312 instead of 0.364 ms)
         ingest_on_tracker = ingest_placement == 1 || (ingest_placement == 0 && ((q == hipErrorNotReady && !host_direct_now) || ingest_wait[0] != nullptr));
-        if (ingest_on_tracker && chained)
-        {
-            if (!chain_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));
-            LVK_HIP_CHECK(ctx, hipEventRecord(chain_done, st)); chain_event_armed = true;
-        }
+    }
+    // (an announced next frame: its downscale + pyramid go behind the chain too, so the push waits for the chain through the event as well)
+    const bool build_ahead = chained && ahead_announced.luma != nullptr && pyr_w == cur_w && pyr_h == cur_h;
+    if (chained && ((deferred_ingest && tracker_ingest_capable && ingest_on_tracker) || build_ahead))
+    {
+        if (!chain_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventRecord(chain_done, st)); chain_event_armed = true;
     }
     if (deferred_ingest && (rc = run_deferred_ingest()) != LVK_HIP_OK) return rc;
+    if (build_ahead)
+    {
+        // `P` (the previous frame's pyramid) has been read for the last time by the flow kernel above; at the next push it is `C`
+        const LumaAhead a = ahead_announced;
+        ahead_announced = LumaAhead();
+        pe = prof_begin(LVK_STAGE_DOWNSCALE);
+        if ((rc = lvk_launch_luma_area_resize(ctx, a.luma, a.step, a.pix, a.channel, a.rows, a.cols, const_cast<uint8_t*>(P.args.lv[0].img), P.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+        pe = prof_begin(LVK_STAGE_PYRAMID);
+        if ((rc = P.build(ctx)) != LVK_HIP_OK) return rc;
+        prof_end(pe);
+        ahead_built = a; ahead_built_for = push_seq + 1;
+    }
     if (lens && !chained)
     {
         if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
@@ -1496,6 +1532,8 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     lvk_device_guard device_guard(st->ctx);
     st->trace.begin();
     st->prof_tick++;
+    st->push_seq++;
+    struct AnnouncementEnds { lvk_hip_stab* s; ~AnnouncementEnds() { s->ahead_announced = lvk_hip_stab::LumaAhead(); } } announcement_ends{st};
     if (st->queue.empty()) st->queue_kind = 0;
     if (st->queue_kind == 2) return st->fail(LVK_HIP_ERR_ARG, "frames of lvk_hip_stab_push_yuv420 are still queued: restart() before switching to lvk_hip_stab_push");
     st->queue_kind = 1;
@@ -1523,6 +1561,8 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     lvk_hip_ctx* ctx = st->ctx;
     st->trace.begin();
     st->prof_tick++;
+    st->push_seq++;
+    struct AnnouncementEnds { lvk_hip_stab* s; ~AnnouncementEnds() { s->ahead_announced = lvk_hip_stab::LumaAhead(); } } announcement_ends{st};
     if (produced) *produced = 0;
     if (st->queue.empty()) st->queue_kind = 0;
     if (st->queue_kind == 1) return st->fail(LVK_HIP_ERR_ARG, "borrowed frames of lvk_hip_stab_push are still queued: restart() before switching to lvk_hip_stab_push_yuv420");
@@ -1610,6 +1650,40 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     return LVK_HIP_OK;
 }
 
+// Look-ahead for DEVICE-resident frames (a caller that has the next frame in HBM already: the reader thread of VideoFilter::stream runs ahead of
+// the filter thread, Filters/VideoFilter.cpp:62-209; a transcoder with its clip resident).  Announce frame n + 1, THEN push frame n: the push
+// puts the downscale and the pyramid of frame n + 1 on the tracking stream behind its own chain, where the GPU runs them while the host has its
+// turn (results, path smoother, remap launch), and the push of frame n + 1 starts at the optical flow.  Only the luma is read ahead (the Y plane /
+// channel 0 of a packed YUV frame / the grey value of BGR, RGB); it must not change between this call and the return of the push that carries it.
+// The announcement holds for the very next push only: a push that carries other planes, an other geometry or that does not track (the first
+// frame, a restart, stabilize_output off) simply works as if nothing had been announced.  Same pixels either way.
+static int stab_announce(lvk_hip_stab* st, const void* luma, int step, int pix, int channel, int rows, int cols)
+{
+    st->ahead_announced.luma = luma; st->ahead_announced.step = step; st->ahead_announced.pix = pix; st->ahead_announced.channel = channel;
+    st->ahead_announced.rows = rows; st->ahead_announced.cols = cols;
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_stab_prefetch(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, int format)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);
+    LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
+    return stab_announce(st, d_frame, step, 3, format == LVK_FORMAT_YUV ? 0 : (format == LVK_FORMAT_BGR ? -1 : -2), rows, cols);
+}
+
+int lvk_hip_stab_prefetch_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12, int rows, int cols)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    lvk_hip_ctx* ctx = st->ctx;
+    LVK_HIP_REQUIRE(ctx, d_y && d_u && (nv12 || d_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
+    LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
+    return stab_announce(st, d_y, y_step, 1, 0, rows, cols);
+}
+
+long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* st) { return st ? (long long)st->lookahead_frames : 0; }
+
 // Look-ahead for streaming callers (the reader thread of VideoFilter::stream uploads frames ahead of the filter thread,
 // Filters/VideoFilter.cpp:62-209): starts the upload of the planes that the NEXT lvk_hip_stab_push_yuv420_host call will push, so that the
 // link is busy with frame n + 1 while frame n is tracked: announce frame n + 1, THEN push frame n.  Announced frames are pushed in order; at
@@ -1639,6 +1713,7 @@ int lvk_hip_stab_prefetch_cancel(lvk_hip_stab* st)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_device_guard device_guard(st->ctx);
+    st->forget_device_lookahead();
     return st->cancel_lookahead();
 }
 

@@ -218,6 +218,20 @@ class StabilizationFilter:
         if rc != 0:
             self.ctx._check(rc)
 
+    def prefetch(self, frame, fmt=FORMAT_YUV):
+        """lvk_hip_stab_prefetch: announce the packed device frame the NEXT apply() will carry (call it before applying the current one)."""
+        self.ctx._check(self.lib.lvk_hip_stab_prefetch(self.handle, frame.data_ptr(), frame.stride(0), frame.shape[0], frame.shape[1], fmt))
+
+    def prefetch_yuv420_prepared(self, src):
+        """lvk_hip_stab_prefetch_yuv420: announce the device planes the NEXT apply_yuv420_prepared call will carry."""
+        rc = self.lib.lvk_hip_stab_prefetch_yuv420(self.handle, *src["args"], src["nv12"], src["rows"], src["cols"])
+        if rc != 0:
+            self.ctx._check(rc)
+
+    def lookahead_frames(self):
+        """lvk_hip_stab_lookahead_frames: pushes so far that found their downscale + pyramid built ahead."""
+        return int(self.lib.lvk_hip_stab_lookahead_frames(self.handle))
+
     def prefetch_cancel(self):
         """lvk_hip_stab_prefetch_cancel: forget the announced frames that have not been pushed."""
         self.ctx._check(self.lib.lvk_hip_stab_prefetch_cancel(self.handle))

@@ -552,3 +552,138 @@ def test_suppression_grid_on_the_device(ctx, oracle, clip, preset, monkeypatch):
         dev, host = ghost.detector_frames()
         assert dev == 0 and host >= 3, (preset, dev, host)
         ost.close(); gdev.close(); ghost.close()
+
+
+def _run_planes(gst, ctx, clips, order, announce, sync_every=False, out_sets=4):
+    """Push `order` (indices into the prepared plane sets `clips`) through apply_yuv420_prepared; `announce(k)` = index to announce before the
+    k-th push, or None.  Returns the emitted planes as numpy arrays."""
+    import torch
+    outs = [tuple(torch.empty_like(p) for p in clips[0]["planes"]) for _ in range(out_sets)]
+    outs_p = [gst.prepare_yuv420(o) for o in outs]
+    emitted = []
+    for k, idx in enumerate(order):
+        a = announce(k)
+        if a is not None:
+            gst.prefetch_yuv420_prepared(clips[a])
+        got, _ = gst.apply_yuv420_prepared(clips[idx], k, outs_p[k % out_sets])
+        if sync_every or got is not None:
+            ctx.sync()                                                   # (the output planes are reused every out_sets pushes: read them now)
+        if got is not None:
+            emitted.append(tuple(p.cpu().numpy().copy() for p in got))
+    ctx.sync()
+    return emitted
+
+
+@pytest.mark.parametrize("preset,nv12", [("homography", False), ("field", True)])
+def test_device_lookahead_same_frames(ctx, oracle, clip, preset, nv12):
+    """lvk_hip_stab_prefetch_yuv420: announcing frame n + 1 before pushing frame n moves its downscale + pyramid behind frame n's chain and nothing
+    else -- every emitted plane equals the run without announcements (which the tests above hold to the oracle); a wrong announcement, a
+    restart in between and buffers whose CONTENT changes behind the same addresses fall back to the plain path."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    n = 24
+    s = oracle_lib.preset(preset, predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
+
+    def make():
+        g = lvk.StabilizationFilter(_to_settings(s), context=ctx); g.set_overlap(True); return g
+
+    plane_sets = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in oracle.egress_yuv420(f, nv12=nv12)) for f in frames[:n]]
+    gst = make(); clips = [gst.prepare_yuv420(p) for p in plane_sets]
+    plain = _run_planes(gst, ctx, clips, list(range(n)), lambda k: None)
+    assert gst.lookahead_frames() == 0
+    gst.close()
+    assert len(plain) == n - 3
+
+    gst = make(); clips = [gst.prepare_yuv420(p) for p in plane_sets]
+    ahead = _run_planes(gst, ctx, clips, list(range(n)), lambda k: k + 1 if k + 1 < n else None)
+    hits = gst.lookahead_frames()
+    gst.close()
+    assert hits >= n - 3, hits                                            # (the first push has no chain to hide anything behind)
+    assert len(ahead) == len(plain)
+    for i, (a, b) in enumerate(zip(ahead, plain)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (preset, i)
+
+    # wrong announcements (another frame than the one pushed next), every other push
+    gst = make(); clips = [gst.prepare_yuv420(p) for p in plane_sets]
+    wrong = _run_planes(gst, ctx, clips, list(range(n)), lambda k: (k + 5) % n if k % 2 else (k + 1 if k + 1 < n else None))
+    assert 0 < gst.lookahead_frames() < hits
+    gst.close()
+    for i, (a, b) in enumerate(zip(wrong, plain)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), ("wrong announcement", i)
+
+    # two buffers only, rewritten between pushes: an announcement is good for the very next push and never outlives it
+    gst = make()
+    bufs = [tuple(torch.empty_like(p) for p in plane_sets[0]) for _ in range(2)]
+    bufs_p = [gst.prepare_yuv420(b) for b in bufs]
+    outs = [tuple(torch.empty_like(p) for p in plane_sets[0]) for _ in range(2)]
+    outs_p = [gst.prepare_yuv420(o) for o in outs]
+    reused = []
+    for k in range(n):
+        if k == 0:
+            for d, src in zip(bufs[0], plane_sets[0]): d.copy_(src)
+        if k + 1 < n and k % 3 != 2:                                     # announce two of three: fill the other buffer first, then announce it
+            ctx.sync()
+            for d, src in zip(bufs[(k + 1) % 2], plane_sets[k + 1]): d.copy_(src)
+            torch.cuda.synchronize()
+            gst.prefetch_yuv420_prepared(bufs_p[(k + 1) % 2])
+        got, _ = gst.apply_yuv420_prepared(bufs_p[k % 2], k, outs_p[k % 2])
+        ctx.sync()
+        if got is not None:
+            reused.append(tuple(p.cpu().numpy().copy() for p in got))
+        if k + 1 < n and k % 3 == 2:                                      # not announced: the buffer gets its new content only now
+            for d, src in zip(bufs[(k + 1) % 2], plane_sets[k + 1]): d.copy_(src)
+            torch.cuda.synchronize()
+    gst.close()
+    assert len(reused) == len(plain)
+    for i, (a, b) in enumerate(zip(reused, plain)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), ("reused buffers", i)
+
+    # a restart between the announcement and the push forgets it; so does prefetch_cancel
+    def with_restart(announcing):
+        g = make(); c = [g.prepare_yuv420(p) for p in plane_sets]
+        _run_planes(g, ctx, c, list(range(6)), (lambda k: k + 1) if announcing else (lambda k: None))
+        before = g.lookahead_frames()
+        if announcing:
+            g.prefetch_yuv420_prepared(c[7])
+        g.restart()
+        out = _run_planes(g, ctx, c, list(range(n)), (lambda k: k + 1 if k + 1 < n else None) if announcing else (lambda k: None))
+        if announcing:
+            g.prefetch_yuv420_prepared(c[0]); g.prefetch_cancel()
+            assert g.lookahead_frames() >= before + n - 3
+        g.close()
+        return out
+    a_run, b_run = with_restart(True), with_restart(False)
+    assert len(a_run) == len(b_run) and len(a_run) >= n - 3
+    for i, (a, b) in enumerate(zip(a_run, b_run)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), ("after restart", i)
+
+
+def test_device_lookahead_packed_frames(ctx, oracle, clip):
+    """lvk_hip_stab_prefetch (packed BGR frames: the grey value is what is read ahead) against the plain run."""
+    import torch
+    import livevisionkit_amd as lvk
+    frames, _ = clip
+    n = 16
+    s = oracle_lib.preset("homography", predictive_samples=2, min_scene_quality=0.3, min_tracking_quality=0.2)
+    dev = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames[:n]]
+    runs = []
+    for announce in (False, True):
+        gst = lvk.StabilizationFilter(_to_settings(s), context=ctx); gst.set_overlap(True)
+        outs = []
+        for k in range(n):
+            if announce and k + 1 < n:
+                gst.prefetch(dev[k + 1], fmt=0)
+            got, _ = gst.apply(dev[k], timestamp=k, fmt=0)
+            if got is not None:
+                ctx.sync(); outs.append(got.cpu().numpy().copy())
+        ctx.sync()
+        assert (gst.lookahead_frames() >= n - 2) == announce
+        runs.append(outs); gst.close()
+    assert len(runs[0]) == len(runs[1]) == n - 2
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert np.array_equal(a, b), i
