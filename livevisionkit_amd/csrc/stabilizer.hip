@@ -297,6 +297,7 @@ struct lvk_hip_stab
     LumaAhead ahead_built;                     // what pyr[cur ^ 1] holds already
     unsigned long long push_seq = 0, ahead_built_for = 0;      // a built pyramid is only good for the very next push
     long lookahead_frames = 0;
+    bool early_post_off = std::getenv("LVK_HIP_LATE_POST") != nullptr;      // experiments: keep the bookkeeping at the start of the next push
     void forget_device_lookahead() { ahead_announced = LumaAhead(); ahead_built = LumaAhead(); ahead_built_for = 0; }
     int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
     void free_hostio();
@@ -1625,6 +1626,9 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     if (released) st->pool_free.push_back(const_cast<void*>(released));
     if (side_ingest)
     {
+        // (the next frame's pyramid is on its way behind this chain: nothing will shadow the list bookkeeping at the start of the next push --
+        //  track() does it behind the two launches that are no longer there --, so it runs here, while the conversion is still running anyway)
+        if (st->ahead_built_for == st->push_seq + 1 && !st->early_post_off) st->finish_post();
         // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago).  An event, not
         // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
         LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
