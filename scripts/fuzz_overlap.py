@@ -2,7 +2,8 @@
 I420 / NV12, frame delays 1..4), the GPU pushes FREE RUNNING (no synchronisation between them) with the 4:2:0 conversion pinned to the
 tracking stream, pinned to the bulk stream, or placed per push.  Round 3: a third of the trials feed HOST-resident planes
 (lvk_hip_stab_push_yuv420_host, with and without one frame of upload look-ahead, direct / copy sink), and the vector-field trials draw
-their motion resolution from the nested-dissection range, the register-window band range and the generic kernels' range."""
+their motion resolution from the nested-dissection range, the register-window band range and the generic kernels' range.  Round 4: half of
+the device-resident trials announce their frames one push ahead, some of them wrongly."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,8 +35,16 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "18"))):
     dev_planes = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes) for planes in host_planes]
     torch.cuda.synchronize()
     if entry == "device":
-        gots = [gst.apply_yuv420(dev_planes[i], timestamp=i)[0] for i in range(n)]            # free running
+        # round 4: half of the device trials announce their frames one push ahead (lvk_hip_stab_prefetch_yuv420), one announcement in five a wrong one
+        announce = bool((trial // 6) & 1)
+        pa = [gst.prepare_yuv420(p) for p in dev_planes]
+        gots = []
+        for i in range(n):                                                                    # free running
+            if announce and i + 1 < n:
+                gst.prefetch_yuv420_prepared(pa[(i + 3) % n] if rng.integers(0, 5) == 0 else pa[i + 1])
+            gots.append(gst.apply_yuv420(dev_planes[i], timestamp=i)[0])
         ctx.sync()
+        entry = "device+lookahead(%d)" % gst.lookahead_frames() if announce else entry
     else:
         hin = [gst.host_planes(rows, cols, nv12) for _ in range(n)]; hout = [gst.host_planes(rows, cols, nv12) for _ in range(n)]
         for i in range(n):
