@@ -638,6 +638,18 @@ public:
                                                        next.rows, next.cols), "StabilizationFilter::prefetch");
     }
 
+    // Device-resident planes known one frame ahead (a reader that runs ahead of the filter, as VideoFilter::stream's does): announce frame
+    // n + 1, then apply frame n -- its downscale and pyramid run behind frame n's chain (lvk_hip_stab_prefetch_yuv420).  The planes must not
+    // change until their apply() has returned; an announcement that the next apply() does not match is ignored.  Same pixels either way.
+    void prefetch(const VideoFrame420& next)
+    {
+        LVK_HIP_ASSERT(!next.empty());
+        if (next.context() != m_Ctx) m_Ctx->wait_for(*next.context());      // what has produced the planes so far is ahead of our stream
+        hip::ContextLock lock(m_Ctx->mutex());
+        m_Ctx->check(lvk_hip_stab_prefetch_yuv420(m_Stab, next.y(), next.y_step(), next.u(), next.uv_step(), next.v(), next.uv_step(), next.nv12 ? 1 : 0,
+                                                  next.rows, next.cols), "StabilizationFilter::prefetch(4:2:0)");
+    }
+
     // a frame was announced and will not be applied (the source ended, seeked or switched buffers)
     void cancel_prefetch() { hip::ContextLock lock(m_Ctx->mutex()); m_Ctx->check(lvk_hip_stab_prefetch_cancel(m_Stab), "StabilizationFilter::cancel_prefetch"); }
 

@@ -384,6 +384,23 @@ static int run_file_input_case(const char* dir, const bool nv12)
                 want420.emplace_back(frames[i].size()); out.download(want420.back().data());
             }
         }
+        {
+            // device planes announced one apply() ahead (StabilizationFilter::prefetch(const VideoFrame420&)): the same bytes
+            lvk::StabilizationFilter ahead(st);
+            std::vector<lvk::VideoFrame420> dev((size_t)n);
+            for (int i = 0; i < n; i++) dev[(size_t)i].upload(frames[i].data(), rows, cols, nv12, i);
+            size_t e = 0;
+            for (int i = 0; i < n; i++)
+            {
+                if (i + 1 < n) ahead.prefetch(dev[(size_t)i + 1]);
+                lvk::VideoFrame420 out; ahead.apply(dev[(size_t)i], out);
+                if (out.empty()) continue;
+                std::vector<uint8_t> got(frames[i].size()); out.download(got.data());
+                if (e >= want420.size() || got != want420[e]) { std::printf("file input: announced device frame %zu differs\n", e); return 1; }
+                e++;
+            }
+            if (e != want420.size()) { std::printf("file input: the announced run emitted %zu\n", e); return 1; }
+        }
         lvk::StabilizationFilter filter(st);
         lvk::RawYuvCapture cap(path, cols, rows, fps, nv12);
         lvk::HostFrame420 in; size_t k = 0;
