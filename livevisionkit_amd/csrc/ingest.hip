@@ -126,8 +126,12 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
     {
         // odd row 2k - 1: weights (3/4, 1/4) on chroma rows (k - 1, k); even row 2k: (1/4, 3/4)
         const uint32_t u0 = tu0[p], u1 = tu1[p], v0 = tv0[p], v1 = tv1[p];
+#ifdef LVK_INGEST_CHEAP_PROBE      // timing probe only (scripts/ingest_cost_probe.sh): WRONG pixels, about half the arithmetic -- what would a cheaper conversion buy?
+        const uint32_t ua = u0 >> 4, ub = u1 >> 4, va = v0 >> 4, vb = v1 >> 4;
+#else
         const uint32_t ua = ((((u0 + u0 + u0) >> 2) + (u1 >> 2) + 2u) >> 2), ub = (((u0 >> 2) + ((u1 + u1 + u1) >> 2) + 2u) >> 2);
         const uint32_t va = ((((v0 + v0 + v0) >> 2) + (v1 >> 2) + 2u) >> 2), vb = (((v0 >> 2) + ((v1 + v1 + v1) >> 2) + 2u) >> 2);
+#endif
         pa[p] = ((ywa >> (8 * p)) & 0xffu) | (ua << 8) | (va << 16);
         pb[p] = ((ywb >> (8 * p)) & 0xffu) | (ub << 8) | (vb << 16);
     }
