@@ -45,7 +45,7 @@ inline float step_toward(float current, float target, float amount)   // Functio
 // Host-side wall-clock trace of one push (LVK_HIP_HOST_TRACE=1: summary on stderr at destroy) -- development aid
 struct HostTrace
 {
-    enum { ENTER, DOWN_PYR_LAUNCH, FAST_SYNC, GRID, LK_LAUNCH, LK_SYNC, FILTER, RANSAC_LAUNCH, RANSAC_SYNC, POST, SMOOTH, REMAP_LAUNCH, EXIT, N };
+    enum { ENTER, DOWN_PYR_LAUNCH, FAST_SYNC, GRID, LK_LAUNCH, LK_SYNC, FILTER, RANSAC_LAUNCH, RANSAC_SYNC, POST, SMOOTH, REMAP_LAUNCH, EXIT, EMIT_WAITS, EMIT_KERNEL, EMIT_EVENT, EXIT_PRE, EXIT_WAIT, N };
     bool on = std::getenv("LVK_HIP_HOST_TRACE") != nullptr;
     double acc[N] = {0}; long cnt[N] = {0};
     std::chrono::steady_clock::time_point last;
@@ -60,7 +60,8 @@ struct HostTrace
     {
         if (!on) return;
         static const char* names[N] = {"enter", "downscale+pyramid launch", "fast launch+sync", "grid (host)", "lk upload+launch", "lk sync", "filter (host)",
-                                       "ransac upload+launch", "ransac sync", "post (host)", "qa+smoother (host)", "remap launch", "exit"};
+                                       "ransac upload+launch", "ransac sync", "post (host)", "qa+smoother (host)", "remap launch", "exit",
+                                       "  emit: stream waits", "  emit: remap kernel launch", "  emit: slot event record", "  exit: up to the conversion wait", "  exit: conversion wait"};
         double total = 0; long frames = cnt[DOWN_PYR_LAUNCH] ? cnt[DOWN_PYR_LAUNCH] : 1;
         for (int i = 0; i < N; i++) total += acc[i];
         std::fprintf(stderr, "[lvk host trace] %ld frames, %.1f us/frame inside push\n", frames, total / frames);
@@ -1225,6 +1226,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         ctx->co_blocks_per_cu = pinned != 0 ? pinned : ((persistent && st->host_direct_now) ? 1 : 0);
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
         if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(rs, e, 0)); }
+        st->trace.mark(HostTrace::EMIT_WAITS);
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
         if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
         if (mesh && o420 && o420->y)
@@ -1241,6 +1243,7 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
             if (e != hipSuccess) rc = ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
         }
         st->prof_end(pe, rs);
+        st->trace.mark(HostTrace::EMIT_KERNEL);
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
         if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222
@@ -1629,9 +1632,11 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         // (the next frame's pyramid is on its way behind this chain: nothing will shadow the list bookkeeping at the start of the next push --
         //  track() does it behind the two launches that are no longer there --, so it runs here, while the conversion is still running anyway)
         if (st->ahead_built_for == st->push_seq + 1 && !st->early_post_off) st->finish_post();
+        st->trace.mark(HostTrace::EXIT_PRE);
         // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago).  An event, not
         // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
         LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
+        st->trace.mark(HostTrace::EXIT_WAIT);
     }
     // same contract without a tracker pass (delay-only mode, stabilize_output off): nothing has synchronised behind the conversion yet
     else if (!st->s.stabilize_output) LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -37,6 +37,8 @@ def main():
     for i in range(steps):
         if i == 200:
             torch.cuda.synchronize(); t0 = time.perf_counter()
+        if os.environ.get("LVK_TIMELINE_ANNOUNCE"):                                  # round 4: every frame announced one push ahead
+            filt.prefetch_yuv420_prepared(pa[(i + 1) % pool])
         filt.apply_yuv420_prepared(pa[i % pool], i, oa[i & 3])
     torch.cuda.synchronize()
     print(f"{(steps - 200) / (time.perf_counter() - t0):.0f} frames/s free-running")
