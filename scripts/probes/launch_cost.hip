@@ -87,5 +87,44 @@ int main()
     std::printf("back to back, plain: %.2f us per chain on the GPU\n", ms * 1000 / 200);
     CK(hipEventRecord(e0, s)); for (int r = 0; r < 200; r++) CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     std::printf("back to back, graph: %.2f us per chain on the GPU\n", ms * 1000 / 200);
+    // (e) ONE launch onto a stream that is idle at that moment (the bulk stream's situation when the remap is launched), by stream priority and
+    //     argument size; the other stream keeps running a chain meanwhile
+    {
+        int lo = 0, hi = 0; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        hipStream_t s_lo, s_def; CK(hipStreamCreateWithPriority(&s_lo, hipStreamNonBlocking, lo)); CK(hipStreamCreateWithFlags(&s_def, hipStreamNonBlocking));
+        struct Big { const float* in; float* out; int n; int pad[45]; };      // ~200 bytes
+        auto one = [&](hipStream_t q, const char* what) -> int {
+            double t_call = 0; const int R = 500;
+            for (int r = 0; r < R; r++)
+            {
+                chain(buf[1]);                                             // the other stream is busy
+                CK(hipStreamSynchronize(q));                               // ... and this one idle
+                Args a{}; a.in = alt; a.out = alt; a.n = n;
+                const double t0 = now_us(); hipLaunchKernelGGL(k_step, dim3(n / 256), dim3(256), 0, q, a); t_call += now_us() - t0;
+                CK(hipStreamSynchronize(s));
+            }
+            std::printf("one launch onto an idle %s stream: %.2f us\n", what, t_call / R);
+            return 0;
+        };
+        // (f) the same launch when the stream's previous command was an event record that another stream then waited for (what every remap launch follows)
+        {
+            hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            double t_call = 0, t_rec = 0; const int R = 500;
+            for (int r = 0; r < R; r++)
+            {
+                chain(buf[1]);
+                CK(hipStreamSynchronize(s_lo));
+                Args a{}; a.in = alt; a.out = alt; a.n = n;
+                double t0 = now_us(); hipLaunchKernelGGL(k_step, dim3(n / 256), dim3(256), 0, s_lo, a); t_call += now_us() - t0;
+                t0 = now_us(); CK(hipEventRecord(ev, s_lo)); t_rec += now_us() - t0;
+                CK(hipStreamWaitEvent(s, ev, 0));
+                CK(hipStreamSynchronize(s));
+            }
+            std::printf("launch after an event record on that stream: %.2f us; the event record itself: %.2f us\n", t_call / R, t_rec / R);
+        }
+        if (one(s_def, "default-priority")) return 1;
+        if (one(s_lo, "lowest-priority")) return 1;
+        if (one(s, "(the busy one itself, idle now)")) return 1;
+    }
     return 0;
 }
