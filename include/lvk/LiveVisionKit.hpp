@@ -588,6 +588,8 @@ public:
     {
         LVK_HIP_ASSERT(!input.empty());
         if (input.context() != m_Ctx) m_Ctx->wait_for(*input.context());      // (takes both contexts' locks: before ours is held)
+        bool give_back = false;
+        {
         hip::ContextLock lock(m_Ctx->mutex());
         sync_gpu(profile);
         m_LastRows = input.rows; m_LastCols = input.cols;
@@ -602,7 +604,11 @@ public:
         else output.release();
         sync_gpu(profile);
         // the planes are consumed when the push returns only in overlap mode; otherwise their conversion is merely enqueued on our stream
-        if (!m_Overlap && input.context() != m_Ctx) input.context()->wait_for(*m_Ctx);
+        give_back = !m_Overlap && input.context() != m_Ctx;
+        }
+        // (both contexts' locks, taken together: ours is no longer held -- two filters on different contexts that feed each other 4:2:0 frames
+        //  from two threads would otherwise each keep their own mutex while waiting for the other's, round-4 ADVICE)
+        if (give_back) input.context()->wait_for(*m_Ctx);
     }
 
     // Frames in pinned host memory: upload_planes -> to_ocl -> filter -> to_obs -> download_planes (FrameIngest.cpp:415-474,494-602) as one

@@ -518,6 +518,24 @@ class OracleStabilizer:
         return a[:max(n, 0)].copy(), b[:max(n, 0)].copy(), e.value
 
 
+def require_live_warp(ost, what="", min_trust=0.1):
+    """Every full-size parity test calls this on its ORACLE stabilizer after the last push: the comparison only says something about the
+    stabilizing warp when the quality-assurance trust factor (Filters/StabilizationFilter.cpp:101-115) has left zero -- with trust 0 the
+    correction is scaled to nothing and every compared frame is crop (+ lens) only, the tracker's estimate never reaches a pixel.  Fails
+    (does not skip) so that a clip or preset change cannot silently turn a warp test back into a crop test."""
+    st = ost.stats()
+    if not st.trust > min_trust:
+        raise AssertionError(f"{what}: the oracle's trust factor ended at {st.trust:.2f} (<= {min_trust}): the compared frames carry no "
+                             f"stabilizing warp (scene quality {st.scene_quality:.3f}, tracking stability {st.tracking_stability:.3f}); "
+                             f"relax min_scene_quality / min_tracking_quality or push more frames")
+    motion, corr = ost.meshes()
+    if st.n_matched < 50 or not np.abs(motion).max() > 0:
+        raise AssertionError(f"{what}: the last frame's motion estimate is empty ({st.n_matched} matches, zero motion mesh): nothing was tracked")
+    if not np.abs(corr).max() > 0:
+        raise AssertionError(f"{what}: the correction mesh is all zero")
+    return st.trust
+
+
 _inst = None
 
 

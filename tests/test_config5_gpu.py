@@ -57,6 +57,8 @@ def _run(ctx, oracle, frames, settings, nv12, lens, n_delay, check_stats=True):
             wants.append(oracle.egress_yuv420(want, nv12=nv12)); gots.append(got)
     ctx.sync()
     assert len(wants) == len(frames) - n_delay
+    oracle_lib.require_live_warp(ost, f"{frames.shape[1]}x{frames.shape[2]} nv12={nv12} lens={lens is not None}")
+    assert ost.stats().trust == gst.stats().trust
     for i, (w, g) in enumerate(zip(wants, gots)):
         for k, (a, b) in enumerate(zip(g, w)):
             a = a.cpu().numpy()
@@ -71,12 +73,12 @@ def _run(ctx, oracle, frames, settings, nv12, lens, n_delay, check_stats=True):
 @pytest.mark.parametrize("size,nv12", [((1080, 1920), False), ((1080, 1920), True), ((2160, 3840), False), ((2160, 3840), True)])
 def test_config5_fused_lens_overlap_yuv420(ctx, oracle, size, nv12, preset):
     rows, cols = size
-    n = 6 if rows > 1080 else 7
+    n = 9
     frames = _clip(rows, cols, n, seed=rows + 11 * int(nv12) + (5 if preset == "field" else 0), up=4)
-    over = dict(predictive_samples=2)
-    if preset == "field":
-        over.update(min_scene_quality=0.4, min_tracking_quality=0.2)
-    s = oracle_lib.preset(preset, **over)
+    # relaxed quality assurance (both presets): the trust factor leaves zero within the clip, so the compared frames carry the lens, the
+    # crop AND the stabilizing warp the tracker estimated (with the presets' strict 0.95 the scene-quality EMA keeps trust at 0 for the
+    # whole clip and the comparison would be lens + crop only); _run asserts it through oracle_lib.require_live_warp
+    s = oracle_lib.preset(preset, predictive_samples=2, min_scene_quality=0.4, min_tracking_quality=0.2)
     assert _run(ctx, oracle, frames, s, nv12, survey_profile(rows, cols), 2) == n - 2
 
 
@@ -84,9 +86,9 @@ def test_config5_fused_lens_overlap_yuv420(ctx, oracle, size, nv12, preset):
 def test_field_preset_overlap_yuv420_full_size(ctx, oracle, size, nv12):
     """Vector-field preset, no lens: k_remap_mesh_420 (in-kernel 16 x 16 mesh interpolation + 4:2:0 egress) on the persistent grid."""
     rows, cols = size
-    n = 6
+    n = 10
     frames = _clip(rows, cols, n, seed=rows + 3, up=4)
-    s = oracle_lib.preset("field", predictive_samples=2, min_scene_quality=0.4, min_tracking_quality=0.2)
+    s = oracle_lib.preset("field", predictive_samples=2, min_scene_quality=0.3, min_tracking_quality=0.2)
     assert _run(ctx, oracle, frames, s, nv12, None, 2) == n - 2
 
 
@@ -101,6 +103,6 @@ def test_overlap_yuv420_random_ragged_sizes(ctx, oracle, trial):
     lens = survey_profile(rows, cols) if trial % 2 == 0 else None
     if trial == 5:
         lens = np.array([0.7 * cols, 0.75 * cols, 0.52 * cols, 0.47 * rows, -0.2, 0.05, 1e-3, -2e-3, 0.01])     # decentred, tangential terms
-    frames = _clip(rows, cols, 6, seed=trial + 100, up=2)
-    s = oracle_lib.preset(preset, predictive_samples=2, min_scene_quality=0.4, min_tracking_quality=0.2)
-    assert _run(ctx, oracle, frames, s, nv12, lens, 2) == 4
+    frames = _clip(rows, cols, 9, seed=trial + 100, up=2)
+    s = oracle_lib.preset(preset, predictive_samples=2, min_scene_quality=0.3, min_tracking_quality=0.2)
+    assert _run(ctx, oracle, frames, s, nv12, lens, 2) == 7

@@ -93,4 +93,5 @@ def test_free_running_pushes_bit_exact(oracle, placement, monkeypatch):
                 assert np.array_equal(a.cpu().numpy(), b), f"frame {i} ({placement})"
             emitted += 1
     assert emitted == n - s.predictive_samples
+    oracle_lib.require_live_warp(ost, "4K free-running pushes")
     ost.close(); gst.close(); ctx.close()

@@ -302,10 +302,12 @@ def test_1080p_and_4k_streams_match_oracle(ctx, oracle):
     frame bit-identical."""
     import torch
     import livevisionkit_amd as lvk
-    for (rows, cols, n) in [(720, 1280, 8), (1080, 1920, 7), (2160, 3840, 5)]:
+    for (rows, cols, n) in [(720, 1280, 9), (1080, 1920, 9), (2160, 3840, 9)]:
         small, _ = synth.make_clip(rows // 4, cols // 4, n, seed=rows, jitter=1.0)
         frames = np.ascontiguousarray(small.repeat(4, axis=1).repeat(4, axis=2))            # cheap full-size frames with corners
-        s = oracle_lib.preset("homography", predictive_samples=2)
+        # relaxed quality assurance: the trust factor leaves zero within the clip (require_live_warp below), so the compared frames carry
+        # the warp the tracker estimated, not the crop alone
+        s = oracle_lib.preset("homography", predictive_samples=2, min_scene_quality=0.4, min_tracking_quality=0.2)
         ost = oracle_lib.OracleStabilizer(oracle, s)
         gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
         emitted = 0
@@ -319,6 +321,8 @@ def test_1080p_and_4k_streams_match_oracle(ctx, oracle):
                 assert np.array_equal(got.cpu().numpy(), want), (rows, i)
                 emitted += 1
         assert emitted == n - 2
+        oracle_lib.require_live_warp(ost, f"{cols}x{rows} packed")
+        assert ost.stats().trust == gst.stats().trust
         ost.close(); gst.close()
 
 
@@ -403,7 +407,8 @@ def test_overlap_yuv420_full_size_persistent_grid_bit_exact(ctx, oracle, size, n
         if want is not None:
             wants.append(oracle.egress_yuv420(want, nv12=nv12)); gots.append(got)
     ctx.sync()
-    assert len(wants) == n - 2 and ost.stats().trust > 0.1
+    assert len(wants) == n - 2
+    oracle_lib.require_live_warp(ost, f"{cols}x{rows} overlap nv12={nv12}")
     for i, (w, g) in enumerate(zip(wants, gots)):
         for a, b in zip(g, w):
             assert np.array_equal(a.cpu().numpy(), b), (size, i)
