@@ -16,8 +16,27 @@ namespace {
 
 constexpr int K_HYPOTHESES = 128;
 constexpr int LO_ROUNDS = 3;
-constexpr int NT = 256;              // threads per block of both kernels (the least-squares sums use NT strided partials)
+constexpr int NT = 256;              // threads per block of k_ransac_hypotheses; also the number of strided partials of the least-squares sums (the specification)
+// k_ransac_finalize runs FT threads: 8 waves share the 44 (14) sums of a refit -- wave w owns the sums w, w + 8, ... and still computes all NT
+// partials of each (four slots per lane), so every total keeps the specification's pairing and order bit for bit; the sums phase of a
+// round is ~5.5 instead of 11 sums deep per wave, the scoring passes run two pairs per SIMD lane-slot instead of one.
+#ifndef LVK_FINALIZE_THREADS
+#define LVK_FINALIZE_THREADS 512
+#endif
+constexpr int FT = LVK_FINALIZE_THREADS;
+static_assert(FT == 256 || FT == 512, "4 or 8 waves");
 constexpr int LDS_POINTS = 2048;     // point pairs staged in LDS (16 B each); larger sets are read from global memory
+
+// threadIdx.x through an opaque move.  The local-optimisation rounds of k_ransac_finalize are one loop around ~7 000 inlined instructions; what
+// the compiler can derive from the thread index alone (lane predicates, LDS addresses per slot, permute addresses, per-lane selects of the
+// normalisation) it computes once in front of that loop and keeps in registers across all of it -- 109-113 VGPRs, where two waves per SIMD
+// next to the remap may take 96.  Re-deriving those few values where they are used costs a handful of cheap instructions per round.
+__device__ __forceinline__ int tid_now()
+{
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& s)
 {
@@ -59,9 +78,9 @@ __device__ __forceinline__ double lane_value(double v, int src_lane)          //
 template <int N>
 __device__ bool solve_n(double* A, double* b, int* s_verdict)
 {
-    if (threadIdx.x < 64)
+    if (tid_now() < 64)
     {
-        const int q = threadIdx.x;
+        const int q = tid_now();
         double a[N];
 #pragma unroll
         for (int r = 0; r < N; r++) a[r] = q < N ? A[r * N + q] : (q == N ? b[r] : 0.0);
@@ -141,16 +160,17 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
     return v;
 }
 
-// Exact integer sum over the whole block (order free).  scratch: NT / 64 int64 in LDS.
+// Exact integer sum over the whole block of BT threads (order free).  scratch: BT / 64 int64 in LDS.
+template <int BT>
 __device__ __forceinline__ long long block_sum_ll(long long v, long long* scratch)
 {
     v = wave_sum_ll(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    if ((tid_now() & 63) == 0) scratch[tid_now() >> 6] = v;
     __syncthreads();
     long long t = 0;
 #pragma unroll
-    for (int w = 0; w < NT / 64; w++) t += scratch[w];
+    for (int w = 0; w < BT / 64; w++) t += scratch[w];
     return t;
 }
 
@@ -162,11 +182,12 @@ __device__ __forceinline__ double wave_sum_f64(double v)          // xor butterf
 }
 
 // Scores model H over all pairs with the whole wave; optionally writes the inlier mask. Returns (score, #inliers) on every lane.
+template <int BT>
 __device__ long long score_model(const double* H, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, double t2,
                                  uint8_t* mask, int* ninl, long long* scratch)
 {
     long long score = 0; long long cnt = 0;
-    for (int i = threadIdx.x; i < n; i += NT)
+    for (int i = tid_now(); i < n; i += BT)
     {
         const float2 a = p1[i], b = p2[i];
         const double e2 = reproj_err2(H, (double)a.x, (double)a.y, (double)b.x, (double)b.y);
@@ -175,7 +196,7 @@ __device__ long long score_model(const double* H, const float2* __restrict__ p1,
         if (mask) mask[i] = in ? 1 : 0;
     }
     // one block reduction for both: the score of a pair is below 2^10, so the sum over <= 2^22 pairs stays below bit 40
-    const long long both = block_sum_ll(score + (cnt << 40), scratch);
+    const long long both = block_sum_ll<BT>(score + (cnt << 40), scratch);
     if (ninl) *ninl = (int)(both >> 40);
     return both & ((1ll << 40) - 1);
 }
@@ -356,7 +377,7 @@ void k_ransac_hypotheses(const float2* __restrict__ g1, const float2* __restrict
     if (ok) ok = model_from_sample(full != 0, p1, p2, idx, sA, sb, sH);
     (void)s_ok;
     if (!ok) { if (threadIdx.x == 0) hyp_score[h] = -1; return; }
-    const long long s = score_model(sH, p1, p2, n, t2, nullptr, nullptr, s_scratch);
+    const long long s = score_model<NT>(sH, p1, p2, n, t2, nullptr, nullptr, s_scratch);
     if (threadIdx.x == 0)
     {
         hyp_score[h] = s;
@@ -373,7 +394,7 @@ __device__ __forceinline__ double lane_plus(double v)
     int lo = (int)(unsigned)(u & 0xffffffffu), hi = (int)(unsigned)(u >> 32);
     if (O >= 16)
     {
-        const int src = (((int)threadIdx.x & 63) + O) << 2;
+        const int src = ((tid_now() & 63) + O) << 2;
         lo = __builtin_amdgcn_ds_bpermute(src, lo); hi = __builtin_amdgcn_ds_bpermute(src, hi);
     }
     else
@@ -436,24 +457,25 @@ __device__ __forceinline__ double partial_term(const double (&r0)[4], const doub
     if constexpr (ID < 10) { constexpr int a = tri_row(ID, 4), c = tri_col(ID, 4); return r0[a] * r0[c] + r1[a] * r1[c]; }
     else return r0[ID - 10] * u + r1[ID - 10] * v;
 }
+constexpr int NW = FT / 64;          // waves of k_ransac_finalize: wave W owns the sums W, W + NW, W + 2 NW, ...
 template <int W, int NS, int... K>
 __device__ __forceinline__ void add_full_terms(double (&acc)[NS], const double (&r0)[8], const double (&r1)[8], double u, double v, bool on, std::integer_sequence<int, K...>)
 {
     auto one = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        if constexpr (!full_term_is_zero<W + 4 * k>()) acc[k] = acc[k] + (on ? full_term<W + 4 * k>(r0, r1, u, v) : 0.0);      // (a sum of structural zeros stays +0)
+        if constexpr (!full_term_is_zero<W + NW * k>()) acc[k] = acc[k] + (on ? full_term<W + NW * k>(r0, r1, u, v) : 0.0);      // (a sum of structural zeros stays +0)
     };
     (one(std::integral_constant<int, K>{}), ...);
 }
 template <int W, int NS, int... K>
 __device__ __forceinline__ void add_partial_terms(double (&acc)[NS], const double (&r0)[4], const double (&r1)[4], double u, double v, bool on, std::integer_sequence<int, K...>)
 {
-    ((acc[K] = acc[K] + (on ? partial_term<W + 4 * K>(r0, r1, u, v) : 0.0)), ...);
+    ((acc[K] = acc[K] + (on ? partial_term<W + NW * K>(r0, r1, u, v) : 0.0)), ...);
 }
 template <int W, int N, int NS, int... K>
 __device__ __forceinline__ void store_totals(const double (&acc)[4][NS], int n_tri, double* A, double* b, std::integer_sequence<int, K...>)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = tid_now() & 63;
     // level by level over ALL sums of this wave, so that the NS independent lane shifts of a level are in flight together (a
     // ds_bpermute round trip is ~100 cycles; sum after sum they would serialise into 6 x NS of them)
     double t[NS];
@@ -467,7 +489,7 @@ __device__ __forceinline__ void store_totals(const double (&acc)[4][NS], int n_t
     if (lane == 0)
     {
         auto one = [&](auto kc) {
-            constexpr int k = decltype(kc)::value, id = W + 4 * k;
+            constexpr int k = decltype(kc)::value, id = W + NW * k;
             if constexpr (id < N * (N + 1) / 2) { constexpr int a = tri_row(id, N), c = tri_col(id, N); A[a * N + c] = t[k]; A[c * N + a] = t[k]; }
             else b[id - N * (N + 1) / 2] = t[k];
         };
@@ -482,10 +504,11 @@ __device__ __forceinline__ void store_totals(const double (&acc)[4][NS], int n_t
 // conversions and products of one overlap the others' (in-kernel clocks, n = 700: 3.4 -> ~1.3 us per refit round).
 template <int W>
 __device__ __forceinline__ void refit_sums_full(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
-                                                double cx, double cy, double sc, double* A, double* b)
+                                                const double* par, double* A, double* b)
 {
-    constexpr int NS = 11;                           // ids W, W + 4, ..., W + 40
-    const int lane = threadIdx.x & 63;
+    const double cx = par[0], cy = par[1], sc = par[2];      // (read from LDS where they are used: kept live across the whole kernel they spill)
+    constexpr int NS = (44 - W + NW - 1) / NW;       // ids W, W + NW, ... < 44  (4 waves: 11 each; 8 waves: 6, 6, 6, 6, 5, 5, 5, 5)
+    const int lane = tid_now() & 63;
     double acc[4][NS];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -513,10 +536,11 @@ __device__ __forceinline__ void refit_sums_full(const float2* __restrict__ p1, c
 // Similarity: 10 upper-triangle entries of the 4 x 4 normal matrix (ids 0 .. 9) + 4 right-hand sides (10 .. 13).
 template <int W>
 __device__ __forceinline__ void refit_sums_partial(const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
-                                                   double cx, double cy, double sc, double* A, double* b)
+                                                   const double* par, double* A, double* b)
 {
-    constexpr int NS = W < 2 ? 4 : 3;                // ids W, W + 4, W + 8 (, W + 12)
-    const int lane = threadIdx.x & 63;
+    const double cx = par[0], cy = par[1], sc = par[2];
+    constexpr int NS = (14 - W + NW - 1) / NW;       // ids W, W + NW, ... < 14  (4 waves: 4, 4, 3, 3; 8 waves: 2 x 6, 1 x 2)
+    const int lane = tid_now() & 63;
     double acc[4][NS];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -542,21 +566,25 @@ __device__ __forceinline__ void refit_sums_partial(const float2* __restrict__ p1
 }
 
 __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, const float2* __restrict__ p2, int n, const uint8_t* mask,
-                      double cx, double cy, double sc, double* A, double* b, double* H)
+                      const double* par, double* A, double* b, double* H)
 {
-    const int lane = threadIdx.x;
+    const int lane = tid_now();
 #ifdef LVK_RANSAC_TIMING
     const long long r0 = wall_clock64(); long long r1 = 0, r2 = 0;
 #endif
     if (full)
     {
-        static_assert(NT == 256, "four waves, four partials per lane");
-        switch (threadIdx.x >> 6)
+        static_assert(NT == 256, "four partials per lane");
+        switch (tid_now() >> 6)
         {
-            case 0: refit_sums_full<0>(p1, p2, n, mask, cx, cy, sc, A, b); break;
-            case 1: refit_sums_full<1>(p1, p2, n, mask, cx, cy, sc, A, b); break;
-            case 2: refit_sums_full<2>(p1, p2, n, mask, cx, cy, sc, A, b); break;
-            default: refit_sums_full<3>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            case 0: refit_sums_full<0>(p1, p2, n, mask, par, A, b); break;
+            case 1: refit_sums_full<1>(p1, p2, n, mask, par, A, b); break;
+            case 2: refit_sums_full<2>(p1, p2, n, mask, par, A, b); break;
+            case 3: refit_sums_full<3>(p1, p2, n, mask, par, A, b); break;
+            case 4: if constexpr (NW > 4) refit_sums_full<4 % NW>(p1, p2, n, mask, par, A, b); break;
+            case 5: if constexpr (NW > 4) refit_sums_full<5 % NW>(p1, p2, n, mask, par, A, b); break;
+            case 6: if constexpr (NW > 4) refit_sums_full<6 % NW>(p1, p2, n, mask, par, A, b); break;
+            default: if constexpr (NW > 4) refit_sums_full<7 % NW>(p1, p2, n, mask, par, A, b); break;
         }
         __syncthreads();
 #ifdef LVK_RANSAC_TIMING
@@ -574,6 +602,7 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
         {
             if (ok)
             {
+                const double cx = par[0], cy = par[1], sc = par[2];
                 const double Hn[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
                 // T = [sc 0 -cx sc; 0 sc -cy sc; 0 0 1], T^-1 = [1/sc 0 cx; 0 1/sc cy; 0 0 1]: column c of T and row r of T^-1 by selects (same
                 // operand values as the indexed arrays of the sequential form, zeros included)
@@ -601,12 +630,16 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
     }
     else
     {
-        switch (threadIdx.x >> 6)
+        switch (tid_now() >> 6)
         {
-            case 0: refit_sums_partial<0>(p1, p2, n, mask, cx, cy, sc, A, b); break;
-            case 1: refit_sums_partial<1>(p1, p2, n, mask, cx, cy, sc, A, b); break;
-            case 2: refit_sums_partial<2>(p1, p2, n, mask, cx, cy, sc, A, b); break;
-            default: refit_sums_partial<3>(p1, p2, n, mask, cx, cy, sc, A, b); break;
+            case 0: refit_sums_partial<0>(p1, p2, n, mask, par, A, b); break;
+            case 1: refit_sums_partial<1>(p1, p2, n, mask, par, A, b); break;
+            case 2: refit_sums_partial<2>(p1, p2, n, mask, par, A, b); break;
+            case 3: refit_sums_partial<3>(p1, p2, n, mask, par, A, b); break;
+            case 4: if constexpr (NW > 4) refit_sums_partial<4 % NW>(p1, p2, n, mask, par, A, b); break;
+            case 5: if constexpr (NW > 4) refit_sums_partial<5 % NW>(p1, p2, n, mask, par, A, b); break;
+            case 6: if constexpr (NW > 4) refit_sums_partial<6 % NW>(p1, p2, n, mask, par, A, b); break;
+            default: if constexpr (NW > 4) refit_sums_partial<7 % NW>(p1, p2, n, mask, par, A, b); break;
         }
         __syncthreads();
         __shared__ int s_solved4, s_ok2;
@@ -615,10 +648,11 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
         {
             if (ok)
             {
+                const double cx = par[0], cy = par[1], sc = par[2];
                 const double a = b[0], bb = b[1], tx = b[2], ty = b[3];
                 H[0] = a; H[1] = -bb; H[2] = (tx / sc + cx) - (a * cx - bb * cy);
                 H[3] = bb; H[4] = a;  H[5] = (ty / sc + cy) - (bb * cx + a * cy);
-                H[6] = 0; H[7] = 0; H[8] = 1;
+                // (H[6..8] = 0, 0, 1: constant for this model, written once by the caller)
             }
             s_ok2 = ok ? 1 : 0;
         }
@@ -627,11 +661,12 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
     }
 }
 
-// Single wavefront: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
-// At most 168 VGPRs (3 waves per SIMD's worth): the block has to fit NEXT TO the co-scheduled remap of the overlap mode (4 waves x 80
-// VGPRs per SIMD leave 192); the unconstrained allocation of 250 made it wait for remap workgroups to retire.
+// One block: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
+// The block has to fit NEXT TO the co-scheduled remap of the overlap mode (4 waves x 80 VGPRs per SIMD leave 192 of a SIMD's 512): as 4
+// waves (one per SIMD) it may take 168 VGPRs, as 8 waves (two per SIMD) 96 each; the unconstrained allocation of 250 made it wait for remap
+// workgroups to retire.
 template <bool STAGED>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(FT == 512 ? 5 : 3)))
 void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__ g2, int n, const int* __restrict__ n_dev, double t2, int full,
                        const int* __restrict__ full_dev, double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
@@ -641,18 +676,18 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     LVK_TL(1);
     LVK_TRACKER_PRIORITY();
     __shared__ double sA[64], sb[8], sH[9], sBest[9];
-    __shared__ long long s_scratch[NT / 64];
-    __shared__ long long s_best[NT / 64]; __shared__ int s_best_h[NT / 64];
+    __shared__ double s_par[4];                           // cx, cy, sc, t2: read back where they are used (see refit_sums_full)
+    __shared__ long long s_scratch[FT / 64];
+    __shared__ long long s_best[FT / 64]; __shared__ int s_best_h[FT / 64];
     __shared__ float2 s_p1[STAGED ? LDS_POINTS : 1], s_p2[STAGED ? LDS_POINTS : 1];
     __shared__ uint8_t s_mask[2][STAGED ? LDS_POINTS : 1];
     const int lane = threadIdx.x;
     if (n_dev) n = max(min(*n_dev, n), 0);
     if (full_dev) full = *full_dev;
+    if (lane == 0) { s_par[0] = cx; s_par[1] = cy; s_par[2] = sc; s_par[3] = t2; }
     if (STAGED)
-    {
-        for (int i = lane; i < n; i += NT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
-        __syncthreads();
-    }
+        for (int i = lane; i < n; i += FT) { s_p1[i] = g1[i]; s_p2[i] = g2[i]; }
+    __syncthreads();
     const float2* p1 = STAGED ? s_p1 : g1;
     const float2* p2 = STAGED ? s_p2 : g2;
     uint8_t* mask_a = STAGED ? s_mask[0] : gmask_a;
@@ -667,7 +702,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     RT_MARK();
     // argmax over the hypotheses: highest score, lowest index on ties
     long long best = -1; int best_h = -1;
-    for (int h = lane; h < K_HYPOTHESES; h += NT)
+    for (int h = lane; h < K_HYPOTHESES; h += FT)
     {
         const long long s = hyp_score[h];
         if (s > best) { best = s; best_h = h; }
@@ -681,14 +716,14 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     if ((lane & 63) == 0) { s_best[lane >> 6] = best; s_best_h[lane >> 6] = best_h; }
     __syncthreads();
     best = s_best[0]; best_h = s_best_h[0];
-    for (int w = 1; w < NT / 64; w++)
+    for (int w = 1; w < FT / 64; w++)
     {
         const long long os = s_best[w]; const int oh = s_best_h[w];
         if (os > best || (os == best && oh >= 0 && (best_h < 0 || oh < best_h))) { best = os; best_h = oh; }
     }
     if (best_h < 0 || best < 0)
     {
-        for (int i = lane; i < n; i += NT) out_mask[i] = 0;
+        for (int i = lane; i < n; i += FT) out_mask[i] = 0;
         if (lane == 0) { for (int q = 0; q < 9; q++) out_H[q] = (q % 4 == 0) ? 1.0 : 0.0; *out_ninl = -2; }
         return;
     }
@@ -696,17 +731,18 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     __syncthreads();
     uint8_t* cur = mask_a; uint8_t* trial = mask_b;
     int ninl = 0;
+    if (!full && lane == 0) { sH[6] = 0.0; sH[7] = 0.0; sH[8] = 1.0; }      // the last row of a similarity (refit() writes sH[0..5]); ordered by the barriers below
     RT_MARK();
-    long long best_score = score_model(sBest, p1, p2, n, t2, cur, &ninl, s_scratch);
+    long long best_score = score_model<FT>(sBest, p1, p2, n, s_par[3], cur, &ninl, s_scratch);
     __syncthreads();
     RT_MARK();
     for (int round = 0; round < LO_ROUNDS; round++)
     {
         if (ninl < m) break;
-        if (!refit(full != 0, p1, p2, n, cur, cx, cy, sc, sA, sb, sH)) break;
+        if (!refit(full != 0, p1, p2, n, cur, s_par, sA, sb, sH)) break;
         RT_MARK();
         int nt = 0;
-        const long long s = score_model(sH, p1, p2, n, t2, trial, &nt, s_scratch);
+        const long long s = score_model<FT>(sH, p1, p2, n, s_par[3], trial, &nt, s_scratch);
         __syncthreads();
         RT_MARK();
         if (s <= best_score) break;
@@ -715,7 +751,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
         uint8_t* t = cur; cur = trial; trial = t;
         __syncthreads();
     }
-    for (int i = lane; i < n; i += NT) out_mask[i] = cur[i];
+    for (int i = lane; i < n; i += FT) out_mask[i] = cur[i];
     if (lane < 9) out_H[lane] = sBest[lane];
     if (lane == 0) *out_ninl = ninl;
 #ifdef LVK_RANSAC_TIMING
@@ -781,13 +817,13 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     if (n <= LDS_POINTS)
     {
         hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
-        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
+        hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(FT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     else
     {
         hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
-        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
+        hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(FT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
                            region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     }
     LVK_HIP_CHECK(ctx, hipGetLastError());
@@ -829,7 +865,7 @@ int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const floa
     const CompactArgs ca{d_prev, d_matched, d_status, d_und, region_wf, region_hf, d_p1, d_p2, d_count, h_count, h_matched, h_status, d_n_raw, d_full};
     hipLaunchKernelGGL((k_ransac_hypotheses<true, true>), dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, (const float2*)nullptr, (const float2*)nullptr, n, (const int*)nullptr,
                        t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
-    hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(NT), 0, ctx->stream, (const float2*)d_p1, (const float2*)d_p2, n, (const int*)d_count, t2, full_homography ? 1 : 0, d_full,
+    hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(FT), 0, ctx->stream, (const float2*)d_p1, (const float2*)d_p2, n, (const int*)d_count, t2, full_homography ? 1 : 0, d_full,
                        region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;

@@ -189,17 +189,26 @@ __device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, flo
 }
 
 // EASU with the 12 taps gathered straight from global memory (8 + 16 + 16 + 8 byte loads like FSR.cl:196-202).
-template <bool YUV>
-__device__ __forceinline__ uint32_t easu_gather(const uint8_t* __restrict__ src, int step, int sx, int sy, float ppx, float ppy)
+// Addressing: ONE 32-bit byte offset per pixel (a frame is < 4 GB: the launchers assert it) against four block-uniform row bases
+// (src, src + step - 3, src + 2 step - 3, src + 3 step: scalar registers, computed once per kernel) -- the loads take the form
+// global_load_dwordx2/x4 v, v_off, s[base:base+1], and the per-pixel address arithmetic is one v_mad_u32_u24-class instruction instead of
+// the 2 x v_mad_u64_u32 + 4-5 x v_lshl_add_u64 (slow issue class) that 64-bit per-row pointers cost (round-4 VERDICT, item 5).
+struct TapBases { const uint8_t* __restrict__ r0; const uint8_t* __restrict__ r1; const uint8_t* __restrict__ r2; const uint8_t* __restrict__ r3; };
+__device__ __forceinline__ TapBases tap_bases(const uint8_t* __restrict__ src, int step)
 {
-    const uint8_t* r0p = src + (long)(sy - 1) * step + 3 * sx;      // b, c
-    const uint8_t* r1p = r0p + step - 3;                            // e, f, g, h
-    const uint8_t* r2p = r1p + step;                                // i, j, k, l
-    const uint8_t* r3p = r0p + 3 * (long)step;                      // n, o
-    const U8B r0 = *reinterpret_cast<const U8B*>(r0p);
-    const U16B r1 = *reinterpret_cast<const U16B*>(r1p);
-    const U16B r2 = *reinterpret_cast<const U16B*>(r2p);
-    const U8B r3 = *reinterpret_cast<const U8B*>(r3p);
+    return TapBases{src, src + step - 3, src + 2 * (long)step - 3, src + 3 * (long)step};
+}
+
+template <bool YUV>
+__device__ __forceinline__ uint32_t easu_gather(const TapBases& tb, int step, int sx, int sy, float ppx, float ppy)
+{
+    // sy >= 1, sx >= 1 here (interior pixels only): the offset of tap b (row sy - 1, column sx) is non-negative
+    // (24-bit operands: rows and the row pitch are far below 2^24 -- v_mad_u32_u24, not the quarter-rate v_mad_u64_u32 of a full 32-bit product)
+    const uint32_t off = __umul24((uint32_t)(sy - 1), (uint32_t)step) + 3u * (uint32_t)sx;
+    const U8B r0 = *reinterpret_cast<const U8B*>(tb.r0 + off);      // b, c
+    const U16B r1 = *reinterpret_cast<const U16B*>(tb.r1 + off);    // e, f, g, h
+    const U16B r2 = *reinterpret_cast<const U16B*>(tb.r2 + off);    // i, j, k, l
+    const U8B r3 = *reinterpret_cast<const U8B*>(tb.r3 + off);      // n, o
     float4 t[12];
     t[TB] = make_tap<YUV>(r0.w[0]);                                t[TC] = make_tap<YUV>(byte_window(r0.w[0], r0.w[1], 3));
     t[TE] = make_tap<YUV>(r1.w[0]);                                t[TF] = make_tap<YUV>(byte_window(r1.w[0], r1.w[1], 3));
@@ -208,6 +217,13 @@ __device__ __forceinline__ uint32_t easu_gather(const uint8_t* __restrict__ src,
     t[TK] = make_tap<YUV>(byte_window(r2.w[1], r2.w[2], 2));       t[TL] = make_tap<YUV>(byte_window(r2.w[2], 0u, 1));
     t[TN] = make_tap<YUV>(r3.w[0]);                                t[TO] = make_tap<YUV>(byte_window(r3.w[0], r3.w[1], 3));
     return easu_core(t, ppx, ppy);
+}
+
+// the object at `base` + a 32-bit byte offset (base block-uniform: global_load v, v_off, s[base:base+1])
+template <class T>
+__device__ __forceinline__ T at_byte(const void* __restrict__ base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T*>(static_cast<const uint8_t*>(base) + byte_off);
 }
 
 // ---- coordinate generators: destination pixel -> source coordinate -------------------------------------------
@@ -233,15 +249,19 @@ struct MeshCoord            // WarpMesh.cpp:190-191 per pixel (HResizeLinear, VR
     float sw, sh;
     __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
     {
-        const LinTabEntry ty = ytab[y], tx = xtab[x];
-        const float* __restrict__ m0 = mesh + (long)ty.s0 * mesh_cols * 2;
-        const float* __restrict__ m1 = mesh + (long)ty.s1 * mesh_cols * 2;
+        // (32-bit BYTE offsets against the block-uniform bases: the table and mesh loads take the scalar-base + 32-bit-offset form, no 64-bit
+        //  address arithmetic per pixel)
+        const LinTabEntry ty = at_byte<LinTabEntry>(ytab, (uint32_t)y << 4), tx = at_byte<LinTabEntry>(xtab, (uint32_t)x << 4);
+        static_assert(sizeof(LinTabEntry) == 16, "table entries are addressed by a shift");
+        const uint32_t r0 = __umul24((uint32_t)ty.s0, (uint32_t)mesh_cols) << 3, r1 = __umul24((uint32_t)ty.s1, (uint32_t)mesh_cols) << 3;
+        const uint32_t c0 = (uint32_t)tx.s0 << 3, c1 = (uint32_t)tx.s1 << 3;
         float off[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ch++)
         {
-            const float h0 = (tx.s1 == tx.s0) ? m0[2 * tx.s0 + ch] * 1.0f : m0[2 * tx.s0 + ch] * tx.a0 + m0[2 * tx.s1 + ch] * tx.a1;
-            const float h1 = (tx.s1 == tx.s0) ? m1[2 * tx.s0 + ch] * 1.0f : m1[2 * tx.s0 + ch] * tx.a0 + m1[2 * tx.s1 + ch] * tx.a1;
+            const uint32_t b = 4u * (uint32_t)ch;
+            const float h0 = (tx.s1 == tx.s0) ? at_byte<float>(mesh, r0 + c0 + b) * 1.0f : at_byte<float>(mesh, r0 + c0 + b) * tx.a0 + at_byte<float>(mesh, r0 + c1 + b) * tx.a1;
+            const float h1 = (tx.s1 == tx.s0) ? at_byte<float>(mesh, r1 + c0 + b) * 1.0f : at_byte<float>(mesh, r1 + c0 + b) * tx.a0 + at_byte<float>(mesh, r1 + c1 + b) * tx.a1;
             off[ch] = (h0 * ty.a0 + h1 * ty.a1) * (ch == 0 ? sw : sh);
         }
         subx = (float)x + off[0];
@@ -254,7 +274,7 @@ struct MapCoord             // FSR.cl:376-381: a materialised offset map (pixels
     const uint8_t* __restrict__ map; int map_step;
     __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
     {
-        const float2 o = *reinterpret_cast<const float2*>(map + (long)y * map_step + 8 * (long)x);
+        const float2 o = *reinterpret_cast<const float2*>(map + (__umul24((uint32_t)y, (uint32_t)map_step) + 8u * (uint32_t)x));
         subx = (float)x + o.x;
         suby = (float)y + o.y;
     }
@@ -353,7 +373,8 @@ struct PackedSink
     __device__ __forceinline__ void store(int x0, int y, int npx, const uint32_t px[PXT], bool active, int /*parity*/) const
     {
         if (!active) return;
-        uint8_t* drow = dst + (long)y * dst_step;
+        // (32-bit row offset against the block-uniform base, like the tap loads: a frame is < 4 GB)
+        uint8_t* drow = dst + __umul24((uint32_t)y, (uint32_t)dst_step);
         store_pixels(drow, x0, npx, px, ((reinterpret_cast<uintptr_t>(drow) & 3u) == 0));
     }
 };
@@ -378,7 +399,7 @@ struct Sink420
         s_uv[t] = make_uint2(u01 | (u23 << 16), v01 | (v23 << 16));
         if (active)
         {
-            uint8_t* yr = yp + (long)y * y_step + x0;
+            uint8_t* yr = yp + (__umul24((uint32_t)y, (uint32_t)y_step) + (uint32_t)x0);
             const uint32_t yy = (px[0] & 0xffu) | ((px[1] & 0xffu) << 8) | ((px[2] & 0xffu) << 16) | ((px[3] & 0xffu) << 24);
             if (npx == PXT && ((reinterpret_cast<uintptr_t>(yr) & 3u) == 0)) LVK_STREAM_STORE(reinterpret_cast<uint32_t*>(yr), yy);
             else for (int p = 0; p < npx; p++) yr[p] = (uint8_t)(yy >> (8 * p));
@@ -392,13 +413,13 @@ struct Sink420
             const int cx = x0 >> 1, cy = y >> 1, nc = npx >> 1;
             if (NV12)
             {
-                uint8_t* d = up + (long)cy * u_step + 2 * cx;
+                uint8_t* d = up + (__umul24((uint32_t)cy, (uint32_t)u_step) + 2u * (uint32_t)cx);
                 d[0] = (uint8_t)u0; d[1] = (uint8_t)v0;
                 if (nc > 1) { d[2] = (uint8_t)u1; d[3] = (uint8_t)v1; }
             }
             else
             {
-                uint8_t* du = up + (long)cy * u_step + cx; uint8_t* dv = vp + (long)cy * v_step + cx;
+                uint8_t* du = up + (__umul24((uint32_t)cy, (uint32_t)u_step) + (uint32_t)cx); uint8_t* dv = vp + (__umul24((uint32_t)cy, (uint32_t)v_step) + (uint32_t)cx);
                 du[0] = (uint8_t)u0; dv[0] = (uint8_t)v0;
                 if (nc > 1) { du[1] = (uint8_t)u1; dv[1] = (uint8_t)v1; }
             }
@@ -416,6 +437,7 @@ __device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src,
     const int y = sy_ * STRIP_H + (int)(threadIdx.x >> 6);
     const bool active = strip < nstrips && x0 < dst_cols && y < dst_rows;
     const int npx = active ? min(PXT, dst_cols - x0) : 0;
+    const TapBases tb = tap_bases(src, src_step);
     uint32_t px[PXT];
 #pragma unroll
     for (int p = 0; p < PXT; p++)
@@ -434,12 +456,12 @@ __device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src,
             {
                 if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)
                 {
-                    const uint8_t* s = src + (long)sy * src_step + 3 * sx;
+                    const uint8_t* s = src + (__umul24((uint32_t)sy, (uint32_t)src_step) + 3u * (uint32_t)sx);
                     px[p] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
                 }
                 else px[p] = bg;
             }
-            else px[p] = easu_gather<YUV>(src, src_step, sx, sy, ppx, ppy);
+            else px[p] = easu_gather<YUV>(tb, src_step, sx, sy, ppx, ppy);
         }
     }
     sink.store(x0, y, npx, px, active, parity);
@@ -629,6 +651,10 @@ inline dim3 lvk_co_grid(lvk_hip_ctx* ctx, int dst_rows, int dst_cols)
     return dim3(full < persistent ? full : persistent);
 }
 
+// The kernels address a frame with ONE 32-bit byte offset per pixel built from 24-bit factors (easu_gather, the sinks): the whole frame
+// must lie within 4 GB of its base and rows / pitch below 2^24 (an 8K packed frame is 100 MB with a 23 KB pitch).
+inline bool fits_u32(int step, int rows) { return step > 0 && rows > 0 && step < (1 << 24) && rows < (1 << 24) && (uint64_t)step * (uint64_t)rows < (1ull << 32); }
+
 inline uint32_t pack_bg(const uint8_t bg[3]) { return (uint32_t)bg[0] | ((uint32_t)bg[1] << 8) | ((uint32_t)bg[2] << 16); }
 
 // cv::getPerspectiveTransform (OpenCV 4.8 imgproc; call site Math/WarpMesh.cpp:214): 8x8 double system,
@@ -680,6 +706,7 @@ int lvk_launch_remap_homography(lvk_hip_ctx* ctx, hipStream_t stream,
     LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && H != nullptr && bg != nullptr);
     LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0 && dst_cols > 0 && dst_rows > 0);
     LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * dst_cols);
+    LVK_HIP_REQUIRE(ctx, fits_u32(src_step, src_rows) && fits_u32(dst_step, dst_rows));
     HomographyArgs args;
     std::memcpy(args.h, H, sizeof(args.h));
     const dim3 block(256), grid = remap_grid(dst_rows, dst_cols), cogrid = lvk_co_grid(ctx, dst_rows, dst_cols);
@@ -710,6 +737,7 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
     LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0);
     LVK_HIP_REQUIRE(ctx, mesh_rows >= 2 && mesh_cols >= 2);           // WarpMesh::MinimumSize
     LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * src_cols);
+    LVK_HIP_REQUIRE(ctx, fits_u32(src_step, src_rows) && fits_u32(dst_step, src_rows));
     const size_t mesh_bytes = (size_t)mesh_rows * mesh_cols * 2 * sizeof(float);
     LVK_HIP_REQUIRE(ctx, mesh_bytes <= lvk_hip_ctx::kStageBytes);
 
@@ -744,6 +772,7 @@ int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src
     LVK_HIP_REQUIRE(ctx, d_src != nullptr && d_dst != nullptr && d_map != nullptr && bg != nullptr);     // Image.cpp:30-34
     LVK_HIP_REQUIRE(ctx, cols > 0 && rows > 0 && src_step >= 3 * cols && dst_step >= 3 * cols && map_step >= 8 * cols);
     LVK_HIP_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_map) | (uintptr_t)map_step) & 7u) == 0);
+    LVK_HIP_REQUIRE(ctx, fits_u32(src_step, rows) && fits_u32(dst_step, rows) && fits_u32(map_step, rows));
     const dim3 block(256), grid = remap_grid(rows, cols);
     if (yuv) hipLaunchKernelGGL(k_remap_map<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, (const uint8_t*)d_map, map_step, pack_bg(bg));
     else hipLaunchKernelGGL(k_remap_map<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, (uint8_t*)d_dst, dst_step, (const uint8_t*)d_map, map_step, pack_bg(bg));
@@ -759,6 +788,7 @@ int lvk_launch_upscale(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, 
     LVK_HIP_REQUIRE(ctx, src_cols > 0 && src_rows > 0);                                         // Image.cpp:158
     LVK_HIP_REQUIRE(ctx, dst_cols >= src_cols && dst_rows >= src_rows);                         // Image.cpp:157
     LVK_HIP_REQUIRE(ctx, src_step >= 3 * src_cols && dst_step >= 3 * dst_cols);
+    LVK_HIP_REQUIRE(ctx, fits_u32(src_step, src_rows) && fits_u32(dst_step, dst_rows));
     if (dst_cols == src_cols && dst_rows == src_rows)                                           // Image.cpp:162-166
     {
         LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_step, d_src, (size_t)src_step, 3 * (size_t)src_cols, (size_t)src_rows,
@@ -819,6 +849,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
     LVK_HIP_REQUIRE(ctx, d_src && o_y && o_u && (nv12 || o_v) && mesh && bg && mesh_rows >= 2 && mesh_cols >= 2);
     LVK_HIP_REQUIRE(ctx, rows > 0 && cols > 0 && (rows & 1) == 0 && (cols & 1) == 0 && src_step >= 3 * cols);
     LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
+    LVK_HIP_REQUIRE(ctx, fits_u32(src_step, rows) && fits_u32(oy_step, rows) && fits_u32(ou_step, rows / 2) && (nv12 || fits_u32(ov_step, rows / 2)));
     const Planes420 o{(uint8_t*)o_y, oy_step, (uint8_t*)o_u, ou_step, (uint8_t*)(nv12 ? o_u : o_v), nv12 ? ou_step : ov_step};
     const dim3 block(256), grid = co ? lvk_co_grid(ctx, rows, cols) : remap_grid(rows, cols);
     int stage_slot = -1;

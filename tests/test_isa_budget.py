@@ -43,21 +43,37 @@ def test_no_scratch_and_vgpr_budgets(unit):
 
 
 def test_remap_instruction_ceiling():
-    """The remap is bound by how many VALU instructions it issues per pixel: 498.9 per pixel measured (rocprofv3
-    SQ_INSTS_VALU, profiles/r04_sq_counters_per_kernel.txt) = 2 124 static VALU instructions per 4-pixel thread of k_remap_homography_420
-    (both paths of every branch counted).  This keeps a refactor from quietly adding to it, and holds the two round-4 savings in place: EASU's
-    saturate as the `clamp` modifier of the multiply that feeds it (no v_min_f32 / v_max_f32 pair with 1.0 / 0 behind it) and the final clamp
-    between the centre taps' minimum and maximum as one v_med3_f32."""
+    """The remap is bound by how many VALU instructions it issues per pixel.  Round 4: 498.9 per pixel measured
+    (rocprofv3 SQ_INSTS_VALU, profiles/r04_sq_counters_per_kernel.txt) = 2 124 static VALU instructions per 4-pixel thread of
+    k_remap_homography_420 (both paths of every branch counted).  Round 5 took the 64-bit address arithmetic out of the per-pixel path: the
+    four tap-row loads, the border copy, the mesh / table loads and the sinks address their frames with ONE 32-bit byte offset against
+    block-uniform scalar bases (global_load v, v_off, s[base:base+1]) -- 2 066 static VALU for the homography kernel, 2 155 for the mesh
+    kernel (was 2 241), no v_mad_u64_u32 anywhere in them and a handful of v_lshl_add_u64 per THREAD (ragged-edge stores) instead of 6-7
+    per pixel.  This test keeps a refactor from quietly adding to it, and holds the round-4 savings in place: EASU's saturate as the
+    `clamp` modifier of the multiply that feeds it and the final clamp between the centre taps' minimum and maximum as one v_med3_f32."""
     out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, "remap.hip")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(\S*k_remap_homography_420\S*):[^\n]*\n(.*?)\.Lfunc_end", out.stdout, re.S | re.M)}
-    assert len(bodies) == 2, list(bodies)                                  # <false> (I420) and <true> (NV12)
-    for name, body in bodies.items():
+
+    def bodies_of(kernel):
+        return {m.group(1): m.group(2) for m in re.finditer(r"^(\S*" + kernel + r"I\S*):[^\n]*\n(.*?)\.Lfunc_end", out.stdout, re.S | re.M)}
+
+    def valu_of(body):
         ops = [ln.split()[0] for ln in body.splitlines() if ln.strip() and not ln.strip().startswith((";", ".", "//")) and not ln.strip().endswith(":")]
-        valu = [o for o in ops if o.startswith("v_")]
-        assert len(valu) <= 2140, f"{name}: {len(valu)} static VALU instructions (ceiling 2 140; round 3: 2 200)"
-        clamped = [ln for ln in body.splitlines() if re.search(r"v_mul_f32_e64 .* clamp", ln)]
-        assert len(clamped) >= 32, f"{name}: {len(clamped)} clamped multiplies (8 per pixel expected)"
-        assert sum(1 for o in valu if o.startswith("v_med3_f32")) >= 12, name
-        assert not re.search(r"v_min_f32_e32 v\d+, 1\.0,", body), f"{name}: a saturate compiled to v_min 1.0 / v_max 0 again"
+        return [o for o in ops if o.startswith("v_")]
+    for kernel, ceiling, addr64 in (("k_remap_homography_420", 2080, 12), ("k_remap_mesh_420", 2170, 20), ("k_remap_homography_lens_420", 2245, 12),
+                                    ("k_remap_mesh_lens_420", 2335, 20)):
+        bodies = bodies_of(kernel)
+        assert len(bodies) == 2, (kernel, list(bodies))                    # <false> (I420) and <true> (NV12)
+        for name, body in bodies.items():
+            valu = valu_of(body)
+            assert len(valu) <= ceiling, f"{name}: {len(valu)} static VALU instructions (ceiling {ceiling})"
+            # the tap loads: scalar base + 32-bit offset (no per-pixel 64-bit pointer arithmetic)
+            assert not any(o.startswith("v_mad_u64_u32") for o in valu), f"{name}: 64-bit multiply-add in the address path again"
+            assert sum(1 for o in valu if o.startswith("v_lshl_add_u64")) <= addr64, f"{name}: 64-bit address adds are back in the per-pixel path"
+            taps = [ln for ln in body.splitlines() if re.search(r"global_load_dwordx[23] v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", ln)]
+            assert len(taps) >= 16, f"{name}: {len(taps)} tap-row loads in the scalar-base form (16 expected: 4 rows x 4 pixels)"
+            clamped = [ln for ln in body.splitlines() if re.search(r"v_mul_f32_e64 .* clamp", ln)]
+            assert len(clamped) >= 32, f"{name}: {len(clamped)} clamped multiplies (8 per pixel expected)"
+            assert sum(1 for o in valu if o.startswith("v_med3_f32")) >= 12, name
+            assert not re.search(r"v_min_f32_e32 v\d+, 1\.0,", body), f"{name}: a saturate compiled to v_min 1.0 / v_max 0 again"
