@@ -16,7 +16,16 @@
  *     reference's `run_(..., false)` kernel launches (Functions/Image.cpp:76); results are complete
  *     after lvk_hip_sync() (reference: Stopwatch::sync_gpu -> cv::ocl::finish, Timing/Stopwatch.cpp:127-131).
  *   - One context is driven by one host thread at a time; different contexts are independent
- *     (reference threading contract: SURVEY.md section 8b).
+ *     (reference threading contract: SURVEY.md section 8b).  Every entry point makes its context's device current for
+ *     the duration of the call and restores the caller's: a context of device 3 may be driven from a thread that never
+ *     called hipSetDevice (one host thread + one context per GPU).
+ *
+ * Layout of this header
+ *   PART 1 -- STABLE ABI: what a host of the reference binds (the filter, its frames and memory, the lvk:: image operations).
+ *             A change that breaks one of these signatures or contracts increments LVK_HIP_ABI_VERSION.
+ *   PART 2 -- EXPERIMENTAL / DIAGNOSTICS: per-stage entry points the parity tests drive, taps, profiling, the device-frame
+ *             look-ahead.  They may change between builds of the library without a version increment; production hosts
+ *             do not need them.
  */
 #ifndef LVK_HIP_H
 #define LVK_HIP_H
@@ -35,6 +44,10 @@ extern "C" {
 
 typedef struct lvk_hip_ctx lvk_hip_ctx;
 
+/* =====================================================================================================================================
+ * PART 1 -- STABLE ABI
+ * ===================================================================================================================================== */
+
 /* ---- context ------------------------------------------------------------------------------------
  * Replaces the implicit OpenCL context/queue of cv::ocl (Functions/OpenCL/Kernels.cpp:27-45).
  * lvk_hip_ctx_create makes its own non-blocking stream; lvk_hip_ctx_create_on_stream enqueues on the caller's
@@ -45,7 +58,14 @@ void lvk_hip_ctx_destroy(lvk_hip_ctx* ctx);
 int  lvk_hip_sync(lvk_hip_ctx* ctx);                 /* Stopwatch::sync_gpu, Timing/Stopwatch.cpp:127-131 */
 void* lvk_hip_stream(lvk_hip_ctx* ctx);              /* the hipStream_t work is enqueued on */
 const char* lvk_hip_last_error(lvk_hip_ctx* ctx);    /* NULL ctx: last error of a failed ctx_create */
-const char* lvk_hip_version(void);
+const char* lvk_hip_version(void);                   /* human-readable build string */
+/* ABI number of PART 1 of this header as the library was built (compare with LVK_HIP_ABI_VERSION of the header a host was compiled against;
+ * tests/test_abi.py holds the two together). */
+#define LVK_HIP_ABI_VERSION 5
+int  lvk_hip_abi_version(void);
+/* usable gfx950 devices in this process (0 when there is none; never an error): one lvk_hip_ctx + one host thread per device is the
+ * multi-GPU partitioning (no collective, no peer access) */
+int  lvk_hip_device_count(void);
 
 /* Ordering between contexts: everything enqueued so far on `producer` (its stream and the streams of its stabilizers) happens
  * before whatever is enqueued on `ctx` from now on.  GPU-side (an event per stream), no host wait.  What the reference gets from
@@ -64,6 +84,11 @@ int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr);
 int lvk_hip_trim(lvk_hip_ctx* ctx);
 int lvk_hip_upload(lvk_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* async on the stream */
 int lvk_hip_download(lvk_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* async on the stream */
+
+/* pinned host memory for the planes of lvk_hip_stab_push_yuv420_host */
+int  lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr);      /* pinned, device-visible host memory */
+int  lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr);
+
 
 /* ---- a15/a16: dense remap ------------------------------------------------------------------------
  * lvk::remap(src, dst, homography, background, inverted=true)  (Functions/Image.cpp:85-151) running
@@ -99,11 +124,6 @@ int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_r
  * with writes; the defined result is that of distinct buffers, and aliasing is rejected.  Border pixels are copied. */
 int lvk_hip_sharpen(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step, float sharpness);
 
-/* native_recip(x) of FSR.cl as the EASU / RCAS kernels of this library evaluate it (v_rcp_f32, what the reference's OpenCL source
- * compiles to for gfx950), elementwise over n binary32 values on the device.  OpenCL leaves native_recip implementation-defined:
- * this entry point lets a host (and the parity tests' CPU model of the kernels) read the device's definition. */
-int lvk_hip_native_rcp(lvk_hip_ctx* ctx, const float* d_in, float* d_out, size_t n);
-
 /* Lens correction: the offset map LCFilter::prepare_undistort_maps builds
  * (Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-171) for a camera profile in the plugin's format
  * (Modules/OBS-Plugin/Sources/Tools/CCTool.cpp:120-153); LCFilter::filter == lvk_hip_remap_map with it. */
@@ -133,59 +153,6 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
                            void* d_dst, int dst_step,
                            const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv);
 
-/* ---- a10: local motion estimate (vector-field preset) ---------------------------------------------------------------
- * FrameTracker::estimate_local_motions with the constraint system of generate_mesh_constraints (Vision/FrameTracker.cpp:200-321,
- * 380-457) for a mesh of cols x rows vertices: the least-squares positions of the mesh vertices from the tracked -> matched point pairs
- * (host arrays of n x 2 floats, tracking-frame coordinates), the temporal rows pulling towards the previous solution, which the
- * solver object keeps (the reference's m_OptimizedMesh; _reset zeroes it like FrameTracker::restart).  gen_region / the smoothing
- * weights are those in force when the reference (re)generates the constraints (:74-82); region / temporal_now those of the call.
- * Outputs: inlier flag per pair (L1 reprojection error < threshold) and the cols x rows x 2 normalised backward offsets of the motion
- * mesh.  Returns 0, or 2 / 3 when no estimate is possible (a point in the mesh's last cell row / column, singular system).
- * Solved on the device (normal equations, band L D L^T in binary64).  Any mesh size the remap takes (cols x rows x 8 bytes <= 64 KB,
- * up to 167 columns): meshes up to 16 columns and 2048 unknowns (16 x 64 vertices) run the register-window kernels (the 16 x 16 preset:
- * ~0.2 ms), larger or wider ones (17 x 17, 32 x 32, ...) generic kernels with the same arithmetic and the same bits (milliseconds). */
-typedef struct lvk_hip_mesh_solver lvk_hip_mesh_solver;
-int  lvk_hip_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_region_w, float gen_region_h,
-                                float temporal_smoothing, float local_smoothing, int max_points, lvk_hip_mesh_solver** out);
-void lvk_hip_mesh_solver_destroy(lvk_hip_mesh_solver* solver);
-int  lvk_hip_mesh_solver_reset(lvk_hip_mesh_solver* solver);
-int  lvk_hip_mesh_solver_solve(lvk_hip_mesh_solver* solver, const float* tracked, const float* matched, int n, float region_w, float region_h,
-                               float temporal_now, float threshold, uint8_t* inliers, float* offsets);
-
-/* ---- a3/a4: luma + INTER_AREA downscale ---------------------------------------------------------------
- * VideoFrame::viewAsFormat(GRAY) for YUV frames (= channel 0, Data/VideoFrame.cpp:260) fused with
- * cv::resize(gray, detection_resolution, INTER_AREA) (Vision/FrameTracker.cpp:117).
- * pix_stride = bytes per source pixel (3 packed 8UC3, 1 planar); d_dst is 8UC1 drows x dcols.  Any pair of sizes: integer and fractional
- * reductions, and (a frame smaller than the detection resolution) cv::resize's bilinear emulation of INTER_AREA towards a larger image. */
-int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
-                             int srows, int scols, void* d_dst, int dst_step, int drows, int dcols);
-
-/* ---- a7 (pyramid): cv::pyrDown and the Scharr derivative image that cv::SparsePyrLKOpticalFlow::calc builds
- * internally (Vision/FrameTracker.cpp:140-146).  d_dst of pyr_down is ((cols+1)/2) x ((rows+1)/2) 8UC1;
- * d_dst of scharr is rows x cols x (Ix, Iy) int16, tightly packed. */
-int lvk_hip_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
-int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
-
-/* The whole optical-flow pyramid of buildOpticalFlowPyramid (levels until one would be <= the window) plus every
- * level's Scharr image, returned to the host tightly packed level after level.  Returns the level count.  Synchronous. */
-int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, int max_level, int win_w, int win_h,
-                          uint8_t* levels, int16_t* derivs, int* level_rows, int* level_cols);
-
-/* ---- a5 (inner): FAST-9/16 + non-max suppression per detection region -----------------------------------
- * cv::FastFeatureDetector(threshold, true, TYPE_9_16)->detect(frame(region)) (Vision/FeatureDetector.cpp:130-134).
- * regions = nregions x {x, y, w, h, threshold, active} ints; out = nregions x cap keypoints packed as
- * x | y << 12 | score << 24 (region-local, row-major like the CPU detector); counts = nregions totals.
- * Synchronous (returns after the results are on the host). */
-int lvk_hip_fast_detect(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
-                        const int* regions, int nregions, uint32_t* out, int cap, int* counts);
-
-/* ---- a7: cv::SparsePyrLKOpticalFlow::calc(prev, next, prevPts, nextPts, status) -----------------------------
- * (Vision/FrameTracker.cpp:42-48,140-146).  Device images of the tracking resolution, host point arrays
- * (n x 2 floats), status n bytes.  Synchronous. */
-int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const void* d_next, int next_step, int rows, int cols,
-                  const float* prev_pts, int n, float* next_pts, uint8_t* status,
-                  int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
-
 /* ---- section 8f row 2: YUV420 <-> packed YUV444 either side of the filter --------------------------------------
  * I4XXIngest::to_ocl / NV12Ingest::to_ocl (Modules/OBS-Plugin/Interop/FrameIngest.cpp:494-522,567-585): chroma
  * cv::resize(INTER_LINEAR) + merge into the packed 8UC3 frame the filter consumes; and ::to_obs (:526-557,589-602):
@@ -195,21 +162,6 @@ int lvk_hip_ingest_yuv420(lvk_hip_ctx* ctx, const void* d_y, int y_step, const v
                           int rows, int cols, void* d_dst, int dst_step);
 int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
                           void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
-
-/* ---- a9: robust global motion --------------------------------------------------------------------------
- * cv::findHomography(tracked, matched, mask, UsacParams{threshold}) (full_homography != 0) or
- * cv::estimateAffinePartial2D(..., RANSAC, threshold, 50) + Homography::FromAffineMatrix (full_homography == 0)
- * as used by FrameTracker::estimate_global_motion (Vision/FrameTracker.cpp:325-375).  Host point arrays (n x 2
- * floats); H = 3x3 row-major double normalised by H22; mask = n bytes.  (region_w, region_h) = tracking resolution.
- * Returns the inlier count, or a negative value when no model exists (H = identity, mask = 0).  Synchronous.
- * The estimator is the deterministic RANSAC of DESIGN.md (OpenCV's USAC is randomised and not restated). */
-int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const float* pts2, int n, double threshold,
-                                   double region_w, double region_h, int full_homography, double H[9], uint8_t* mask);
-
-/* fast_filter (Functions/Container.tpp:97-121; call site Vision/FrameTracker.cpp:149) as the GPU runs it between the optical
- * flow and the motion estimate: keeps the pairs whose status is non-zero, in the order the reference's back-to-front swap-erase
- * leaves them.  Host arrays (n x 2 floats, n bytes); returns the number of pairs kept (>= 0) or LVK_HIP_ERR_*. */
-int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matched, const uint8_t* status, int n, float* out_prev, float* out_matched);
 
 /* ---- a1/a2: the stabilization filter ----------------------------------------------------------------------
  * lvk_stab_settings flattens lvk::StabilizationFilterSettings (Filters/StabilizationFilter.hpp:28-39) and its bases
@@ -325,21 +277,6 @@ int  lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* stab, const void* h_y, int 
  * VideoFilter::stream's reader thread ending on a failed read, Filters/VideoFilter.cpp:77-103).  Returns once their uploads no longer
  * read the caller's planes.  lvk_hip_stab_restart() implies it. */
 int  lvk_hip_stab_prefetch_cancel(lvk_hip_stab* stab);
-/* Look-ahead for DEVICE-resident frames, for callers that hold the next frame already (VideoFilter::stream's reader thread runs ahead of
- * its filter thread, Filters/VideoFilter.cpp:62-209; a transcoder whose clip is resident): announce frame n + 1, then push frame n.  The
- * push puts the luma downscale and the pyramid of frame n + 1 on the tracking stream behind its own chain, where the GPU runs them during
- * the host's turn, and the push of frame n + 1 starts at the optical flow.  Only the luma is read ahead (Y plane; channel 0 / the grey
- * value of a packed frame); it must not change between the announcement and the return of the push that carries it.  The announcement
- * holds for the very next push only; a push that carries other planes or another geometry, or that does not track, works as if nothing
- * had been announced.  Same pixels either way.  lvk_hip_stab_prefetch_cancel / lvk_hip_stab_restart forget it.
- * lvk_hip_stab_lookahead_frames: the pushes so far that found their pyramid built. */
-int  lvk_hip_stab_prefetch(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, int format);
-int  lvk_hip_stab_prefetch_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step,
-                                  int nv12, int rows, int cols);
-long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* stab);
-int  lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr);      /* pinned, device-visible host memory */
-int  lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr);
-
 /* Optional: run the bulk kernels (4:2:0 ingest, the output remap) on a second, low-priority HIP stream so that they overlap the
  * tracking of the next frame (the reference gets the same effect from OpenCL's asynchronous `run_(..., false)` launches,
  * Functions/Image.cpp:76); the remap then uses its occupancy-capped variants.  With overlap enabled d_out is complete only after
@@ -358,15 +295,34 @@ int  lvk_hip_stab_set_bulk_context(lvk_hip_stab* stab, lvk_hip_ctx* bulk);
  * lvk_hip_sync().  Changes when lvk_hip_stab_set_overlap or stabilize_output change. */
 void* lvk_hip_stab_output_stream(lvk_hip_stab* stab);
 
+
+/* =====================================================================================================================================
+ * PART 2 -- EXPERIMENTAL / DIAGNOSTICS  (no ABI promise: per-stage entry points of the parity tests, taps, profiling, device look-ahead)
+ * ===================================================================================================================================== */
+
+/* Look-ahead for DEVICE-resident frames, for callers that hold the next frame already (VideoFilter::stream's reader thread runs ahead of
+ * its filter thread, Filters/VideoFilter.cpp:62-209; a transcoder whose clip is resident): announce frame n + 1, then push frame n.  The
+ * push puts the luma downscale and the pyramid of frame n + 1 on the tracking stream behind its own chain, where the GPU runs them during
+ * the host's turn, and the push of frame n + 1 starts at the optical flow.  Only the luma is read ahead (Y plane; channel 0 / the grey
+ * value of a packed frame); it must not change between the announcement and the return of the push that carries it.  The announcement
+ * holds for the very next push only; a push that carries other planes or another geometry, or that does not track, works as if nothing
+ * had been announced.  Same pixels either way.  lvk_hip_stab_prefetch_cancel / lvk_hip_stab_restart forget it.
+ * lvk_hip_stab_lookahead_frames: the pushes so far that found their pyramid built. */
+int  lvk_hip_stab_prefetch(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, int format);
+int  lvk_hip_stab_prefetch_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step,
+                                  int nv12, int rows, int cols);
+long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* stab);
+
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
-/* last frame motion (after the trust factor) and last applied correction; each motion_height x motion_width x 2 floats */
 /* Frames on which FeatureDetector::detect ran FAST so far (Vision/FeatureDetector.cpp:125-157), by where the corners went through the
  * suppression grid: on the device inside the tracker's chain of kernels, or in the host loop (grids beyond 4096 cells, detection regions off
  * the pixel grid, LVK_HIP_HOST_GRID=1).  Same features either way; a tap for tests and tuning. */
 int  lvk_hip_stab_detector_frames(const lvk_hip_stab* stab, long long* on_device, long long* on_host);
+/* last frame motion (after the trust factor) and last applied correction; each motion_height x motion_width x 2 floats */
 int  lvk_hip_stab_get_meshes(const lvk_hip_stab* stab, float* motion, float* correction, int cap_floats);
 /* FrameTracker::features(): (x, y, response, age) per tracked feature; returns the total count */
 int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int cap);
+
 
 /* ---- timing (reference: VideoFilter::timings() / Stopwatch::sync_gpu, Filters/VideoFilter.cpp:46-51) ---------
  * Per-stage GPU time from HIP events recorded on the launch stream around each stage's kernels. */
@@ -384,6 +340,79 @@ int  lvk_hip_stab_get_features(const lvk_hip_stab* stab, float* xy_resp_age, int
  * of one push in N only (0 / 1 = every push), which keeps a live measurement from slowing the stream it measures */
 int  lvk_hip_stab_set_profiling(lvk_hip_stab* stab, int enable);
 int  lvk_hip_stab_get_profile(lvk_hip_stab* stab, double total_ms[LVK_STAGE_COUNT], long long launches[LVK_STAGE_COUNT]);
+
+/* native_recip(x) of FSR.cl as the EASU / RCAS kernels of this library evaluate it (v_rcp_f32, what the reference's OpenCL source
+ * compiles to for gfx950), elementwise over n binary32 values on the device.  OpenCL leaves native_recip implementation-defined:
+ * this entry point lets a host (and the parity tests' CPU model of the kernels) read the device's definition. */
+int lvk_hip_native_rcp(lvk_hip_ctx* ctx, const float* d_in, float* d_out, size_t n);
+
+/* ---- a10: local motion estimate (vector-field preset) ---------------------------------------------------------------
+ * FrameTracker::estimate_local_motions with the constraint system of generate_mesh_constraints (Vision/FrameTracker.cpp:200-321,
+ * 380-457) for a mesh of cols x rows vertices: the least-squares positions of the mesh vertices from the tracked -> matched point pairs
+ * (host arrays of n x 2 floats, tracking-frame coordinates), the temporal rows pulling towards the previous solution, which the
+ * solver object keeps (the reference's m_OptimizedMesh; _reset zeroes it like FrameTracker::restart).  gen_region / the smoothing
+ * weights are those in force when the reference (re)generates the constraints (:74-82); region / temporal_now those of the call.
+ * Outputs: inlier flag per pair (L1 reprojection error < threshold) and the cols x rows x 2 normalised backward offsets of the motion
+ * mesh.  Returns 0, or 2 / 3 when no estimate is possible (a point in the mesh's last cell row / column, singular system).
+ * Solved on the device (normal equations, band L D L^T in binary64).  Any mesh size the remap takes (cols x rows x 8 bytes <= 64 KB,
+ * up to 167 columns): meshes up to 16 columns and 2048 unknowns (16 x 64 vertices) run the register-window kernels (the 16 x 16 preset:
+ * ~0.2 ms), larger or wider ones (17 x 17, 32 x 32, ...) generic kernels with the same arithmetic and the same bits (milliseconds). */
+typedef struct lvk_hip_mesh_solver lvk_hip_mesh_solver;
+int  lvk_hip_mesh_solver_create(lvk_hip_ctx* ctx, int cols, int rows, float gen_region_w, float gen_region_h,
+                                float temporal_smoothing, float local_smoothing, int max_points, lvk_hip_mesh_solver** out);
+void lvk_hip_mesh_solver_destroy(lvk_hip_mesh_solver* solver);
+int  lvk_hip_mesh_solver_reset(lvk_hip_mesh_solver* solver);
+int  lvk_hip_mesh_solver_solve(lvk_hip_mesh_solver* solver, const float* tracked, const float* matched, int n, float region_w, float region_h,
+                               float temporal_now, float threshold, uint8_t* inliers, float* offsets);
+
+/* ---- a3/a4: luma + INTER_AREA downscale ---------------------------------------------------------------
+ * VideoFrame::viewAsFormat(GRAY) for YUV frames (= channel 0, Data/VideoFrame.cpp:260) fused with
+ * cv::resize(gray, detection_resolution, INTER_AREA) (Vision/FrameTracker.cpp:117).
+ * pix_stride = bytes per source pixel (3 packed 8UC3, 1 planar); d_dst is 8UC1 drows x dcols.  Any pair of sizes: integer and fractional
+ * reductions, and (a frame smaller than the detection resolution) cv::resize's bilinear emulation of INTER_AREA towards a larger image. */
+int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
+                             int srows, int scols, void* d_dst, int dst_step, int drows, int dcols);
+
+/* ---- a7 (pyramid): cv::pyrDown and the Scharr derivative image that cv::SparsePyrLKOpticalFlow::calc builds
+ * internally (Vision/FrameTracker.cpp:140-146).  d_dst of pyr_down is ((cols+1)/2) x ((rows+1)/2) 8UC1;
+ * d_dst of scharr is rows x cols x (Ix, Iy) int16, tightly packed. */
+int lvk_hip_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step);
+int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst);
+
+/* The whole optical-flow pyramid of buildOpticalFlowPyramid (levels until one would be <= the window) plus every
+ * level's Scharr image, returned to the host tightly packed level after level.  Returns the level count.  Synchronous. */
+int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, int max_level, int win_w, int win_h,
+                          uint8_t* levels, int16_t* derivs, int* level_rows, int* level_cols);
+
+/* ---- a5 (inner): FAST-9/16 + non-max suppression per detection region -----------------------------------
+ * cv::FastFeatureDetector(threshold, true, TYPE_9_16)->detect(frame(region)) (Vision/FeatureDetector.cpp:130-134).
+ * regions = nregions x {x, y, w, h, threshold, active} ints; out = nregions x cap keypoints packed as
+ * x | y << 12 | score << 24 (region-local, row-major like the CPU detector); counts = nregions totals.
+ * Synchronous (returns after the results are on the host). */
+int lvk_hip_fast_detect(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
+                        const int* regions, int nregions, uint32_t* out, int cap, int* counts);
+
+/* ---- a7: cv::SparsePyrLKOpticalFlow::calc(prev, next, prevPts, nextPts, status) -----------------------------
+ * (Vision/FrameTracker.cpp:42-48,140-146).  Device images of the tracking resolution, host point arrays
+ * (n x 2 floats), status n bytes.  Synchronous. */
+int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const void* d_next, int next_step, int rows, int cols,
+                  const float* prev_pts, int n, float* next_pts, uint8_t* status,
+                  int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold);
+
+/* ---- a9: robust global motion --------------------------------------------------------------------------
+ * cv::findHomography(tracked, matched, mask, UsacParams{threshold}) (full_homography != 0) or
+ * cv::estimateAffinePartial2D(..., RANSAC, threshold, 50) + Homography::FromAffineMatrix (full_homography == 0)
+ * as used by FrameTracker::estimate_global_motion (Vision/FrameTracker.cpp:325-375).  Host point arrays (n x 2
+ * floats); H = 3x3 row-major double normalised by H22; mask = n bytes.  (region_w, region_h) = tracking resolution.
+ * Returns the inlier count, or a negative value when no model exists (H = identity, mask = 0).  Synchronous.
+ * The estimator is the deterministic RANSAC of DESIGN.md (OpenCV's USAC is randomised and not restated). */
+int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const float* pts2, int n, double threshold,
+                                   double region_w, double region_h, int full_homography, double H[9], uint8_t* mask);
+
+/* fast_filter (Functions/Container.tpp:97-121; call site Vision/FrameTracker.cpp:149) as the GPU runs it between the optical
+ * flow and the motion estimate: keeps the pairs whose status is non-zero, in the order the reference's back-to-front swap-erase
+ * leaves them.  Host arrays (n x 2 floats, n bytes); returns the number of pairs kept (>= 0) or LVK_HIP_ERR_*. */
+int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matched, const uint8_t* status, int n, float* out_prev, float* out_matched);
 
 #ifdef __cplusplus
 }

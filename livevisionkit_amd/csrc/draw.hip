@@ -97,14 +97,14 @@ extern "C" {
 
 int lvk_hip_draw_grid(lvk_hip_ctx* ctx, void* d_dst, int dst_step, int rows, int cols, int grid_w, int grid_h, const uint8_t colour[3], int thickness)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_draw_grid(ctx, ctx->stream, d_dst, dst_step, rows, cols, grid_w, grid_h, colour, thickness);
 }
 
 int lvk_hip_draw_crosses(lvk_hip_ctx* ctx, void* d_dst, int dst_step, int rows, int cols, const float* pts_xy, int n,
                          float scale_x, float scale_y, const uint8_t colour[3], int cross_size, int thickness)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_draw_crosses(ctx, ctx->stream, d_dst, dst_step, rows, cols, pts_xy, n, scale_x, scale_y, colour, cross_size, thickness);
 }
 

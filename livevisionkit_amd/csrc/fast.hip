@@ -221,13 +221,6 @@ __global__ __launch_bounds__(INS_NT)
 void k_fast_insert(int nregions, FastInsertArgs a)
 {
     LVK_TRACKER_PRIORITY();
-#ifdef LVK_INS_TIMING
-    long long tk[8]; int ntk = 0;
-#define INS_MARK() do { tk[ntk++] = wall_clock64(); } while (0)
-#else
-#define INS_MARK() do { } while (0)
-#endif
-    INS_MARK();
     extern __shared__ __attribute__((aligned(16))) uint8_t ins_smem[];
     const int bwords = (a.nkeys + 31) / 32;
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(ins_smem);
@@ -255,7 +248,6 @@ void k_fast_insert(int nregions, FastInsertArgs a)
     if (t < nregions && my_count) a.region_count[t] = 0;
     if (t < 16) s_bucket[t] = a.occ_bucket[t];
     __syncthreads();
-    INS_MARK();
 
     // the cells that received a corner and hold no propagated feature: their first corner's key into the bitmap; slots cleared for the next
     // frame.  The distribution buckets of the PROPAGATED cells come counted from the host (it marked them); only the new cells are counted
@@ -272,7 +264,6 @@ void k_fast_insert(int nregions, FastInsertArgs a)
         }
     }
     __syncthreads();
-    INS_MARK();
     // exclusive prefix popcount over the bitmap words: consecutive words per thread, one wave scan, one barrier
     const int wpt = (bwords + INS_NT - 1) / INS_NT, wb0 = t * wpt, wb1 = min(wb0 + wpt, bwords);
     int mine = 0;
@@ -290,7 +281,6 @@ void k_fast_insert(int nregions, FastInsertArgs a)
 #pragma unroll 1
     for (int w = wb0; w < wb1; w++) { s_pre[w] = (unsigned short)run; run += __popc(s_bits[w]); }
     __syncthreads();
-    INS_MARK();
 
     // the winners, in the order of their cells' first corners: the record rode along in the lower half of the slot
 #pragma unroll
@@ -303,7 +293,6 @@ void k_fast_insert(int nregions, FastInsertArgs a)
             a.pts[a.n_held + pos] = make_float2((float)(rec & 0xFFFu), (float)((rec >> 12) & 0xFFFu));
             a.new_kp[pos] = rec;
         }
-    INS_MARK();
 
     // distribution quality over the occupied cells, the early-outs and the model choice
     if (t < nregions) a.counts[t] = s_count[t];
@@ -331,11 +320,6 @@ void k_fast_insert(int nregions, FastInsertArgs a)
         a.result[0] = n_new; a.result[1] = n_eff; a.result[2] = __float_as_int(q); a.result[3] = full; a.result[4] = total;
         *a.d_n = n_eff; *a.d_full = full;
     }
-#ifdef LVK_INS_TIMING
-    INS_MARK();
-    if (t == 0) printf("k_fast_insert (100 MHz ticks): loads+init %lld, slots+buckets %lld, prefix %lld, winners %lld, verdict %lld | new %d\n",
-                       tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], n_new);
-#endif
 }
 
 } // namespace
@@ -419,7 +403,7 @@ extern "C" {
 int lvk_hip_fast_detect(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols,
                         const int* regions, int nregions, uint32_t* out, int cap, int* counts)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, regions && out && counts && nregions > 0 && cap > 0);
     std::vector<FastRegion> rg((size_t)nregions);
     int max_rw = 1, max_rh = 1;

@@ -626,19 +626,19 @@ extern "C" {
 int lvk_hip_luma_area_resize(lvk_hip_ctx* ctx, const void* d_src, int src_step, int pix_stride, int channel,
                              int srows, int scols, void* d_dst, int dst_step, int drows, int dcols)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_luma_area_resize(ctx, d_src, src_step, pix_stride, channel, srows, scols, d_dst, dst_step, drows, dcols);
 }
 
 int lvk_hip_pyr_down(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_pyr_down(ctx, d_src, src_step, rows, cols, d_dst, dst_step);
 }
 
 int lvk_hip_scharr(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_scharr(ctx, d_src, src_step, rows, cols, d_dst);
 }
 

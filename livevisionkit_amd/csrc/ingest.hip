@@ -126,12 +126,8 @@ void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_
     {
         // odd row 2k - 1: weights (3/4, 1/4) on chroma rows (k - 1, k); even row 2k: (1/4, 3/4)
         const uint32_t u0 = tu0[p], u1 = tu1[p], v0 = tv0[p], v1 = tv1[p];
-#ifdef LVK_INGEST_CHEAP_PROBE      // timing probe only (scripts/ingest_cost_probe.sh): WRONG pixels, about half the arithmetic -- what would a cheaper conversion buy?
-        const uint32_t ua = u0 >> 4, ub = u1 >> 4, va = v0 >> 4, vb = v1 >> 4;
-#else
         const uint32_t ua = ((((u0 + u0 + u0) >> 2) + (u1 >> 2) + 2u) >> 2), ub = (((u0 >> 2) + ((u1 + u1 + u1) >> 2) + 2u) >> 2);
         const uint32_t va = ((((v0 + v0 + v0) >> 2) + (v1 >> 2) + 2u) >> 2), vb = (((v0 >> 2) + ((v1 + v1 + v1) >> 2) + 2u) >> 2);
-#endif
         pa[p] = ((ywa >> (8 * p)) & 0xffu) | (ua << 8) | (va << 16);
         pb[p] = ((ywb >> (8 * p)) & 0xffu) | (ub << 8) | (vb << 16);
     }
@@ -258,39 +254,19 @@ int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
     return LVK_HIP_OK;
 }
 
-// Plain byte mover for planes that cross the host link under the library's control (lvk_hip_stab_push_yuv420_host): a few workgroups
-// with 16-byte accesses saturate the link (scripts/pcie_probe.hip: 64 blocks = 52-56 GB/s either way) and leave the CUs to the filter.
-__global__ __launch_bounds__(256)
-void k_copy_bytes(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
-    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
-}
-
-int lvk_launch_copy_bytes(lvk_hip_ctx* ctx, hipStream_t stream, void* dst, const void* src, size_t bytes, int blocks)
-{
-    LVK_HIP_REQUIRE(ctx, dst && src && ((uintptr_t)dst & 15) == 0 && ((uintptr_t)src & 15) == 0 && blocks > 0);
-    const size_t n16 = bytes / 16; const int tail = (int)(bytes - n16 * 16);
-    hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, n16,
-                       (const uint8_t*)src + n16 * 16, (uint8_t*)dst + n16 * 16, tail);
-    LVK_HIP_CHECK(ctx, hipGetLastError());
-    return LVK_HIP_OK;
-}
-
 extern "C" {
 
 int lvk_hip_ingest_yuv420(lvk_hip_ctx* ctx, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
                           int rows, int cols, void* d_dst, int dst_step)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_ingest_yuv420(ctx, ctx->stream, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, d_dst, dst_step);
 }
 
 int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
                           void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_egress_yuv420(ctx, ctx->stream, d_src, src_step, rows, cols, d_y, y_step, d_u, u_step, d_v, v_step, nv12);
 }
 

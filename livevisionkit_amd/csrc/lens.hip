@@ -146,7 +146,7 @@ extern "C" {
 int lvk_hip_lens_undistort_points(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, double sx, double sy,
                                   const float* pts, int n, float* out)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, params && pts && out && n >= 0);
     if (n == 0) return LVK_HIP_OK;
     LensModel m;
@@ -167,7 +167,7 @@ int lvk_hip_lens_undistort_points(lvk_hip_ctx* ctx, const lvk_camera_params* par
 
 int lvk_hip_lens_map_create(lvk_hip_ctx* ctx, const lvk_camera_params* params, int rows, int cols, void** d_map, int view_xywh[4])
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, params && d_map && rows > 1 && cols > 1 && params->fx != 0.0 && params->fy != 0.0);
     std::vector<float> off; int view[4];
     build_offsets(*params, rows, cols, off, view);
@@ -182,7 +182,7 @@ int lvk_hip_lens_map_create(lvk_hip_ctx* ctx, const lvk_camera_params* params, i
 
 int lvk_hip_lens_map_destroy(lvk_hip_ctx* ctx, void* d_map)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     LVK_HIP_CHECK(ctx, hipFree(d_map));
     return LVK_HIP_OK;

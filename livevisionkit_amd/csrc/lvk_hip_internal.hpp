@@ -90,6 +90,11 @@ struct lvk_device_guard
     lvk_device_guard& operator=(const lvk_device_guard&) = delete;
 };
 
+// First statement of every public entry point that takes a context and touches the HIP runtime: NULL check + device guard
+#define LVK_HIP_ENTRY(ctx)                         \
+    if (!(ctx)) return LVK_HIP_ERR_ARG;            \
+    lvk_device_guard lvk_entry_device_guard(ctx)
+
 #define LVK_HIP_CHECK(ctx, expr)                                                                      \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
@@ -103,6 +108,12 @@ struct lvk_device_guard
 #define LVK_TRACKER_PRIO 3
 #endif
 #define LVK_TRACKER_PRIORITY() __builtin_amdgcn_s_setprio(LVK_TRACKER_PRIO)
+
+// Instrumented kernels (in-kernel clocks, printf) never go into the product library: the defines below are only accepted together with
+// -DLVK_PROBE_BUILD, which scripts/variant_build.sh passes for the variants under livevisionkit_amd/variants/ (round-4 ADVICE).
+#if (defined(LVK_TIMELINE) || defined(LVK_RANSAC_TIMING) || defined(LVK_MESH_TIMING)) && !defined(LVK_PROBE_BUILD)
+#error "instrumented build: pass -DLVK_PROBE_BUILD (scripts/variant_build.sh); never the library the tests and the bench load by default"
+#endif
 
 // Debug builds with -DLVK_TIMELINE (scripts/timeline_build.sh): every instrumented kernel logs the wall clock (100 MHz) at which its
 // first block started and its last block finished into a per-translation-unit ring, read back by lvk_tl_read_<unit>().  rocprofv3's
@@ -254,7 +265,6 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
 int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                              void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
 
-int lvk_launch_copy_bytes(lvk_hip_ctx* ctx, hipStream_t stream, void* dst, const void* src, size_t bytes, int blocks);      // 16-byte aligned
 
 int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                          void* d_dst, int dst_step, const void* d_map, int map_step, const uint8_t bg[3], int yuv);

@@ -878,7 +878,7 @@ extern "C" {
 int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const float* pts2, int n, double threshold,
                                    double region_w, double region_h, int full_homography, double H[9], uint8_t* mask)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, pts1 && pts2 && H && mask && n >= 0);
     for (int q = 0; q < 9; q++) H[q] = (q % 4 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < n; i++) mask[i] = 0;
@@ -910,7 +910,7 @@ int lvk_hip_estimate_global_motion(lvk_hip_ctx* ctx, const float* pts1, const fl
 // Synchronous test entry point of the GPU-side fast_filter: host arrays in, compacted pairs + count out.
 int lvk_hip_fast_filter(lvk_hip_ctx* ctx, const float* prev, const float* matched, const uint8_t* status, int n, float* out_prev, float* out_matched)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, prev && matched && status && out_prev && out_matched && n >= 0 && n <= CMP_CAP);
     if (n == 0) return 0;
     float2 *d = nullptr, *h_m = nullptr; uint8_t *d_s = nullptr, *h_s = nullptr; int *d_c = nullptr, *h_c = nullptr;

@@ -568,7 +568,7 @@ int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const voi
                   const float* prev_pts, int n, float* next_pts, uint8_t* status,
                   int win_w, int win_h, int max_level, int max_count, double epsilon, double min_eig_threshold)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, d_prev && d_next && rows > 0 && cols > 0 && n >= 0 && (n == 0 || (prev_pts && next_pts && status)));
     DevicePyramid P, N;
     int rc;
@@ -604,7 +604,7 @@ int lvk_hip_pyrlk(lvk_hip_ctx* ctx, const void* d_prev, int prev_step, const voi
 int lvk_hip_build_pyramid(lvk_hip_ctx* ctx, const void* d_img, int step, int rows, int cols, int max_level, int win_w, int win_h,
                           uint8_t* levels, int16_t* derivs, int* level_rows, int* level_cols)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, d_img && levels && derivs && level_rows && level_cols && rows > 0 && cols > 0);
     DevicePyramid P;
     int rc;

@@ -46,6 +46,10 @@ __device__ __forceinline__ float rcp_cl(float x)
 
 struct F3 { float x, y, z; };
 
+// (Round 5, measured and rejected: the 256 products convert_float(uchar) * norm_factor in an LDS table, one ds_read_b32 per channel behind a
+//  byte-select shift instead of v_cvt_f32_ubyteN + v_mul_f32 -- 36 VALU instructions per pixel fewer (1 949 instead of 2 066 static per
+//  4-pixel thread, same bits), and 94.5 instead of 82.5 us alone / 117.5 instead of 109.3 us next to the tracker: 36 data-dependent LDS reads
+//  per pixel cost more in the LDS pipe than the 36 instructions they save in the VALU.  profiles/r05_ab_remap_lds_table.txt.)
 __device__ __forceinline__ F3 unpack3(uint32_t lo_bytes)   // bytes 0,1,2 of the dword
 {
     const float norm_factor = 0.00392156862f;               // FSR.cl:205
@@ -913,7 +917,7 @@ int lvk_hip_remap_homography(lvk_hip_ctx* ctx,
                              void* d_dst, int dst_step, int dst_rows, int dst_cols,
                              int off_x, int off_y, const float H[9], const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_remap_homography(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, dst_rows, dst_cols, off_x, off_y, H, bg, yuv);
 }
 
@@ -922,21 +926,21 @@ int lvk_hip_remap_mesh(lvk_hip_ctx* ctx,
                        void* d_dst, int dst_step,
                        const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_remap_mesh(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
 }
 
 int lvk_hip_remap_map(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
                       const void* d_map, int map_step, const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_remap_map(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, d_map, map_step, bg, yuv);
 }
 
 int lvk_hip_warpmesh_apply_lens(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step,
                                 const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv, const lvk_camera_params* lens)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, lens != nullptr && rows > 1 && cols > 1);
     LensModel m; LensArgs a;
     const int rc = lvk_lens_model_build(*lens, rows, cols, m);
@@ -949,7 +953,7 @@ int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_s
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
                                   const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3])
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_warpmesh_apply_420(ctx, ctx->stream, d_src, src_step, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12,
                                          mesh, mesh_rows, mesh_cols, bg, nullptr, false);
 }
@@ -957,7 +961,7 @@ int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_s
 int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_rows, int src_cols,
                     void* d_dst, int dst_step, int dst_rows, int dst_cols, int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_upscale(ctx, ctx->stream, d_src, src_step, src_rows, src_cols, d_dst, dst_step, dst_rows, dst_cols, yuv);
 }
 
@@ -966,7 +970,7 @@ int lvk_hip_warpmesh_apply(lvk_hip_ctx* ctx,
                            void* d_dst, int dst_step,
                            const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], int yuv)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_warpmesh_apply(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, mesh, mesh_rows, mesh_cols, bg, yuv);
 }
 

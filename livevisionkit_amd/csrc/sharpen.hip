@@ -200,7 +200,7 @@ int lvk_launch_sharpen(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, 
 
 extern "C" int lvk_hip_sharpen(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols, void* d_dst, int dst_step, float sharpness)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     return lvk_launch_sharpen(ctx, ctx->stream, d_src, src_step, rows, cols, d_dst, dst_step, sharpness);
 }
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_native_rcp(const float* __restrict__ in
 
 extern "C" int lvk_hip_native_rcp(lvk_hip_ctx* ctx, const float* d_in, float* d_out, size_t n)
 {
-    if (!ctx) return LVK_HIP_ERR_ARG;
+    LVK_HIP_ENTRY(ctx);
     LVK_HIP_REQUIRE(ctx, d_in != nullptr && d_out != nullptr);
     if (n == 0) return LVK_HIP_OK;
     const size_t blocks = (n + 255) / 256;

@@ -1,0 +1,323 @@
+// State of one stabilization filter (struct lvk_hip_stab) shared by the translation units that implement it:
+//   stab_configure.hip   allocation, configure / restart / overlap / profiling / overlays / taps  (StabilizationFilter.cpp:42-65,139-206)
+//   stabilizer.hip       the per-frame schedule: track(), push_impl(), the packed and the 4:2:0 device entry points  (:69-135, FrameTracker.cpp:108-196)
+//   stab_hostio.hip      frames in host memory: staging planes, transfer streams, deferred downloads, upload look-ahead  (FrameIngest.cpp:415-474,567-602)
+//   stab_lookahead.hip   device-resident frames announced one push ahead  (VideoFilter.cpp:62-209: the reader thread runs ahead of the filter)
+// Not installed; the C-ABI is include/lvk_hip.h.
+#pragma once
+#include "lvk_hip_internal.hpp"
+#include "host_logic.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+
+namespace lvkstab {
+
+using lvkh::Feature;
+using lvkh::WarpMeshF;
+
+constexpr int LK_WIN = 11, LK_LEVELS = 3, LK_ITERS = 5;        // FrameTracker.cpp:33-35
+constexpr double LK_EPS = 0.01, LK_MIN_EIG = 1e-4;
+constexpr float HOMOGRAPHY_DISTRIBUTION_THRESHOLD = 0.6f;      // FrameTracker.cpp:37
+constexpr float QA_UPDATE_RATE = 0.1f, QA_BLEND_STEP = 0.05f;   // StabilizationFilter.cpp:30-31
+
+inline float step_toward(float current, float target, float amount)   // Functions/Math.tpp:133-142
+{
+    return current > target ? std::max(current - amount, target) : std::min(current + amount, target);
+}
+
+// Host-side wall-clock trace of one push (LVK_HIP_HOST_TRACE=1: summary on stderr at destroy) -- development aid
+struct HostTrace
+{
+    enum { ENTER, DOWN_PYR_LAUNCH, FAST_SYNC, GRID, LK_LAUNCH, LK_SYNC, FILTER, RANSAC_LAUNCH, RANSAC_SYNC, POST, SMOOTH, REMAP_LAUNCH, EXIT, EMIT_WAITS, EMIT_KERNEL, EMIT_EVENT, EXIT_PRE, EXIT_WAIT, N };
+    bool on = std::getenv("LVK_HIP_HOST_TRACE") != nullptr;
+    double acc[N] = {0}; long cnt[N] = {0};
+    std::chrono::steady_clock::time_point last;
+    void begin() { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(int k)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(now - last).count(); cnt[k]++; last = now;
+    }
+    void dump() const
+    {
+        if (!on) return;
+        static const char* names[N] = {"enter", "downscale+pyramid launch", "fast launch+sync", "grid (host)", "lk upload+launch", "lk sync", "filter (host)",
+                                       "ransac upload+launch", "ransac sync", "post (host)", "qa+smoother (host)", "remap launch", "exit",
+                                       "  emit: stream waits", "  emit: remap kernel launch", "  emit: slot event record", "  exit: up to the conversion wait", "  exit: conversion wait"};
+        double total = 0; long frames = cnt[DOWN_PYR_LAUNCH] ? cnt[DOWN_PYR_LAUNCH] : 1;
+        for (int i = 0; i < N; i++) total += acc[i];
+        std::fprintf(stderr, "[lvk host trace] %ld frames, %.1f us/frame inside push\n", frames, total / frames);
+        for (int i = 0; i < N; i++) if (cnt[i]) std::fprintf(stderr, "  %-28s %8.1f us/frame (%ld marks)\n", names[i], acc[i] / frames, cnt[i]);
+    }
+};
+
+struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; int format; };
+
+
+// planes of a 4:2:0 output: when given, a warped frame leaves through the fused remap + egress kernel instead of d_out
+struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; };
+
+} // namespace lvkstab
+
+struct lvk_hip_stab
+{
+    using Feature = lvkstab::Feature; using WarpMeshF = lvkstab::WarpMeshF; using QueuedFrame = lvkstab::QueuedFrame; using HostTrace = lvkstab::HostTrace;
+    using OutPlanes420 = lvkstab::OutPlanes420;
+    lvk_hip_ctx* ctx = nullptr;
+    lvk_stab_settings s{};
+    bool configured = false;
+    bool buffers_ok = false;                   // the tracker's buffers match the committed settings (false after a failed allocation)
+
+    // ---- tracker device state
+    DevicePyramid pyr[2];
+    int cur = 0;                               // pyr[cur] = current frame, pyr[cur ^ 1] = previous frame
+    int pyr_w = 0, pyr_h = 0;                  // resolution the pyramids are allocated for
+    int prev_w = 0, prev_h = 0, cur_w = 0, cur_h = 0;
+    bool initialized = false;
+    size_t cap_features = 0;                   // suppression-grid capacity (max features)
+    int fast_cap = 0, fast_max_rw = 0, fast_max_rh = 0, fast_regions = 0;
+    void* d_fast_masks = nullptr; void* d_fast_scores = nullptr;
+    float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr; uint8_t* d_status = nullptr;      // d_p1: 2 * cap_features pairs (p1 | p2)
+    void* d_ransac_ws = nullptr;
+    int* d_count = nullptr;                    // number of matches after the GPU-side fast_filter
+    // the suppression grid on the device (fast.hip k_fast_insert): the grid's tables, the point count / model choice the chain's kernels read,
+    // and (pinned) which cells hold propagated features, the new features and the kernel's verdicts
+    uint16_t* d_grid_col = nullptr; uint32_t* d_grid_row = nullptr; uint8_t* d_grid_bucket = nullptr;
+    uint32_t* d_cell_first = nullptr; void* d_cell_best = nullptr; int* d_region_count = nullptr;      // per-cell slots / per-region counters the detector folds its corners into
+    int* d_n_points = nullptr; int* d_full = nullptr;
+    uint32_t* h_occ = nullptr; uint32_t* h_new_kp = nullptr; int* h_insert = nullptr;
+    bool device_grid = [] { const char* e = std::getenv("LVK_HIP_HOST_GRID"); return !(e && e[0] == '1'); }();      // LVK_HIP_HOST_GRID=1: the host loop (A/B, tests)
+    long device_grid_frames = 0, host_grid_frames = 0;
+    float2* d_und = nullptr;                   // fused lens mode, chained path: lens-corrected (previous | matched) positions
+    // pinned host mirrors
+    uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
+    float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr; uint8_t* h_status = nullptr;
+    double* h_H = nullptr; int* h_ninl = nullptr; uint8_t* h_mask = nullptr;
+    int* h_count = nullptr;                    // d_count as the GPU-side fast_filter reported it (checked against the host's own)
+    float2* h_und = nullptr;                   // fused lens mode: lens-corrected (previous | matched) point positions
+
+    // ---- fused lens pre-warp (lvk_hip_stab_set_lens): model of the current frame size
+    bool lens = false;
+    lvk_camera_params lens_params{};
+    LensModel lens_model{}; LensArgs lens_args{};
+    int lens_rows = 0, lens_cols = 0;
+    int ensure_lens(int rows, int cols)
+    {
+        if (!lens || (rows == lens_rows && cols == lens_cols)) return LVK_HIP_OK;
+        if (lvk_lens_model_build(lens_params, rows, cols, lens_model) != LVK_HIP_OK) return fail(LVK_HIP_ERR_ARG, "invalid camera profile for this frame size");
+        std::memcpy(lens_args.f, lens_model.f, sizeof(lens_args.f));
+        lens_rows = rows; lens_cols = cols;
+        return LVK_HIP_OK;
+    }
+
+    HostTrace trace;
+
+    // ---- host state
+    lvkh::FeatureGridH grid;
+    lvkh::PathSmootherH smoother;
+    // FrameTracker's m_MeshConstraints + m_OptimizedMesh live on the device (mesh.hip); the parameters the constraints were generated with:
+    struct MeshGen { int cols = 0, rows = 0; float w = 0, h = 0, temporal = 0, local = 0; } mesh_gen;
+    lvk_mesh_solver_dev* mesh_dev = nullptr;
+    void* d_mesh_scratch = nullptr; float* h_offsets = nullptr; int* h_mesh_status = nullptr; size_t h_offsets_floats = 0;
+    lvk_stab_settings tracker_s{};             // FrameTracker::m_Settings (what the tracker was last configured with)
+    std::vector<Feature> tracked;
+    std::vector<FastRegion> plan;
+    std::deque<QueuedFrame> queue;
+    size_t queue_capacity = 1;
+    float tracking_stability = 0.0f, scene_quality = 0.0f, trust = 0.0f;
+    // taps for stats / tests
+    float last_distribution = 0.0f; int last_detected = 0, last_matched = 0;
+    double last_H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    WarpMeshF last_motion, last_correction;
+
+    // ---- optional overlap of the output remap with the next frame's tracking (second stream)
+    bool overlap = false;
+    hipStream_t remap_stream = nullptr;
+    bool remap_stream_owned = false;             // created by lvk_hip_stab_set_overlap (else: the caller's, lvk_hip_stab_set_bulk_context)
+    hipEvent_t remap_done[2] = {nullptr, nullptr};
+    int remap_slot = 0;
+    const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
+    bool pool_frames = false;                  // the queued frames are pool slots that only stream-ordered kernels of remap_stream touch
+    int queue_kind = 0;                        // who owns the queued frames: 0 = queue empty, 1 = borrowed from the caller, 2 = pool slots
+    std::function<int()> deferred_ingest;      // the newest frame's 4:2:0 conversion, not yet launched (see lvk_hip_stab_push_yuv420)
+    int run_deferred_ingest() { auto f = std::move(deferred_ingest); deferred_ingest = nullptr; return f ? f() : LVK_HIP_OK; }
+    hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame
+    // Overlap mode with a frame delay: the conversion runs on the TRACKING stream, in the slot that stream has free between the last
+    // kernel of a frame's chain and the first of the next frame's (the host's turn: ~25 us) -- behind an event the push waits on instead
+    // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which
+    // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
+    hipEvent_t chain_done = nullptr;
+    bool ingest_on_tracker = false, tracker_ingest_capable = false;
+    bool bulk_busy_at_push = false;            // the previous remap was still running when this push began
+    // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
+    // for its frames synchronises and reads back in between: at least a remap's duration)
+    bool caller_runs_free = false;
+    std::chrono::steady_clock::time_point last_push_end{};
+    // tests: LVK_HIP_INGEST_PLACEMENT=tracker|bulk pins the placement that is otherwise decided per push (see track())
+    int ingest_placement = [] { const char* e = std::getenv("LVK_HIP_INGEST_PLACEMENT"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
+    std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr
+    std::vector<char> slot_read_armed;
+    int slot_index(const void* p) const { for (size_t i = 0; i < pool_all.size(); i++) if (pool_all[i] == p) return (int)i; return -1; }
+    int pending_slot = -1;
+    // Overlap mode: what the caller enqueued on the context's stream before a push (a decode / copy that fills the frame or the planes)
+    // must be visible to the kernels of the bulk stream that read it.  The event is recorded when the push starts -- before the tracker's
+    // own kernels, so that the bulk stream never waits for those -- and the bulk stream waits for it ahead of its first launch of the push.
+    hipEvent_t caller_ready = nullptr;
+    bool caller_wait_pending = false;
+    int mark_caller_work()
+    {
+        if (!(overlap && s.stabilize_output && remap_stream)) return LVK_HIP_OK;
+        // nothing pending on the context's stream (the steady state of a caller whose frames are already resident): nothing to order
+        if (hipStreamQuery(ctx->stream) == hipSuccess) { caller_wait_pending = false; return LVK_HIP_OK; }
+        (void)hipGetLastError();
+        if (!caller_ready) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&caller_ready, hipEventDisableTiming));
+        LVK_HIP_CHECK(ctx, hipEventRecord(caller_ready, ctx->stream));
+        caller_wait_pending = true;
+        return LVK_HIP_OK;
+    }
+    int bulk_stream_sees_caller_work()
+    {
+        if (!caller_wait_pending) return LVK_HIP_OK;
+        caller_wait_pending = false;
+        LVK_HIP_CHECK(ctx, hipStreamWaitEvent(remap_stream, caller_ready, 0));
+        return LVK_HIP_OK;
+    }
+    // Borrowed frames that left the queue outside a push (queue shrunk by configure(), overlap / stabilize_output toggled while a remap
+    // was pending): handed back through *released by the following pushes, one per push.
+    std::deque<const void*> orphaned;
+
+    // ---- optional per-stage GPU timing (HIP events on the launch stream)
+    bool profiling = false;
+    unsigned prof_mask = ~0u;                  // stages that are timed while profiling is on (bit = LVK_STAGE_*)
+    unsigned prof_every = 1, prof_tick = 0;    // time the stages of one push in `prof_every` (the event records cost host time per frame)
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> ev_pool; size_t ev_used = 0;
+    double prof_ms[LVK_STAGE_COUNT] = {0}; long prof_n[LVK_STAGE_COUNT] = {0};
+    int prof_begin(int kind, hipStream_t stream = nullptr);
+    void prof_end(int idx, hipStream_t stream = nullptr);
+    int prof_collect();
+
+    int fail(int code, const std::string& msg) { return ctx->fail(code, msg); }
+    void free_tracker_buffers();
+    int alloc_tracker_buffers();
+    int alloc_pyramids();
+    int configure(const lvk_stab_settings& st);
+    void tracker_restart();
+    void reset_context() { tracker_restart(); smoother.restart(); }
+    // Chained path: the host's own fast_filter pass, the ageing of the features and the re-seeding of the suppression grid are not
+    // needed to launch the remap (the motion estimate, the match count and the inlier mask come from the GPU): they run after the
+    // launch, before the push returns.  post_n >= 0: pending for a frame with post_n tracked points / post_m matches.
+    int post_n = -1, post_m = 0;
+    bool post_error = false;
+    void finish_post();
+    int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion);
+
+    // ---- host-resident frames (lvk_hip_stab_push_yuv420_host): the transfers either side of the 4:2:0 path.  One copy stream per
+    // direction (scripts/pcie_probe.hip, profiles/r03_pcie_probe.txt: ONE copy engine stream each way moves 46.8 GB/s each way at once,
+    // two per direction fall to 31), the luma plane first so that the tracker starts while the chroma planes are still on the link.
+    struct HostIO
+    {
+        static constexpr int K_IN = 2, K_OUT = 3;
+        hipStream_t up = nullptr, down = nullptr, down2 = nullptr;
+        struct Pending { bool valid = false; int slot = 0; void* y; void* u; void* v; int ys, us, vs, nv12; } pending;      // a download not yet handed to the copy engine
+        int rows = 0, cols = 0;
+        void* d_in[K_IN] = {nullptr, nullptr}; void* d_out[K_OUT] = {nullptr, nullptr, nullptr};      // contiguous planes: Y | U | V  (or Y | UV)
+        hipEvent_t y_done[K_IN] = {}, c_done[K_IN] = {}, out_ready[K_OUT] = {}, down_done[K_OUT] = {};
+        bool down_armed[K_OUT] = {false, false, false};
+        bool y_is_c[K_IN] = {false, false};                      // the slot's frame came as one copy: c_done covers the luma plane too
+        // look-ahead (lvk_hip_stab_prefetch_yuv420_host): the planes whose upload is already under way, and the slot they go to
+        struct Ahead { int slot; const void* key[3]; int rows, cols, nv12; };
+        std::deque<Ahead> ahead;                                // in upload order; a push consumes the oldest
+        const uint8_t* last_dst_lo = nullptr; const uint8_t* last_dst_hi = nullptr;      // luma plane of the newest download's destination
+        int in_next = 0, out_next = 0, last_down = -1;       // last_down: slot of the newest download (its event orders a later direct write behind it)
+        std::chrono::steady_clock::time_point last_end{};      // when the previous host push returned
+    } hostio;
+    bool host_free_running_hint = false;                 // lvk_hip_stab_push_yuv420_host's own finding, for the push it wraps
+    bool host_direct_now = false;                        // the push being wrapped writes its output planes straight into host memory
+    hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
+    hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
+    int ensure_hostio(int rows, int cols);
+    // The host entry points hand these pointers to copy engines and (output planes) to a kernel: pageable memory there is a GPU fault, not an
+    // error code.  Looked up on EVERY call (hipPointerGetAttributes: ~1 us) -- an address that was pinned once may be pageable memory the next
+    // time it is seen (hipHostFree / hipHostUnregister, then malloc) -- and at BOTH ends of the byte range, so that a plane that runs past
+    // its registration is refused too.
+    int require_pinned(const void* p, size_t bytes, const char* what)
+    {
+        if (!p || bytes == 0) return LVK_HIP_OK;
+        for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + (bytes - 1)})
+        {
+            hipPointerAttribute_t attr{};
+            const hipError_t e = hipPointerGetAttributes(&attr, q);
+            if (e != hipSuccess) (void)hipGetLastError();
+            if (e != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeDevice))
+                return fail(LVK_HIP_ERR_ARG, std::string(what) + ": the planes of the host entry points must be PINNED host memory "
+                                             "(lvk_hip_host_malloc, hipHostMalloc or hipHostRegister) over their whole extent; this pointer is pageable memory");
+        }
+        return LVK_HIP_OK;
+    }
+    // the planes of one 4:2:0 frame: one range when they are contiguous (the OBS layout), else plane by plane
+    int require_pinned_planes(const void* y, int y_step, const void* u, int u_step, const void* v, int v_step, int nv12, int rows, int cols, const char* what)
+    {
+        if (!y) return LVK_HIP_OK;
+        const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;
+        const size_t yb = (size_t)y_step * (rows - 1) + cols, ub = (size_t)u_step * (crows - 1) + ccols, vb = nv12 ? 0 : (size_t)v_step * (crows - 1) + ccols;
+        const uint8_t* ye = (const uint8_t*)y + yb; const uint8_t* ue = (const uint8_t*)u + ub;
+        if (y_step == cols && u_step == ccols && (const uint8_t*)u == ye && (nv12 || (v_step == ccols && (const uint8_t*)v == ue)))
+            return require_pinned(y, yb + ub + vb, what);
+        int rc;
+        if ((rc = require_pinned(y, yb, what)) != LVK_HIP_OK || (rc = require_pinned(u, ub, what)) != LVK_HIP_OK) return rc;
+        return nv12 ? LVK_HIP_OK : require_pinned(v, vb, what);
+    }
+    int host_stream(hipStream_t& s)                          // a transfer stream, created on first use; lvk_hip_sync() covers it
+    {
+        if (s) return LVK_HIP_OK;
+        LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        ctx->aux_streams.push_back(s);
+        return LVK_HIP_OK;
+    }
+    int flush_download(bool wait);
+    int cancel_lookahead();
+    // ---- look-ahead for DEVICE-resident frames (lvk_hip_stab_prefetch / _yuv420): the luma of the frame the next push will carry.  Its
+    // downscale and pyramid are put on the tracking stream BEHIND this push's chain (into the pyramid that becomes `cur` at the next push), where
+    // the GPU runs them during the host's turn between two chains; the next push then starts at the optical flow.
+    struct LumaAhead { const void* luma = nullptr; int step = 0, pix = 0, channel = 0, rows = 0, cols = 0;
+                       bool same(const void* l, int st, int px, int ch, int r, int c) const { return luma && luma == l && step == st && pix == px && channel == ch && rows == r && cols == c; } };
+    LumaAhead ahead_announced;                 // announced, not yet on the stream (cleared by the push that follows, whatever it does with it)
+    LumaAhead ahead_built;                     // what pyr[cur ^ 1] holds already
+    unsigned long long push_seq = 0, ahead_built_for = 0;      // a built pyramid is only good for the very next push
+    long lookahead_frames = 0;
+    hipEvent_t ahead_read_done = nullptr;      // recorded behind the build-ahead kernels: the announced luma plane has been read
+    bool ahead_read_armed = false;
+    void forget_device_lookahead() { ahead_announced = LumaAhead(); ahead_built = LumaAhead(); ahead_built_for = 0; }
+    // lvk_hip_stab_prefetch_cancel / _restart: "returns once the announced planes are no longer read" holds for DEVICE frames too -- a pyramid
+    // that was being built ahead (behind the previous push's chain on the tracking stream) has read its luma plane when this returns
+    int finish_device_lookahead_reads()
+    {
+        if (ahead_read_armed) { ahead_read_armed = false; LVK_HIP_CHECK(ctx, hipEventSynchronize(ahead_read_done)); }
+        return LVK_HIP_OK;
+    }
+    int launch_build_ahead(DevicePyramid& P, int cur_w, int cur_h);      // stab_lookahead.hip
+    int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
+    void free_hostio();
+    bool caller_free_running_now();
+    double host_trace_acc[6] = {0, 0, 0, 0, 0, 0}; long host_trace_n = 0;      // LVK_HIP_HOST_TRACE: us inside lvk_hip_stab_push_yuv420_host, by phase
+    int host_sink_mode = [] { const char* e = std::getenv("LVK_HIP_HOST_SINK"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();      // tests: direct | copy
+
+    // ---- YUV420 front/back end: pool of packed frames the planes are converted into
+    std::vector<void*> pool_all; std::deque<void*> pool_free;      // free slots are reused oldest first: the remap that read a slot is long done
+    void* pool_out = nullptr;
+    int pool_rows = 0, pool_cols = 0;
+    int ensure_pool(int rows, int cols);
+    void free_pool();
+};
+
+// StabilizationFilter::filter (stabilizer.hip); the entry points of the other units wrap it
+int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
+                       const void* luma, int luma_step, int luma_pix,
+                       void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released, lvkstab::OutPlanes420* o420 = nullptr);

@@ -17,561 +17,9 @@
 //   pre-warp composed in, optionally with the 4:2:0 egress fused)                         [ingest.hip, remap.hip]
 // Packed frames are never copied: the filter borrows the caller's device buffer until that frame has been emitted
 // (the reference moves the input frame into its queue, StabilizationFilter.cpp:118).
-#include "lvk_hip_internal.hpp"
-#include "host_logic.hpp"
+#include "stab_state.hpp"
 
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <functional>
-
-using lvkh::Feature;
-using lvkh::WarpMeshF;
-
-namespace {
-
-constexpr int LK_WIN = 11, LK_LEVELS = 3, LK_ITERS = 5;        // FrameTracker.cpp:33-35
-constexpr double LK_EPS = 0.01, LK_MIN_EIG = 1e-4;
-constexpr float HOMOGRAPHY_DISTRIBUTION_THRESHOLD = 0.6f;      // FrameTracker.cpp:37
-constexpr float QA_UPDATE_RATE = 0.1f, QA_BLEND_STEP = 0.05f;   // StabilizationFilter.cpp:30-31
-
-inline float step_toward(float current, float target, float amount)   // Functions/Math.tpp:133-142
-{
-    return current > target ? std::max(current - amount, target) : std::min(current + amount, target);
-}
-
-// Host-side wall-clock trace of one push (LVK_HIP_HOST_TRACE=1: summary on stderr at destroy) -- development aid
-struct HostTrace
-{
-    enum { ENTER, DOWN_PYR_LAUNCH, FAST_SYNC, GRID, LK_LAUNCH, LK_SYNC, FILTER, RANSAC_LAUNCH, RANSAC_SYNC, POST, SMOOTH, REMAP_LAUNCH, EXIT, EMIT_WAITS, EMIT_KERNEL, EMIT_EVENT, EXIT_PRE, EXIT_WAIT, N };
-    bool on = std::getenv("LVK_HIP_HOST_TRACE") != nullptr;
-    double acc[N] = {0}; long cnt[N] = {0};
-    std::chrono::steady_clock::time_point last;
-    void begin() { if (on) last = std::chrono::steady_clock::now(); }
-    void mark(int k)
-    {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        acc[k] += std::chrono::duration<double, std::micro>(now - last).count(); cnt[k]++; last = now;
-    }
-    void dump() const
-    {
-        if (!on) return;
-        static const char* names[N] = {"enter", "downscale+pyramid launch", "fast launch+sync", "grid (host)", "lk upload+launch", "lk sync", "filter (host)",
-                                       "ransac upload+launch", "ransac sync", "post (host)", "qa+smoother (host)", "remap launch", "exit",
-                                       "  emit: stream waits", "  emit: remap kernel launch", "  emit: slot event record", "  exit: up to the conversion wait", "  exit: conversion wait"};
-        double total = 0; long frames = cnt[DOWN_PYR_LAUNCH] ? cnt[DOWN_PYR_LAUNCH] : 1;
-        for (int i = 0; i < N; i++) total += acc[i];
-        std::fprintf(stderr, "[lvk host trace] %ld frames, %.1f us/frame inside push\n", frames, total / frames);
-        for (int i = 0; i < N; i++) if (cnt[i]) std::fprintf(stderr, "  %-28s %8.1f us/frame (%ld marks)\n", names[i], acc[i] / frames, cnt[i]);
-    }
-};
-
-struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; int format; };
-
-} // namespace
-
-struct lvk_hip_stab
-{
-    lvk_hip_ctx* ctx = nullptr;
-    lvk_stab_settings s{};
-    bool configured = false;
-    bool buffers_ok = false;                   // the tracker's buffers match the committed settings (false after a failed allocation)
-
-    // ---- tracker device state
-    DevicePyramid pyr[2];
-    int cur = 0;                               // pyr[cur] = current frame, pyr[cur ^ 1] = previous frame
-    int pyr_w = 0, pyr_h = 0;                  // resolution the pyramids are allocated for
-    int prev_w = 0, prev_h = 0, cur_w = 0, cur_h = 0;
-    bool initialized = false;
-    size_t cap_features = 0;                   // suppression-grid capacity (max features)
-    int fast_cap = 0, fast_max_rw = 0, fast_max_rh = 0, fast_regions = 0;
-    void* d_fast_masks = nullptr; void* d_fast_scores = nullptr;
-    float2 *d_pts = nullptr, *d_matched = nullptr, *d_p1 = nullptr; uint8_t* d_status = nullptr;      // d_p1: 2 * cap_features pairs (p1 | p2)
-    void* d_ransac_ws = nullptr;
-    int* d_count = nullptr;                    // number of matches after the GPU-side fast_filter
-    // the suppression grid on the device (fast.hip k_fast_insert): the grid's tables, the point count / model choice the chain's kernels read,
-    // and (pinned) which cells hold propagated features, the new features and the kernel's verdicts
-    uint16_t* d_grid_col = nullptr; uint32_t* d_grid_row = nullptr; uint8_t* d_grid_bucket = nullptr;
-    uint32_t* d_cell_first = nullptr; void* d_cell_best = nullptr; int* d_region_count = nullptr;      // per-cell slots / per-region counters the detector folds its corners into
-    int* d_n_points = nullptr; int* d_full = nullptr;
-    uint32_t* h_occ = nullptr; uint32_t* h_new_kp = nullptr; int* h_insert = nullptr;
-    bool device_grid = [] { const char* e = std::getenv("LVK_HIP_HOST_GRID"); return !(e && e[0] == '1'); }();      // LVK_HIP_HOST_GRID=1: the host loop (A/B, tests)
-    long device_grid_frames = 0, host_grid_frames = 0;
-    float2* d_und = nullptr;                   // fused lens mode, chained path: lens-corrected (previous | matched) positions
-    // pinned host mirrors
-    uint32_t* h_fast_out = nullptr; int* h_fast_counts = nullptr; FastRegion* h_regions = nullptr;
-    float2 *h_pts = nullptr, *h_matched = nullptr, *h_p1 = nullptr; uint8_t* h_status = nullptr;
-    double* h_H = nullptr; int* h_ninl = nullptr; uint8_t* h_mask = nullptr;
-    int* h_count = nullptr;                    // d_count as the GPU-side fast_filter reported it (checked against the host's own)
-    float2* h_und = nullptr;                   // fused lens mode: lens-corrected (previous | matched) point positions
-
-    // ---- fused lens pre-warp (lvk_hip_stab_set_lens): model of the current frame size
-    bool lens = false;
-    lvk_camera_params lens_params{};
-    LensModel lens_model{}; LensArgs lens_args{};
-    int lens_rows = 0, lens_cols = 0;
-    int ensure_lens(int rows, int cols)
-    {
-        if (!lens || (rows == lens_rows && cols == lens_cols)) return LVK_HIP_OK;
-        if (lvk_lens_model_build(lens_params, rows, cols, lens_model) != LVK_HIP_OK) return fail(LVK_HIP_ERR_ARG, "invalid camera profile for this frame size");
-        std::memcpy(lens_args.f, lens_model.f, sizeof(lens_args.f));
-        lens_rows = rows; lens_cols = cols;
-        return LVK_HIP_OK;
-    }
-
-    HostTrace trace;
-
-    // ---- host state
-    lvkh::FeatureGridH grid;
-    lvkh::PathSmootherH smoother;
-    // FrameTracker's m_MeshConstraints + m_OptimizedMesh live on the device (mesh.hip); the parameters the constraints were generated with:
-    struct MeshGen { int cols = 0, rows = 0; float w = 0, h = 0, temporal = 0, local = 0; } mesh_gen;
-    lvk_mesh_solver_dev* mesh_dev = nullptr;
-    void* d_mesh_scratch = nullptr; float* h_offsets = nullptr; int* h_mesh_status = nullptr; size_t h_offsets_floats = 0;
-    lvk_stab_settings tracker_s{};             // FrameTracker::m_Settings (what the tracker was last configured with)
-    std::vector<Feature> tracked;
-    std::vector<FastRegion> plan;
-    std::deque<QueuedFrame> queue;
-    size_t queue_capacity = 1;
-    float tracking_stability = 0.0f, scene_quality = 0.0f, trust = 0.0f;
-    // taps for stats / tests
-    float last_distribution = 0.0f; int last_detected = 0, last_matched = 0;
-    double last_H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    WarpMeshF last_motion, last_correction;
-
-    // ---- optional overlap of the output remap with the next frame's tracking (second stream)
-    bool overlap = false;
-    hipStream_t remap_stream = nullptr;
-    bool remap_stream_owned = false;             // created by lvk_hip_stab_set_overlap (else: the caller's, lvk_hip_stab_set_bulk_context)
-    hipEvent_t remap_done[2] = {nullptr, nullptr};
-    int remap_slot = 0;
-    const void* pending_release = nullptr;     // frame whose remap is still in flight on remap_stream
-    bool pool_frames = false;                  // the queued frames are pool slots that only stream-ordered kernels of remap_stream touch
-    int queue_kind = 0;                        // who owns the queued frames: 0 = queue empty, 1 = borrowed from the caller, 2 = pool slots
-    std::function<int()> deferred_ingest;      // the newest frame's 4:2:0 conversion, not yet launched (see lvk_hip_stab_push_yuv420)
-    int run_deferred_ingest() { auto f = std::move(deferred_ingest); deferred_ingest = nullptr; return f ? f() : LVK_HIP_OK; }
-    hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame
-    // Overlap mode with a frame delay: the conversion runs on the TRACKING stream, in the slot that stream has free between the last
-    // kernel of a frame's chain and the first of the next frame's (the host's turn: ~25 us) -- behind an event the push waits on instead
-    // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which
-    // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
-    hipEvent_t chain_done = nullptr;
-    bool ingest_on_tracker = false, tracker_ingest_capable = false;
-    bool bulk_busy_at_push = false;            // the previous remap was still running when this push began
-    // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
-    // for its frames synchronises and reads back in between: at least a remap's duration)
-    bool caller_runs_free = false;
-    std::chrono::steady_clock::time_point last_push_end{};
-    // tests: LVK_HIP_INGEST_PLACEMENT=tracker|bulk pins the placement that is otherwise decided per push (see track())
-    int ingest_placement = [] { const char* e = std::getenv("LVK_HIP_INGEST_PLACEMENT"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
-    std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr
-    std::vector<char> slot_read_armed;
-    int slot_index(const void* p) const { for (size_t i = 0; i < pool_all.size(); i++) if (pool_all[i] == p) return (int)i; return -1; }
-    int pending_slot = -1;
-    // Overlap mode: what the caller enqueued on the context's stream before a push (a decode / copy that fills the frame or the planes)
-    // must be visible to the kernels of the bulk stream that read it.  The event is recorded when the push starts -- before the tracker's
-    // own kernels, so that the bulk stream never waits for those -- and the bulk stream waits for it ahead of its first launch of the push.
-    hipEvent_t caller_ready = nullptr;
-    bool caller_wait_pending = false;
-    int mark_caller_work()
-    {
-        if (!(overlap && s.stabilize_output && remap_stream)) return LVK_HIP_OK;
-        // nothing pending on the context's stream (the steady state of a caller whose frames are already resident): nothing to order
-        if (hipStreamQuery(ctx->stream) == hipSuccess) { caller_wait_pending = false; return LVK_HIP_OK; }
-        (void)hipGetLastError();
-        if (!caller_ready) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&caller_ready, hipEventDisableTiming));
-        LVK_HIP_CHECK(ctx, hipEventRecord(caller_ready, ctx->stream));
-        caller_wait_pending = true;
-        return LVK_HIP_OK;
-    }
-    int bulk_stream_sees_caller_work()
-    {
-        if (!caller_wait_pending) return LVK_HIP_OK;
-        caller_wait_pending = false;
-        LVK_HIP_CHECK(ctx, hipStreamWaitEvent(remap_stream, caller_ready, 0));
-        return LVK_HIP_OK;
-    }
-    // Borrowed frames that left the queue outside a push (queue shrunk by configure(), overlap / stabilize_output toggled while a remap
-    // was pending): handed back through *released by the following pushes, one per push.
-    std::deque<const void*> orphaned;
-
-    // ---- optional per-stage GPU timing (HIP events on the launch stream)
-    bool profiling = false;
-    unsigned prof_mask = ~0u;                  // stages that are timed while profiling is on (bit = LVK_STAGE_*)
-    unsigned prof_every = 1, prof_tick = 0;    // time the stages of one push in `prof_every` (the event records cost host time per frame)
-    struct EvPair { hipEvent_t a, b; int kind; };
-    std::vector<EvPair> ev_pool; size_t ev_used = 0;
-    double prof_ms[LVK_STAGE_COUNT] = {0}; long prof_n[LVK_STAGE_COUNT] = {0};
-    int prof_begin(int kind, hipStream_t stream = nullptr);
-    void prof_end(int idx, hipStream_t stream = nullptr);
-    int prof_collect();
-
-    int fail(int code, const std::string& msg) { return ctx->fail(code, msg); }
-    void free_tracker_buffers();
-    int alloc_tracker_buffers();
-    int alloc_pyramids();
-    int configure(const lvk_stab_settings& st);
-    void tracker_restart();
-    void reset_context() { tracker_restart(); smoother.restart(); }
-    // Chained path: the host's own fast_filter pass, the ageing of the features and the re-seeding of the suppression grid are not
-    // needed to launch the remap (the motion estimate, the match count and the inlier mask come from the GPU): they run after the
-    // launch, before the push returns.  post_n >= 0: pending for a frame with post_n tracked points / post_m matches.
-    int post_n = -1, post_m = 0;
-    bool post_error = false;
-    void finish_post();
-    int track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion);
-
-    // ---- host-resident frames (lvk_hip_stab_push_yuv420_host): the transfers either side of the 4:2:0 path.  One copy stream per
-    // direction (scripts/pcie_probe.hip, profiles/r03_pcie_probe.txt: ONE copy engine stream each way moves 46.8 GB/s each way at once,
-    // two per direction fall to 31), the luma plane first so that the tracker starts while the chroma planes are still on the link.
-    struct HostIO
-    {
-        static constexpr int K_IN = 2, K_OUT = 3;
-        hipStream_t up = nullptr, up2 = nullptr, down = nullptr, down2 = nullptr;
-        struct Pending { bool valid = false; int slot = 0; void* y; void* u; void* v; int ys, us, vs, nv12; } pending;      // a download not yet handed to the copy engine
-        int rows = 0, cols = 0;
-        void* d_in[K_IN] = {nullptr, nullptr}; void* d_out[K_OUT] = {nullptr, nullptr, nullptr};      // contiguous planes: Y | U | V  (or Y | UV)
-        hipEvent_t y_done[K_IN] = {}, c_done[K_IN] = {}, out_ready[K_OUT] = {}, down_done[K_OUT] = {};
-        bool down_armed[K_OUT] = {false, false, false};
-        bool y_is_c[K_IN] = {false, false};                      // the slot's frame came as one copy: c_done covers the luma plane too
-        // look-ahead (lvk_hip_stab_prefetch_yuv420_host): the planes whose upload is already under way, and the slot they go to
-        struct Ahead { int slot; const void* key[3]; int rows, cols, nv12; };
-        std::deque<Ahead> ahead;                                // in upload order; a push consumes the oldest
-        const uint8_t* last_dst_lo = nullptr; const uint8_t* last_dst_hi = nullptr;      // luma plane of the newest download's destination
-        int in_next = 0, out_next = 0, last_down = -1;       // last_down: slot of the newest download (its event orders a later direct write behind it)
-        std::chrono::steady_clock::time_point last_end{};      // when the previous host push returned
-    } hostio;
-    bool host_free_running_hint = false;                 // lvk_hip_stab_push_yuv420_host's own finding, for the push it wraps
-    bool host_direct_now = false;                        // the push being wrapped writes its output planes straight into host memory
-    hipEvent_t ingest_wait[2] = {nullptr, nullptr};      // events the newest frame's 4:2:0 conversion waits for (the plane uploads), or nullptr
-    hipEvent_t remap_wait = nullptr;                     // event the next remap waits for (the download that last read its output planes)
-    int ensure_hostio(int rows, int cols);
-    // The host entry points hand these pointers to copy engines and (output planes) to a kernel: pageable memory there is a GPU fault, not an
-    // error code.  Looked up on EVERY call (hipPointerGetAttributes: ~1 us) -- an address that was pinned once may be pageable memory the next
-    // time it is seen (hipHostFree / hipHostUnregister, then malloc) -- and at BOTH ends of the byte range, so that a plane that runs past
-    // its registration is refused too.
-    int require_pinned(const void* p, size_t bytes, const char* what)
-    {
-        if (!p || bytes == 0) return LVK_HIP_OK;
-        for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + (bytes - 1)})
-        {
-            hipPointerAttribute_t attr{};
-            const hipError_t e = hipPointerGetAttributes(&attr, q);
-            if (e != hipSuccess) (void)hipGetLastError();
-            if (e != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeDevice))
-                return fail(LVK_HIP_ERR_ARG, std::string(what) + ": the planes of the host entry points must be PINNED host memory "
-                                             "(lvk_hip_host_malloc, hipHostMalloc or hipHostRegister) over their whole extent; this pointer is pageable memory");
-        }
-        return LVK_HIP_OK;
-    }
-    // the planes of one 4:2:0 frame: one range when they are contiguous (the OBS layout), else plane by plane
-    int require_pinned_planes(const void* y, int y_step, const void* u, int u_step, const void* v, int v_step, int nv12, int rows, int cols, const char* what)
-    {
-        if (!y) return LVK_HIP_OK;
-        const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;
-        const size_t yb = (size_t)y_step * (rows - 1) + cols, ub = (size_t)u_step * (crows - 1) + ccols, vb = nv12 ? 0 : (size_t)v_step * (crows - 1) + ccols;
-        const uint8_t* ye = (const uint8_t*)y + yb; const uint8_t* ue = (const uint8_t*)u + ub;
-        if (y_step == cols && u_step == ccols && (const uint8_t*)u == ye && (nv12 || (v_step == ccols && (const uint8_t*)v == ue)))
-            return require_pinned(y, yb + ub + vb, what);
-        int rc;
-        if ((rc = require_pinned(y, yb, what)) != LVK_HIP_OK || (rc = require_pinned(u, ub, what)) != LVK_HIP_OK) return rc;
-        return nv12 ? LVK_HIP_OK : require_pinned(v, vb, what);
-    }
-    int host_stream(hipStream_t& s)                          // a transfer stream, created on first use; lvk_hip_sync() covers it
-    {
-        if (s) return LVK_HIP_OK;
-        LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        ctx->aux_streams.push_back(s);
-        return LVK_HIP_OK;
-    }
-    int flush_download(bool wait);
-    int cancel_lookahead();
-    // ---- look-ahead for DEVICE-resident frames (lvk_hip_stab_prefetch / _yuv420): the luma of the frame the next push will carry.  Its
-    // downscale and pyramid are put on the tracking stream BEHIND this push's chain (into the pyramid that becomes `cur` at the next push), where
-    // the GPU runs them during the host's turn between two chains; the next push then starts at the optical flow.
-    struct LumaAhead { const void* luma = nullptr; int step = 0, pix = 0, channel = 0, rows = 0, cols = 0;
-                       bool same(const void* l, int st, int px, int ch, int r, int c) const { return luma && luma == l && step == st && pix == px && channel == ch && rows == r && cols == c; } };
-    LumaAhead ahead_announced;                 // announced, not yet on the stream (cleared by the push that follows, whatever it does with it)
-    LumaAhead ahead_built;                     // what pyr[cur ^ 1] holds already
-    unsigned long long push_seq = 0, ahead_built_for = 0;      // a built pyramid is only good for the very next push
-    long lookahead_frames = 0;
-    bool early_post_off = std::getenv("LVK_HIP_LATE_POST") != nullptr;      // experiments: keep the bookkeeping at the start of the next push
-    void forget_device_lookahead() { ahead_announced = LumaAhead(); ahead_built = LumaAhead(); ahead_built_for = 0; }
-    int host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead);
-    void free_hostio();
-    bool caller_free_running_now();
-    // experiments (scripts/host_feed_probe.py, scripts/host_feed_matrix.sh): LVK_HIP_HOST_UP2=1 announced frames alternate between two upload streams
-    // (default: one, see host_upload); LVK_HIP_HOST_H2D=<blocks> the uploads as copy kernels of that many workgroups instead of hipMemcpyAsync
-    double host_trace_acc[6] = {0, 0, 0, 0, 0, 0}; long host_trace_n = 0;      // LVK_HIP_HOST_TRACE: us inside lvk_hip_stab_push_yuv420_host, by phase
-    int host_up2 = [] { const char* e = std::getenv("LVK_HIP_HOST_UP2"); return e ? std::atoi(e) : 0; }();
-    int host_h2d_blocks = [] { const char* e = std::getenv("LVK_HIP_HOST_H2D"); return e ? std::atoi(e) : 0; }();
-    int host_sink_mode = [] { const char* e = std::getenv("LVK_HIP_HOST_SINK"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();      // tests: direct | copy
-
-    // ---- YUV420 front/back end: pool of packed frames the planes are converted into
-    std::vector<void*> pool_all; std::deque<void*> pool_free;      // free slots are reused oldest first: the remap that read a slot is long done
-    void* pool_out = nullptr;
-    int pool_rows = 0, pool_cols = 0;
-    int ensure_pool(int rows, int cols);
-    void free_pool();
-};
-
-int lvk_hip_stab::prof_begin(int kind, hipStream_t stream)
-{
-    if (!stream) stream = ctx->stream;
-    if (!profiling || !((prof_mask >> kind) & 1u) || (prof_tick % prof_every) != 0) return -1;
-    if (ev_used >= 1024 && prof_collect() != LVK_HIP_OK) return -1;      // long sessions: fold the pending pairs in (one stream sync) and reuse them
-    if (ev_used == ev_pool.size())
-    {
-        EvPair p{nullptr, nullptr, kind};
-        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
-        ev_pool.push_back(p);
-    }
-    ev_pool[ev_used].kind = kind;
-    (void)hipEventRecord(ev_pool[ev_used].a, stream);
-    return (int)ev_used++;
-}
-
-void lvk_hip_stab::prof_end(int idx, hipStream_t stream) { if (idx >= 0) (void)hipEventRecord(ev_pool[(size_t)idx].b, stream ? stream : ctx->stream); }
-
-int lvk_hip_stab::prof_collect()
-{
-    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
-    for (size_t i = 0; i < ev_used; i++)
-    {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev_pool[i].a, ev_pool[i].b) == hipSuccess) { prof_ms[ev_pool[i].kind] += ms; prof_n[ev_pool[i].kind]++; }
-    }
-    ev_used = 0;
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab::alloc_pyramids()
-{
-    int rc;
-    if ((rc = pyr[0].allocate(ctx, s.detection_height, s.detection_width, LK_LEVELS, LK_WIN, LK_WIN)) != LVK_HIP_OK) return rc;
-    if ((rc = pyr[1].allocate(ctx, s.detection_height, s.detection_width, LK_LEVELS, LK_WIN, LK_WIN)) != LVK_HIP_OK) return rc;
-    pyr_w = s.detection_width; pyr_h = s.detection_height;
-    forget_device_lookahead();
-    return LVK_HIP_OK;
-}
-
-void lvk_hip_stab::free_tracker_buffers()
-{
-    void* dev[] = {d_fast_masks, d_fast_scores, d_pts, d_matched, d_p1, d_status, d_ransac_ws, d_count, d_und, d_mesh_scratch,
-                   d_grid_col, d_grid_row, d_grid_bucket, d_n_points, d_full, d_cell_first, d_cell_best, d_region_count};
-    for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h_fast_out, h_fast_counts, h_regions, h_pts, h_matched, h_p1, h_status, h_H, h_ninl, h_mask, h_und, h_count, h_occ, h_new_kp, h_insert};
-    for (void* p : host) if (p) (void)hipHostFree(p);
-    d_grid_col = nullptr; d_grid_row = nullptr; d_grid_bucket = nullptr; d_n_points = d_full = nullptr; d_cell_first = nullptr; d_cell_best = nullptr; d_region_count = nullptr; h_occ = h_new_kp = nullptr; h_insert = nullptr;
-    d_fast_masks = d_fast_scores = nullptr;
-    d_pts = d_matched = d_p1 = nullptr; d_status = nullptr; d_ransac_ws = nullptr; d_count = nullptr; d_und = nullptr; d_mesh_scratch = nullptr;
-    h_fast_out = nullptr; h_fast_counts = nullptr; h_regions = nullptr; h_pts = h_matched = h_p1 = nullptr; h_status = nullptr;
-    h_H = nullptr; h_ninl = nullptr; h_mask = nullptr; h_und = nullptr; h_count = nullptr;
-}
-
-int lvk_hip_stab::alloc_tracker_buffers()
-{
-    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    free_tracker_buffers();
-    // the grid holds at most one feature per cell; features left over from before a reset() can add as many again
-    cap_features = 2 * grid.capacity() + 16;
-    fast_regions = (int)grid.zones.size();
-    fast_max_rw = fast_max_rh = 1;
-    grid.plan(plan);
-    for (const FastRegion& r : plan) { fast_max_rw = std::max(fast_max_rw, r.w); fast_max_rh = std::max(fast_max_rh, r.h); }
-    // NMS keeps at most one pixel of every 2x2 block: that bounds the raw corner count of a region.
-    fast_cap = ((fast_max_rw + 1) / 2) * ((fast_max_rh + 1) / 2);
-    size_t mb, sb;
-    lvk_fast_workspace_bytes(fast_regions, fast_max_rw, fast_max_rh, &mb, &sb);
-    const size_t n = cap_features;
-    LVK_HIP_CHECK(ctx, hipMalloc(&d_fast_masks, mb));
-    LVK_HIP_CHECK(ctx, hipMalloc(&d_fast_scores, sb));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_pts, n * sizeof(float2)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_matched, n * sizeof(float2)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_p1, 2 * n * sizeof(float2)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_status, n));
-    LVK_HIP_CHECK(ctx, hipMalloc(&d_ransac_ws, lvk_ransac_workspace_bytes((int)n)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_count, sizeof(int)));
-    LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_und, 2 * n * sizeof(float2)));
-    LVK_HIP_CHECK(ctx, hipMalloc(&d_mesh_scratch, 32 * n));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_pts, n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_matched, n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, 2 * n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_status, n, hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_und, 2 * n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_count, sizeof(int), hipHostMallocDefault));
-    // the suppression grid's tables for k_fast_insert (constant per configuration)
-    {
-        const auto& col = grid.col_table(); const auto& row = grid.row_base_table(); const auto& bucket = grid.bucket_table();
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_grid_col, std::max<size_t>(col.size(), 1) * sizeof(uint16_t)));
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_grid_row, std::max<size_t>(row.size(), 1) * sizeof(uint32_t)));
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_grid_bucket, std::max<size_t>(bucket.size(), 1)));
-        LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_col, col.data(), col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_row, row.data(), row.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        LVK_HIP_CHECK(ctx, hipMemcpy(d_grid_bucket, bucket.data(), bucket.size(), hipMemcpyHostToDevice));
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_cell_first, std::max<size_t>(grid.capacity(), 1) * sizeof(uint32_t)));
-        LVK_HIP_CHECK(ctx, hipMalloc(&d_cell_best, std::max<size_t>(grid.capacity(), 1) * sizeof(unsigned long long)));
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_region_count, LVK_FAST_INLINE_REGIONS * sizeof(int)));
-        { const int crc = lvk_fast_cells_reset(ctx, d_cell_first, d_cell_best, (int)std::max<size_t>(grid.capacity(), 1), d_region_count); if (crc != LVK_HIP_OK) return crc; }
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_n_points, sizeof(int)));
-        LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_full, sizeof(int)));
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_occ, ((grid.capacity() + 31) / 32 + 1) * sizeof(uint32_t), hipHostMallocDefault));
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_new_kp, std::max<size_t>(grid.capacity(), 1) * sizeof(uint32_t), hipHostMallocDefault));
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_insert, 8 * sizeof(int), hipHostMallocDefault));
-    }
-    return LVK_HIP_OK;
-}
-
-void lvk_hip_stab::tracker_restart()            // FrameTracker::restart (FrameTracker.cpp:97-104)
-{
-    finish_post();                              // the last frame's bookkeeping first: the detector keeps its propagated features across a reset
-    tracking_stability = 0.0f;
-    tracked.clear();
-    grid.reset();
-    initialized = false;
-    if (mesh_dev) (void)lvk_mesh_solver_reset(mesh_dev, ctx->stream);
-    post_n = -1;
-    forget_device_lookahead();
-}
-
-void lvk_hip_stab::finish_post()
-{
-    if (post_n < 0) return;
-    const int n = post_n, m_gpu = post_m;
-    post_n = -1;
-    // fast_filter(features, tracked points, matched points; keep = status): back-to-front swap-erase (Container.tpp:97-121)
-    int m = n;
-    for (int k = n - 1; k >= 0; k--)
-        if (!h_status[k])
-        {
-            m--;
-            std::swap(tracked[k], tracked[m]);
-            std::swap(h_pts[k], h_pts[m]);
-            std::swap(h_matched[k], h_matched[m]);
-        }
-    tracked.resize(m);
-    if (m != m_gpu) { post_error = true; tracked.clear(); return; }                       // reported by the next push
-    for (int i = m - 1; i >= 0; i--)                                                     // FrameTracker.cpp:183-192
-    {
-        if (h_mask[i]) { tracked[i].age++; tracked[i].x = h_matched[i].x; tracked[i].y = h_matched[i].y; }
-        else { std::swap(tracked[i], tracked.back()); tracked.pop_back(); }
-    }
-    grid.propagate(tracked);
-}
-
-int lvk_hip_stab::configure(const lvk_stab_settings& st)
-{
-    // pre-conditions the reference asserts: StabilizationFilter.cpp:44-45, FrameTracker.cpp:59-65, FeatureDetector.cpp:50-57, PathSmoother.cpp:38-44
-    LVK_HIP_REQUIRE(ctx, st.min_tracking_quality >= 0 && st.min_tracking_quality <= 1 && st.min_scene_quality >= 0 && st.min_scene_quality <= 1);
-    LVK_HIP_REQUIRE(ctx, st.motion_width >= 2 && st.motion_height >= 2);
-    LVK_HIP_REQUIRE(ctx, st.acceptance_threshold >= 0 && st.temporal_smoothing >= 0 && st.local_smoothing >= 0 && st.min_motion_samples >= 4);
-    LVK_HIP_REQUIRE(ctx, st.uniformity_threshold >= 0 && st.uniformity_threshold <= 1);
-    LVK_HIP_REQUIRE(ctx, st.detection_regions_x > 0 && st.detection_regions_y > 0);
-    LVK_HIP_REQUIRE(ctx, st.detection_regions_x <= st.detection_width && st.detection_regions_y <= st.detection_height);
-    LVK_HIP_REQUIRE(ctx, st.min_feature_density <= st.max_feature_density && st.min_feature_density > 0 && st.max_feature_density <= 1 && st.accumulation_rate > 0);
-    LVK_HIP_REQUIRE(ctx, st.corrective_limit_x >= 0 && st.corrective_limit_x <= 1 && st.corrective_limit_y >= 0 && st.corrective_limit_y <= 1);
-    LVK_HIP_REQUIRE(ctx, st.predictive_samples > 0 && st.smoothing_steps > 0 && st.response_rate >= 0 && st.response_rate <= 1);
-    LVK_HIP_REQUIRE(ctx, st.detection_width >= 8 && st.detection_height >= 8 && st.detection_width < 4096 && st.detection_height < 4096);
-    // the remap kernels take the mesh through a staging slot
-    LVK_HIP_REQUIRE(ctx, (size_t)st.motion_width * (size_t)st.motion_height * 2 * sizeof(float) <= lvk_hip_ctx::kStageBytes);
-
-    // ---- everything that can be refused is decided BEFORE any state changes: a configure() that returns an error leaves the filter as it was
-    lvk_stab_settings prev_tracker = tracker_s;
-    MeshGen gen = mesh_gen;
-    if (gen.cols == 0)
-    {
-        // The reference's FrameTracker member is default-constructed first: FrameTracker(FrameTrackerSettings{}) generates the
-        // mesh constraints for a 16x16 mesh over its default 256x256 region with weights 1.0 / 20.0 (FrameTracker.cpp:41-53,
-        // FrameTracker.hpp:31-44).  configure() below then only regenerates them when the motion resolution changes.
-        lvk_stab_default_settings(&prev_tracker);
-        prev_tracker.motion_width = 16; prev_tracker.motion_height = 16;
-        gen = MeshGen{16, 16, 256.0f, 256.0f, prev_tracker.temporal_smoothing, prev_tracker.local_smoothing};
-    }
-    const bool regenerate = st.motion_width != prev_tracker.motion_width || st.motion_height != prev_tracker.motion_height;
-    // FrameTracker.cpp:74-82: new region, but the PREVIOUS settings' smoothing weights; m_OptimizedMesh starts from zero again
-    if (regenerate) gen = MeshGen{st.motion_width, st.motion_height, (float)st.detection_width, (float)st.detection_height, prev_tracker.temporal_smoothing, prev_tracker.local_smoothing};
-    lvk_mesh_solver_dev* new_solver = nullptr;
-    float* new_offsets = nullptr;
-    const size_t want_offsets = (size_t)st.motion_width * st.motion_height * 2;
-    if (st.track_local_motions)
-    {
-        // the mesh the tracker solves for has the motion resolution; a configuration whose constraints were generated for another one
-        // (cannot happen: a resolution change regenerates them) would index past the mesh
-        LVK_HIP_REQUIRE(ctx, gen.cols == st.motion_width && gen.rows == st.motion_height);
-        if (regenerate || !mesh_dev)
-        {
-            const int mrc = lvk_mesh_solver_create(ctx, gen.cols, gen.rows, gen.w, gen.h, gen.temporal, gen.local, &new_solver);
-            if (mrc != LVK_HIP_OK) return mrc;
-        }
-        if (h_offsets_floats < want_offsets && hipHostMalloc((void**)&new_offsets, want_offsets * sizeof(float), hipHostMallocDefault) != hipSuccess)
-        { lvk_mesh_solver_free(new_solver); return fail(LVK_HIP_ERR_RUNTIME, "mesh offsets: pinned allocation failed"); }
-        if (!h_mesh_status && hipHostMalloc((void**)&h_mesh_status, sizeof(int), hipHostMallocDefault) != hipSuccess)
-        { lvk_mesh_solver_free(new_solver); if (new_offsets) (void)hipHostFree(new_offsets); return fail(LVK_HIP_ERR_RUNTIME, "mesh status: pinned allocation failed"); }
-    }
-
-    // ---- commit
-    if (configured && s.stabilize_output != st.stabilize_output && remap_stream)
-    {
-        // the 4:2:0 conversions change streams with this flag: drain the bulk stream so that no pool slot is shared across the switch
-        LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
-        if (pending_release) { if (queue_kind == 1) orphaned.push_back(pending_release); pending_release = nullptr; pending_slot = -1; }
-    }
-    if (configured && s.stabilize_output && !st.stabilize_output) reset_context();        // StabilizationFilter.cpp:49-52
-    const bool res_changed = !configured || st.detection_width != s.detection_width || st.detection_height != s.detection_height;
-    const bool layout_changed = res_changed || st.detection_regions_x != s.detection_regions_x || st.detection_regions_y != s.detection_regions_y
-                                || st.max_feature_density != s.max_feature_density;
-    mesh_gen = gen;
-    if (regenerate || new_solver)
-    {
-        // the solver of the previous motion resolution (or none): nothing on the stream may still be using it
-        if (mesh_dev) { (void)hipStreamSynchronize(ctx->stream); lvk_mesh_solver_free(mesh_dev); }
-        mesh_dev = new_solver;
-    }
-    if (new_offsets)
-    {
-        (void)hipStreamSynchronize(ctx->stream);
-        if (h_offsets) (void)hipHostFree(h_offsets);
-        h_offsets = new_offsets; h_offsets_floats = want_offsets;
-    }
-    tracker_s = st;
-    smoother.configure(st);
-    queue_capacity = (size_t)st.predictive_samples + 1;
-    while (queue.size() > queue_capacity)
-    {
-        if (queue_kind == 1) orphaned.push_back(queue.front().d_ptr);      // a borrowed frame nobody will emit: give it back
-        queue.pop_front();
-    }
-    grid.configure(st);
-    if (configured && res_changed && initialized) grid.reset();                          // FrameTracker.cpp:86-91
-    s = st;
-    configured = true;
-    if (layout_changed || !buffers_ok)
-    {
-        // New tracking geometry: the cached frame no longer matches, which costs one nullopt frame exactly as the
-        // reference's size check does (FrameTracker.cpp:120-124).  (An allocation failure here -- out of device memory -- leaves the
-        // filter unusable until a later configure() succeeds: buffers_ok stays false and every push reports it.)
-        buffers_ok = false;
-        int rc = alloc_tracker_buffers();
-        if (rc != LVK_HIP_OK) return rc;
-        if (res_changed || pyr_w != s.detection_width || pyr_h != s.detection_height)
-        {
-            if ((rc = alloc_pyramids()) != LVK_HIP_OK) return rc;
-            prev_w = prev_h = cur_w = cur_h = 0;
-        }
-        buffers_ok = true;
-    }
-    return LVK_HIP_OK;
-}
+using namespace lvkstab;
 
 // FrameTracker::track (FrameTracker.cpp:108-196)
 int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, int luma_pix, int luma_channel, WarpMeshF& motion, bool& have_motion)
@@ -734,19 +182,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         LVK_HIP_CHECK(ctx, hipEventRecord(chain_done, st)); chain_event_armed = true;
     }
     if (deferred_ingest && (rc = run_deferred_ingest()) != LVK_HIP_OK) return rc;
-    if (build_ahead)
-    {
-        // `P` (the previous frame's pyramid) has been read for the last time by the flow kernel above; at the next push it is `C`
-        const LumaAhead a = ahead_announced;
-        ahead_announced = LumaAhead();
-        pe = prof_begin(LVK_STAGE_DOWNSCALE);
-        if ((rc = lvk_launch_luma_area_resize(ctx, a.luma, a.step, a.pix, a.channel, a.rows, a.cols, const_cast<uint8_t*>(P.args.lv[0].img), P.args.lv[0].step, cur_h, cur_w)) != LVK_HIP_OK) return rc;
-        prof_end(pe);
-        pe = prof_begin(LVK_STAGE_PYRAMID);
-        if ((rc = P.build(ctx)) != LVK_HIP_OK) return rc;
-        prof_end(pe);
-        ahead_built = a; ahead_built_for = push_seq + 1;
-    }
+    if (build_ahead && (rc = launch_build_ahead(P, cur_w, cur_h)) != LVK_HIP_OK) return rc;
     if (lens && !chained)
     {
         if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
@@ -888,303 +324,12 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     return LVK_HIP_OK;
 }
 
-extern "C" {
-
-void lvk_stab_default_settings(lvk_stab_settings* s)
-{
-    if (!s) return;
-    // FeatureDetector.hpp:28-37, FrameTracker.hpp:31-44, PathSmoother.hpp:29-39, StabilizationFilter.hpp:28-39
-    s->detection_width = 256; s->detection_height = 256; s->detection_regions_x = 2; s->detection_regions_y = 2; s->force_detection = 0;
-    s->max_feature_density = 0.20f; s->min_feature_density = 0.05f; s->accumulation_rate = 2.0f;
-    s->track_local_motions = 1; s->temporal_smoothing = 1.0f; s->local_smoothing = 20.0f;
-    s->min_motion_samples = 75; s->acceptance_threshold = 8.0f; s->uniformity_threshold = 0.20f;
-    s->predictive_samples = 10; s->corrective_limit_x = 0.1f; s->corrective_limit_y = 0.1f; s->smoothing_steps = 20.0f; s->response_rate = 0.04f;
-    s->motion_width = 2; s->motion_height = 2;
-    s->background[0] = 255; s->background[1] = 0; s->background[2] = 255;
-    s->crop_to_stable_region = 0; s->stabilize_output = 1; s->min_scene_quality = 0.8f; s->min_tracking_quality = 0.3f;
-}
-
-int lvk_hip_stab_create(lvk_hip_ctx* ctx, const lvk_stab_settings* settings, lvk_hip_stab** out)
-{
-    if (!ctx) return LVK_HIP_ERR_ARG;
-    LVK_HIP_REQUIRE(ctx, settings && out);
-    lvk_device_guard device_guard(ctx);
-    *out = nullptr;
-    auto* st = new lvk_hip_stab();
-    st->ctx = ctx;
-    const int rc = st->configure(*settings);
-    if (rc != LVK_HIP_OK)
-    {
-        st->free_tracker_buffers(); lvk_mesh_solver_free(st->mesh_dev); st->pyr[0].release(); st->pyr[1].release();
-        if (st->h_offsets) (void)hipHostFree(st->h_offsets);
-        if (st->h_mesh_status) (void)hipHostFree(st->h_mesh_status);
-        delete st; return rc;
-    }
-    *out = st;
-    return LVK_HIP_OK;
-}
-
-static void rehome_stage_events(lvk_hip_ctx* ctx);
-
-void lvk_hip_stab_destroy(lvk_hip_stab* st)
-{
-    if (!st) return;
-    lvk_device_guard device_guard(st->ctx);
-    (void)hipStreamSynchronize(st->ctx->stream);
-    st->trace.dump();
-    if (st->trace.on && st->host_trace_n)
-        std::fprintf(stderr, "[lvk host trace] push_yuv420_host, us/frame: uploads enqueued %.1f, stream wait + sink choice %.1f, inner push %.1f, chroma wait %.1f, download enqueued %.1f\n",
-                     st->host_trace_acc[0] / st->host_trace_n, st->host_trace_acc[1] / st->host_trace_n, st->host_trace_acc[2] / st->host_trace_n,
-                     st->host_trace_acc[3] / st->host_trace_n, st->host_trace_acc[4] / st->host_trace_n);
-    st->free_tracker_buffers();
-    lvk_mesh_solver_free(st->mesh_dev);
-    if (st->h_offsets) (void)hipHostFree(st->h_offsets);
-    if (st->h_mesh_status) (void)hipHostFree(st->h_mesh_status);
-    st->pyr[0].release(); st->pyr[1].release();
-    st->free_pool();
-    st->free_hostio();
-    if (st->remap_stream)
-    {
-        (void)hipStreamSynchronize(st->remap_stream);
-        rehome_stage_events(st->ctx);
-        auto& aux = st->ctx->aux_streams;
-        aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
-        if (st->remap_stream_owned) (void)hipStreamDestroy(st->remap_stream);
-    }
-    for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventDestroy(st->remap_done[i]);
-    if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
-    if (st->chain_done) (void)hipEventDestroy(st->chain_done);
-    if (st->caller_ready) (void)hipEventDestroy(st->caller_ready);
-    for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    delete st;
-}
-
-// Overlap mode: the EASU remap of the delayed frame runs on a second stream, concurrently with the tracking of the
-// next frame (the two are independent: the delayed frame was uploaded at least one push earlier).  The output of a
-// push is then complete only after lvk_hip_sync(), and a borrowed frame is handed back (*released) one push later,
-// after its remap has finished.
-// The stream the output of the next pushes is produced on (the bulk stream in overlap mode, else the context's): a caller that
-// wants to chain its own stream-ordered work behind an output (a D2H copy, an encoder) enqueues it there instead of synchronising.
-void* lvk_hip_stab_output_stream(lvk_hip_stab* st)
-{
-    if (!st) return nullptr;
-    return (void*)((st->overlap && st->s.stabilize_output && st->remap_stream) ? st->remap_stream : st->ctx->stream);
-}
-
-// The context's staging slots carry an event "the kernel that read this slot is done", recorded on whatever stream launched that kernel --
-// also on a bulk stream that is about to go away.  An event whose stream has been destroyed cannot be waited for any more
-// (hipEventSynchronize fails), so before a stream of this stabilizer dies the slots' events move to the context's own stream (everything
-// on the dying stream has completed: it was synchronised).
-static void rehome_stage_events(lvk_hip_ctx* ctx)
-{
-    for (int i = 0; i < lvk_hip_ctx::kStageSlots; i++) if (ctx->stage_done[i]) (void)hipEventRecord(ctx->stage_done[i], ctx->stream);
-}
-
-static int stab_detach_bulk_stream(lvk_hip_stab* st)
-{
-    lvk_hip_ctx* ctx = st->ctx;
-    if (!st->remap_stream) return LVK_HIP_OK;
-    (void)hipStreamSynchronize(st->remap_stream);
-    rehome_stage_events(ctx);
-    // Events of this stabilizer that were recorded on the stream that goes away: everything on it has completed, so nothing has to wait for
-    // them any more -- and an event whose stream has been destroyed must not be waited for at all.  The per-slot "remap has read this pool
-    // slot" events are disarmed; the events a later push waits on unconditionally (remap_done of a pending release, ingest_done) are
-    // re-recorded on the context's own stream.
-    std::fill(st->slot_read_armed.begin(), st->slot_read_armed.end(), (char)0);
-    for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventRecord(st->remap_done[i], ctx->stream);
-    if (st->ingest_done) (void)hipEventRecord(st->ingest_done, ctx->stream);
-    st->remap_wait = nullptr;
-    auto& aux = ctx->aux_streams;
-    aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
-    if (st->remap_stream_owned) LVK_HIP_CHECK(ctx, hipStreamDestroy(st->remap_stream));
-    st->remap_stream = nullptr; st->remap_stream_owned = false;
-    return LVK_HIP_OK;
-}
-
-static int stab_set_overlap(lvk_hip_stab* st, bool enable, lvk_hip_ctx* bulk)
-{
-    lvk_hip_ctx* ctx = st->ctx;
-    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (st->remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st->remap_stream));
-    // both streams are idle: a frame whose remap was pending is free again
-    if (st->pending_release) { if (st->queue_kind == 1) st->orphaned.push_back(st->pending_release); st->pending_release = nullptr; st->pending_slot = -1; }
-    st->caller_wait_pending = false;
-    if (enable)
-    {
-        hipStream_t want = bulk ? bulk->stream : nullptr;
-        if (bulk) LVK_HIP_REQUIRE(ctx, bulk != ctx && bulk->device == ctx->device && bulk->stream != ctx->stream);
-        if (st->remap_stream && (bulk ? st->remap_stream != want : !st->remap_stream_owned))
-        { const int rc = stab_detach_bulk_stream(st); if (rc != LVK_HIP_OK) return rc; }
-        if (!st->remap_stream)
-        {
-            if (bulk) { st->remap_stream = want; st->remap_stream_owned = false; }
-            else
-            {
-                // lowest priority: the bulk kernels of this stream (remap, 4:2:0 conversion) fill every CU; the tracker's small,
-                // latency-bound kernels on the main stream should get the wave slots they free first
-                int prio_least = 0, prio_greatest = 0;
-                LVK_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-                LVK_HIP_CHECK(ctx, hipStreamCreateWithPriority(&st->remap_stream, hipStreamNonBlocking, prio_least));
-                st->remap_stream_owned = true;
-            }
-            ctx->aux_streams.push_back(st->remap_stream);
-        }
-        for (int i = 0; i < 2; i++)
-            if (!st->remap_done[i]) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[i], hipEventDisableTiming));
-    }
-    else if (st->remap_stream && !st->remap_stream_owned)
-    {
-        // a caller-owned bulk stream is let go of when the overlap ends (lvk_hip.h: NULL = overlap off): the caller may destroy that context
-        // now, and nothing here -- lvk_hip_sync through aux_streams, configure(), destroy -- touches its stream again
-        const int rc = stab_detach_bulk_stream(st); if (rc != LVK_HIP_OK) return rc;
-    }
-    st->overlap = enable;
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    return stab_set_overlap(st, enable != 0, nullptr);
-}
-
-// Overlap mode on a stream the CALLER owns: the bulk kernels run on `bulk`'s stream (NULL: overlap off).  For hosts whose output frames
-// outlive the stabilizer or are consumed by stream-ordered work of their own: the frames then belong to `bulk` (the C++ facade does this).
-int lvk_hip_stab_set_bulk_context(lvk_hip_stab* st, lvk_hip_ctx* bulk)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    return stab_set_overlap(st, bulk != nullptr, bulk);
-}
-
-// Per-stage GPU time measured with HIP events on the launch stream.  enable != 0 starts (and resets) the
-// accumulation; lvk_hip_stab_get_profile synchronises the stream and reports, per stage, the summed milliseconds
-// and the number of timed launches (stage ids: LVK_STAGE_*).
-int lvk_hip_stab_set_profiling(lvk_hip_stab* st, int enable)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    const int rc = st->prof_collect();
-    st->profiling = enable != 0;
-    st->prof_mask = enable == 1 ? ~0u : ((unsigned)enable & 0xffffu) >> 1;   // 1: every stage; otherwise (1 << (stage + 1)) bits
-    st->prof_every = std::max(1u, ((unsigned)enable >> 16) & 0xffu);        // bits 16..23: sample one push in N (0 / 1 = every push)
-    st->prof_tick = 0;
-    for (int i = 0; i < LVK_STAGE_COUNT; i++) { st->prof_ms[i] = 0; st->prof_n[i] = 0; }
-    return rc;
-}
-
-int lvk_hip_stab_get_profile(lvk_hip_stab* st, double total_ms[LVK_STAGE_COUNT], long long launches[LVK_STAGE_COUNT])
-{
-    if (!st || !total_ms || !launches) return LVK_HIP_ERR_ARG;
-    const int rc = st->prof_collect();
-    for (int i = 0; i < LVK_STAGE_COUNT; i++) { total_ms[i] = st->prof_ms[i]; launches[i] = st->prof_n[i]; }
-    return rc;
-}
-
-int lvk_hip_stab_configure(lvk_hip_stab* st, const lvk_stab_settings* settings)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    LVK_HIP_REQUIRE(st->ctx, settings);
-    st->finish_post();
-    return st->configure(*settings);
-}
-
-// lvk::col::{RED, GREEN, BLUE}[format] (Functions/Drawing.hpp:27-71)
-static void overlay_colours(int format, double red[3], double green[3], double blue[3])
-{
-    const double R[3][3] = {{0, 0, 255}, {255, 0, 0}, {76, 84, 255}}, G[3][3] = {{0, 255, 0}, {0, 255, 0}, {149, 43, 21}},
-                 B[3][3] = {{255, 0, 0}, {0, 0, 255}, {29, 255, 107}};
-    const int k = format == LVK_FORMAT_YUV ? 2 : (format == LVK_FORMAT_RGB || format == LVK_FORMAT_RGBA ? 1 : 0);
-    for (int i = 0; i < 3; i++) { red[i] = R[k][i]; green[i] = G[k][i]; blue[i] = B[k][i]; }
-}
-
-// StabilizationFilter::draw_trackers (StabilizationFilter.cpp:163-175): crosses (size 7, thickness 4 -- FrameTracker.cpp:498-503
-// passes a literal 4, not its `thickness` argument) at the tracked features, coloured lerp(RED, GREEN, trust), into the newest
-// queued frame (the caller's borrowed buffer).
-int lvk_hip_stab_draw_trackers(lvk_hip_stab* st)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());                                           // StreamBuffer::newest: !is_empty()
-    st->finish_post();
-    const QueuedFrame& f = st->queue.back();
-    double r[3], g[3], b[3];
-    overlay_colours(f.format, r, g, b);
-    uint8_t col[3];
-    for (int i = 0; i < 3; i++) col[i] = (uint8_t)(r[i] + (double)st->trust * (g[i] - r[i]));      // Math.tpp:124-129, Drawing.tpp:184-189
-    std::vector<float> pts(st->tracked.size() * 2);
-    for (size_t i = 0; i < st->tracked.size(); i++) { pts[2 * i] = st->tracked[i].x; pts[2 * i + 1] = st->tracked[i].y; }
-    const float sx = (float)f.cols / (float)st->tracker_s.detection_width, sy = (float)f.rows / (float)st->tracker_s.detection_height;
-    return lvk_launch_draw_crosses(st->ctx, st->ctx->stream, const_cast<void*>(f.d_ptr), f.step, f.rows, f.cols, pts.data(), (int)st->tracked.size(),
-                                   sx, sy, col, 7, 4);
-}
-
-// StabilizationFilter::draw_motion_mesh (:179-188): BLUE grid of motion_resolution - 1 cells, thickness 1
-int lvk_hip_stab_draw_motion_mesh(lvk_hip_stab* st)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    LVK_HIP_REQUIRE(st->ctx, !st->queue.empty());
-    const QueuedFrame& f = st->queue.back();
-    double r[3], g[3], b[3];
-    overlay_colours(f.format, r, g, b);
-    const uint8_t col[3] = {(uint8_t)b[0], (uint8_t)b[1], (uint8_t)b[2]};
-    return lvk_launch_draw_grid(st->ctx, st->ctx->stream, const_cast<void*>(f.d_ptr), f.step, f.rows, f.cols, st->s.motion_width - 1, st->s.motion_height - 1, col, 1);
-}
-
-int lvk_hip_stab_restart(lvk_hip_stab* st);
-int lvk_hip_stab_set_lens(lvk_hip_stab* st, const lvk_camera_params* params)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    if (params && (params->fx == 0.0 || params->fy == 0.0)) return st->fail(LVK_HIP_ERR_ARG, "camera profile with zero focal length");
-    st->lens = params != nullptr;
-    if (params) st->lens_params = *params;
-    st->lens_rows = st->lens_cols = 0;
-    return lvk_hip_stab_restart(st);
-}
-
-int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::restart (StabilizationFilter.cpp:139-144)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    // the queue's frames go back to their owners: nothing on the bulk stream may still be reading them
-    if (st->remap_stream) LVK_HIP_CHECK(st->ctx, hipStreamSynchronize(st->remap_stream));
-    // host entry points: the emitted frame whose download has not been handed to the copy engine yet still goes out (*produced was
-    // reported); frames that were announced and never pushed are forgotten -- a restart is where a caller seeks or switches sources, and a
-    // stale announcement would otherwise refuse every later push ("another frame has been announced") or, matched by pointer identity,
-    // feed a reused buffer's pre-restart upload to the tracker
-    { int hrc; if ((hrc = st->flush_download(true)) != LVK_HIP_OK || (hrc = st->cancel_lookahead()) != LVK_HIP_OK) return hrc; }
-    st->scene_quality = 1.0f;
-    st->queue.clear(); st->queue_kind = 0;
-    st->pending_release = nullptr; st->pending_slot = -1;
-    st->orphaned.clear();                          // restart(): every borrowed frame is the caller's again
-    st->reset_context();
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab_reset_context(lvk_hip_stab* st)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    st->reset_context();
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab_ready(const lvk_hip_stab* st) { return st && st->queue.size() == st->queue_capacity ? 1 : 0; }
-int lvk_hip_stab_frame_delay(const lvk_hip_stab* st) { return st ? st->s.predictive_samples : 0; }
-
-} // extern "C"
-
 // StabilizationFilter::filter (StabilizationFilter.cpp:69-135).  (luma, luma_step, luma_pix): where the tracker reads the
 // luma of this frame from -- the packed frame itself (pix 3) or, on the YUV420 path, the caller's planar Y (pix 1).
-// planes of a 4:2:0 output: when given, a warped frame leaves through the fused remap + egress kernel instead of d_out
-struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; };
 
-static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
+int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
                      const void* luma, int luma_step, int luma_pix,
-                     void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released, OutPlanes420* o420 = nullptr)
+                     void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released, OutPlanes420* o420)
 {
     lvk_hip_ctx* ctx = st->ctx;
     if (produced) *produced = 0;
@@ -1218,12 +363,11 @@ static int push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, 
         // The persistent grid (4 remap blocks per CU) leaves room for the tracker's blocks of the NEXT frame; 5 or 6 starve them (8 450 /
         // 7 700 instead of 8 780 frames/s).  That only matters to a caller that runs free: one that waits for every frame (the previous
         // push ended long ago and the bulk stream is idle) gets the full grid -- the remap then has the GPU to itself (p50 latency -6 %).
-        static const int pinned = [] { const char* e = std::getenv("LVK_HIP_CO_BLOCKS"); return e ? std::atoi(e) : 0; }();      // experiments: blocks per CU, always
-        const bool persistent = side && (pinned != 0 || st->caller_runs_free);
+        const bool persistent = side && st->caller_runs_free;
         // a remap whose stores cross the host link (lvk_hip_stab_push_yuv420_host) is bound by the link, not by the chip: ONE block per CU
         // for a free-running caller -- measured (two upload streams at the time) 2 800 frames/s against 2 560 with the 4 blocks per CU of a device-resident stream (the
         // stores of more blocks only fill the link's write queue sooner, which stalls the tracker's kernels), 2 450 with one per two CUs
-        ctx->co_blocks_per_cu = pinned != 0 ? pinned : ((persistent && st->host_direct_now) ? 1 : 0);
+        ctx->co_blocks_per_cu = (persistent && st->host_direct_now) ? 1 : 0;
         if (side && (rc = st->bulk_stream_sees_caller_work()) != LVK_HIP_OK) return rc;
         if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(rs, e, 0)); }
         st->trace.mark(HostTrace::EMIT_WAITS);
@@ -1330,167 +474,6 @@ bool lvk_hip_stab::caller_free_running_now()
     return bulk_busy_at_push || (last_push_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - last_push_end < std::chrono::microseconds(15));
 }
 
-int lvk_hip_stab::ensure_hostio(int rows, int cols)
-{
-    HostIO& h = hostio;
-    if (h.rows == rows && h.cols == cols && h.up) return LVK_HIP_OK;
-    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
-    // (LVK_HIP_HOST_SINK=copy: the last emitted frame of the old size may not have been handed to the copy engine yet -- it was reported as
-    //  produced, so it goes out before its staging planes are freed)
-    { const int frc = flush_download(true); if (frc != LVK_HIP_OK) return frc; }
-    free_hostio();
-    const size_t bytes = (size_t)rows * cols + 2 * (size_t)((rows + 1) / 2) * ((cols + 1) / 2);
-    for (auto& p : h.d_in) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
-    for (auto& p : h.d_out) LVK_HIP_CHECK(ctx, hipMalloc(&p, bytes));
-    // The streams that exist are the streams that are used: every stream of the process is a queue the runtime maps onto its few hardware
-    // queues, and a transfer stream that lands on the hardware queue of the caller's stream stalls the tracker's kernels behind its copies
-    // (measured, 4K free running with look-ahead: 3 140-3 190 frames/s with ONE upload stream, 2 700-2 850 with two, 2 040-2 130 with a third
-    // side stream next to them).  The second upload stream (chroma of a frame pushed without look-ahead) and the download streams
-    // (LVK_HIP_HOST_SINK=copy) are made on first use.  [The mechanism was narrowed down with scripts/sdma_interference_probe.py and the timelines
-    // G-H of profiles/r03_host_feed_timeline.txt: whichever kernel comes first on the tracking stream after a look-ahead upload has started
-    // -- the downscale, the flow kernel, a 5 KB copy, even a kernel that only stores its arguments -- ends ~220 us after that upload began.]
-    { const int rcs = host_stream(h.up); if (rcs != LVK_HIP_OK) return rcs; }
-    ctx->sync_hooks.emplace_back((void*)this, [this]() { return flush_download(true); });          // lvk_hip_sync() covers the transfers
-    for (int i = 0; i < HostIO::K_IN; i++)
-    {
-        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.y_done[i], hipEventDisableTiming));
-        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.c_done[i], hipEventDisableTiming));
-    }
-    for (int i = 0; i < HostIO::K_OUT; i++)
-    {
-        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.out_ready[i], hipEventDisableTiming));
-        LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&h.down_done[i], hipEventDisableTiming));
-        h.down_armed[i] = false;
-    }
-    h.rows = rows; h.cols = cols; h.in_next = h.out_next = 0; h.last_down = -1; h.ahead.clear();
-    return LVK_HIP_OK;
-}
-
-void lvk_hip_stab::free_hostio()
-{
-    HostIO& h = hostio;
-    auto& aux = ctx->aux_streams;
-    { auto& hooks = ctx->sync_hooks; hooks.erase(std::remove_if(hooks.begin(), hooks.end(), [this](const auto& kv) { return kv.first == (void*)this; }), hooks.end()); }
-    h.pending.valid = false;
-    for (hipStream_t s : {h.up, h.down, h.up2, h.down2})
-        if (s) { (void)hipStreamSynchronize(s); aux.erase(std::remove(aux.begin(), aux.end(), s), aux.end()); (void)hipStreamDestroy(s); }
-    h.up = h.down = h.up2 = h.down2 = nullptr;
-    for (auto& p : h.d_in) { if (p) (void)hipFree(p); p = nullptr; }
-    for (auto& p : h.d_out) { if (p) (void)hipFree(p); p = nullptr; }
-    for (auto* arr : {h.y_done, h.c_done}) for (int i = 0; i < HostIO::K_IN; i++) if (arr[i]) { (void)hipEventDestroy(arr[i]); arr[i] = nullptr; }
-    for (auto* arr : {h.out_ready, h.down_done}) for (int i = 0; i < HostIO::K_OUT; i++) if (arr[i]) { (void)hipEventDestroy(arr[i]); arr[i] = nullptr; }
-    h.rows = h.cols = 0;
-}
-
-// The uploads of one host frame into staging slot k, on the upload stream.
-//   * pushed now (the caller waits for this frame): luma, event, chroma, event -- the tracker starts on the luma plane while the chroma planes
-//     are still on the link;
-//   * announced ahead (the link is the bottleneck, not this frame's latency): ONE copy when the planes are contiguous.  A copy engine
-//     that has to wait for anything but its own previous copy -- here: the event between the two copies -- is restarted by the
-//     runtime's signal handler 60-80 us late (timeline in profiles/r03_host_feed_timeline.txt): 341 us of link time per frame instead of 265.
-int lvk_hip_stab::host_upload(const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols, int k, bool ahead)
-{
-    HostIO& io = hostio;
-    const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;
-    uint8_t* d_y = (uint8_t*)io.d_in[k];
-    uint8_t* d_u = d_y + (size_t)rows * cols;
-    uint8_t* d_v = nv12 ? d_u : d_u + (size_t)crows * ccols;
-    int rc;
-    // (the staging slot is free: the kernels that read it -- downscale, conversion -- were complete when the push that used it returned)
-    auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height, hipStream_t s) -> hipError_t {
-        if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, hipMemcpyHostToDevice, s);
-        return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, s);
-    };
-    const bool contiguous = y_step == cols && u_step == ccols && (const uint8_t*)h_u == (const uint8_t*)h_y + (size_t)rows * cols &&
-                            (nv12 || (v_step == ccols && (const uint8_t*)h_v == (const uint8_t*)h_u + (size_t)crows * ccols));
-    if (ahead && contiguous)
-    {
-        const size_t bytes = (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols;
-        // ONE upload stream.  (hipMemcpyAsync blocks the host while an earlier copy of the same stream is still in flight, which two alternating
-        // streams avoid -- LVK_HIP_HOST_UP2=1 --, but the second stream costs more than that wait: see ensure_hostio.)
-        if (host_up2 && (k & 1)) { if ((rc = host_stream(io.up2)) != LVK_HIP_OK) return rc; }
-        hipStream_t us = (host_up2 && (k & 1)) ? io.up2 : io.up;
-        if (host_h2d_blocks > 0 && ((uintptr_t)h_y & 15) == 0) { if ((rc = lvk_launch_copy_bytes(ctx, us, d_y, h_y, bytes, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
-        else LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_y, h_y, bytes, hipMemcpyHostToDevice, us));
-        LVK_HIP_CHECK(ctx, hipEventRecord(io.c_done[k], us));
-        io.y_is_c[k] = true;
-        return LVK_HIP_OK;
-    }
-    io.y_is_c[k] = false;
-    hipStream_t cs = io.up;                                                          // luma and chroma of a frame pushed now: one stream, in order
-    const bool kernel_up = host_h2d_blocks > 0 && y_step == cols && ((uintptr_t)h_y & 15) == 0 && ((uintptr_t)h_u & 15) == 0 && ((size_t)rows * cols) % 16 == 0;
-    if (kernel_up) { if ((rc = lvk_launch_copy_bytes(ctx, io.up, d_y, h_y, (size_t)rows * cols, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
-    else LVK_HIP_CHECK(ctx, copy_plane(d_y, cols, h_y, y_step, cols, rows, io.up));
-    LVK_HIP_CHECK(ctx, hipEventRecord(io.y_done[k], io.up));
-    if (!nv12 && u_step == ccols && v_step == ccols && (const uint8_t*)h_v == (const uint8_t*)h_u + (size_t)crows * ccols)
-    {
-        if (kernel_up) { if ((rc = lvk_launch_copy_bytes(ctx, cs, d_u, h_u, 2 * (size_t)crows * ccols, host_h2d_blocks)) != LVK_HIP_OK) return rc; }
-        else LVK_HIP_CHECK(ctx, hipMemcpyAsync(d_u, h_u, 2 * (size_t)crows * ccols, hipMemcpyHostToDevice, cs));      // U | V contiguous: one copy
-    }
-    else
-    {
-        LVK_HIP_CHECK(ctx, copy_plane(d_u, ccols, h_u, u_step, ccols, crows, cs));
-        if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(d_v, ccols, h_v, v_step, ccols, crows, cs));
-    }
-    LVK_HIP_CHECK(ctx, hipEventRecord(io.c_done[k], cs));
-    return LVK_HIP_OK;
-}
-
-// Deferred download (LVK_HIP_HOST_SINK=copy): the D2H copy of an emitted frame is handed to the runtime only once the remap that wrote the
-// device planes is KNOWN to be complete, on a stream with nothing pending -- a copy that has to wait for a kernel is performed by the
-// runtime with a blit kernel (which saturates the link's write queue and stalls every other kernel), an unencumbered one by a copy engine.
-// wait = false: only if the remap has finished (polled at the start and at the end of the following push); true: wait for it.
-int lvk_hip_stab::flush_download(bool wait)
-{
-    HostIO& io = hostio;
-    if (!io.pending.valid) return LVK_HIP_OK;
-    const int j = io.pending.slot;
-    const hipError_t q = hipEventQuery(io.out_ready[j]);
-    if (q == hipErrorNotReady) { (void)hipGetLastError(); if (!wait) return LVK_HIP_OK; LVK_HIP_CHECK(ctx, hipEventSynchronize(io.out_ready[j])); }
-    else if (q != hipSuccess) return fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(q));
-    const int rows = io.rows, cols = io.cols, nv12 = io.pending.nv12, crows = rows / 2, ccols = nv12 ? cols : cols / 2;
-    uint8_t* o_y = (uint8_t*)io.d_out[j]; uint8_t* o_u = o_y + (size_t)rows * cols; uint8_t* o_v = nv12 ? o_u : o_u + (size_t)crows * ccols;
-    { int rcs; if ((rcs = host_stream(io.down)) != LVK_HIP_OK || (rcs = host_stream(io.down2)) != LVK_HIP_OK) return rcs; }
-    hipStream_t ds = (j & 1) ? io.down2 : io.down;           // (hipMemcpyAsync blocks the host while an earlier copy of the same stream is in flight)
-    auto copy_plane = [&](void* dst, int dpitch, const void* src, int spitch, int width, int height) -> hipError_t {
-        if (spitch == width && dpitch == width) return hipMemcpyAsync(dst, src, (size_t)width * height, hipMemcpyDeviceToHost, ds);
-        return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, ds);
-    };
-    const auto& p = io.pending;
-    {
-        // a destination the previous download (on the other stream) may still be writing: order behind it
-        const uint8_t* lo = (const uint8_t*)p.y; const uint8_t* hi = lo + (size_t)p.ys * rows;
-        if (io.last_down >= 0 && io.last_down != j && io.down_armed[io.last_down] && io.last_dst_lo < hi && lo < io.last_dst_hi)
-            LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ds, io.down_done[io.last_down], 0));
-        io.last_dst_lo = lo; io.last_dst_hi = hi;
-    }
-    const bool contiguous = p.ys == cols && p.us == ccols && (uint8_t*)p.u == (uint8_t*)p.y + (size_t)rows * cols &&
-                            (nv12 || (p.vs == ccols && (uint8_t*)p.v == (uint8_t*)p.u + (size_t)crows * ccols));
-    if (contiguous) LVK_HIP_CHECK(ctx, hipMemcpyAsync(p.y, o_y, (size_t)rows * cols + (size_t)(nv12 ? 1 : 2) * crows * ccols, hipMemcpyDeviceToHost, ds));
-    else
-    {
-        LVK_HIP_CHECK(ctx, copy_plane(p.y, p.ys, o_y, cols, cols, rows));
-        LVK_HIP_CHECK(ctx, copy_plane(p.u, p.us, o_u, ccols, ccols, crows));
-        if (!nv12) LVK_HIP_CHECK(ctx, copy_plane(p.v, p.vs, o_v, ccols, ccols, crows));
-    }
-    LVK_HIP_CHECK(ctx, hipEventRecord(io.down_done[j], ds));
-    io.down_armed[j] = true; io.last_down = j;
-    io.pending.valid = false;
-    return LVK_HIP_OK;
-}
-
-// Announced frames that will not be pushed (the caller stopped, seeked or restarted): their uploads are waited for -- the staging slots are
-// rewritten by the next upload on the same stream anyway, but the caller's planes must not be read after this returns -- and forgotten.
-int lvk_hip_stab::cancel_lookahead()
-{
-    HostIO& io = hostio;
-    for (hipStream_t us : {io.up, io.up2}) if (us) LVK_HIP_CHECK(ctx, hipStreamSynchronize(us));
-    io.ahead.clear();
-    for (hipEvent_t& e : ingest_wait) e = nullptr;
-    return LVK_HIP_OK;
-}
-
 int lvk_hip_stab::ensure_pool(int rows, int cols)
 {
     const size_t want = (size_t)s.predictive_samples + 4;
@@ -1544,7 +527,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     st->pool_frames = false;
     int rc = st->mark_caller_work();
     if (rc != LVK_HIP_OK) return rc;
-    rc = push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+    rc = lvk_stab_push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
     if (released && !*released && !st->orphaned.empty()) { *released = st->orphaned.front(); st->orphaned.pop_front(); }
     st->trace.mark(HostTrace::EXIT);
     st->last_push_end = std::chrono::steady_clock::now();
@@ -1624,14 +607,14 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     st->pool_frames = side_ingest;
     OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false};
     if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
-    rc = push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released, &o420);
+    rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released, &o420);
     if (st->deferred_ingest) { const int r2 = st->run_deferred_ingest(); if (rc == LVK_HIP_OK) rc = r2; }      // (track() returned before its launches)
     if (released) st->pool_free.push_back(const_cast<void*>(released));
     if (side_ingest)
     {
         // (the next frame's pyramid is on its way behind this chain: nothing will shadow the list bookkeeping at the start of the next push --
         //  track() does it behind the two launches that are no longer there --, so it runs here, while the conversion is still running anyway)
-        if (st->ahead_built_for == st->push_seq + 1 && !st->early_post_off) st->finish_post();
+        if (st->ahead_built_for == st->push_seq + 1) st->finish_post();
         st->trace.mark(HostTrace::EXIT_PRE);
         // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago).  An event, not
         // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
@@ -1656,261 +639,6 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     }
     st->trace.mark(HostTrace::EXIT);
     st->last_push_end = std::chrono::steady_clock::now();
-    return LVK_HIP_OK;
-}
-
-// Look-ahead for DEVICE-resident frames (a caller that has the next frame in HBM already: the reader thread of VideoFilter::stream runs ahead of
-// the filter thread, Filters/VideoFilter.cpp:62-209; a transcoder with its clip resident).  Announce frame n + 1, THEN push frame n: the push
-// puts the downscale and the pyramid of frame n + 1 on the tracking stream behind its own chain, where the GPU runs them while the host has its
-// turn (results, path smoother, remap launch), and the push of frame n + 1 starts at the optical flow.  Only the luma is read ahead (the Y plane /
-// channel 0 of a packed YUV frame / the grey value of BGR, RGB); it must not change between this call and the return of the push that carries it.
-// The announcement holds for the very next push only: a push that carries other planes, an other geometry or that does not track (the first
-// frame, a restart, stabilize_output off) simply works as if nothing had been announced.  Same pixels either way.
-static int stab_announce(lvk_hip_stab* st, const void* luma, int step, int pix, int channel, int rows, int cols)
-{
-    st->ahead_announced.luma = luma; st->ahead_announced.step = step; st->ahead_announced.pix = pix; st->ahead_announced.channel = channel;
-    st->ahead_announced.rows = rows; st->ahead_announced.cols = cols;
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab_prefetch(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, int format)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_hip_ctx* ctx = st->ctx;
-    LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);
-    LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
-    return stab_announce(st, d_frame, step, 3, format == LVK_FORMAT_YUV ? 0 : (format == LVK_FORMAT_BGR ? -1 : -2), rows, cols);
-}
-
-int lvk_hip_stab_prefetch_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12, int rows, int cols)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_hip_ctx* ctx = st->ctx;
-    LVK_HIP_REQUIRE(ctx, d_y && d_u && (nv12 || d_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
-    LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
-    return stab_announce(st, d_y, y_step, 1, 0, rows, cols);
-}
-
-long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* st) { return st ? (long long)st->lookahead_frames : 0; }
-
-// Look-ahead for streaming callers (the reader thread of VideoFilter::stream uploads frames ahead of the filter thread,
-// Filters/VideoFilter.cpp:62-209): starts the upload of the planes that the NEXT lvk_hip_stab_push_yuv420_host call will push, so that the
-// link is busy with frame n + 1 while frame n is tracked: announce frame n + 1, THEN push frame n.  Announced frames are pushed in order; at
-// most two may be outstanding.  The planes stay the caller's until their push has returned.
-int lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12, int rows, int cols)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    lvk_hip_ctx* ctx = st->ctx;
-    LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
-    LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
-    int rc;
-    if ((rc = st->require_pinned_planes(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, "lvk_hip_stab_prefetch_yuv420_host")) != LVK_HIP_OK) return rc;
-    if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
-    lvk_hip_stab::HostIO& io = st->hostio;
-    // two staging slots: the frame being pushed and the one on the link -- at most two announced frames that have not been pushed yet
-    LVK_HIP_REQUIRE(ctx, io.ahead.size() < (size_t)lvk_hip_stab::HostIO::K_IN);
-    const int k = io.in_next; io.in_next = (k + 1) % lvk_hip_stab::HostIO::K_IN;
-    if ((rc = st->host_upload(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, k, true)) != LVK_HIP_OK) return rc;
-    io.ahead.push_back({k, {h_y, h_u, nv12 ? h_u : h_v}, rows, cols, nv12 ? 1 : 0});
-    return LVK_HIP_OK;
-}
-
-// Forget the announced frames that have not been pushed (lvk_hip_stab_restart does the same): for a caller that announced frame n + 1 and
-// then stops, seeks or switches to other buffers.  Returns once the uploads no longer read the caller's planes.
-int lvk_hip_stab_prefetch_cancel(lvk_hip_stab* st)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    st->forget_device_lookahead();
-    return st->cancel_lookahead();
-}
-
-// Host-resident frames: FrameIngest::upload_planes -> to_ocl -> StabilizationFilter::filter -> to_obs -> download_planes in one call
-// (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602, VisionFilter.cpp:151-212) -- SURVEY.md section 8d's metric ("p99 ms/frame
-// including H2D of the input and D2H of the output when frames are host-resident").  h_* / oh_*: planes in PINNED host memory
-// (lvk_hip_host_malloc, hipHostMalloc, hipHostRegister).  What the link gives (profiles/r03_pcie_probe.txt): 55 GB/s one way, 46.8 GB/s
-// each way with ONE copy-engine stream per direction at once, 31 with two per direction -- so:
-//   in:  one upload stream; the luma plane goes first and the tracker's stream waits for IT only (downscale, pyramid, flow and the motion
-//        estimate run while the chroma planes are still on the link); the 4:2:0 conversion waits for both.  Planes that are contiguous in
-//        host memory (the OBS frame layout, FrameIngest.cpp:441-453 "uploads are done in bulk") travel as one copy each.
-//   out: a caller that waits for every frame gets the planes written by the remap kernel ITSELF into the pinned host planes (zero copy:
-//        the stores go over the link as they are produced -- no remap -> download serialisation, ~0.1 ms less per frame); a caller that
-//        runs free gets remap -> device planes -> one download on the download stream behind an event (a copy engine both ways is the
-//        faster pair when the link is saturated: 46.8 vs 43 GB/s).  Same pixels either way.
-// Input planes are consumed when the call returns; output planes are complete after lvk_hip_sync().
-int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
-                                  int rows, int cols, uint64_t timestamp,
-                                  void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
-                                  int* produced, uint64_t* out_timestamp)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    lvk_hip_ctx* ctx = st->ctx;
-    if (produced) *produced = 0;
-    LVK_HIP_REQUIRE(ctx, h_y && h_u && (nv12 || h_v) && rows > 0 && cols > 0 && rows % 2 == 0 && cols % 2 == 0);
-    LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
-    int rc;
-    if ((rc = st->require_pinned_planes(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, "lvk_hip_stab_push_yuv420_host")) != LVK_HIP_OK) return rc;
-    if (oh_y && oh_u && (nv12 || oh_v))
-    {
-        LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
-        if ((rc = st->require_pinned_planes(oh_y, oy_step, oh_u, ou_step, oh_v, ov_step, nv12, rows, cols, "lvk_hip_stab_push_yuv420_host (output)")) != LVK_HIP_OK) return rc;
-    }
-    if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
-    lvk_hip_stab::HostIO& io = st->hostio;
-    if ((rc = st->flush_download(false)) != LVK_HIP_OK) return rc;
-    auto tr_last = std::chrono::steady_clock::now();
-    auto tr_mark = [&](int k) { if (!st->trace.on) return; const auto now = std::chrono::steady_clock::now(); st->host_trace_acc[k] += std::chrono::duration<double, std::micro>(now - tr_last).count(); tr_last = now; };
-    const int crows = rows / 2, ccols = nv12 ? cols : cols / 2;                     // chroma plane geometry (bytes per row)
-    int k;
-    if (!io.ahead.empty())
-    {
-        // its upload has been under way since the look-ahead call; look-ahead frames are pushed in the order they were announced
-        const auto a = io.ahead.front();
-        if (!(a.key[0] == h_y && a.key[1] == h_u && a.key[2] == (nv12 ? h_u : h_v) && a.rows == rows && a.cols == cols && a.nv12 == (nv12 ? 1 : 0)))
-            return st->fail(LVK_HIP_ERR_ARG, "lvk_hip_stab_push_yuv420_host: another frame has been announced (lvk_hip_stab_prefetch_yuv420_host) and not pushed yet -- "
-                                             "announced frames are pushed in the order announced, and a frame pushed while announcements are outstanding must be the oldest of them");
-        io.ahead.pop_front();
-        k = a.slot;
-    }
-    else
-    {
-        k = io.in_next; io.in_next = (k + 1) % lvk_hip_stab::HostIO::K_IN;
-        if ((rc = st->host_upload(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, k, false)) != LVK_HIP_OK) return rc;
-    }
-    uint8_t* d_y = (uint8_t*)io.d_in[k];
-    uint8_t* d_u = d_y + (size_t)rows * cols;
-    uint8_t* d_v = nv12 ? d_u : d_u + (size_t)crows * ccols;
-    tr_mark(0);
-    // what this call hands to the push it wraps (events to wait for, the sink hints) never outlives it, whichever way it returns
-    struct ClearHooks
-    {
-        lvk_hip_stab* s;
-        ~ClearHooks() { s->remap_wait = nullptr; s->ingest_wait[0] = s->ingest_wait[1] = nullptr; s->host_free_running_hint = false; s->host_direct_now = false; }
-    } clear_hooks{st};
-    LVK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, io.y_is_c[k] ? io.c_done[k] : io.y_done[k], 0));           // the tracker needs the luma plane only
-    st->ingest_wait[0] = io.y_is_c[k] ? nullptr : io.y_done[k]; st->ingest_wait[1] = io.c_done[k];
-
-    // where the output planes are written: by the remap kernel itself, straight into the pinned host planes (measured, 4K, free running:
-    // 2 800 frames/s against 2 490 for remap -> device planes -> download, whose D2H copy the runtime performs with a blit KERNEL that
-    // saturates the link's write queue and stalls every other kernel's memory traffic while it runs -- timelines under profiles/).
-    // LVK_HIP_HOST_SINK=copy keeps the download route for comparison.
-    const bool have_out = oh_y && oh_u && (nv12 || oh_v);
-    st->host_free_running_hint = st->caller_free_running_now() ||
-                                 (io.last_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - io.last_end < std::chrono::microseconds(15));
-    const bool direct = have_out && st->host_sink_mode != 2;
-    const int j = io.out_next;
-    uint8_t* o_y = nullptr; uint8_t* o_u = nullptr; uint8_t* o_v = nullptr;
-    int oys = oy_step, ous = ou_step, ovs = ov_step;
-    if (have_out && !direct)
-    {
-        o_y = (uint8_t*)io.d_out[j]; o_u = o_y + (size_t)rows * cols; o_v = nv12 ? o_u : o_u + (size_t)crows * ccols;
-        oys = cols; ous = ccols; ovs = ccols;
-        if (io.pending.valid && io.pending.slot == j) { if ((rc = st->flush_download(true)) != LVK_HIP_OK) return rc; }
-        if (io.down_armed[j]) st->remap_wait = io.down_done[j];                      // the download that last read this slot
-    }
-    else if (have_out)
-    {
-        o_y = (uint8_t*)oh_y; o_u = (uint8_t*)oh_u; o_v = (uint8_t*)oh_v;
-        // a download of an earlier frame may still be writing the caller's (possibly the same) host planes: the kernel's stores follow it
-        if ((rc = st->flush_download(true)) != LVK_HIP_OK) return rc;
-        if (io.last_down >= 0 && io.down_armed[io.last_down]) st->remap_wait = io.down_done[io.last_down];
-    }
-    int prod = 0;
-    tr_mark(1);
-    st->host_direct_now = direct;
-    rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, &prod, out_timestamp);
-    tr_mark(2);
-    // "consumed on return": the conversion (which waited for both uploads) has finished in every mode by now; the event costs nothing then
-    LVK_HIP_CHECK(ctx, hipEventSynchronize(io.c_done[k]));
-    tr_mark(3);
-    if (rc != LVK_HIP_OK) return rc;
-    if ((rc = st->flush_download(false)) != LVK_HIP_OK) return rc;                  // the previous frame's remap has usually finished by now
-    if (prod && have_out && !direct)
-    {
-        if ((rc = st->flush_download(true)) != LVK_HIP_OK) return rc;               // (one deferred download at a time)
-        io.out_next = (j + 1) % lvk_hip_stab::HostIO::K_OUT;
-        hipStream_t os = (hipStream_t)lvk_hip_stab_output_stream(st);
-        LVK_HIP_CHECK(ctx, hipEventRecord(io.out_ready[j], os));
-        io.pending.valid = true; io.pending.slot = j; io.pending.y = oh_y; io.pending.u = oh_u; io.pending.v = oh_v;
-        io.pending.ys = oy_step; io.pending.us = ou_step; io.pending.vs = ov_step; io.pending.nv12 = nv12 ? 1 : 0;
-        io.down_armed[j] = false;
-    }
-    if (produced) *produced = prod;
-    tr_mark(4); st->host_trace_n++;
-    io.last_end = std::chrono::steady_clock::now();
-    return LVK_HIP_OK;
-}
-
-// Pinned host memory for the planes of lvk_hip_stab_push_yuv420_host (what obs_source_frame buffers would be registered as)
-int lvk_hip_host_malloc(lvk_hip_ctx* ctx, size_t bytes, void** h_ptr)
-{
-    if (!ctx || !h_ptr) return LVK_HIP_ERR_ARG;
-    LVK_HIP_REQUIRE(ctx, bytes > 0);
-    LVK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    LVK_HIP_CHECK(ctx, hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_host_free(lvk_hip_ctx* ctx, void* h_ptr)
-{
-    if (!ctx) return LVK_HIP_ERR_ARG;
-    if (h_ptr) LVK_HIP_CHECK(ctx, hipHostFree(h_ptr));
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab_get_stats(const lvk_hip_stab* st, lvk_stab_stats* o)
-{
-    if (!st || !o) return LVK_HIP_ERR_ARG;
-    const_cast<lvk_hip_stab*>(st)->finish_post();
-    o->tracking_stability = st->tracking_stability; o->scene_quality = st->scene_quality; o->trust = st->trust;
-    o->distribution = st->last_distribution; o->n_detected = st->last_detected; o->n_matched = st->last_matched;
-    o->n_tracked = (int)st->tracked.size(); o->frame_delay = st->s.predictive_samples;
-    o->smoothing_factor = st->smoother.smoothing_factor();
-    for (int i = 0; i < 9; i++) o->homography[i] = st->last_H[i];
-    return LVK_HIP_OK;
-}
-
-// How many frames ran the detector so far, and where their corners went through the suppression grid: inside the chain on the device
-// (k_fast_insert) or in the host loop between two halves of it (grids / regions the kernel does not cover, LVK_HIP_HOST_GRID=1).
-int lvk_hip_stab_detector_frames(const lvk_hip_stab* st, long long* on_device, long long* on_host)
-{
-    if (!st || !on_device || !on_host) return LVK_HIP_ERR_ARG;
-    *on_device = st->device_grid_frames; *on_host = st->host_grid_frames;
-    return LVK_HIP_OK;
-}
-
-int lvk_hip_stab_get_meshes(const lvk_hip_stab* st, float* motion, float* correction, int cap_floats)
-{
-    if (!st || !motion || !correction) return LVK_HIP_ERR_ARG;
-    const int n = (int)st->last_motion.off.size();
-    if (n > cap_floats) return LVK_HIP_ERR_ARG;
-    std::memcpy(motion, st->last_motion.off.data(), n * sizeof(float));
-    if ((int)st->last_correction.off.size() == n) std::memcpy(correction, st->last_correction.off.data(), n * sizeof(float));
-    return n;
-}
-
-int lvk_hip_stab_get_features(const lvk_hip_stab* st, float* xy_resp_age, int cap)
-{
-    if (!st || !xy_resp_age) return LVK_HIP_ERR_ARG;
-    const_cast<lvk_hip_stab*>(st)->finish_post();
-    const int n = std::min(cap, (int)st->tracked.size());
-    for (int i = 0; i < n; i++)
-    {
-        xy_resp_age[4 * i] = st->tracked[i].x; xy_resp_age[4 * i + 1] = st->tracked[i].y;
-        xy_resp_age[4 * i + 2] = st->tracked[i].response; xy_resp_age[4 * i + 3] = (float)st->tracked[i].age;
-    }
-    return (int)st->tracked.size();
-}
-
-// StabilizationFilter::stable_region (StabilizationFilter.cpp:199-205): margins * frame size -> cv::Rect (rounded)
-int lvk_hip_stab_stable_region(const lvk_hip_stab* st, int rows, int cols, int rect[4])
-{
-    if (!st || !rect) return LVK_HIP_ERR_ARG;
-    float m[4]; st->smoother.margins(m);
-    rect[0] = lvkh::cv_round(m[0] * (float)cols); rect[1] = lvkh::cv_round(m[1] * (float)rows);
-    rect[2] = lvkh::cv_round(m[2] * (float)cols); rect[3] = lvkh::cv_round(m[3] * (float)rows);
     return LVK_HIP_OK;
 }
 

@@ -1,5 +1,5 @@
 """Free-running cross-stream kernel timeline from in-kernel wall-clock stamps (library built with -DLVK_TIMELINE by
-scripts/timeline_build.sh and selected with LVK_HIP_LIB).  rocprofv3's kernel trace slows the host enough to change how the tracker
+scripts/variant_build.sh timeline -DLVK_TIMELINE and selected with LVK_HIP_LIB).  rocprofv3's kernel trace slows the host enough to change how the tracker
 and the bulk stream overlap; this costs two atomics per workgroup.  Usage: LVK_HIP_LIB=<timeline .so> python scripts/timeline_free.py"""
 import ctypes
 import os

@@ -26,6 +26,57 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"liblvk_hip.so does not export {name}"
 
 
+def test_abi_version_of_header_and_library_agree():
+    """include/lvk_hip.h groups its declarations into PART 1 (stable ABI) and PART 2 (experimental / diagnostics); the number of PART 1 is
+    compiled into the library.  A host built against another PART 1 can tell before it calls anything."""
+    from livevisionkit_amd import _native
+    text = open(os.path.join(ROOT, "include", "lvk_hip.h")).read()
+    want = int(re.search(r"#define LVK_HIP_ABI_VERSION (\d+)", text).group(1))
+    lib = _native.load()
+    assert lib.lvk_hip_abi_version() == want
+    assert ("ABI %d" % want).encode() in lib.lvk_hip_version()
+    assert "PART 1 -- STABLE ABI" in text and "PART 2 -- EXPERIMENTAL / DIAGNOSTICS" in text
+    stable, experimental = text.split("PART 2 -- EXPERIMENTAL / DIAGNOSTICS  (no ABI promise")
+    # what a host of the reference binds sits in PART 1 ...
+    for name in ("lvk_hip_stab_push(", "lvk_hip_stab_push_yuv420(", "lvk_hip_stab_push_yuv420_host(", "lvk_hip_stab_configure(", "lvk_hip_ctx_create(", "lvk_hip_malloc(",
+                 "lvk_hip_remap_homography(", "lvk_hip_upscale(", "lvk_hip_stab_set_overlap(", "lvk_hip_device_count("):
+        assert name in stable and name not in experimental, name
+    # ... the per-stage test entry points, taps and profiling in PART 2
+    for name in ("lvk_hip_fast_detect(", "lvk_hip_pyrlk(", "lvk_hip_estimate_global_motion(", "lvk_hip_mesh_solver_solve(", "lvk_hip_stab_get_stats(",
+                 "lvk_hip_stab_set_profiling(", "lvk_hip_stab_prefetch_yuv420(", "lvk_hip_native_rcp("):
+        assert name in experimental and name not in stable, name
+
+
+def test_environment_knobs_are_documented_with_their_tests():
+    """Every getenv of the product is listed in INTEGRATION.md section 4 together with the test that exercises it (round-4 VERDICT: every rejected
+    experiment that keeps a code path is a path no test pins)."""
+    knobs = set()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "livevisionkit_amd")):
+        if "variants" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".py")):
+                knobs |= set(re.findall(r'getenv\("(LVK_[A-Z0-9_]+)"\)|environ(?:\.get)?\(?\[?"(LVK_[A-Z0-9_]+)"', open(os.path.join(dirpath, f), errors="ignore").read()))
+    knobs = {a or b for a, b in knobs}
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = doc[doc.index("## 4. Diagnostics (environment)"):]
+    rows = {m.group(1): m.group(0) for m in re.finditer(r"^\| `(LVK_[A-Z0-9_]+)[^|]*\|.*$", section, re.M)}
+    assert knobs and knobs <= set(rows), (sorted(knobs), sorted(rows))
+    for k in knobs:
+        assert re.search(r"tests/\w+\.py|scripts/\w+\.sh", rows[k]), f"{k}: no test named in INTEGRATION.md section 4"
+        for t in re.findall(r"(tests/\w+\.py)", rows[k]):
+            assert os.path.exists(os.path.join(ROOT, t)), t
+
+
+def test_no_source_file_of_the_library_is_a_monolith():
+    """csrc/ stays navigable: no translation unit above 1 200 lines (round-4 VERDICT; stabilizer.hip was 1 917, mesh.hip 1 351)."""
+    csrc = os.path.join(ROOT, "livevisionkit_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            n = sum(1 for _ in open(os.path.join(csrc, f), errors="ignore"))
+            assert n <= 1200, f"{f}: {n} lines"
+
+
 def test_no_device_fails_loudly_not_silently():
     """Without a GPU the product path must refuse to run (no CPU fallback)."""
     import torch

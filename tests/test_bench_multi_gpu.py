@@ -34,7 +34,33 @@ def test_bench_two_ranks_on_a_shared_gpu():
     assert abs(r["value"] - 40 / slowest) <= 0.02 * r["value"]                  # aggregate = sum of the frames / max over ranks of the time
     assert abs(r["ms_per_step"] - slowest / 20 * 1e3) <= 0.02 * r["ms_per_step"]
     assert r["sustained"]["frames"] >= 1200
+    # per-rank latency (north star: throughput AND p99 at 1 / 2 / 4 / 8 GPUs): every rank reports its own pair, the line's is the slowest rank's
+    assert all(x["latency_ms"]["p99"] >= x["latency_ms"]["p50"] > 0 for x in ranks) and all(len(x["stream_latency_ms"]) == 1 for x in ranks)
+    assert r["latency_ms"]["p99"] == max(x["latency_ms"]["p99"] for x in ranks) and r["latency_ms"]["p50"] == max(x["latency_ms"]["p50"] for x in ranks)
+    assert r["extras"].startswith("single-rank only") and r["pcie_inclusive"] is None and r["configs"] is None and "cpu_baseline" not in r
     print("\n[bench --gpus 2 on a shared GPU] value %.0f frames/s; per rank: %s" % (r["value"], [(x["device"], x["numa_cpus"], round(x["frames_per_s"])) for x in ranks]))
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_a_shared_gpu():
+    """The driver's 8-GPU launch, functionally, on however many GPUs this box has (LVK_BENCH_SHARE_GPU=1): `bench.py --gpus 8` spawns eight
+    ranks, each with its own stream (eight clip seeds), and the ONE line carries n_gpus 8, eight per-rank p50 / p99 pairs and the whole-job
+    value = all frames / the slowest rank's time.  No scaling claim (the ranks share GPUs here); it is the line the first real 8-GPU run prints."""
+    p = _run_bench(["--gpus", "8", "--pool", "32"], env={"LVK_BENCH_SHARE_GPU": "1"}, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    ranks = r["ranks"]
+    assert r["n_gpus"] == 8 and [x["rank"] for x in ranks] == list(range(8))
+    assert len({x["clip_seed"] for x in ranks}) == 8                             # eight different streams
+    assert all(x["frames"] == 20 for x in ranks)
+    assert all(x["latency_ms"]["p99"] >= x["latency_ms"]["p50"] > 0 for x in ranks)
+    assert r["latency_ms"]["p99"] == max(x["latency_ms"]["p99"] for x in ranks)
+    slowest = max(x["elapsed_s"] for x in ranks)
+    assert abs(r["value"] - 160 / slowest) <= 0.02 * r["value"]
+    assert "8 rank(s)" in r["config"]["parallelism"] and r["scaling"] == "weak"
+    print("\n[bench --gpus 8 on shared GPU(s)] value %.0f frames/s; per-rank p99 ms: %s" % (r["value"], [round(x["latency_ms"]["p99"], 3) for x in ranks]))
 
 
 def _run_bench(extra, env=None, timeout=900):

@@ -3,8 +3,8 @@
 Round 3 lost 2x on k_mesh_backsolve to an innocent-looking refactor (its LDS array handed to a helper as a generic pointer: 32 VGPRs less,
 112 bytes of the walking wavefront's state in scratch, 43 -> 89 us) and only a timeline caught it.  This test catches that class on the
 CPU: no kernel may use scratch, and the kernels whose occupancy the schedule depends on stay within their VGPR budgets (DESIGN.md
-sections 4-5: the remap's persistent grid needs <= 80 VGPRs to fit 4 blocks per CU next to the tracker; k_ransac_finalize is compiled for
-<= 168 so that it fits next to the remap)."""
+sections 4-5: the remap's persistent grid needs <= 80 VGPRs to fit 4 blocks per CU next to the tracker; k_ransac_finalize runs 8 waves of
+<= 96 VGPRs so that two of them per SIMD fit next to the remap's 4 x 80)."""
 import os
 import re
 import subprocess
@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "livevisionkit_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 MESH_FLAGS = ["-mllvm", "-amdgpu-load-store-vectorizer=0", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]      # as csrc/Makefile
-VGPR_BUDGET = {r"k_fast_insert": 48, r"k_remap_\w+": 80, r"k_easu_scale": 80, r"k_ransac_finalize": 168, r"k_mesh_backsolve(?!_generic)": 168, r"k_pyrlk": 96, r"k_mesh_solve(?!_generic)": 256}
+VGPR_BUDGET = {r"k_fast_insert": 48, r"k_remap_\w+": 80, r"k_easu_scale": 80, r"k_ransac_finalize": 96, r"k_mesh_backsolve(?!_generic)": 168, r"k_pyrlk": 96, r"k_mesh_solve(?!_generic)": 256}
 
 
 def _kernels(unit):

@@ -120,3 +120,41 @@ def test_staging_slots_survive_the_bulk_stream_they_were_used_on(ctx, oracle):
         got = ctx.remap_mesh(d, mesh, bg=(0, 128, 128), yuv=True)
         ctx.sync()
         assert np.array_equal(got.cpu().numpy(), oracle.remap_mesh(src, mesh, bg=(0, 128, 128), yuv=True))
+
+
+def test_host_trace_prints_and_changes_nothing(tmp_path):
+    """LVK_HIP_HOST_TRACE=1: the per-phase host times of a push are printed when the stabilizer is destroyed,
+    and the emitted planes are those of a run without it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import sys, zlib, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import livevisionkit_amd as lvk\n"
+        "from tests import synth\n"
+        "frames, _ = synth.make_clip(270, 480, 12, seed=5, jitter=1.0)\n"
+        "ctx = lvk.Context(0)\n"
+        "f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)\n"
+        "f.configure(lvk.StabilizationFilterSettings.obs_preset('homography', strict=False, predictive_samples=2)); f.set_overlap(True)\n"
+        "crc = 0\n"
+        "for i, fr in enumerate(frames):\n"
+        "    y = torch.from_numpy(np.ascontiguousarray(fr[..., 0])).cuda(); u = torch.from_numpy(np.ascontiguousarray(fr[::2, ::2, 1])).cuda(); v = torch.from_numpy(np.ascontiguousarray(fr[::2, ::2, 2])).cuda()\n"
+        "    out, _ = f.apply_yuv420((y, u, v), timestamp=i)\n"
+        "    ctx.sync()\n"
+        "    if out is not None:\n"
+        "        for p in out: crc = zlib.crc32(p.cpu().numpy().tobytes(), crc)\n"
+        "f.close(); ctx.close(); print('crc', crc)\n")
+    outs = {}
+    for trace in (False, True):
+        env = dict(os.environ)
+        env.pop("LVK_HIP_HOST_TRACE", None)
+        if trace:
+            env["LVK_HIP_HOST_TRACE"] = "1"
+        p = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[trace] = (p.stdout.strip().splitlines()[-1], p.stderr)
+    assert outs[False][0] == outs[True][0] and outs[True][0].startswith("crc ")
+    assert "[lvk host trace]" in outs[True][1] and "frames" in outs[True][1]
+    assert "[lvk host trace]" not in outs[False][1]
