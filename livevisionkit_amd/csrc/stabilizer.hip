@@ -188,6 +188,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         if ((rc = lvk_launch_lens_undistort(ctx, st, lens_model, (double)f.cols / (double)cur_w, (double)f.rows / (double)cur_h,
                                             d_pts, n, h_matched, n, h_und)) != LVK_HIP_OK) return rc;
     }
+    // (Round 5, measured and rejected: putting this push's output remap on the bulk stream HERE, behind a hipStreamWaitValue32 the host releases
+    //  with one store once the smoother has the correction -- the launch left the host's turn (7.4 -> 0.3 us) and the rate fell 2 %: the chain
+    //  ran 3.7 us slower and the push waited 5.5 us longer for the new frame's conversion, which sits behind the chain on this stream.  The
+    //  cycle is bound by this STREAM, not by the host's turn.  profiles/r05_ab_prelaunch_remap.txt, scripts/probes/waitvalue_probe.hip.)
     if (chain_event_armed) LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done));
     else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
     trace.mark(HostTrace::LK_SYNC);

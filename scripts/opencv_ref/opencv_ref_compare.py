@@ -12,7 +12,9 @@ It is the hook that lets someone with OpenCV 4.8.0 pin the rows whose arithmetic
 Bars: a3 / a4 exact (+-1 LSB at non-integer scales); a5 exact set equality of (x, y, score) in row-major order; a7
 |d| <= 0.01 px for >= 99.9 % of the points and <= 0.1 % status flips; a9 reported, not asserted bit for bit (the product's estimator is its
 own: corner displacement of H against OpenCV's USAC, p95 <= 0.25 px, inlier flags >= 99 % equal); a12 <= 1e-7; a14 matrix 1e-9 relative,
-mesh map exact; the 4:2:0 chroma planes exact."""
+mesh map exact; the 4:2:0 chroma planes exact; a10 (needs Eigen 3.4 as well, -DLVK_WITH_EIGEN): the mesh Eigen's LeastSquaresConjugateGradient::
+solveWithGuess stops at, on the exporter's five warm-started systems of the vector-field preset, within 1e-5 (normalised offsets) of the
+oracle's least-squares solution.  `scripts/opencv_ref/run.sh` does the four steps in one command."""
 import os
 import struct
 import sys
@@ -90,7 +92,45 @@ def export(d):
     save(f"{d}/persp.quads", np.array(quads, np.float32))
     save(f"{d}/meshmap.mesh", synth.random_mesh(16, 16, rng, amp=0.01).astype(np.float32)); save(f"{d}/meshmap.size", np.array([1280, 720], np.int32))
     save(f"{d}/chroma.plane", synth.textured_frame(270, 480, seed=77, channels=1))
+    # a10: the sparse least-squares systems of FrameTracker::estimate_local_motions (Vision/FrameTracker.cpp:219-268) on five warm-started frames
+    # of the vector-field preset (16 x 16 mesh over 480 x 270), as triplets + right-hand side + the guess (the oracle's previous mesh), for
+    # Eigen::LeastSquaresConjugateGradient::solveWithGuess (:274-276)
+    for k, (A, b, x0, _) in enumerate(lscg_systems(oracle)):
+        r, c = np.nonzero(A)
+        save(f"{d}/lscg_{k}.rows", r.astype(np.int32)); save(f"{d}/lscg_{k}.cols", c.astype(np.int32)); save(f"{d}/lscg_{k}.vals", A[r, c].astype(np.float32))
+        save(f"{d}/lscg_{k}.b", b.astype(np.float32)); save(f"{d}/lscg_{k}.x0", x0.astype(np.float32)); save(f"{d}/lscg_{k}.shape", np.array(A.shape, np.int32))
     print("inputs written to", d)
+
+
+LSCG_MESH, LSCG_REGION = (16, 16), (480, 270)
+
+
+def lscg_systems(oracle):
+    """[(A, b, x0, oracle offsets)] of five consecutive frames: every system is built around the ORACLE's previous mesh (temporal rows and
+    guess), so each one stands alone -- a real Eigen solves it from the same state the specification solved it from."""
+    from tests import oracle_lib, test_mesh_lstsq as ml
+    cols, rows = LSCG_MESH
+    rng = np.random.default_rng(cols * 31 + rows)
+    static = ml.static_rows(cols, rows, LSCG_REGION, 1.0, 20.0)
+    ref = oracle_lib.OracleMeshSolver(oracle, cols, rows, gen_region=LSCG_REGION, temporal=1.0, local=20.0)
+    out = []
+    for frame in range(5):
+        a, b2 = ml.field_pairs(rng, 700 - 50 * frame, LSCG_REGION, frame)
+        x0 = ref.mesh().reshape(-1).astype(np.float32)                      # m_OptimizedMesh before this frame's solve
+        A, b, feats = ml.build_system(cols, rows, static, LSCG_REGION, 1.0, x0, a, b2)
+        rc, _, off = ref.solve(a, b2, region=LSCG_REGION, temporal=1.0, threshold=10.0)
+        assert rc == 0
+        out.append((A, b, x0, off.astype(np.float64).reshape(rows, cols, 2)))
+    ref.close()
+    return out
+
+
+def lscg_offsets(x):
+    """normalised offsets (FrameTracker.cpp:316-320) of a solved mesh vector"""
+    from tests import test_mesh_lstsq as ml
+    cols, rows = LSCG_MESH
+    kw, kh = ml.key_size(cols, rows, LSCG_REGION)
+    return ml.mesh_to_result(cols, rows, LSCG_REGION, kw, kh, np.asarray(x, np.float32), [], [], 10.0)[1]
 
 
 def compare(d):
@@ -171,6 +211,18 @@ def compare(d):
         report("f2 chroma INTER_LINEAR x2", np.array_equal(packed[..., 1], load(f"{d}/chroma.out_up")), "bilinear upsampling of a plane")
         yy, u, v = oracle.egress_yuv420(packed)
         report("f2 chroma INTER_AREA 0.5", np.array_equal(u, load(f"{d}/chroma.out_down")), "2 x 2 box")
+    if os.path.exists(f"{d}/lscg_0.out"):
+        worst, iters = 0.0, []
+        for k, (_, _, _, off_oracle) in enumerate(lscg_systems(oracle)):
+            if not os.path.exists(f"{d}/lscg_{k}.out"):
+                break
+            worst = max(worst, float(np.abs(lscg_offsets(load(f"{d}/lscg_{k}.out")) - off_oracle).max()))
+            if os.path.exists(f"{d}/lscg_{k}.out_iters"):
+                iters.append(int(load(f"{d}/lscg_{k}.out_iters")[0]))
+        report("a10 Eigen LSCG solveWithGuess vs the oracle's least-squares mesh", worst <= 1e-5,
+               f"max |offset difference| {worst:.2e} (normalised; {worst * LSCG_REGION[0]:.4f} px), iterations {iters}")
+    else:
+        print("--   a10 Eigen LSCG: no lscg_*.out (the dump tool was built without -DLVK_WITH_EIGEN)")
     print("%d stage(s) outside their bar" % len(bad) if bad else "all stages within their bars")
     return 1 if bad else 0
 
@@ -205,6 +257,14 @@ def selftest_outputs(d):
     plane = load(f"{d}/chroma.plane")
     packed = oracle.ingest_yuv420(np.zeros((plane.shape[0] * 2, plane.shape[1] * 2), np.uint8), plane, plane)
     save(f"{d}/chroma.out_up", packed[..., 1]); save(f"{d}/chroma.out_down", oracle.egress_yuv420(packed)[1])
+    from tests import test_mesh_lstsq as ml
+    k = 0
+    while os.path.exists(f"{d}/lscg_{k}.rows"):                             # the exported triplets, solved by the RESTATED Eigen LSCG (tests/test_mesh_lstsq.py)
+        m, n = load(f"{d}/lscg_{k}.shape")
+        A = np.zeros((int(m), int(n)), np.float64)
+        A[load(f"{d}/lscg_{k}.rows"), load(f"{d}/lscg_{k}.cols")] = load(f"{d}/lscg_{k}.vals")
+        x, it, _ = ml.eigen_lscg(A, load(f"{d}/lscg_{k}.b").astype(np.float64), load(f"{d}/lscg_{k}.x0"))
+        save(f"{d}/lscg_{k}.out", x.astype(np.float32)); save(f"{d}/lscg_{k}.out_iters", np.array([it], np.int32)); k += 1
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@
 // rows whose arithmetic lives in that library -- a4 / a5 / a7 / a9 / a12 / a14 -- against the real thing:
 //
 //   g++ -O2 -std=c++17 opencv_ref_dump.cpp -o opencv_ref_dump $(pkg-config --cflags --libs opencv4)
+//   (with Eigen 3.4, the reference's pin -- Scripts/setup_deb.sh:133 --, add  -DLVK_WITH_EIGEN $(pkg-config --cflags eigen3)  : row a10 as well;
+//    scripts/opencv_ref/run.sh does all of it in one command)
 //   python scripts/opencv_ref/opencv_ref_compare.py export /tmp/lvk_cv          # inputs, from tests/golden + the clip generator
 //   ./opencv_ref_dump /tmp/lvk_cv                                                # <name>.out.* next to the inputs
 //   python scripts/opencv_ref/opencv_ref_compare.py compare /tmp/lvk_cv          # per-stage report, exit code 1 on a bound violated
@@ -18,6 +20,10 @@
 #include <opencv2/features2d.hpp>
 #include <opencv2/imgproc.hpp>
 #include <opencv2/video/tracking.hpp>
+#ifdef LVK_WITH_EIGEN
+#include <Eigen/Sparse>
+#include <Eigen/IterativeLinearSolvers>
+#endif
 
 #include <cstdio>
 #include <cstdint>
@@ -182,6 +188,30 @@ int main(int argc, char** argv)
         save(dir + "chroma.out_up", 0, {up.rows, up.cols}, up.data);
         save(dir + "chroma.out_down", 0, {down.rows, down.cols}, down.data);
     }
+#ifdef LVK_WITH_EIGEN
+    // ---- a10: Eigen::LeastSquaresConjugateGradient<SparseMatrix<float>>::solveWithGuess         Vision/FrameTracker.cpp:219-222,270-276
+    // (the system as the reference assembles it: float triplets -> setFromTriplets, float right-hand side, m_OptimizedMesh as the guess)
+    for (int k = 0; load(dir + "lscg_" + std::to_string(k) + ".rows", a); k++)
+    {
+        Array cols_, vals_, rhs_, x0_, shape_;
+        const std::string stem = dir + "lscg_" + std::to_string(k);
+        if (!load(stem + ".cols", cols_) || !load(stem + ".vals", vals_) || !load(stem + ".b", rhs_) || !load(stem + ".x0", x0_) || !load(stem + ".shape", shape_)) break;
+        const int* rr = reinterpret_cast<const int*>(a.data.data()); const int* cc = reinterpret_cast<const int*>(cols_.data.data());
+        const float* vv = reinterpret_cast<const float*>(vals_.data.data()); const int* shp = reinterpret_cast<const int*>(shape_.data.data());
+        std::vector<Eigen::Triplet<float>> triplets;
+        for (int i = 0; i < a.dims[0]; i++) triplets.emplace_back(rr[i], cc[i], vv[i]);
+        Eigen::SparseMatrix<float> A(shp[0], shp[1]);
+        A.setFromTriplets(triplets.begin(), triplets.end());
+        const Eigen::Map<const Eigen::VectorXf> rhs(reinterpret_cast<const float*>(rhs_.data.data()), shp[0]);
+        const Eigen::Map<const Eigen::VectorXf> guess(reinterpret_cast<const float*>(x0_.data.data()), shp[1]);
+        Eigen::LeastSquaresConjugateGradient<Eigen::SparseMatrix<float>> solver(A);
+        const Eigen::VectorXf x = solver.solveWithGuess(rhs, guess);
+        const int32_t iters = (int32_t)solver.iterations();
+        save(stem + ".out", 2, {shp[1]}, x.data());
+        save(stem + ".out_iters", 1, {1}, &iters);
+    }
+    std::printf("Eigen %d.%d.%d\n", EIGEN_WORLD_VERSION, EIGEN_MAJOR_VERSION, EIGEN_MINOR_VERSION);
+#endif
     std::printf("done\n");
     return 0;
 }

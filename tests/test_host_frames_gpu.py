@@ -242,3 +242,24 @@ def test_host_and_device_pushes_mixed_in_one_stream(ctx):
         if x is not None:
             for p, q in zip(x, y):
                 assert np.array_equal(p, q), i
+
+
+def test_pinned_planes_sit_on_the_gpus_numa_node(ctx):
+    """lvk_hip_host_malloc makes its context's device current, and the runtime takes pinned host memory from the memory pool of the CPU agent
+    nearest to that device: the planes of a host-fed stream land on the socket the GPU hangs off without the caller binding anything
+    (eight host-fed 4K streams move ~80 GB/s per GPU through host DRAM).  Checked against /proc/self/numa_maps where the
+    host has more than one node; reported either way."""
+    import os
+    import livevisionkit_amd as lvk
+    from livevisionkit_amd import shard
+    f = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx)
+    planes = f.host_planes(2160, 3840)
+    for p in planes:
+        p[...] = 7                                                          # touched
+    node_gpu = shard.gpu_numa_node(0)
+    node_mem = shard.numa_node_of_address(planes[0].ctypes.data)
+    nodes = [d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()] if os.path.isdir("/sys/devices/system/node") else []
+    print(f"\n[numa] GPU 0 on node {node_gpu}, pinned 4K I420 frame on node {node_mem}, host has {len(nodes)} node(s)")
+    if len(nodes) > 1 and node_gpu >= 0 and node_mem >= 0:
+        assert node_mem == node_gpu, (node_mem, node_gpu)
+    f.close()

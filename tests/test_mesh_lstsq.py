@@ -94,9 +94,21 @@ def eigen_lscg(A, b, x0):
     return x, i, float(np.sqrt(res2 / rhs2))
 
 
+def build_system(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched):
+    """The sparse least-squares system of estimate_local_motions (:219-268) as a dense (A, b) pair plus, per feature, its four vertex indices and
+    barycentric weights.  (Also what scripts/opencv_ref/opencv_ref_compare.py exports for a real Eigen to solve.)"""
+    return _system(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched)
+
+
 def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched, threshold, solver="lstsq", info=None):
     """estimate_local_motions (:200-321); solver "lstsq": np.linalg.lstsq (binary64 SVD) in place of Eigen::LeastSquaresConjugateGradient,
     "lscg": the restated Eigen solver itself, warm-started from prev_mesh (:274-276)."""
+    kw, kh = key_size(cols, rows, region)
+    A, b, feats = _system(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched)
+    return _finish(cols, rows, region, kw, kh, A, b, feats, prev_mesh, matched, threshold, solver, info)
+
+
+def _system(cols, rows, static, region, temporal_now, prev_mesh, tracked, matched):
     kw, kh = key_size(cols, rows, region)
     n = 2 * cols * rows
     m = len(static) + 2 * len(tracked)
@@ -124,6 +136,10 @@ def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, ma
                 A[at, ids[q] + comp] += float(w[q])
             b[at] = float(dst); at += 1
         feats.append((ids, w))
+    return A, b, feats
+
+
+def _finish(cols, rows, region, kw, kh, A, b, feats, prev_mesh, matched, threshold, solver, info):
     if solver == "lscg":
         # the reference's operands are binary32: A's triplets and b are floats (:221-222)
         x, iters, rel = eigen_lscg(A, b, np.asarray(prev_mesh, f32))
@@ -132,7 +148,12 @@ def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, ma
     else:
         x = np.linalg.lstsq(A, b, rcond=None)[0]
     mesh = x.astype(f32)                                                    # Eigen::VectorXf m_OptimizedMesh
-    inl = np.zeros(len(tracked), np.uint8)
+    return (mesh,) + mesh_to_result(cols, rows, region, kw, kh, mesh, feats, matched, threshold)
+
+
+def mesh_to_result(cols, rows, region, kw, kh, mesh, feats, matched, threshold):
+    """inlier flags (:279-310) and normalised offsets (:316-320) of a solved mesh"""
+    inl = np.zeros(len(matched), np.uint8)
     for k, ((ids, w), (dx, dy)) in enumerate(zip(feats, matched)):          # :279-310
         px = sum(float(w[q]) * float(mesh[ids[q]]) for q in range(4)); py = sum(float(w[q]) * float(mesh[ids[q] + 1]) for q in range(4))
         inl[k] = (abs(px - dx) + abs(py - dy)) < threshold
@@ -141,7 +162,7 @@ def solve_frame(cols, rows, static, region, temporal_now, prev_mesh, tracked, ma
         for c in range(cols):
             off[r, c, 0] = (float(f32(c) * kw) - float(mesh[2 * (r * cols + c)])) / region[0]
             off[r, c, 1] = (float(f32(r) * kh) - float(mesh[2 * (r * cols + c) + 1])) / region[1]
-    return mesh, inl, off
+    return inl, off
 
 
 def field_pairs(rng, n, region, frame, outliers=0.12):

@@ -52,3 +52,17 @@ def test_cpulist_parsing_and_unbound_fallback():
     assert shard._parse_cpulist("") == []
     # without a visible GPU (or without the sysfs entries) the process is left unbound
     assert shard.gpu_numa_cpus(0, sysfs="/nonexistent") == []
+
+
+def test_numa_node_of_address_reads_numa_maps(tmp_path):
+    from livevisionkit_amd import shard
+    maps = tmp_path / "numa_maps"
+    maps.write_text("7f0000000000 default anon=10 dirty=10 N0=2 N1=8 kernelpagesize_kB=4\n"
+                    "7f0000100000 default file=/x mapped=3 N0=3 kernelpagesize_kB=4\n"
+                    "7f0000200000 prefer:1 anon=512 dirty=512 N1=512 kernelpagesize_kB=4\n")
+    assert shard.numa_node_of_address(0x7f0000000000 + 4096, str(maps)) == 1          # most pages on node 1
+    assert shard.numa_node_of_address(0x7f0000100010, str(maps)) == 0
+    assert shard.numa_node_of_address(0x7f0000200000 + (1 << 20), str(maps)) == 1     # inside the last mapping
+    assert shard.numa_node_of_address(0x1000, str(maps)) == -1                         # below every mapping
+    assert shard.numa_node_of_address(0x1000, "/nonexistent") == -1
+    assert shard.gpu_numa_node(0, sysfs="/nonexistent") == -1
