@@ -246,11 +246,34 @@ struct HomographyCoord      // FSR.cl:422-430
     }
 };
 
-struct MeshCoord            // WarpMesh.cpp:190-191 per pixel (HResizeLinear, VResizeLinear, * (cols, rows)) + FSR.cl:381
+// The mesh in LDS (meshes up to MESH_LDS_FLOATS values: the 16 x 16 preset is 512): a pixel's coordinate is table entry -> 4 mesh vertices ->
+// tap rows, three DEPENDENT memory round trips where the homography kernels have one; with the vertices a ds_read away the mesh kernel runs
+// 110.5 -> 106.6 us alone, 131 -> 122 us next to the vector-field tracker, four concurrent field streams 5 810 -> 6 030 frames/s
+// (profiles/r05_ab_mesh_in_lds.txt).  Filled once per block by mesh_to_lds().
+#ifndef LVK_MESH_LDS_FLOATS
+#define LVK_MESH_LDS_FLOATS 2048
+#endif
+constexpr int MESH_LDS_FLOATS = LVK_MESH_LDS_FLOATS;               // 0: always the global-memory path (A / B partner)
+__shared__ float s_mesh_lds[MESH_LDS_FLOATS > 0 ? MESH_LDS_FLOATS : 1];
+__device__ __forceinline__ bool mesh_to_lds(const float* __restrict__ mesh, int mesh_floats)
+{
+    if (mesh_floats > MESH_LDS_FLOATS) return false;                   // block-uniform
+    for (int i = (int)threadIdx.x; i < mesh_floats; i += (int)blockDim.x) s_mesh_lds[i] = mesh[i];
+    __syncthreads();
+    return true;
+}
+
+template <bool LDS>
+struct MeshCoordT           // WarpMesh.cpp:190-191 per pixel (HResizeLinear, VResizeLinear, * (cols, rows)) + FSR.cl:381
 {
     const float* __restrict__ mesh; int mesh_cols;
     const LinTabEntry* __restrict__ xtab; const LinTabEntry* __restrict__ ytab;
     float sw, sh;
+    __device__ __forceinline__ float vertex(uint32_t byte_off) const
+    {
+        if constexpr (LDS) return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(s_mesh_lds) + byte_off);
+        else return at_byte<float>(mesh, byte_off);
+    }
     __device__ __forceinline__ void operator()(int x, int y, float& subx, float& suby) const
     {
         // (32-bit BYTE offsets against the block-uniform bases: the table and mesh loads take the scalar-base + 32-bit-offset form, no 64-bit
@@ -264,8 +287,8 @@ struct MeshCoord            // WarpMesh.cpp:190-191 per pixel (HResizeLinear, VR
         for (int ch = 0; ch < 2; ch++)
         {
             const uint32_t b = 4u * (uint32_t)ch;
-            const float h0 = (tx.s1 == tx.s0) ? at_byte<float>(mesh, r0 + c0 + b) * 1.0f : at_byte<float>(mesh, r0 + c0 + b) * tx.a0 + at_byte<float>(mesh, r0 + c1 + b) * tx.a1;
-            const float h1 = (tx.s1 == tx.s0) ? at_byte<float>(mesh, r1 + c0 + b) * 1.0f : at_byte<float>(mesh, r1 + c0 + b) * tx.a0 + at_byte<float>(mesh, r1 + c1 + b) * tx.a1;
+            const float h0 = (tx.s1 == tx.s0) ? vertex(r0 + c0 + b) * 1.0f : vertex(r0 + c0 + b) * tx.a0 + vertex(r0 + c1 + b) * tx.a1;
+            const float h1 = (tx.s1 == tx.s0) ? vertex(r1 + c0 + b) * 1.0f : vertex(r1 + c0 + b) * tx.a0 + vertex(r1 + c1 + b) * tx.a1;
             off[ch] = (h0 * ty.a0 + h1 * ty.a1) * (ch == 0 ? sw : sh);
         }
         subx = (float)x + off[0];
@@ -518,22 +541,26 @@ template <bool YUV>
 __global__ __launch_bounds__(256)
 void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                   uint8_t* __restrict__ dst, int dst_step,
-                  const float* __restrict__ mesh, int mesh_cols,
+                  const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
                   const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
-    const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
+    if (mesh_to_lds(mesh, mesh_floats))
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, bg);
+    else
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, bg);
 }
 
 template <bool YUV>
 __global__ __launch_bounds__(256) LVK_CO_SCHEDULED
 void k_remap_mesh_co(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                   uint8_t* __restrict__ dst, int dst_step,
-                  const float* __restrict__ mesh, int mesh_cols,
+                  const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
                   const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
-    const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
+    if (mesh_to_lds(mesh, mesh_floats))
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, bg);
+    else
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, bg);
 }
 
 template <bool YUV>
@@ -560,22 +587,30 @@ template <bool YUV>
 __global__ __launch_bounds__(256)
 void k_remap_mesh_lens(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                        uint8_t* __restrict__ dst, int dst_step,
-                       const float* __restrict__ mesh, int mesh_cols,
+                       const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
                        const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, LensArgs L, uint32_t bg)
 {
-    const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
+    if (mesh_to_lds(mesh, mesh_floats))
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols,
+                         LensCoord<MeshCoordT<true>>{MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols}, bg);
+    else
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols,
+                         LensCoord<MeshCoordT<false>>{MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols}, bg);
 }
 
 template <bool YUV>
 __global__ __launch_bounds__(256) LVK_CO_SCHEDULED
 void k_remap_mesh_lens_co(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                        uint8_t* __restrict__ dst, int dst_step,
-                       const float* __restrict__ mesh, int mesh_cols,
+                       const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
                        const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, LensArgs L, uint32_t bg)
 {
-    const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols};
-    remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols, coord, bg);
+    if (mesh_to_lds(mesh, mesh_floats))
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols,
+                         LensCoord<MeshCoordT<true>>{MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols}, bg);
+    else
+        remap_strip<YUV>(src, src_step, src_rows, src_cols, PackedSink{dst, dst_step}, src_rows, src_cols,
+                         LensCoord<MeshCoordT<false>>{MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)src_cols, (float)src_rows}, L, src_rows, src_cols}, bg);
 }
 
 template <bool YUV>
@@ -622,20 +657,24 @@ void k_remap_homography_lens_420(const uint8_t* __restrict__ src, int src_step, 
 template <bool NV12>
 __global__ __launch_bounds__(256) LVK_CO_SCHEDULED
 void k_remap_mesh_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
-                      const float* __restrict__ mesh, int mesh_cols, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
+                      const float* __restrict__ mesh, int mesh_cols, int mesh_floats, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
-    const MeshCoord coord{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows};
-    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
+    const Sink420<NV12> sink{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step};
+    if (mesh_to_lds(mesh, mesh_floats)) remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, bg);
+    else remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, bg);
 }
 
 template <bool NV12>
 __global__ __launch_bounds__(256) LVK_CO_SCHEDULED
 void k_remap_mesh_lens_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
-                           const float* __restrict__ mesh, int mesh_cols, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab,
+                           const float* __restrict__ mesh, int mesh_cols, int mesh_floats, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab,
                            LensArgs L, uint32_t bg)
 {
-    const LensCoord<MeshCoord> coord{MeshCoord{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols};
-    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg);
+    const Sink420<NV12> sink{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step};
+    if (mesh_to_lds(mesh, mesh_floats))
+        remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, LensCoord<MeshCoordT<true>>{MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols}, bg);
+    else
+        remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, LensCoord<MeshCoordT<false>>{MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols}, bg);
 }
 
 inline dim3 remap_grid(int dst_rows, int dst_cols)
@@ -756,10 +795,10 @@ int lvk_launch_remap_mesh(lvk_hip_ctx* ctx, hipStream_t stream,
 
     const dim3 block(256), grid = remap_grid(src_rows, src_cols), cogrid = lvk_co_grid(ctx, src_rows, src_cols);
     if (lens)
-        LVK_LAUNCH_REMAP(k_remap_mesh_lens, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols,
+        LVK_LAUNCH_REMAP(k_remap_mesh_lens, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2,
                          xtab, ytab, *lens, pack_bg(bg));
     else
-        LVK_LAUNCH_REMAP(k_remap_mesh, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols,
+        LVK_LAUNCH_REMAP(k_remap_mesh, (const uint8_t*)d_src, src_step, src_rows, src_cols, (uint8_t*)d_dst, dst_step, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2,
                          xtab, ytab, pack_bg(bg));
 #undef LVK_LAUNCH_REMAP
     const hipError_t le = hipGetLastError();
@@ -895,13 +934,13 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
         if ((rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot)) != LVK_HIP_OK) return rc;
         if (lens)
         {
-            if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
-            else hipLaunchKernelGGL(k_remap_mesh_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, *lens, pack_bg(bg));
+            if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_mesh_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
         }
         else
         {
-            if (nv12) hipLaunchKernelGGL(k_remap_mesh_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
-            else hipLaunchKernelGGL(k_remap_mesh_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, xtab, ytab, pack_bg(bg));
+            if (nv12) hipLaunchKernelGGL(k_remap_mesh_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_mesh_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, pack_bg(bg));
         }
     }
     const hipError_t le = hipGetLastError();
