@@ -12,6 +12,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -305,6 +307,68 @@ int run_two_threads_check()
     return 0;
 }
 
+// Two filters on DIFFERENT contexts that feed each other 4:2:0 frames from two threads, overlap off (round-4 ADVICE, medium): filter A
+// (context A, thread 0) consumes planes that live on context B, filter B (context B, thread 1) planes that live on context A.  The
+// non-overlap apply(const VideoFrame420&) ends with a cross-context wait that takes BOTH contexts' mutexes: held while the filter's own is
+// still locked it is an ABBA deadlock between the two threads; the facade releases its own lock first.  A watchdog turns a hang into a failure;
+// the outputs must equal the single-threaded runs.
+int run_cross_context_420_check()
+{
+    // small frames, many pushes: the window in which both threads sit in their trailing waits is a microsecond wide -- 1 500 pushes per thread and
+    // round make it certain that the pre-round-5 locking hangs here (checked: scripts/probes/cross_context_lock_check.sh)
+    const int rows = 136, cols = 240, n = 1500;
+    auto planes_of = [&](int stream, int i, std::vector<uint8_t>& buf) {
+        buf.resize((size_t)rows * cols * 3 / 2);
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++)
+            {
+                const int xs = x + (2 + stream) * (i % 4) + 11 * stream, ys = y + (i % 3), cell = 12 + 3 * stream;
+                buf[(size_t)y * cols + x] = (uint8_t)((((xs / cell) + (ys / cell)) % 2) ? 200 : 36 + (xs * 5 + ys * 9) % 31);
+            }
+        std::memset(buf.data() + (size_t)rows * cols, 120 + 8 * stream, (size_t)rows * cols / 2);
+    };
+    lvk::StabilizationFilterSettings st; st.predictive_samples = 2; st.detection_resolution = {480, 270}; st.track_local_motions = false;
+    st.min_scene_quality = 0.4f; st.min_tracking_quality = 0.2f;
+    using Outputs = std::vector<std::vector<uint8_t>>;
+    // stream s: frames uploaded on `frames_ctx`, filtered on `filter_ctx`
+    auto run = [&](int s, const std::shared_ptr<lvk::hip::Context>& frames_ctx, const std::shared_ptr<lvk::hip::Context>& filter_ctx, Outputs& outs) {
+        lvk::StabilizationFilter filter(st, filter_ctx);                       // overlap stays OFF: the path with the trailing cross-context wait
+        std::vector<uint8_t> buf;
+        for (int i = 0; i < n; i++)
+        {
+            planes_of(s, i, buf);
+            lvk::VideoFrame420 in, out;
+            in.upload(buf.data(), rows, cols, false, 100 * s + i, frames_ctx);
+            filter.apply(in, out);
+            if (out.empty() || i % 100 != 99) continue;                      // (a download synchronises: compare one frame in a hundred)
+            outs.emplace_back((size_t)rows * cols * 3 / 2);
+            out.download(outs.back().data());
+        }
+    };
+    Outputs want[2];
+    for (int s = 0; s < 2; s++) { auto c = std::make_shared<lvk::hip::Context>(); run(s, c, c, want[s]); }
+    if (want[0].size() != (size_t)n / 100 || want[0][5] == want[1][5]) { std::printf("cross-context: reference runs implausible\n"); return 1; }
+    for (int round = 0; round < 3; round++)
+    {
+        auto A = std::make_shared<lvk::hip::Context>(), B = std::make_shared<lvk::hip::Context>();
+        Outputs got[2];
+        std::atomic<int> done{0};
+        std::thread t0([&] { run(0, B, A, got[0]); done++; });              // filter on A, frames on B
+        std::thread t1([&] { run(1, A, B, got[1]); done++; });              // filter on B, frames on A
+        for (int ms = 0; ms < 30000 && done.load() < 2; ms += 5) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        if (done.load() < 2) { std::printf("cross-context: DEADLOCK (two filters on two contexts feeding each other 4:2:0 frames, round %d)\n", round); std::fflush(stdout); std::_Exit(1); }
+        t0.join(); t1.join();
+        for (int s = 0; s < 2; s++)
+        {
+            if (got[s].size() != want[s].size()) { std::printf("cross-context: stream %d emitted %zu frames\n", s, got[s].size()); return 1; }
+            for (size_t k = 0; k < got[s].size(); k++)
+                if (got[s][k] != want[s][k]) { std::printf("cross-context: stream %d frame %zu differs from its single-context run (round %d)\n", s, k, round); return 1; }
+        }
+    }
+    std::printf("cross-context ok: 2 filters on 2 contexts feeding each other 4:2:0 frames from 2 threads, no overlap: no deadlock, bytes equal\n");
+    return 0;
+}
+
 // A clip FILE through VideoFilter::stream (the reference's harness: VideoProcessor.cpp:148-230 opens a cv::VideoCapture on a path and
 // streams it): lvk::RawYuvCapture on a raw I420 file.  Delivered as YUV the emitted frames must equal apply() on the same frames ingested
 // by lvk_hip_ingest_yuv420, stamped with the stream position; delivered as BGR (the reference's assumption) the run must complete with BGR
@@ -485,7 +549,7 @@ int main(int argc, char** argv)
 #ifdef RUN_ON_GPU
     if (argc >= 7 && std::string(argv[1]) == "--golden") return run_golden(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
     if (argc >= 7 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5], std::atoi(argv[6]));
-    if (argc >= 3 && std::string(argv[1]) == "--threads-and-files") return (run_two_threads_check() != 0 || run_file_input_check(argv[2]) != 0) ? 1 : 0;
+    if (argc >= 3 && std::string(argv[1]) == "--threads-and-files") return (run_two_threads_check() != 0 || run_cross_context_420_check() != 0 || run_file_input_check(argv[2]) != 0) ? 1 : 0;
     if (run_chain_race_check() != 0) return 1;
     {
         // VideoFilter::stream (Filters/VideoFilter.cpp:62-209; CLI use Modules/VideoEditor/VideoProcessor.cpp:148-230): reader thread ->

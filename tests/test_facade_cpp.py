@@ -44,6 +44,7 @@ def test_two_filters_on_two_threads_and_a_clip_file(tmp_path):
     exe = _build(tmp_path, ["-DRUN_ON_GPU", "-O1", "-pthread"])
     out = subprocess.check_output([exe, "--threads-and-files", str(tmp_path)], timeout=600).decode()
     assert "threads ok: 2 filters on 2 threads" in out
+    assert "cross-context ok: 2 filters on 2 contexts feeding each other" in out          # (round-4 ADVICE: was an ABBA deadlock in the non-overlap 4:2:0 apply)
     assert "file input ok (I420):" in out and "file input ok (NV12):" in out
 
 
