@@ -5,7 +5,8 @@ The fuzz: one 4:2:0 stream whose pushes are drawn at random from everything a ho
   * device-resident planes (lvk_hip_stab_push_yuv420) or pinned host planes (lvk_hip_stab_push_yuv420_host), interleaved;
   * the next frame announced (lvk_hip_stab_prefetch_yuv420 / _yuv420_host), announced WRONGLY (another frame's planes), or announced and
     cancelled (lvk_hip_stab_prefetch_cancel); a wrong host announcement must be refused by the push and leave the filter usable;
-  * overlap mode switched on / off, restart(), reconfigure (frame delay up and down, homography <-> vector-field preset);
+  * overlap mode switched on / off, restart(), reconfigure (frame delay up and down, homography <-> vector-field preset, stabilize_output off
+    and on again = the delay-only passthrough), the fused lens pre-warp switched on / off (restarts the filter);
   * one resolution change in the middle of the stream;
 the pushes free-running (no synchronisation between them beyond what the calls do themselves), every output in a buffer of its own.
 After the last push every emitted plane is compared, BY TIMESTAMP, with the oracle chain ingest_yuv420 -> OracleStabilizer ->
@@ -35,9 +36,9 @@ def _conv(o):
     return s
 
 
-def _settings(preset, delay):
+def _settings(preset, delay, stabilize=True):
     # relaxed quality assurance: the trust factor leaves zero a few frames after every (re)start, so the emitted planes carry the warp
-    return oracle_lib.preset(preset, predictive_samples=delay, min_scene_quality=0.3, min_tracking_quality=0.2)
+    return oracle_lib.preset(preset, predictive_samples=delay, min_scene_quality=0.3, min_tracking_quality=0.2, stabilize_output=1 if stabilize else 0)
 
 
 # LVK_FUZZ_SEEDS="5-40" (or "7,9,11"): more seeds for a one-off sweep on a GPU box; the suite itself runs four
@@ -72,7 +73,7 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
     s = _settings(preset, delay)
     ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
     gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_conv(s))
-    overlap = True
+    overlap, stabilize, lens_on, stab_back_at = True, True, False, 0
     gst.set_overlap(overlap)
     dev_args = [gst.prepare_yuv420(p) for p in planes_d]
 
@@ -93,16 +94,28 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
     for i in range(n):
         # ---- what happens BETWEEN two pushes
         ev = int(rng.integers(0, 20))
+        if not stabilize and i >= stab_back_at:
+            ev = 4                                                   # the passthrough lasts four pushes, then the stream is stabilized again
         if ev == 0 and i > 4:
             ost.restart(); gst.restart(); host_announced = None; log.append((i, "restart"))
         elif ev == 1:
             overlap = not overlap; gst.set_overlap(overlap); log.append((i, "overlap %d" % overlap))
         elif ev == 2:
             delay = 3 if delay == 2 else 2
-            s = _settings(preset, delay); ost.configure(s); gst.configure(_conv(s)); log.append((i, "delay %d" % delay))
+            s = _settings(preset, delay, stabilize); ost.configure(s); gst.configure(_conv(s)); log.append((i, "delay %d" % delay))
         elif ev == 3 and i > 6:
             preset = "field" if preset == "homography" else "homography"
-            s = _settings(preset, delay); ost.configure(s); gst.configure(_conv(s)); log.append((i, preset))
+            s = _settings(preset, delay, stabilize); ost.configure(s); gst.configure(_conv(s)); log.append((i, preset))
+        elif ev == 4 and i > 3:
+            # stabilize_output off = the delay-only passthrough (StabilizationFilter.cpp:77-95; switching it off resets tracker and smoother, :49-52)
+            stabilize = not stabilize; stab_back_at = i + 4
+            s = _settings(preset, delay, stabilize); ost.configure(s); gst.configure(_conv(s)); log.append((i, "stabilize %d" % stabilize))
+        elif ev == 5 and i > 8:
+            # the fused lens pre-warp switched on / off in the middle of the stream: both sides restart (lvk_hip_stab_set_lens)
+            lens_on = not lens_on
+            r, c = frames[i].shape[:2]
+            prof = np.array([0.8 * c, 0.8 * c, c / 2.0, r / 2.0, -0.12, 0.03, 0.0, 0.0, 0.0]) if lens_on else None
+            ost.set_lens(prof); gst.set_lens(prof); host_announced = None; log.append((i, "lens %d" % lens_on))
         # ---- the oracle's push
         buf = big.copy()
         w, wts = ost.push(oracle.ingest_yuv420(*planes_h[i]), ts=i, nthreads=32, out=buf)
@@ -152,8 +165,8 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
     # frames of the old size still queued when the size changed are dropped by the 4:2:0 pool (the oracle, like the reference, emits them late)
     dropped = {ts for ts, at in want_push.items() if ts < change_at <= at}
     assert sorted(got) == sorted(set(want) - dropped), (log, sorted(dropped))
-    assert len(got) >= n // 2, (len(got), log)
-    assert live >= 8, f"only {live} emitted frames had a trust factor above zero: the schedule restarts too often to test the warp ({log})"
+    assert len(got) >= 10, (len(got), log)                           # (schedules that restart every few pushes emit little: the suite's seeds emit 25-35)
+    assert live >= 4, f"only {live} emitted frames had a trust factor above zero: the schedule restarts too often to test the warp ({log})"
     for ts, (kind, planes) in sorted(got.items()):
         for k, (p, q) in enumerate(zip(planes, want[ts])):
             p = p.cpu().numpy() if kind == "device" else np.asarray(p)
