@@ -175,8 +175,11 @@ int lvk_hip_free(lvk_hip_ctx* ctx, void* d_ptr)
             // last to touch the block (a remap that wrote an output frame, a download that read it) -- round-4 VERDICT, weak #10.
             glock.unlock();
             if (hipStreamQuery(caller->stream) != hipSuccess) { (void)hipGetLastError(); LVK_HIP_CHECK(caller, hipStreamSynchronize(caller->stream)); }
-            for (hipStream_t a : caller->aux_streams)
-                if (hipStreamQuery(a) != hipSuccess) { (void)hipGetLastError(); LVK_HIP_CHECK(caller, hipStreamSynchronize(a)); }
+            {
+                std::lock_guard<std::mutex> alock(caller->aux_mutex);      // (the list, and the streams in it, stay as they are while they are looked at)
+                for (hipStream_t a : caller->aux_streams)
+                    if (hipStreamQuery(a) != hipSuccess) { (void)hipGetLastError(); LVK_HIP_CHECK(caller, hipStreamSynchronize(a)); }
+            }
             glock.lock();
             o = g_block_owner.find(d_ptr);                                 // the owner may have gone meanwhile: then it is plain device memory
             owner = o != g_block_owner.end() ? o->second : caller;
@@ -218,6 +221,7 @@ int lvk_hip_ctx_wait(lvk_hip_ctx* ctx, lvk_hip_ctx* producer)
     if (ctx == producer) return LVK_HIP_OK;
     LVK_HIP_REQUIRE(ctx, ctx->device == producer->device);
     lvk_device_guard device_guard(ctx);
+    std::lock_guard<std::mutex> alock(producer->aux_mutex);
     const size_t need = 1 + producer->aux_streams.size();
     while (ctx->wait_events.size() < need)
     {

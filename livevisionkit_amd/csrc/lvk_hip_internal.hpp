@@ -43,6 +43,9 @@ struct lvk_hip_ctx
 
     // extra streams owned by objects of this context (synchronised by lvk_hip_sync as well)
     std::vector<hipStream_t> aux_streams;
+    // lvk_hip_free through ANOTHER context (any thread: a frame dropped where it was last used) and lvk_hip_ctx_wait read this list while the
+    // owning thread may be changing it (overlap switched on / off, transfer streams created): changes and foreign reads hold this mutex
+    std::mutex aux_mutex;
     // work that objects of this context still have to enqueue before "everything is complete" can be waited for (deferred downloads):
     // (owner, hook) pairs run by lvk_hip_sync ahead of the stream synchronisations
     std::vector<std::pair<void*, std::function<int()>>> sync_hooks;

@@ -320,7 +320,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
         (void)hipStreamSynchronize(st->remap_stream);
         rehome_stage_events(st->ctx);
         auto& aux = st->ctx->aux_streams;
-        aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
+        { std::lock_guard<std::mutex> alock(st->ctx->aux_mutex); aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end()); }
         if (st->remap_stream_owned) (void)hipStreamDestroy(st->remap_stream);
     }
     for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventDestroy(st->remap_done[i]);
@@ -368,7 +368,7 @@ static int stab_detach_bulk_stream(lvk_hip_stab* st)
     if (st->ingest_done) (void)hipEventRecord(st->ingest_done, ctx->stream);
     st->remap_wait = nullptr;
     auto& aux = ctx->aux_streams;
-    aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end());
+    { std::lock_guard<std::mutex> alock(ctx->aux_mutex); aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end()); }
     if (st->remap_stream_owned) LVK_HIP_CHECK(ctx, hipStreamDestroy(st->remap_stream));
     st->remap_stream = nullptr; st->remap_stream_owned = false;
     return LVK_HIP_OK;
@@ -400,7 +400,7 @@ static int stab_set_overlap(lvk_hip_stab* st, bool enable, lvk_hip_ctx* bulk)
                 LVK_HIP_CHECK(ctx, hipStreamCreateWithPriority(&st->remap_stream, hipStreamNonBlocking, prio_least));
                 st->remap_stream_owned = true;
             }
-            ctx->aux_streams.push_back(st->remap_stream);
+            { std::lock_guard<std::mutex> alock(ctx->aux_mutex); ctx->aux_streams.push_back(st->remap_stream); }
         }
         for (int i = 0; i < 2; i++)
             if (!st->remap_done[i]) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->remap_done[i], hipEventDisableTiming));

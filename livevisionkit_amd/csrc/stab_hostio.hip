@@ -49,7 +49,12 @@ void lvk_hip_stab::free_hostio()
     { auto& hooks = ctx->sync_hooks; hooks.erase(std::remove_if(hooks.begin(), hooks.end(), [this](const auto& kv) { return kv.first == (void*)this; }), hooks.end()); }
     h.pending.valid = false;
     for (hipStream_t s : {h.up, h.down, h.down2})
-        if (s) { (void)hipStreamSynchronize(s); aux.erase(std::remove(aux.begin(), aux.end(), s), aux.end()); (void)hipStreamDestroy(s); }
+        if (s)
+        {
+            (void)hipStreamSynchronize(s);
+            { std::lock_guard<std::mutex> alock(ctx->aux_mutex); aux.erase(std::remove(aux.begin(), aux.end(), s), aux.end()); }
+            (void)hipStreamDestroy(s);
+        }
     h.up = h.down = h.down2 = nullptr;
     for (auto& p : h.d_in) { if (p) (void)hipFree(p); p = nullptr; }
     for (auto& p : h.d_out) { if (p) (void)hipFree(p); p = nullptr; }

@@ -278,7 +278,7 @@ struct lvk_hip_stab
     {
         if (s) return LVK_HIP_OK;
         LVK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        ctx->aux_streams.push_back(s);
+        { std::lock_guard<std::mutex> alock(ctx->aux_mutex); ctx->aux_streams.push_back(s); }
         return LVK_HIP_OK;
     }
     int flush_download(bool wait);
