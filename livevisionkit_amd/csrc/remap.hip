@@ -477,8 +477,11 @@ __device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src,
             // shared tail of FSR.cl:380-402 / 429-451
             const int sx = (int)subx;                 // v_cvt_i32_f32: truncates, saturates, NaN -> 0
             const int sy = (int)suby;
-            const float ppx = subx - __builtin_floorf(subx);
-            const float ppy = suby - __builtin_floorf(suby);
+            // `coord - floor(coord)` (FSR.cl:383,432) as ONE v_fract_f32: for every coordinate that reaches the EASU path (1 <= coord < size - 4) x and
+            // floor(x) lie in the same or neighbouring binades and the difference is exact in either form, so the bits are the same; the border
+            // and background paths do not use pp (where a tiny negative coordinate would round x - floor(x) up to 1.0 and v_fract stays below it)
+            const float ppx = __builtin_amdgcn_fractf(subx);
+            const float ppy = __builtin_amdgcn_fractf(suby);
             if (sx < 1 || sy < 1 || sx >= src_cols - 4 || sy >= src_rows - 4)
             {
                 if (sx >= 0 && sx < src_cols && sy >= 0 && sy < src_rows)

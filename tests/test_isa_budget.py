@@ -49,7 +49,7 @@ def test_remap_instruction_ceiling():
     four tap-row loads, the border copy, the mesh / table loads and the sinks address their frames with ONE 32-bit byte offset against
     block-uniform scalar bases (global_load v, v_off, s[base:base+1]) -- 2 066 static VALU for the homography kernel, 2 155 for the mesh
     kernel (was 2 241), no v_mad_u64_u32 anywhere in them and a handful of v_lshl_add_u64 per THREAD (ragged-edge stores) instead of 6-7
-    per pixel.  This test keeps a refactor from quietly adding to it, and holds the round-4 savings in place: EASU's saturate as the
+    per pixel -- and made `coord - floor(coord)` one v_fract_f32 (exact for every coordinate that reaches the EASU path): 2 058.  This test keeps a refactor from quietly adding to it, and holds the round-4 savings in place: EASU's saturate as the
     `clamp` modifier of the multiply that feeds it and the final clamp between the centre taps' minimum and maximum as one v_med3_f32."""
     out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, "remap.hip")],
                          capture_output=True, text=True, timeout=600)
@@ -63,7 +63,7 @@ def test_remap_instruction_ceiling():
         return [o for o in ops if o.startswith("v_")]
     # (the mesh kernels hold TWO copies of the strip body since round 5 -- the mesh in LDS for meshes up to 2048 values, in global memory beyond --
     #  and run one of them: their static counts are the sum of both)
-    for kernel, ceiling, addr64 in (("k_remap_homography_420", 2080, 12), ("k_remap_mesh_420", 2 * 2200, 40), ("k_remap_homography_lens_420", 2245, 12),
+    for kernel, ceiling, addr64 in (("k_remap_homography_420", 2066, 12), ("k_remap_mesh_420", 2 * 2200, 40), ("k_remap_homography_lens_420", 2245, 12),
                                     ("k_remap_mesh_lens_420", 2 * 2360, 40)):
         bodies = bodies_of(kernel)
         assert len(bodies) == 2, (kernel, list(bodies))                    # <false> (I420) and <true> (NV12)
@@ -81,3 +81,4 @@ def test_remap_instruction_ceiling():
             if "mesh" in kernel:                                   # the LDS copy of the strip body reads its vertices with ds_read
                 assert sum(1 for ln in body.splitlines() if ln.strip().startswith("ds_read")) >= 16, f"{name}: the mesh is not read from LDS"
             assert not re.search(r"v_min_f32_e32 v\d+, 1\.0,", body), f"{name}: a saturate compiled to v_min 1.0 / v_max 0 again"
+            assert "v_floor_f32" not in body and sum(1 for o in valu if o.startswith("v_fract_f32")) >= 8, f"{name}: the sub-pixel phase is not a v_fract_f32"
