@@ -231,11 +231,18 @@ struct DevicePyramid
     void release();
 };
 
+// "The chain's results are in host memory": the LAST kernel of the tracker's chain stores `seq` into a word of pinned host memory after its
+// result stores (system-scope release), and a host that waits for every frame spins on that word instead of waiting for the kernel's
+// completion signal -- the results are there ~3 us before the runtime reports the kernel as finished (teardown, signal, wake-up).
+// flag == nullptr: no signal.
+struct LvkHostSignal { unsigned* flag; unsigned seq; };
+
 // Robust global motion (motion.hip)
 size_t lvk_ransac_workspace_bytes(int n);
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
                       bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n = nullptr,
-                      const int* d_full = nullptr);      // d_full: the model choice lives on the device (full_homography ignored)
+                      const int* d_full = nullptr,       // d_full: the model choice lives on the device (full_homography ignored)
+                      LvkHostSignal done = LvkHostSignal{nullptr, 0});
 // fast_filter (Functions/Container.tpp:97-121) of the optical-flow result on the GPU: compacts (prev, matched) by `status` into
 // (d_p1, d_p2) in exactly the order the host's back-to-front swap-erase produces, writes the count to d_count, and mirrors the raw
 // matched points / status flags into device-visible host memory for the host's own bookkeeping.
@@ -249,7 +256,7 @@ int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const floa
                               float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
                               const float2* d_und, float region_wf, float region_hf,
                               double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask,
-                              const int* d_n_raw = nullptr, const int* d_full = nullptr);
+                              const int* d_n_raw = nullptr, const int* d_full = nullptr, LvkHostSignal done = LvkHostSignal{nullptr, 0});
 
 struct LensArgs;
 // Dense remap on an explicit stream (remap.hip)

@@ -661,6 +661,15 @@ __device__ __forceinline__ bool refit(bool full, const float2* __restrict__ p1, 
     }
 }
 
+// Every thread's stores so far are visible to the host, THEN the word changes (see LvkHostSignal).  Block-uniform call sites only.
+__device__ __forceinline__ void signal_host(LvkHostSignal done)
+{
+    if (!done.flag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One block: pick the best hypothesis, run the local optimisation, emit H (9 doubles), #inliers and the mask.
 // The block has to fit NEXT TO the co-scheduled remap of the overlap mode (4 waves x 80 VGPRs per SIMD leave 192 of a SIMD's 512): as 4
 // waves (one per SIMD) it may take 168 VGPRs, as 8 waves (two per SIMD) 96 each; the unconstrained allocation of 250 made it wait for remap
@@ -671,7 +680,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
                        const int* __restrict__ full_dev, double cx, double cy, double sc,
                        const double* __restrict__ hyp_H, const long long* __restrict__ hyp_score,
                        uint8_t* __restrict__ gmask_a, uint8_t* __restrict__ gmask_b,
-                       double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask)
+                       double* __restrict__ out_H, int* __restrict__ out_ninl, uint8_t* __restrict__ out_mask, LvkHostSignal done)
 {
     LVK_TL(1);
     LVK_TRACKER_PRIORITY();
@@ -725,6 +734,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     {
         for (int i = lane; i < n; i += FT) out_mask[i] = 0;
         if (lane == 0) { for (int q = 0; q < 9; q++) out_H[q] = (q % 4 == 0) ? 1.0 : 0.0; *out_ninl = -2; }
+        signal_host(done);
         return;
     }
     if (lane < 9) sBest[lane] = hyp_H[best_h * 9 + lane];
@@ -754,6 +764,7 @@ void k_ransac_finalize(const float2* __restrict__ g1, const float2* __restrict__
     for (int i = lane; i < n; i += FT) out_mask[i] = cur[i];
     if (lane < 9) out_H[lane] = sBest[lane];
     if (lane == 0) *out_ninl = ninl;
+    signal_host(done);
 #ifdef LVK_RANSAC_TIMING
     RT_MARK();
     if (lane == 0)
@@ -805,7 +816,7 @@ size_t lvk_ransac_workspace_bytes(int n)
 
 // d_p1/d_p2: n pairs; d_ws: lvk_ransac_workspace_bytes(n); outputs d_H (9 doubles), d_ninl, d_mask (n bytes).
 int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, int n, double threshold, double region_w, double region_h,
-                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n, const int* d_full)
+                      bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask, const int* d_n, const int* d_full, LvkHostSignal done)
 {
     CompactArgs ca{}; ca.full_dev = d_full;
     LVK_HIP_REQUIRE(ctx, d_p1 && d_p2 && d_ws && d_H && d_ninl && d_mask && (d_n || n >= (full_homography ? 4 : 2)));
@@ -818,13 +829,13 @@ int lvk_launch_ransac(lvk_hip_ctx* ctx, const float2* d_p1, const float2* d_p2, 
     {
         hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
         hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(FT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
-                           region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+                           region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask, done);
     }
     else
     {
         hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
         hipLaunchKernelGGL(k_ransac_finalize<false>, dim3(1), dim3(FT), 0, ctx->stream, d_p1, d_p2, n, d_n, t2, full_homography ? 1 : 0, d_full,
-                           region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+                           region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask, done);
     }
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
@@ -852,7 +863,7 @@ int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const floa
                               float2* d_p1, float2* d_p2, int* d_count, int* h_count, float2* h_matched, uint8_t* h_status,
                               const float2* d_und, float region_wf, float region_hf,
                               double threshold, double region_w, double region_h, bool full_homography, void* d_ws, double* d_H, int* d_ninl, uint8_t* d_mask,
-                              const int* d_n_raw, const int* d_full)
+                              const int* d_n_raw, const int* d_full, LvkHostSignal done)
 {
     static_assert(LVK_COMPACT_RANSAC_MAX % NT == 0 && LVK_COMPACT_RANSAC_MAX <= LDS_POINTS, "the fused variant compacts into its LDS copy");
     LVK_HIP_REQUIRE(ctx, d_prev && d_matched && d_status && d_p1 && d_p2 && d_count && h_count && h_matched && h_status && n > 0 && n <= LVK_COMPACT_RANSAC_MAX);
@@ -866,7 +877,7 @@ int lvk_launch_compact_ransac(lvk_hip_ctx* ctx, const float2* d_prev, const floa
     hipLaunchKernelGGL((k_ransac_hypotheses<true, true>), dim3(K_HYPOTHESES), dim3(NT), 0, ctx->stream, (const float2*)nullptr, (const float2*)nullptr, n, (const int*)nullptr,
                        t2, full_homography ? 1 : 0, hyp_H, hyp_score, ca);
     hipLaunchKernelGGL(k_ransac_finalize<true>, dim3(1), dim3(FT), 0, ctx->stream, (const float2*)d_p1, (const float2*)d_p2, n, (const int*)d_count, t2, full_homography ? 1 : 0, d_full,
-                       region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask);
+                       region_w * 0.5, region_h * 0.5, 2.0 / (region_w + region_h), hyp_H, hyp_score, mask_a, mask_b, d_H, d_ninl, d_mask, done);
     LVK_HIP_CHECK(ctx, hipGetLastError());
     return LVK_HIP_OK;
 }

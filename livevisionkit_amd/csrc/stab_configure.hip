@@ -328,6 +328,7 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     if (st->chain_done) (void)hipEventDestroy(st->chain_done);
     if (st->caller_ready) (void)hipEventDestroy(st->caller_ready);
     if (st->ahead_read_done) (void)hipEventDestroy(st->ahead_read_done);
+    if (st->h_chain_flag) (void)hipHostFree(st->h_chain_flag);
     for (auto& p : st->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete st;
 }

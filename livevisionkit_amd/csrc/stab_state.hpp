@@ -153,6 +153,8 @@ struct lvk_hip_stab
     // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which
     // bounds the frame rate.  The pool slot it writes was last read by a remap on the bulk stream: one event per slot orders the two.
     hipEvent_t chain_done = nullptr;
+    // a caller that waits for every frame: the chain's last kernel tells the host itself that its results are in host memory (LvkHostSignal)
+    unsigned* h_chain_flag = nullptr; unsigned chain_seq = 0;
     bool ingest_on_tracker = false, tracker_ingest_capable = false;
     bool bulk_busy_at_push = false;            // the previous remap was still running when this push began
     // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits

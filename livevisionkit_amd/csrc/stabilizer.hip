@@ -124,6 +124,15 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // swap-erase order); the host synchronises once and then repeats the cheap bookkeeping on its own copies.
     const bool chained = n <= 4096;
     const bool field = s.track_local_motions != 0;
+    // Global-motion chain of a caller that WAITS for every frame (the OBS plugin's pattern): k_ransac_finalize announces its results with a word
+    // in host memory, and the wait below spins on it.  A free-running caller keeps the completion event: there the remap must not be launched
+    // earlier than it is -- its first wave of blocks would land on the conversion behind the chain (profiles/r05_ab_host_signal_word.txt).
+    LvkHostSignal done{nullptr, 0};
+    if (chained && !field && !caller_runs_free)
+    {
+        if (!h_chain_flag) { LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_chain_flag, 64, hipHostMallocDefault)); *h_chain_flag = 0; }
+        done = LvkHostSignal{h_chain_flag, ++chain_seq};
+    }
     pe = prof_begin(LVK_STAGE_PYRLK);
     if (chained)
     {
@@ -146,9 +155,9 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
         {
             if ((rc = lvk_launch_compact_ransac(ctx, d_pts, d_matched, d_status, n, d_p1, d_p1 + cap_features, d_count, h_count, h_matched, h_status,
                                                 lens ? d_und : nullptr, (float)cur_w, (float)cur_h,
-                                                s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, dn, dfull)) != LVK_HIP_OK) return rc;
+                                                s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, dn, dfull, done)) != LVK_HIP_OK) return rc;
         }
-        else if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count, dfull)) != LVK_HIP_OK) return rc;
+        else if ((rc = lvk_launch_ransac(ctx, d_p1, d_p1 + cap_features, n, s.acceptance_threshold, (double)cur_w, (double)cur_h, full, d_ransac_ws, h_H, h_ninl, h_mask, d_count, dfull, done)) != LVK_HIP_OK) return rc;
         prof_end(pe);
     }
     else
@@ -192,8 +201,25 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     //  with one store once the smoother has the correction -- the launch left the host's turn (7.4 -> 0.3 us) and the rate fell 2 %: the chain
     //  ran 3.7 us slower and the push waited 5.5 us longer for the new frame's conversion, which sits behind the chain on this stream.  The
     //  cycle is bound by this STREAM, not by the host's turn.  profiles/r05_ab_prelaunch_remap.txt, scripts/probes/waitvalue_probe.hip.)
-    if (chain_event_armed) LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done));
-    else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    bool have_results = false;
+    if (done.flag)
+    {
+        // The kernel's completion SIGNAL comes ~3 us after its results (end-of-kernel write-back, the command processor's signal, the runtime's
+        // wake-up); what follows here needs the results, not the signal, and everything that goes on a stream is ordered by the stream.  A word that
+        // does not change within 5 ms (a faulted kernel, a lost device) falls through to the wait that reports errors.
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++)
+        {
+            if (__atomic_load_n(done.flag, __ATOMIC_ACQUIRE) == done.seq) { have_results = true; break; }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!have_results)
+    {
+        if (chain_event_armed) LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done));
+        else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
     trace.mark(HostTrace::LK_SYNC);
 
     if (dev_insert)
