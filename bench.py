@@ -179,7 +179,7 @@ def self_spawn(args):
 
 
 def percentiles(x, ps=(50, 99)):
-    return {"p%d" % p: float(np.percentile(x, p)) for p in ps}
+    return dict({"p%d" % p: float(np.percentile(x, p)) for p in ps}, max=float(np.max(x)))
 
 
 def cpu_baseline(oracle, rig, preset_name, nthreads, budget_s, fmt, lens_params, delay):
@@ -416,9 +416,6 @@ def run_region(rigs, n, device_sync, local_rank):
 
 def latency_pass(rigs, n, local_rank):
     """n synchronised pushes (sync, push, sync) per rig, all rigs at once: per-rig lists of milliseconds."""
-    import threading
-    import torch
-
     def one(rig, out):
         for _ in range(n):
             rig.sync()
@@ -427,6 +424,22 @@ def latency_pass(rigs, n, local_rank):
             rig.sync()
             out.append((time.perf_counter() - t) * 1e3)
     lats = [[] for _ in rigs]
+    # (as timeit does: the interpreter's collector must not stop every host thread in the middle of the pass -- with `max` in the line, one
+    #  4-10 ms sample in all K streams at once was seen on two boxes of five; that is the host process, not the library under test)
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _latency_pass(rigs, one, lats, local_rank)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _latency_pass(rigs, one, lats, local_rank):
+    import threading
+    import torch
     if len(rigs) == 1:
         one(rigs[0], lats[0])
         return lats
@@ -817,7 +830,7 @@ def main():
         # every rank reports the latency of every stream it ran (north star: throughput AND p99 at 1 / 2 / 4 / 8 GPUs): p50 / p99 per stream,
         # and the rank's own figure = its slowest stream
         "latency_ms": {"p50": max(float(np.percentile(x, 50)) for x in lats), "p99": max(float(np.percentile(x, 99)) for x in lats),
-                       "samples": len(lats[0])},
+                       "max": max(float(np.max(x)) for x in lats), "samples": len(lats[0])},
         "stream_latency_ms": [dict(percentiles(x), samples=len(x)) for x in lats]})
 
     result = None
@@ -892,7 +905,7 @@ def main():
             "ranks": rank_reports,
             # whole job: the slowest rank's (= slowest stream's) p50 / p99 of the synchronised pushes; every rank's own pair is in `ranks`
             "latency_ms": {"p50": max(r["latency_ms"]["p50"] for r in rank_reports), "p99": max(r["latency_ms"]["p99"] for r in rank_reports),
-                           "samples": len(lat), "over": f"max over {n_ranks} rank(s) x {K} stream(s); per rank / per stream: ranks[].latency_ms, ranks[].stream_latency_ms"},
+                           "max": max(r["latency_ms"]["max"] for r in rank_reports), "samples": len(lat), "over": f"max over {n_ranks} rank(s) x {K} stream(s); per rank / per stream: ranks[].latency_ms, ranks[].stream_latency_ms"},
             "extras": ("single-rank only: pcie_inclusive, lookahead, reference_kernel, configs, multi_stream, cpu_baseline, quality and roofline.standalone_* run on "
                        "rank 0 of a --gpus 1 --streams-per-gpu 1 run and are null otherwise; free_running_ms / timed_region_ms / stage_us / tracking / roofline "
                        "are rank 0's stream 0") ,
