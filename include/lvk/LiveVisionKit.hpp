@@ -671,12 +671,19 @@ private:
         std::shared_ptr<hip::Context> give_back;           // owner of a released frame that must still wait for our last read of it
         {
         hip::ContextLock lock(m_Ctx->mutex());
+        // dst has the size of the DELAYED frame (the queue holds whole frames, StabilizationFilter.cpp:118-131; WarpMesh::apply creates dst from
+        // the delayed source, WarpMesh.cpp:183-223 -> Image.cpp:53,116): a source that is resized in the middle of a stream -- VSFilter.cpp:352-364
+        // does not restart its filter -- still gets its queued frames at their own size.  Pooled: a no-op in steady state.
         VideoFrame result;
-        result.create(in.size(), CV_8UC3, m_OutCtx);       // pooled: the reference's dst.create is a no-op in steady state (Image.cpp:116)
+        lvk_frame_info due{0, 0, 0}, emitted{0, 0, 0};
+        const int will_emit = lvk_hip_stab_next_output(m_Stab, in.rows, in.cols, (int)in.format, &due);
+        if (will_emit == 1) result.create({due.cols, due.rows}, CV_8UC3, m_OutCtx);
         int produced = 0; uint64_t ts = 0; const void* released = nullptr;
         m_Held.push_back({in.buffer(), in.context()});     // keep the borrowed device buffer alive while it is queued
-        m_Ctx->check(lvk_hip_stab_push(m_Stab, in.device_ptr(), (int)in.step, in.rows, in.cols, in.timestamp, (int)in.format,
-                                       result.device_ptr(), (int)result.step, &produced, &ts, &released), "StabilizationFilter::filter");
+        const int rc = lvk_hip_stab_push(m_Stab, in.device_ptr(), (int)in.step, in.rows, in.cols, in.timestamp, (int)in.format,
+                                         result.device_ptr(), (int)result.step, result.rows, &produced, &ts, &released, &emitted);
+        if (rc == LVK_HIP_ERR_ARG) m_Held.pop_back();      // (a refused push has queued nothing; after any other error the frame may be queued: keep it alive)
+        m_Ctx->check(rc, "StabilizationFilter::filter");
         if (released)
             for (auto it = m_Held.begin(); it != m_Held.end(); ++it)
                 if (it->buffer.get() == released)
@@ -687,7 +694,7 @@ private:
                     m_Held.erase(it);
                     break;
                 }
-        if (produced) { result.timestamp = ts; result.format = in.format; output = std::move(result); }
+        if (produced) { result.timestamp = ts; result.format = (VideoFrame::Format)emitted.format; output = std::move(result); }
         else output.release();
         }
         if (give_back) give_back->wait_for(*m_Ctx);        // (both contexts' locks: ours is no longer held)

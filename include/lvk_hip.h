@@ -61,7 +61,7 @@ const char* lvk_hip_last_error(lvk_hip_ctx* ctx);    /* NULL ctx: last error of 
 const char* lvk_hip_version(void);                   /* human-readable build string */
 /* ABI number of PART 1 of this header as the library was built (compare with LVK_HIP_ABI_VERSION of the header a host was compiled against;
  * tests/test_abi.py holds the two together). */
-#define LVK_HIP_ABI_VERSION 5
+#define LVK_HIP_ABI_VERSION 6
 int  lvk_hip_abi_version(void);
 /* usable gfx950 devices in this process (0 when there is none; never an error): one lvk_hip_ctx + one host thread per device is the
  * multi-GPU partitioning (no collective, no peer access) */
@@ -237,9 +237,22 @@ int  lvk_hip_stab_stable_region(const lvk_hip_stab* stab, int rows, int cols, in
  * returns its pointer (or NULL); the caller may reuse that buffer once the stream has passed this call.
  * d_out receives the stabilized delayed frame when *produced == 1 (and carries *out_timestamp = that frame's
  * timestamp, Math/WarpMesh.cpp:221-222); *produced == 0 while the delay builds ("output.release()").
- * The output remap is only enqueued: call lvk_hip_sync() before reading d_out on the host. */
+ * The output remap is only enqueued: call lvk_hip_sync() before reading d_out on the host.
+ *
+ * SIZE OF THE OUTPUT.  The queue holds whole frames (StabilizationFilter.cpp:118-131) and the emitted frame is the DELAYED one, at ITS
+ * OWN size and format (WarpMesh::apply allocates dst from the delayed source, Math/WarpMesh.cpp:183-223 -> Functions/Image.cpp:53,116):
+ * when the frame size changes in the middle of a stream (an OBS source that is resized -- VSFilter.cpp:352-364 does not restart its
+ * filter), the next `frame_delay` pushes still emit frames of the OLD size.  lvk_hip_stab_next_output() tells the caller, before the
+ * push, whether the push of a rows x cols frame will emit and what (1 / 0; *out = the delayed frame's rows, cols, format) -- size d_out
+ * from it.  d_out is a buffer of out_rows rows of out_step bytes: a push whose output would not fit (out_step < 3 * cols or out_rows <
+ * rows of the frame to be emitted, or d_out == NULL when a frame is due) is REFUSED with LVK_HIP_ERR_ARG BEFORE anything changes -- the
+ * frame is not queued, nothing is released, the filter is as it was; the same push with a large enough d_out then succeeds.  The rows x
+ * cols top-left part of d_out is written, nothing else.  *emitted (optional) = geometry and format of the frame written to d_out. */
+typedef struct lvk_frame_info { int rows, cols, format; } lvk_frame_info;
+int  lvk_hip_stab_next_output(const lvk_hip_stab* stab, int rows, int cols, int format, lvk_frame_info* out);
 int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
-                       void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released);
+                       void* d_out, int out_step, int out_rows, int* produced, uint64_t* out_timestamp, const void** released,
+                       lvk_frame_info* emitted);
 
 /* The OBS asynchronous path in one call (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-212): YUV 4:2:0 planes in
  * (I420, or NV12 with nv12 != 0 and d_u = interleaved UV), ingest -> filter -> egress, 4:2:0 planes out.  The packed

@@ -81,8 +81,9 @@ _SIG = {
     "lvk_hip_stab_ready": (_c.c_int, [_P]),
     "lvk_hip_stab_frame_delay": (_c.c_int, [_P]),
     "lvk_hip_stab_stable_region": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
-    "lvk_hip_stab_push": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _P, _c.c_int,
-                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_P)]),
+    "lvk_hip_stab_next_output": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "lvk_hip_stab_push": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _P, _c.c_int, _c.c_int,
+                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_P), _P]),
     "lvk_hip_stab_push_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,
                                             _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64)]),
     "lvk_hip_stab_push_yuv420_host": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,

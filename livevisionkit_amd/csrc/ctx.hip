@@ -17,7 +17,7 @@ static std::map<void*, lvk_hip_ctx*> g_block_owner;
 
 extern "C" {
 
-const char* lvk_hip_version(void) { return "lvk-hip 0.5 (gfx950, ABI 5)"; }
+const char* lvk_hip_version(void) { return "lvk-hip 0.6 (gfx950, ABI 6)"; }
 
 int lvk_hip_abi_version(void) { return LVK_HIP_ABI_VERSION; }
 

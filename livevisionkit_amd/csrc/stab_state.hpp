@@ -130,6 +130,16 @@ struct lvk_hip_stab
     std::vector<FastRegion> plan;
     std::deque<QueuedFrame> queue;
     size_t queue_capacity = 1;
+    // What the push of `in` will emit (StabilizationFilter.cpp:77-95,118-131: push into the buffer -- a full one drops its oldest --, then the
+    // oldest leaves when the buffer is full): false = nothing, else *f = the delayed frame (its own size and format; `in` itself when the
+    // delay is zero).  The state is not touched.
+    bool next_output(const QueuedFrame& in, QueuedFrame* f) const
+    {
+        const size_t n = queue.size(), drop = n == queue_capacity ? 1 : 0;
+        if (n - drop + 1 != queue_capacity) return false;
+        if (f) *f = n > drop ? queue[drop] : in;
+        return true;
+    }
     float tracking_stability = 0.0f, scene_quality = 0.0f, trust = 0.0f;
     // taps for stats / tests
     float last_distribution = 0.0f; int last_detected = 0, last_matched = 0;
@@ -322,4 +332,5 @@ struct lvk_hip_stab
 // StabilizationFilter::filter (stabilizer.hip); the entry points of the other units wrap it
 int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
                        const void* luma, int luma_step, int luma_pix,
-                       void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released, lvkstab::OutPlanes420* o420 = nullptr);
+                       void* d_out, int out_step, int out_rows, int* produced, uint64_t* out_timestamp, const void** released,
+                       lvkstab::OutPlanes420* o420 = nullptr, lvk_frame_info* emitted = nullptr);

@@ -359,7 +359,8 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
 
 int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
                      const void* luma, int luma_step, int luma_pix,
-                     void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released, OutPlanes420* o420)
+                     void* d_out, int out_step, int out_rows, int* produced, uint64_t* out_timestamp, const void** released, OutPlanes420* o420,
+                     lvk_frame_info* emitted)
 {
     lvk_hip_ctx* ctx = st->ctx;
     if (produced) *produced = 0;
@@ -373,6 +374,19 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
     const int luma_channel = format == LVK_FORMAT_YUV ? 0 : (format == LVK_FORMAT_BGR ? -1 : -2);
     LVK_HIP_REQUIRE(ctx, luma_pix == 3 || format == LVK_FORMAT_YUV);
     const QueuedFrame in{d_frame, step, rows, cols, timestamp, format};
+    // The frame this push will emit is the DELAYED one, at its own size (the queue holds whole frames, StabilizationFilter.cpp:118-131; dst is
+    // allocated from the delayed source, WarpMesh.cpp:183-223 -> Image.cpp:53,116): what cannot be written is refused HERE, before the tracker
+    // runs and before the queue moves -- a refused push leaves the filter as it was, and no borrowed frame is stranded.
+    {
+        QueuedFrame due;
+        if (st->next_output(in, &due))
+        {
+            const bool to_planes = o420 && o420->y && (st->s.stabilize_output || st->s.crop_to_stable_region || st->lens);      // (the fused remap + egress kernel)
+            if (!to_planes && !(d_out != nullptr && out_step >= 3 * due.cols && out_rows >= due.rows))
+                return ctx->fail(LVK_HIP_ERR_ARG, "the output buffer does not hold the frame this push emits: " + std::to_string(due.cols) + " x " + std::to_string(due.rows) +
+                                                      " (the DELAYED frame's own size -- lvk_hip_stab_next_output); nothing was queued");
+        }
+    }
     { const int lrc = st->ensure_lens(rows, cols); if (lrc != LVK_HIP_OK) return lrc; }
     static const WarpMeshF identity_mesh(2, 2);
     const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
@@ -384,7 +398,6 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
     auto emit = [&](const WarpMeshF* mesh) -> int {
         const QueuedFrame f = st->queue.front();
         st->queue.pop_front();
-        LVK_HIP_REQUIRE(ctx, d_out != nullptr && out_step >= 3 * f.cols);
         int rc = LVK_HIP_OK;
         // overlap mode: the delayed frame was pushed >= 1 push ago and the tracker has synchronised the main stream since,
         // so the remap may run on its own stream concurrently with the next frame's tracking
@@ -402,15 +415,26 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(rs, e, 0)); }
         st->trace.mark(HostTrace::EMIT_WAITS);
         const int pe = st->prof_begin(LVK_STAGE_REMAP, rs);
-        if (st->lens && (f.rows != st->lens_rows || f.cols != st->lens_cols)) return ctx->fail(LVK_HIP_ERR_ARG, "frame size changed while a lens profile is set");
+        // fused lens mode: the pre-warp of the DELAYED frame's own size (the tracker's model is that of the incoming frame)
+        LensArgs lens_other; const LensArgs* lens_args = nullptr;
+        if (st->lens)
+        {
+            lens_args = &st->lens_args;
+            if (f.rows != st->lens_rows || f.cols != st->lens_cols)
+            {
+                LensModel m;
+                if (lvk_lens_model_build(st->lens_params, f.rows, f.cols, m) != LVK_HIP_OK) return ctx->fail(LVK_HIP_ERR_ARG, "invalid camera profile for the delayed frame's size");
+                std::memcpy(lens_other.f, m.f, sizeof(lens_other.f)); lens_args = &lens_other;
+            }
+        }
         if (mesh && o420 && o420->y)
         {
             rc = lvk_launch_warpmesh_apply_420(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, o420->y, o420->y_step, o420->u, o420->u_step, o420->v, o420->v_step,
-                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, st->lens ? &st->lens_args : nullptr, persistent);
+                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, lens_args, persistent);
             o420->used = true;
         }
         else if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
-                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, st->lens ? &st->lens_args : nullptr, persistent);
+                                                      f.format == LVK_FORMAT_YUV ? 1 : 0, lens_args, persistent);
         else
         {
             hipError_t e = hipMemcpy2DAsync(d_out, out_step, f.d_ptr, f.step, (size_t)f.cols * 3, f.rows, hipMemcpyDeviceToDevice, ctx->stream);
@@ -421,6 +445,7 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
         if (out_timestamp) *out_timestamp = f.ts;                                         // WarpMesh.cpp:221-222
+        if (emitted) *emitted = lvk_frame_info{f.rows, f.cols, f.format};
         if (side && st->pool_frames)
         {
             // 4:2:0 path in overlap mode: the slot is next written by an ingest -- on this same stream, i.e. after the remap that is
@@ -542,8 +567,17 @@ void lvk_hip_stab::free_pool()
 
 extern "C" {
 
+int lvk_hip_stab_next_output(const lvk_hip_stab* st, int rows, int cols, int format, lvk_frame_info* out)
+{
+    if (!st) return LVK_HIP_ERR_ARG;
+    QueuedFrame due{};
+    if (!st->next_output(QueuedFrame{nullptr, 3 * cols, rows, cols, 0, format}, &due)) return 0;
+    if (out) *out = lvk_frame_info{due.rows, due.cols, due.format};
+    return 1;
+}
+
 int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows, int cols, uint64_t timestamp, int format,
-                      void* d_out, int out_step, int* produced, uint64_t* out_timestamp, const void** released)
+                      void* d_out, int out_step, int out_rows, int* produced, uint64_t* out_timestamp, const void** released, lvk_frame_info* emitted)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_device_guard device_guard(st->ctx);
@@ -557,7 +591,7 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     st->pool_frames = false;
     int rc = st->mark_caller_work();
     if (rc != LVK_HIP_OK) return rc;
-    rc = lvk_stab_push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, produced, out_timestamp, released);
+    rc = lvk_stab_push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, out_rows, produced, out_timestamp, released, nullptr, emitted);
     if (released && !*released && !st->orphaned.empty()) { *released = st->orphaned.front(); st->orphaned.pop_front(); }
     st->trace.mark(HostTrace::EXIT);
     st->last_push_end = std::chrono::steady_clock::now();
@@ -637,7 +671,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     st->pool_frames = side_ingest;
     OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false};
     if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
-    rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, &prod, out_timestamp, &released, &o420);
+    rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, rows, &prod, out_timestamp, &released, &o420);
     if (st->deferred_ingest) { const int r2 = st->run_deferred_ingest(); if (rc == LVK_HIP_OK) rc = r2; }      // (track() returned before its launches)
     if (released) st->pool_free.push_back(const_cast<void*>(released));
     if (side_ingest)

@@ -70,6 +70,11 @@ class StabStats(_c.Structure):
                 ("smoothing_factor", _c.c_double), ("homography", _c.c_double * 9)]
 
 
+class FrameInfo(_c.Structure):
+    """lvk_frame_info: geometry and format of an emitted frame."""
+    _fields_ = [("rows", _c.c_int), ("cols", _c.c_int), ("format", _c.c_int)]
+
+
 class Stopwatch:
     """Subset of lvk::Stopwatch the plugin reads: timings().average() / deviation() in milliseconds (Timing/Stopwatch.hpp)."""
 
@@ -125,27 +130,43 @@ class StabilizationFilter:
     def timings(self):
         return self._timer
 
+    def next_output(self, rows, cols, fmt=FORMAT_YUV):
+        """lvk_hip_stab_next_output: (rows, cols, format) of the frame the push of a rows x cols frame will emit -- the DELAYED frame's own
+        size (the queue holds whole frames, StabilizationFilter.cpp:118-131) --, or None when that push emits nothing."""
+        info = FrameInfo()
+        rc = self.lib.lvk_hip_stab_next_output(self.handle, rows, cols, fmt, _c.byref(info))
+        if rc < 0:
+            self.ctx._check(rc)
+        return (info.rows, info.cols, info.format) if rc == 1 else None
+
     def apply(self, frame, timestamp=0, out=None, profile=False, fmt=FORMAT_YUV):
         """apply(std::move(input), output, profile): returns (output tensor, its timestamp) or (None, None) while the delay builds.
-        `frame` is borrowed (not copied) until it has been emitted; do not modify it in the meantime."""
+        `frame` is borrowed (not copied) until it has been emitted; do not modify it in the meantime.  The output has the size of the
+        DELAYED frame (a stream whose frame size changes emits the queued frames at their own size): `out`, when given, must hold it
+        (next_output()), and the returned tensor is its top-left rows x cols view; self.last_format = that frame's format."""
         import torch
         if profile:
             self.ctx.sync()
         t0 = time.perf_counter()
         if out is None:
-            out = torch.empty_like(frame)
-        produced = _c.c_int(0); ots = _c.c_uint64(0); released = _c.c_void_p()
-        self._borrowed[frame.data_ptr()] = frame
+            due = self.next_output(frame.shape[0], frame.shape[1], fmt)
+            out = torch.empty((due[0], due[1], 3), dtype=torch.uint8, device=frame.device) if due else None
+        produced = _c.c_int(0); ots = _c.c_uint64(0); released = _c.c_void_p(); info = FrameInfo()
         rc = self.lib.lvk_hip_stab_push(self.handle, frame.data_ptr(), frame.stride(0), frame.shape[0], frame.shape[1],
-                                        int(timestamp), fmt, out.data_ptr(), out.stride(0),
-                                        _c.byref(produced), _c.byref(ots), _c.byref(released))
-        self.ctx._check(rc)
+                                        int(timestamp), fmt, out.data_ptr() if out is not None else None, out.stride(0) if out is not None else 0,
+                                        out.shape[0] if out is not None else 0,
+                                        _c.byref(produced), _c.byref(ots), _c.byref(released), _c.byref(info))
+        self.ctx._check(rc)                                      # (a refused push has queued nothing: the frame is still the caller's)
+        self._borrowed[frame.data_ptr()] = frame
         if released.value:
             self._borrowed.pop(released.value, None)
         if profile:
             self.ctx.sync()
         self._timer._add(time.perf_counter() - t0)
-        return (out, ots.value) if produced.value else (None, None)
+        if not produced.value:
+            return None, None
+        self.last_format = info.format
+        return out[:info.rows, :info.cols], ots.value
 
     def apply_yuv420(self, planes, timestamp=0, out=None):
         """The OBS async path in one call: planes = (y, u, v) I420 or (y, uv) NV12 torch uint8 tensors on the GPU.
