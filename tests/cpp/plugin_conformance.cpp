@@ -189,6 +189,56 @@ int run_golden(const char* clip_path, int n, int rows, int cols, const char* out
     return 0;
 }
 
+// --resize <in.bin> <out.bin>: a packed stream whose frame size (and format) changes in the middle -- an OBS source that is resized;
+// VSFilter.cpp:352-364 keeps calling apply(std::move(frame), frame) on the same filter.  The queue holds whole frames
+// (StabilizationFilter.cpp:118-131) and dst is created from the DELAYED source (WarpMesh.cpp:183-223 -> Image.cpp:53,116): every frame
+// leaves, at its own size and format.  Records in / out: int32 rows, cols, format; uint64 timestamp; rows * cols * 3 bytes.  Two passes
+// (plain, overlap); the Python side holds every emitted frame to the oracle's frame of the same timestamp.
+int run_resize(const char* in_path, const char* out_path)
+{
+    struct Rec { int32_t rows, cols, format; uint64_t ts; std::vector<uint8_t> px; };
+    std::vector<Rec> recs;
+    FILE* f = std::fopen(in_path, "rb");
+    if (!f) { std::printf("resize: cannot read the clip\n"); return 1; }
+    for (;;)
+    {
+        Rec r; int32_t head[3];
+        if (std::fread(head, sizeof(int32_t), 3, f) != 3) break;
+        r.rows = head[0]; r.cols = head[1]; r.format = head[2];
+        if (std::fread(&r.ts, sizeof(uint64_t), 1, f) != 1) return 1;
+        r.px.resize((size_t)r.rows * r.cols * 3);
+        if (std::fread(r.px.data(), 1, r.px.size(), f) != r.px.size()) return 1;
+        recs.push_back(std::move(r));
+    }
+    std::fclose(f);
+    FILE* out = std::fopen(out_path, "wb");
+    if (!out) return 1;
+    std::vector<uint8_t> host;
+    for (int pass = 0; pass < 2; pass++)
+    {
+        lvk::StabilizationFilter filter;
+        filter.configure(golden_settings("homography"));
+        if (pass == 1) filter.set_overlap(true);
+        int emitted = 0;
+        for (const Rec& r : recs)
+        {
+            lvk::Frame frame;
+            frame.upload(r.px.data(), r.rows, r.cols, (lvk::VideoFrame::Format)r.format, r.ts);
+            filter.apply(std::move(frame), frame);                       // VSFilter.cpp:358,363: input and output are the same object
+            if (frame.empty()) continue;
+            const int32_t head[3] = {frame.rows, frame.cols, (int32_t)frame.format};
+            host.resize((size_t)frame.rows * frame.cols * 3);
+            frame.download(host.data());
+            std::fwrite(head, sizeof(int32_t), 3, out); std::fwrite(&frame.timestamp, sizeof(uint64_t), 1, out);
+            std::fwrite(host.data(), 1, host.size(), out);
+            emitted++;
+        }
+        std::printf("resize pass %d: %d of %zu frames emitted\n", pass, emitted, recs.size());
+    }
+    std::fclose(out);
+    return 0;
+}
+
 // A chain whose stages run on DIFFERENT streams with nothing but the facade's fences between them: asynchronous upload on the
 // thread's context -> ScalingFilter (same context) -> StabilizationFilter (its own context; overlap: a third stream) -> ScalingFilter
 // on the output frame's context -> download.  Compared with the same chain run with a full synchronisation after every stage.
@@ -548,6 +598,7 @@ int main(int argc, char** argv)
 {
 #ifdef RUN_ON_GPU
     if (argc >= 7 && std::string(argv[1]) == "--golden") return run_golden(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
+    if (argc >= 4 && std::string(argv[1]) == "--resize") return run_resize(argv[2], argv[3]);
     if (argc >= 7 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5], std::atoi(argv[6]));
     if (argc >= 3 && std::string(argv[1]) == "--threads-and-files") return (run_two_threads_check() != 0 || run_cross_context_420_check() != 0 || run_file_input_check(argv[2]) != 0) ? 1 : 0;
     if (run_chain_race_check() != 0) return 1;

@@ -72,6 +72,46 @@ def test_facade_emits_the_golden_frames(tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_emits_old_size_frames_after_a_resize(tmp_path):
+    """lvk::StabilizationFilter::apply(std::move(frame), frame) -- the VSFilter call (VSFilter.cpp:352-364), which never restarts on a resize --
+    over a packed stream that goes 1080p -> 1920x800 -> 720p (BGR) -> 1080p: every frame leaves, at the DELAYED frame's own size and format
+    (StabilizationFilter.cpp:118-131, WarpMesh.cpp:183-223, Image.cpp:53,116), bit-identical to the oracle's frame of the same timestamp."""
+    import struct
+    import numpy as np
+    from tests import oracle_lib
+    from tests.test_golden import STAB_OVER
+    from tests.test_resize_packed_gpu import _segments
+    segs = _segments()
+    with open(tmp_path / "in.bin", "wb") as f:
+        for i, (fr, fmt) in enumerate(segs):
+            f.write(struct.pack("<iiiQ", fr.shape[0], fr.shape[1], fmt, 500 + i)); f.write(fr.tobytes())
+    exe = _build(tmp_path, ["-DRUN_ON_GPU"])
+    out = subprocess.check_output([exe, "--resize", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], timeout=600).decode()
+    n = len(segs)
+    assert f"resize pass 0: {n - 3} of {n} frames emitted" in out and f"resize pass 1: {n - 3} of {n} frames emitted" in out
+    oracle = oracle_lib.load()
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(oracle_lib.preset("homography", **STAB_OVER))
+    want = {}
+    for i, (fr, fmt) in enumerate(segs):
+        big = np.zeros((1080, 1920, 3), np.uint8)
+        w, wts = ost.push(fr, ts=500 + i, fmt=fmt, out=big, nthreads=32)
+        if w is not None:
+            r, c = segs[wts - 500][0].shape[:2]
+            want[wts] = (np.ascontiguousarray(big[:r, :c]), segs[wts - 500][1])
+    ost.close()
+    raw = (tmp_path / "out.bin").read_bytes()
+    pos, seen = 0, []
+    while pos < len(raw):
+        rows, cols, fmt, ts = struct.unpack_from("<iiiQ", raw, pos); pos += 20
+        px = np.frombuffer(raw, np.uint8, rows * cols * 3, pos).reshape(rows, cols, 3); pos += rows * cols * 3
+        w, wfmt = want[ts]
+        assert (rows, cols, fmt) == (*w.shape[:2], wfmt), (ts, rows, cols, fmt)
+        assert np.array_equal(px, w), f"frame {ts} ({cols}x{rows}) differs from the oracle's"
+        seen.append(ts)
+    assert seen == sorted(want) * 2                                      # both passes, every frame, in order
+
+
+@pytest.mark.gpu
 def test_facade_throughput_at_4k(tmp_path):
     """Frames/s through lvk::StabilizationFilter::apply at 3840x2160 with resident frames against the same loop over the C-ABI
     (lvk_hip_stab_push_yuv420, what bench.py times) on the same clip, in the same test on the same box: no per-frame hipMalloc / hipFree

@@ -179,6 +179,124 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
     ost.close(); gst.close()
 
 
+PACKED_SIZES = [(432, 768), (300, 768), (360, 640)]               # same width / fewer rows, then narrower: both ways round in a run
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_schedule_fuzz_packed_stream_with_resizes(ctx, oracle, seed):
+    """The same fuzz over the PACKED entry (lvk_hip_stab_push: what lvk::StabilizationFilter::filter and with it the plugin's VSFilter call):
+    frame size AND format change several times in the middle of the stream, overlap toggles, restarts, the frame delay goes up and down, the
+    delay-only passthrough, the fused lens pre-warp, device look-ahead right / wrong / cancelled, and now and then an output buffer sized from
+    the INCOMING frame -- refused when the delayed frame is larger, before anything changes.  Free-running; every output in a guarded buffer of
+    its own.  The reference's behaviour is the bar (StabilizationFilter.cpp:118-131, WarpMesh.cpp:183-223, Image.cpp:53,116): EVERY frame
+    leaves, at its own size and format, equal to the oracle's frame of the same timestamp, and no byte outside rows x cols x 3 is written."""
+    import torch
+    import livevisionkit_amd as lvk
+    rng = np.random.default_rng(7000 + seed)
+    n = 40
+    clips = [synth.make_clip(r, c, n, seed=60 + seed, jitter=1.0)[0] for r, c in PACKED_SIZES]
+    size_k, fmt = 0, 4
+    preset, delay, overlap, stabilize, lens_on, stab_back_at = "homography", 2, bool(seed & 1), True, False, 0
+    s = _settings(preset, delay)
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
+    gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_conv(s))
+    gst.set_overlap(overlap)
+    GUARD = 0x5A
+
+    def guarded(rows, cols):
+        pitch = cols * 3 + 64
+        buf = torch.full((rows + 8, pitch), GUARD, dtype=torch.uint8, device="cuda")
+        return buf, buf.as_strided((rows, cols, 3), (pitch, 3, 1), 4 * pitch)
+
+    # the schedule is drawn first (the look-ahead needs to know the NEXT frame): events[i] happens before push i
+    events, frames, fmts = [], [], []
+    for i in range(n):
+        ev = int(rng.integers(0, 16))
+        if ev in (6, 7, 8) and i > 2:
+            size_k = (size_k + 1 + int(rng.integers(0, 2))) % 3
+        elif ev == 9:
+            fmt = (4, 0, 2)[int(rng.integers(0, 3))]
+        f = clips[size_k][i]
+        if fmt != 4:
+            f = f[..., [1, 0, 2]]                                     # the textured channel where the grey value weighs most
+        events.append(ev); frames.append(np.ascontiguousarray(f)); fmts.append(fmt)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    want, got, log = {}, {}, []
+    refused = live = resizes = ahead_right = 0
+    big = np.zeros((max(r for r, _ in PACKED_SIZES), max(c for _, c in PACKED_SIZES), 3), np.uint8)
+    for i in range(n):
+        ev = events[i]
+        if not stabilize and i >= stab_back_at:
+            ev = 4
+        if ev == 0 and i > 4:
+            ost.restart(); gst.restart(); log.append((i, "restart"))
+        elif ev == 1:
+            overlap = not overlap; gst.set_overlap(overlap); log.append((i, "overlap %d" % overlap))
+        elif ev == 2:
+            delay = 3 if delay == 2 else 2
+            s = _settings(preset, delay, stabilize); ost.configure(s); gst.configure(_conv(s)); log.append((i, "delay %d" % delay))
+        elif ev == 3 and i > 6:
+            preset = "field" if preset == "homography" else "homography"
+            s = _settings(preset, delay, stabilize); ost.configure(s); gst.configure(_conv(s)); log.append((i, preset))
+        elif ev == 4 and i > 3:
+            stabilize = not stabilize; stab_back_at = i + 4
+            s = _settings(preset, delay, stabilize); ost.configure(s); gst.configure(_conv(s)); log.append((i, "stabilize %d" % stabilize))
+        elif ev == 5 and i > 8:
+            lens_on = not lens_on
+            r, c = PACKED_SIZES[0]
+            prof = np.array([0.8 * c, 0.8 * c, c / 2.0, r / 2.0, -0.12, 0.03, 0.0, 0.0, 0.0]) if lens_on else None
+            ost.set_lens(prof); gst.set_lens(prof); log.append((i, "lens %d" % lens_on))
+        f, fmt, d = frames[i], fmts[i], dev[i]
+        if i > 0 and (f.shape != frames[i - 1].shape or fmt != fmts[i - 1]):
+            resizes += f.shape != frames[i - 1].shape; log.append((i, "%dx%d format %d" % (f.shape[1], f.shape[0], fmt)))
+        buf = big.copy()
+        w, wts = ost.push(f, ts=i, fmt=fmt, nthreads=32, out=buf)
+        if w is not None:
+            r, c = frames[wts].shape[:2]
+            want[wts] = buf[:r, :c].copy()
+            live += 1 if ost.stats().trust > 0.05 else 0
+        # ---- the look-ahead of the packed entry (lvk_hip_stab_prefetch): the next frame announced rightly, wrongly, or announced and cancelled
+        a = int(rng.integers(0, 8))
+        nxt = i + 1 if i + 1 < n else None
+        if nxt is not None and a == 0:
+            gst.prefetch(dev[nxt], fmt=fmts[nxt]); ahead_right += 1
+        elif nxt is not None and a == 1:
+            gst.prefetch(dev[(i + 3) % n], fmt=fmts[(i + 3) % n])
+        elif nxt is not None and a == 2:
+            gst.prefetch(dev[nxt], fmt=fmts[nxt]); gst.prefetch_cancel()
+        due = gst.next_output(f.shape[0], f.shape[1], fmt)
+        assert (due is None) == (w is None), (i, log)
+        if due is not None and (due[0] > f.shape[0] or due[1] > f.shape[1]) and a < 5:
+            with pytest.raises(lvk.LvkHipError):                      # an output sized from the incoming frame: refused, nothing changes
+                gst.apply(d, timestamp=i, out=guarded(*f.shape[:2])[1], fmt=fmt)
+            refused += 1
+        if due is not None:
+            gb, view = guarded(due[0], due[1])
+            g, gts = gst.apply(d, timestamp=i, out=view, fmt=fmt)
+            assert g is not None and tuple(g.shape) == (due[0], due[1], 3) and gst.last_format == fmts[gts] == due[2], (i, log)
+            got[gts] = (gb, g)
+        else:
+            g, _ = gst.apply(d, timestamp=i, fmt=fmt)
+            assert g is None, (i, log)
+    ctx.sync()
+    so, sg = ost.stats(), gst.stats()
+    assert (so.n_detected, so.n_matched, so.n_tracked, so.tracking_stability, so.trust) == (sg.n_detected, sg.n_matched, sg.n_tracked, sg.tracking_stability, sg.trust), log
+    assert sorted(got) == sorted(want), log                            # every frame the oracle emits, old sizes included: nothing is dropped
+    assert len(got) >= 10 and resizes >= 2, (len(got), resizes, log)
+    for ts, (gb, g) in sorted(got.items()):
+        r, c = frames[ts].shape[:2]
+        p, q = g.cpu().numpy(), want[ts]
+        assert p.shape == q.shape, (ts, p.shape, q.shape)
+        if not np.array_equal(p, q):
+            dd = np.abs(p.astype(np.int32) - q.astype(np.int32))
+            raise AssertionError(f"seed {seed}: frame ts {ts} ({c}x{r}, format {fmts[ts]}): {int((dd > 0).sum())} bytes differ, max |d| {dd.max()}; schedule {log}")
+        b = gb.cpu().numpy()
+        assert (b[:4] == GUARD).all() and (b[4 + r:] == GUARD).all() and (b[4:4 + r, c * 3:] == GUARD).all(), f"frame ts {ts}: bytes outside the {c}x{r} output were written; {log}"
+    print(f"\n[packed fuzz seed {seed}] {len(got)} frames compared ({live} with trust > 0), {resizes} size changes, {refused} undersized outputs refused, {gst.lookahead_frames()} of {ahead_right} right announcements found their pyramid built; events {log}")
+    ost.close(); gst.close()
+
+
 def test_soak_3000_pushes_give_every_byte_back():
     """3 000 free-running pushes (1080p I420, device entry, overlap mode) with restarts, reconfigurations and right / wrong / missing
     announcements in between.  When the filter and its context are gone the device has its memory back (pool slots, staging planes,
