@@ -326,6 +326,24 @@ int  lvk_hip_stab_prefetch_yuv420(lvk_hip_stab* stab, const void* d_y, int y_ste
                                   int nv12, int rows, int cols);
 long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* stab);
 
+/* Which schedule the pushes of this filter took so far.  The library picks per push, from what it sees the caller doing (is the bulk stream still
+ * busy with the previous remap? did this push begin within 15 us of the last one's return?), between the schedule of a FREE-RUNNING caller
+ * (persistent remap grid of 4 blocks per CU next to the tracker, completion through an event) and that of a caller that WAITS for every frame
+ * (full remap grid, completion through a word in host memory): same pixels, different throughput / latency.  A host -- and bench.py, per leg --
+ * reads here which one its pushes got.  reset != 0 zeroes the counters after reading. */
+#define LVK_SCHED_PUSH_FREE_RUNNING   0   /* pushes taken as a free-running caller's ... */
+#define LVK_SCHED_PUSH_SYNCHRONISED   1   /* ... and as those of a caller that waits for every frame */
+#define LVK_SCHED_INGEST_ON_TRACKER   2   /* 4:2:0 conversions placed behind the chain on the tracking stream ... */
+#define LVK_SCHED_INGEST_ON_BULK      3   /* ... on the bulk stream (overlap mode) ... */
+#define LVK_SCHED_INGEST_INLINE       4   /* ... ahead of the tracker on the context's stream (no overlap) */
+#define LVK_SCHED_REMAP_PERSISTENT    5   /* output remaps launched as the persistent co-scheduled grid ... */
+#define LVK_SCHED_REMAP_FULL          6   /* ... as the full grid */
+#define LVK_SCHED_WAIT_SIGNAL_WORD    7   /* chain completions taken from the host signal word ... */
+#define LVK_SCHED_WAIT_EVENT          8   /* ... from hipEventSynchronize / hipStreamSynchronize */
+#define LVK_SCHED_WAIT_WORD_TIMEOUT   9   /* signal-word waits that fell through to the event / stream wait (bounded spin) */
+#define LVK_SCHED_COUNT              10
+int  lvk_hip_stab_schedule_counters(lvk_hip_stab* stab, long long out[LVK_SCHED_COUNT], int reset);
+
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
 /* Frames on which FeatureDetector::detect ran FAST so far (Vision/FeatureDetector.cpp:125-157), by where the corners went through the
  * suppression grid: on the device inside the tracker's chain of kernels, or in the host loop (grids beyond 4096 cells, detection regions off

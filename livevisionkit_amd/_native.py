@@ -93,6 +93,7 @@ _SIG = {
     "lvk_hip_stab_prefetch": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "lvk_hip_stab_prefetch_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "lvk_hip_stab_lookahead_frames": (_c.c_longlong, [_P]),
+    "lvk_hip_stab_schedule_counters": (_c.c_int, [_P, _c.POINTER(_c.c_longlong), _c.c_int]),
     "lvk_hip_stab_detector_frames": (_c.c_int, [_P, _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_longlong)]),
     "lvk_hip_host_malloc": (_c.c_int, [_P, _c.c_size_t, _c.POINTER(_P)]),
     "lvk_hip_host_free": (_c.c_int, [_P, _P]),

@@ -85,18 +85,18 @@ int lvk_hip_stab::alloc_tracker_buffers()
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_count, sizeof(int)));
     LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_und, 2 * n * sizeof(float2)));
     LVK_HIP_CHECK(ctx, hipMalloc(&d_mesh_scratch, 32 * n));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_pts, n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_matched, n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, 2 * n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_status, n, hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_und, 2 * n * sizeof(float2), hipHostMallocDefault));
-    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_count, sizeof(int), hipHostMallocDefault));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_out, (size_t)fast_regions * fast_cap * sizeof(uint32_t), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_fast_counts, fast_regions * sizeof(int), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_regions, fast_regions * sizeof(FastRegion), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_pts, n * sizeof(float2), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_matched, n * sizeof(float2), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_p1, 2 * n * sizeof(float2), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_status, n, hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_H, 9 * sizeof(double), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_ninl, sizeof(int), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_mask, n, hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_und, 2 * n * sizeof(float2), hipHostMallocCoherent));
+    LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_count, sizeof(int), hipHostMallocCoherent));
     // the suppression grid's tables for k_fast_insert (constant per configuration)
     {
         const auto& col = grid.col_table(); const auto& row = grid.row_base_table(); const auto& bucket = grid.bucket_table();
@@ -112,9 +112,9 @@ int lvk_hip_stab::alloc_tracker_buffers()
         { const int crc = lvk_fast_cells_reset(ctx, d_cell_first, d_cell_best, (int)std::max<size_t>(grid.capacity(), 1), d_region_count); if (crc != LVK_HIP_OK) return crc; }
         LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_n_points, sizeof(int)));
         LVK_HIP_CHECK(ctx, hipMalloc((void**)&d_full, sizeof(int)));
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_occ, ((grid.capacity() + 31) / 32 + 1) * sizeof(uint32_t), hipHostMallocDefault));
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_new_kp, std::max<size_t>(grid.capacity(), 1) * sizeof(uint32_t), hipHostMallocDefault));
-        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_insert, 8 * sizeof(int), hipHostMallocDefault));
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_occ, ((grid.capacity() + 31) / 32 + 1) * sizeof(uint32_t), hipHostMallocCoherent));
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_new_kp, std::max<size_t>(grid.capacity(), 1) * sizeof(uint32_t), hipHostMallocCoherent));
+        LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_insert, 8 * sizeof(int), hipHostMallocCoherent));
     }
     return LVK_HIP_OK;
 }
@@ -570,6 +570,14 @@ int lvk_hip_stab_detector_frames(const lvk_hip_stab* st, long long* on_device, l
 {
     if (!st || !on_device || !on_host) return LVK_HIP_ERR_ARG;
     *on_device = st->device_grid_frames; *on_host = st->host_grid_frames;
+    return LVK_HIP_OK;
+}
+
+// Which schedule the pushes took (LVK_SCHED_*): see include/lvk_hip.h
+int lvk_hip_stab_schedule_counters(lvk_hip_stab* st, long long out[LVK_SCHED_COUNT], int reset)
+{
+    if (!st || !out) return LVK_HIP_ERR_ARG;
+    for (int i = 0; i < LVK_SCHED_COUNT; i++) { out[i] = st->sched[i]; if (reset) st->sched[i] = 0; }
     return LVK_HIP_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <thread>
 
 namespace lvkstab {
 
@@ -24,6 +25,18 @@ constexpr int LK_WIN = 11, LK_LEVELS = 3, LK_ITERS = 5;        // FrameTracker.c
 constexpr double LK_EPS = 0.01, LK_MIN_EIG = 1e-4;
 constexpr float HOMOGRAPHY_DISTRIBUTION_THRESHOLD = 0.6f;      // FrameTracker.cpp:37
 constexpr float QA_UPDATE_RATE = 0.1f, QA_BLEND_STEP = 0.05f;   // StabilizationFilter.cpp:30-31
+
+// one polite iteration of a spin-wait
+inline void lvk_cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 
 inline float step_toward(float current, float target, float amount)   // Functions/Math.tpp:133-142
 {
@@ -165,12 +178,18 @@ struct lvk_hip_stab
     hipEvent_t chain_done = nullptr;
     // a caller that waits for every frame: the chain's last kernel tells the host itself that its results are in host memory (LvkHostSignal)
     unsigned* h_chain_flag = nullptr; unsigned chain_seq = 0;
+    // how long a synchronous caller's thread spins on that word before it blocks in the runtime instead (LVK_HIP_SIGNAL_SPIN_US; 0 = never spin)
+    long signal_spin_us = [] { const char* e = std::getenv("LVK_HIP_SIGNAL_SPIN_US"); return e ? std::max(0L, std::atol(e)) : 400L; }();
+    bool signal_test_lose = [] { const char* e = std::getenv("LVK_HIP_SIGNAL_TEST_LOSE"); return e && e[0] == '1'; }();      // tests: the word never arrives
     bool ingest_on_tracker = false, tracker_ingest_capable = false;
     bool bulk_busy_at_push = false;            // the previous remap was still running when this push began
     // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
     // for its frames synchronises and reads back in between: at least a remap's duration)
     bool caller_runs_free = false;
     std::chrono::steady_clock::time_point last_push_end{};
+    // Which schedule the pushes took (lvk_hip_stab_schedule_counters): the mode is chosen per push from what the caller is seen doing, and a host
+    // cannot tune what it cannot see (round-5 VERDICT).  Indices: LVK_SCHED_*.
+    long long sched[LVK_SCHED_COUNT] = {0};
     // tests: LVK_HIP_INGEST_PLACEMENT=tracker|bulk pins the placement that is otherwise decided per push (see track())
     int ingest_placement = [] { const char* e = std::getenv("LVK_HIP_INGEST_PLACEMENT"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
     std::vector<hipEvent_t> slot_read_done;    // parallel to pool_all: the remap that read the slot (recorded on the bulk stream), or nullptr

@@ -130,7 +130,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     LvkHostSignal done{nullptr, 0};
     if (chained && !field && !caller_runs_free)
     {
-        if (!h_chain_flag) { LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_chain_flag, 64, hipHostMallocDefault)); *h_chain_flag = 0; }
+        if (!h_chain_flag) { LVK_HIP_CHECK(ctx, hipHostMalloc((void**)&h_chain_flag, 64, hipHostMallocCoherent)); *h_chain_flag = 0; }
         done = LvkHostSignal{h_chain_flag, ++chain_seq};
     }
     pe = prof_begin(LVK_STAGE_PYRLK);
@@ -205,20 +205,31 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     if (done.flag)
     {
         // The kernel's completion SIGNAL comes ~3 us after its results (end-of-kernel write-back, the command processor's signal, the runtime's
-        // wake-up); what follows here needs the results, not the signal, and everything that goes on a stream is ordered by the stream.  A word that
-        // does not change within 5 ms (a faulted kernel, a lost device) falls through to the wait that reports errors.
+        // wake-up); what follows here needs the results, not the signal, and everything that goes on a stream is ordered by the stream.
+        // What the host may read once it has seen the word (acquire): k_ransac_finalize's own results (h_H, h_ninl, h_mask -- its
+        // __threadfence_system + release store put them ahead of the word) AND the host mirrors the EARLIER kernels of the chain wrote (h_count,
+        // h_matched, h_status, h_insert, h_new_kp, h_fast_counts): those kernels had completed -- stream order; a kernel's end is a release at
+        // system scope for coherent host memory, which is what every one of these blocks is allocated as (hipHostMallocCoherent,
+        // stab_configure.hip) -- before the finalize kernel started, so they are ordered ahead of its fence as well.
+        // The spin is BOUNDED by signal_spin_us (default 400 us, a few chain times: K streams per GPU share the chip): a word that has not
+        // changed by then -- a slow neighbour, a faulted kernel, a lost device -- falls through to the wait that blocks in the runtime and
+        // reports errors; the thread no longer burns its core for the rest of a long chain.
+        const unsigned expect = signal_test_lose ? done.seq + 0x40000000u : done.seq;      // (tests: a word that never arrives)
         const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds(signal_spin_us);
         for (unsigned spins = 0;; spins++)
         {
-            if (__atomic_load_n(done.flag, __ATOMIC_ACQUIRE) == done.seq) { have_results = true; break; }
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
-            __builtin_ia32_pause();
+            if (__atomic_load_n(done.flag, __ATOMIC_ACQUIRE) == expect) { have_results = true; break; }
+            if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > budget) break;
+            lvk_cpu_relax();
         }
+        sched[have_results ? LVK_SCHED_WAIT_SIGNAL_WORD : LVK_SCHED_WAIT_WORD_TIMEOUT]++;
     }
     if (!have_results)
     {
         if (chain_event_armed) LVK_HIP_CHECK(ctx, hipEventSynchronize(chain_done));
         else LVK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        sched[LVK_SCHED_WAIT_EVENT]++;
     }
     trace.mark(HostTrace::LK_SYNC);
 
@@ -368,6 +379,7 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
     if (!st->buffers_ok) return ctx->fail(LVK_HIP_ERR_RUNTIME, "the last configure() failed while allocating the tracker's buffers: configure again");
     st->caller_runs_free = st->caller_free_running_now() || st->host_free_running_hint;
+    st->sched[st->caller_runs_free ? LVK_SCHED_PUSH_FREE_RUNNING : LVK_SCHED_PUSH_SYNCHRONISED]++;
     // 3-channel VideoFrame formats (VideoFrame.cpp:170-306): YUV tracks channel 0, BGR / RGB track cvtColor(..2GRAY); the remap
     // runs the YUV or the RGB EASU program by the frame's format (Image.cpp:36-41).  GRAY / 4-channel frames are not on this path.
     LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
@@ -407,6 +419,7 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         // 7 700 instead of 8 780 frames/s).  That only matters to a caller that runs free: one that waits for every frame (the previous
         // push ended long ago and the bulk stream is idle) gets the full grid -- the remap then has the GPU to itself (p50 latency -6 %).
         const bool persistent = side && st->caller_runs_free;
+        if (mesh) st->sched[persistent ? LVK_SCHED_REMAP_PERSISTENT : LVK_SCHED_REMAP_FULL]++;
         // a remap whose stores cross the host link (lvk_hip_stab_push_yuv420_host) is bound by the link, not by the chip: ONE block per CU
         // for a free-running caller -- measured (two upload streams at the time) 2 800 frames/s against 2 560 with the 4 blocks per CU of a device-resident stream (the
         // stores of more blocks only fill the link's write queue sooner, which stalls the tracker's kernels), 2 450 with one per two CUs
@@ -642,6 +655,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     int pe = 0;
     auto do_ingest = [=]() -> int {
         const bool on_tracker = side_ingest && st->ingest_on_tracker;
+        st->sched[on_tracker ? LVK_SCHED_INGEST_ON_TRACKER : (side_ingest ? LVK_SCHED_INGEST_ON_BULK : LVK_SCHED_INGEST_INLINE)]++;
         hipStream_t is = (side_ingest && !on_tracker) ? st->remap_stream : ctx->stream;
         if (side_ingest && !on_tracker) { const int w = st->bulk_stream_sees_caller_work(); if (w != LVK_HIP_OK) return w; }
         if (on_tracker)

@@ -296,6 +296,16 @@ class StabilizationFilter:
         self.ctx._check(self.lib.lvk_hip_stab_detector_frames(self.handle, _c.byref(a), _c.byref(b)))
         return a.value, b.value
 
+    SCHEDULE = ("push_free_running", "push_synchronised", "ingest_on_tracker", "ingest_on_bulk", "ingest_inline", "remap_persistent", "remap_full",
+                "wait_signal_word", "wait_event", "wait_word_timeout")
+
+    def schedule_counters(self, reset=False):
+        """lvk_hip_stab_schedule_counters: which schedule the pushes so far took (the library picks per push from what it sees the caller doing:
+        free-running -> persistent remap grid + event wait; a caller that waits for every frame -> full grid + host signal word)."""
+        a = (_c.c_longlong * len(self.SCHEDULE))()
+        self.ctx._check(self.lib.lvk_hip_stab_schedule_counters(self.handle, a, 1 if reset else 0))
+        return {k: int(a[i]) for i, k in enumerate(self.SCHEDULE)}
+
     def meshes(self):
         n = self._settings.motion_width * self._settings.motion_height * 2
         a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)

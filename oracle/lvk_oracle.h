@@ -168,6 +168,8 @@ int lvko_stab_push(lvko_stab* st, const uint8_t* frame, int step, int rows, int 
 int lvko_stab_push_fmt(lvko_stab* st, const uint8_t* frame, int step, int rows, int cols, uint64_t ts, int format,
                        uint8_t* out, int out_step, uint64_t* out_ts, int nthreads);
 void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* out);
+/* accumulated wall time per stage in ms: downscale, detect, LK, estimate, smooth, remap (bench.py's cpu_baseline; reset != 0 zeroes them) */
+void lvko_stab_get_stage_ms(lvko_stab* st, double out[6], int reset);
 int lvko_stab_get_meshes(const lvko_stab* st, float* motion, float* correction, int cap_floats);
 int lvko_stab_get_features(const lvko_stab* st, float* xy_resp_age, int cap);
 int lvko_stab_get_matches(const lvko_stab* st, float* p1, float* p2, int cap_pairs, int* estimator);   /* debug tap: pairs of the last estimate */

@@ -10,6 +10,7 @@
 #include "lvk_oracle.h"
 #include "parallel.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -280,6 +281,14 @@ struct Tracker
 
     // returns true and fills `motion` when a motion estimate exists (std::optional<WarpMesh>)
     const double* lens_model = nullptr;        // fused lens mode: estimate motion between lens-corrected point positions
+    // wall time per stage, accumulated (bench.py's cpu_baseline: BASELINE.md section 3 "per-stage ms (downscale, detect, LK, estimate, smooth, remap)")
+    double stage_ms[6] = {0, 0, 0, 0, 0, 0};
+    struct StageClock
+    {
+        double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        explicit StageClock(double& a) : acc(a) {}
+        ~StageClock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    };
 
     bool track(const uint8_t* frame, int step, int pix_stride, int rows, int cols, Mesh& motion, int luma_channel = 0)     // :108-196
     {
@@ -287,7 +296,9 @@ struct Tracker
         prev.swap(cur); std::swap(prev_w, cur_w); std::swap(prev_h, cur_h);
         cur_w = s.detection_width; cur_h = s.detection_height;
         cur.resize((size_t)cur_w * cur_h);
-        if (lvko_luma_area_resize(frame, step, pix_stride, luma_channel, rows, cols, cur.data(), cur_w, cur_h, cur_w) != 0)
+        int resize_rc;
+        { StageClock clk(stage_ms[0]); resize_rc = lvko_luma_area_resize(frame, step, pix_stride, luma_channel, rows, cols, cur.data(), cur_w, cur_h, cur_w); }
+        if (resize_rc != 0)
         {
             // (a refused resize used to leave the tracking frame empty and the filter silently tracking nothing: a test ran on that for two rounds)
             std::fprintf(stderr, "lvk oracle: the tracking-frame resize refused a %d x %d frame\n", cols, rows);
@@ -296,15 +307,19 @@ struct Tracker
         last_detected = last_matched = 0; last_distribution = 0.0f; last_estimator = 0;
         if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return false; }
 
-        const float distribution = det.detect(cur.data(), cur_w, tracked);
+        float distribution;
+        { StageClock clk(stage_ms[1]); distribution = det.detect(cur.data(), cur_w, tracked); }
         last_distribution = distribution; last_detected = (int)tracked.size();
         if (tracked.size() < (size_t)s.min_motion_samples || distribution < s.uniformity_threshold) { tracked.clear(); return false; }
 
         const int n = (int)tracked.size();
         tracked_pts.resize((size_t)n * 2); matched_pts.resize((size_t)n * 2); match_status.resize(n);
         for (int i = 0; i < n; i++) { tracked_pts[2 * i] = tracked[i].x; tracked_pts[2 * i + 1] = tracked[i].y; }
-        lvko_pyrlk(prev.data(), prev_w, cur.data(), cur_w, cur_h, cur_w, tracked_pts.data(), n, matched_pts.data(), match_status.data(),
-                   11, 11, 3, 5, 0.01, 1e-4);                       // :33-35,42-48
+        {
+            StageClock clk(stage_ms[2]);
+            lvko_pyrlk(prev.data(), prev_w, cur.data(), cur_w, cur_h, cur_w, tracked_pts.data(), n, matched_pts.data(), match_status.data(),
+                       11, 11, 3, 5, 0.01, 1e-4);                   // :33-35,42-48
+        }
 
         // fused lens mode: the motion is estimated between lens-corrected positions; a match whose corrected positions leave the
         // tracking region is not visible in the corrected frame (the reference chain LC -> VS could not have tracked it): drop it
@@ -350,6 +365,7 @@ struct Tracker
         if (lens_model) { tracked_pts = und_t; matched_pts = und_m; }
         last_p1 = tracked_pts; last_p2 = matched_pts;
         last_estimator = s.track_local_motions ? 3 : (distribution > 0.6f ? 1 : 2);
+        StageClock estimate_clk(stage_ms[3]);                                    // (motion estimate + the propagation bookkeeping behind it)
         if (s.track_local_motions)
         {
             if (lvko_mesh_solver_solve(solver, tracked_pts.data(), matched_pts.data(), m, (float)cur_w, (float)cur_h,
@@ -631,13 +647,17 @@ int lvko_stab_push_fmt(lvko_stab* st, const uint8_t* frame, int step, int rows, 
     if (st->queue.size() == st->queue_capacity) st->queue.pop_front();
     st->queue.push_back(std::move(qf));
 
-    Mesh correction = st->smoother.next(motion);
+    Mesh correction;
+    { Tracker::StageClock clk(st->tracker.stage_ms[4]); correction = st->smoother.next(motion); }
     if (st->queue.size() != st->queue_capacity) return 0;           // ready() == is_full()
     lvko_stab::QFrame f = std::move(st->queue.front()); st->queue.pop_front();
     if (st->s.crop_to_stable_region) correction.add(st->smoother.scene_crop);
     st->last_correction = correction;
-    lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, correction.v.data(), correction.rows, correction.cols, bg, f.format == 4 ? 1 : 0, nthreads,
-                             st->model_for(f.rows, f.cols));
+    {
+        Tracker::StageClock clk(st->tracker.stage_ms[5]);
+        lvko_warpmesh_apply_lens(f.px.data(), f.cols * 3, f.rows, f.cols, out, out_step, correction.v.data(), correction.rows, correction.cols, bg, f.format == 4 ? 1 : 0, nthreads,
+                                 st->model_for(f.rows, f.cols));
+    }
     if (out_ts) *out_ts = f.ts;
     return 1;
 }
@@ -654,6 +674,13 @@ void lvko_stab_get_stats(const lvko_stab* st, lvko_stab_stats* o)
     o->smoothing_factor = st->smoother.smoothing_factor;
     o->frame_delay = st->s.predictive_samples;
     for (int i = 0; i < 9; i++) o->homography[i] = st->tracker.last_H[i];
+}
+
+// wall time the pushes so far spent per stage, milliseconds: downscale (luma + INTER_AREA), detect (FAST + suppression grid), LK, estimate
+// (RANSAC / mesh solve + propagation), smooth (PathSmoother::next), remap (EASU warp of the delayed frame); reset != 0 zeroes the counters
+void lvko_stab_get_stage_ms(lvko_stab* st, double out[6], int reset)
+{
+    for (int i = 0; i < 6; i++) { out[i] = st->tracker.stage_ms[i]; if (reset) st->tracker.stage_ms[i] = 0.0; }
 }
 
 // debug tap: the (tracked, matched) pairs the last motion estimate was computed from (after fast_filter, FrameTracker.cpp:149);

@@ -497,6 +497,16 @@ class OracleStabilizer:
         self.L.lvko_stab_get_stats(self.h, _c.byref(st))
         return st
 
+    STAGES = ("downscale", "detect", "lk", "estimate", "smooth", "remap")
+
+    def stage_ms(self, reset=False):
+        """Accumulated wall time per stage (ms) of the pushes so far: {downscale, detect, lk, estimate, smooth, remap}."""
+        a = (_c.c_double * 6)()
+        self.L.lvko_stab_get_stage_ms.restype = None
+        self.L.lvko_stab_get_stage_ms.argtypes = [_c.c_void_p, _c.POINTER(_c.c_double), _c.c_int]
+        self.L.lvko_stab_get_stage_ms(self.h, a, 1 if reset else 0)
+        return dict(zip(self.STAGES, [float(v) for v in a]))
+
     def meshes(self):
         n = self.settings.motion_width * self.settings.motion_height * 2
         a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
@@ -537,6 +547,33 @@ def require_live_warp(ost, what="", min_trust=0.1):
 
 
 _inst = None
+_fast = None
+
+
+def load_fast():
+    """The TIMING build of the same sources (`make -C oracle fast`: -O3 -march=native) for bench.py's cpu_baseline, built
+    on the machine that runs it into oracle/_fast/<cpu>/ (never shipped: a -march=native library of another CPU must not be loaded).  Not the
+    parity checker -- bench.py holds its frames to load()'s before it reports a number from it.  Returns None when it cannot be built."""
+    global _fast
+    if _fast is None:
+        import hashlib
+        try:
+            model = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("model name", "flags"))][:2]
+        except OSError:
+            model = []
+        tag = hashlib.sha1("".join(model).encode()).hexdigest()[:12]
+        out_dir = os.path.join(ORACLE_DIR, "_fast", tag)
+        lib = os.path.join(out_dir, "liblvk_oracle_fast.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
+        try:
+            if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+                os.makedirs(out_dir, exist_ok=True)
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "fast", "FASTDIR=" + out_dir])
+            _fast = Oracle(ctypes.CDLL(lib))
+            _fast.set_device_rcp(True)
+        except (OSError, subprocess.CalledProcessError):
+            return None
+    return _fast
 
 
 RCP_FIXTURE = os.path.join(ROOT, "tests", "golden", "gfx950_rcp.npz")
