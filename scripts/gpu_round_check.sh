@@ -2,8 +2,8 @@
 # Round-closing validation on the GPU box (through gpurun): the whole GPU suite, smoke(), the driver's bench command, then the rocprofv3 passes of
 # scripts/profile_gpu.sh (kernel stats + FETCH / WRITE / SQ counters, separate runs) for the homography and the vector-field preset, and the
 # in-kernel timeline when the timeline variant of the library is present (scripts/variant_build.sh timeline -DLVK_TIMELINE).
-# usage: bash scripts/gpu_round_check.sh <tag>      e.g. r05   -> gpurun_out/<tag>_check/ (summaries to copy into profiles/)
-TAG=${1:-r05}
+# usage: bash scripts/gpu_round_check.sh <tag>      e.g. r06   -> gpurun_out/<tag>_check/ (summaries to copy into profiles/)
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${TAG}_check; mkdir -p $O/profiles
 timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -4 $O/pytest.log
@@ -24,12 +24,12 @@ for name in ("bench_driver_style", "bench_default"):
 PY
 rm -rf $R/gpurun_out/prof; bash $R/scripts/profile_gpu.sh > $O/profile_homography.log 2>&1
 PROF_DST=$O/profiles python $R/scripts/summarize_prof.py ${TAG} > $O/summary_homography.txt 2>&1; head -16 $O/summary_homography.txt; cat $O/profiles/${TAG}_sq_counters_per_kernel.txt | grep "remap\|finalize"
-cp $O/profiles/remap_pmc_traffic.json $O/profiles/remap_pmc_traffic_${TAG}.json 2>/dev/null
 rm -rf $R/gpurun_out/prof; BENCH_ARGS="--preset field" bash $R/scripts/profile_gpu.sh > $O/profile_field.log 2>&1
-mv $O/profiles/remap_pmc_traffic.json $O/profiles/remap_pmc_traffic_homography.json 2>/dev/null
 PROF_DST=$O/profiles BENCH_ARGS="--preset field" python $R/scripts/summarize_prof.py ${TAG}field > $O/summary_field.txt 2>&1; head -22 $O/summary_field.txt
-mv $O/profiles/remap_pmc_traffic.json $O/profiles/remap_pmc_traffic_field.json 2>/dev/null; mv $O/profiles/remap_pmc_traffic_homography.json $O/profiles/remap_pmc_traffic.json 2>/dev/null
 rm -rf $R/gpurun_out/prof
+# where the remap's issue slots go (SQ stall counters + effective clock of the shipped kernels): profiles/<tag>_remap_stalls.txt, remap_stalls.json
+bash $R/scripts/pmc_stalls.sh > $O/stalls.log 2>&1
+cp $R/gpurun_out/r06_stalls/summary.txt $O/profiles/${TAG}_remap_stalls.txt; cp $R/gpurun_out/r06_stalls/remap_stalls.json $O/profiles/remap_stalls.json
 if [ -f $R/livevisionkit_amd/variants/liblvk_hip_timeline.so ]; then
   LVK_HIP_LIB=$R/livevisionkit_amd/variants/liblvk_hip_timeline.so python $R/scripts/timeline_free.py > $O/profiles/${TAG}_timeline_free_running.txt 2>&1; tail -14 $O/profiles/${TAG}_timeline_free_running.txt
 fi

@@ -27,7 +27,7 @@ rocprofv3 --pmc $P2 --kernel-trace --output-format csv -d $OUT/live_p2 -- $LIVE 
 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $OUT/livefield_p1 -- $LIVE --preset field > $OUT/livefield_p1.log 2>&1
 # un-instrumented durations of the same commands, for the denominators
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/alone_stats -- $ALONE > $OUT/alone_stats.log 2>&1
-python $R/scripts/summarize_stalls.py $OUT > $OUT/summary.txt 2>&1
+python $R/scripts/summarize_stalls.py $OUT $OUT/remap_stalls.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # the raw per-dispatch CSVs are large: keep the summary, the logs and the counter list
 find $OUT -name "*.csv" -size +2M -delete
