@@ -63,9 +63,13 @@ const char* lvk_hip_version(void);                   /* human-readable build str
  * tests/test_abi.py holds the two together). */
 #define LVK_HIP_ABI_VERSION 6
 int  lvk_hip_abi_version(void);
-/* usable gfx950 devices in this process (0 when there is none; never an error): one lvk_hip_ctx + one host thread per device is the
- * multi-GPU partitioning (no collective, no peer access) */
+/* Devices of this process: contexts are addressed by HIP device index, and lvk_hip_device_count() is the number of indices worth trying -- the
+ * highest gfx950 index + 1 (0 when there is no gfx950 device; never an error).  On the usual host every index below it is an MI355X; on a mixed
+ * host (an integrated GPU or another architecture in between) lvk_hip_device_usable(d) says which indices lvk_hip_ctx_create accepts (the others
+ * are refused with LVK_HIP_ERR_NO_DEVICE) -- or set HIP_VISIBLE_DEVICES.  One lvk_hip_ctx + one host thread per usable device is the multi-GPU
+ * partitioning (no collective, no peer access). */
 int  lvk_hip_device_count(void);
+int  lvk_hip_device_usable(int device);
 
 /* Ordering between contexts: everything enqueued so far on `producer` (its stream and the streams of its stabilizers) happens
  * before whatever is enqueued on `ctx` from now on.  GPU-side (an event per stream), no host wait.  What the reference gets from

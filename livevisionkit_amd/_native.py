@@ -23,6 +23,7 @@ _SIG = {
     "lvk_hip_version": (_c.c_char_p, []),
     "lvk_hip_abi_version": (_c.c_int, []),
     "lvk_hip_device_count": (_c.c_int, []),
+    "lvk_hip_device_usable": (_c.c_int, [_c.c_int]),
     "lvk_hip_malloc": (_c.c_int, [_P, _c.c_size_t, _c.POINTER(_P)]),
     "lvk_hip_free": (_c.c_int, [_P, _P]),
     "lvk_hip_trim": (_c.c_int, [_P]),

@@ -21,18 +21,30 @@ const char* lvk_hip_version(void) { return "lvk-hip 0.6 (gfx950, ABI 6)"; }
 
 int lvk_hip_abi_version(void) { return LVK_HIP_ABI_VERSION; }
 
+static bool device_is_gfx950(int d)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0;
+}
+
+// Contexts are addressed by HIP device index.  The count is the number of indices worth trying -- the highest gfx950 index + 1 --, so that a host
+// whose index 0 is an integrated GPU or another architecture still finds its MI355Xs (round-5 ADVICE: the count used to stop at the first other
+// device and such a host saw 0); lvk_hip_device_usable(d) says which of them lvk_hip_ctx_create(d) accepts.
 int lvk_hip_device_count(void)
 {
-    int count = 0, usable = 0;
+    int count = 0, upto = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
     for (int d = 0; d < count; d++)
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); break; }
-        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) break;        // contexts are addressed by HIP device index: count the leading gfx950 devices
-        usable++;
-    }
-    return usable;
+        if (device_is_gfx950(d)) upto = d + 1;
+    return upto;
+}
+
+int lvk_hip_device_usable(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return (device >= 0 && device < count && device_is_gfx950(device)) ? 1 : 0;
 }
 
 static int ctx_create_impl(int device, bool own_stream, void* stream, lvk_hip_ctx** out)
@@ -49,9 +61,10 @@ static int ctx_create_impl(int device, bool own_stream, void* stream, lvk_hip_ct
     if (device < 0 || device >= count) { g_create_error = "device index out of range"; return LVK_HIP_ERR_ARG; }
     // the context's device is current while it is being made, the caller's afterwards (a thread that creates contexts for several devices
     // keeps whatever device it had)
-    struct RestoreDevice { int prev = -1; RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
-                           ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); } } restore_device;
-    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return LVK_HIP_ERR_RUNTIME; }
+    // (only when they differ: a thread that is on this device already -- or never chose one and creates a context on the implicit default -- is left alone)
+    struct RestoreDevice { int prev = -1, want; explicit RestoreDevice(int w) : want(w) { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+                           ~RestoreDevice() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); } } restore_device(device);
+    if (restore_device.prev != device && (e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return LVK_HIP_ERR_RUNTIME; }
 
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return LVK_HIP_ERR_RUNTIME; }

@@ -118,7 +118,7 @@ struct lvk_device_guard
 #error "instrumented build: pass -DLVK_PROBE_BUILD (scripts/variant_build.sh); never the library the tests and the bench load by default"
 #endif
 
-// Debug builds with -DLVK_TIMELINE (scripts/timeline_build.sh): every instrumented kernel logs the wall clock (100 MHz) at which its
+// Debug builds with -DLVK_TIMELINE (scripts/variant_build.sh timeline -DLVK_TIMELINE): every instrumented kernel logs the wall clock (100 MHz) at which its
 // first block started and its last block finished into a per-translation-unit ring, read back by lvk_tl_read_<unit>().  rocprofv3's
 // kernel trace slows the host enough to change how the two streams overlap; this does not.  Expands to nothing in product builds.
 #ifdef LVK_TIMELINE

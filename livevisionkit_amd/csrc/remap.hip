@@ -344,8 +344,10 @@ struct LensCoord
 };
 
 // ---- kernel body ---------------------------------------------------------------------------------------------------
-// rocprofv3 (profiles/r01_remap_pmc_sq.txt) shows this kernel is VALU-issue bound, not memory bound: ~510 VALU
-// instructions per output pixel, SQ_ACTIVE_INST_VALU ~ the whole SIMD time.  Two alternatives were built and
+// rocprofv3 (profiles/r06_remap_stalls.txt: the SQ_* / GRBM counters of THIS kernel, round 6) shows it is VALU-issue bound, not memory bound:
+// 488 VALU instructions per output pixel, one leaving each SIMD every 2.94 cycles (0.68 of the 2-cycle issue slots; 0.85 of what its mix of
+// 2- and 4-cycle opcodes allows), 2.4 of the 4.4 resident waves per SIMD ready and not issued at any moment (SQ_WAIT_INST_ANY 0.52-0.56 of the
+// waves' time), 0.5 waiting for memory (SQ_WAIT_ANY 0.11-0.17).  Alternatives that were built and
 // measured on MI355X at 4K and rejected: (a) staging the source window in LDS as pre-converted float4 (saves the
 // 72 unpack + 24 luma ops per pixel but needs 4 block barriers and 31-36 KB LDS -> 4 waves/SIMD: 126 us), and
 // (b) two pixels per lane on packed v_pk_fma/mul/add_f32 (those issue at half rate on gfx950, scripts/valu_peak.hip:

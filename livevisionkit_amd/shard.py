@@ -72,19 +72,29 @@ def gpu_numa_node(device_index, sysfs="/sys"):
         return -1
 
 
-def numa_node_of_address(address, numa_maps="/proc/self/numa_maps"):
-    """NUMA node holding the pages of the mapping that contains `address` (the node with the most pages of that mapping), or -1.  For checking
-    where pinned frame planes landed: eight host-fed 4K streams move ~80 GB/s per GPU through host DRAM -- on the socket
-    the GPU hangs off, or across the inter-socket links."""
+def numa_node_of_address(address, numa_maps="/proc/self/numa_maps", maps="/proc/self/maps"):
+    """NUMA node holding the pages of the mapping that CONTAINS `address` (the node with the most pages of that mapping), or -1 -- also when the
+    address lies in no mapping, or in one the kernel lists without per-node page counts (device-file backed pinned memory): the mapping is
+    looked up in /proc/self/maps, which has its end address (numa_maps has only the starts; the closest start below an address in a gap is
+    somebody else's mapping).  For checking where pinned frame planes landed: eight host-fed 4K streams move ~80 GB/s per GPU through host DRAM
+     -- on the socket the GPU hangs off, or across the inter-socket links."""
     try:
-        best = (-1, -1)                                                 # (start, node) of the closest mapping at or below the address
+        start = None
+        for line in open(maps):
+            lo, _, hi = line.split()[0].partition("-")
+            lo, hi = int(lo, 16), int(hi, 16)
+            if lo <= address < hi:
+                start = lo
+                break
+        if start is None:
+            return -1
         for line in open(numa_maps):
             parts = line.split()
-            start = int(parts[0], 16)
-            if start <= address and start > best[0]:
-                pages = {int(k[1:]): int(v) for k, v in (t.split("=") for t in parts[1:] if t.startswith("N") and "=" in t and t[1:].split("=")[0].isdigit())}
-                best = (start, max(pages, key=pages.get) if pages else -1)
-        return best[1]
+            if int(parts[0], 16) != start:
+                continue
+            pages = {int(k[1:]): int(v) for k, v in (t.split("=") for t in parts[1:] if t.startswith("N") and "=" in t and t[1:].split("=")[0].isdigit())}
+            return max(pages, key=pages.get) if pages else -1
+        return -1
     except Exception:
         return -1
 

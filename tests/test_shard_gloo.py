@@ -56,13 +56,24 @@ def test_cpulist_parsing_and_unbound_fallback():
 
 def test_numa_node_of_address_reads_numa_maps(tmp_path):
     from livevisionkit_amd import shard
-    maps = tmp_path / "numa_maps"
-    maps.write_text("7f0000000000 default anon=10 dirty=10 N0=2 N1=8 kernelpagesize_kB=4\n"
+    numa = tmp_path / "numa_maps"
+    numa.write_text("7f0000000000 default anon=10 dirty=10 N0=2 N1=8 kernelpagesize_kB=4\n"
                     "7f0000100000 default file=/x mapped=3 N0=3 kernelpagesize_kB=4\n"
-                    "7f0000200000 prefer:1 anon=512 dirty=512 N1=512 kernelpagesize_kB=4\n")
-    assert shard.numa_node_of_address(0x7f0000000000 + 4096, str(maps)) == 1          # most pages on node 1
-    assert shard.numa_node_of_address(0x7f0000100010, str(maps)) == 0
-    assert shard.numa_node_of_address(0x7f0000200000 + (1 << 20), str(maps)) == 1     # inside the last mapping
-    assert shard.numa_node_of_address(0x1000, str(maps)) == -1                         # below every mapping
-    assert shard.numa_node_of_address(0x1000, "/nonexistent") == -1
+                    "7f0000200000 prefer:1 anon=512 dirty=512 N1=512 kernelpagesize_kB=4\n"
+                    "7f0000600000 default file=/dev/kfd mapped=16 kernelpagesize_kB=4\n")
+    maps = tmp_path / "maps"
+    maps.write_text("7f0000000000-7f000000a000 rw-p 00000000 00:00 0\n"
+                    "7f0000100000-7f0000103000 r--p 00000000 08:01 42 /x\n"
+                    "7f0000200000-7f0000400000 rw-p 00000000 00:00 0\n"
+                    "7f0000600000-7f0000610000 rw-s 00000000 00:05 7 /dev/kfd\n")
+    f = lambda a: shard.numa_node_of_address(a, str(numa), str(maps))
+    assert f(0x7f0000000000 + 4096) == 1          # most pages on node 1
+    assert f(0x7f0000100010) == 0
+    assert f(0x7f0000200000 + (1 << 20)) == 1     # inside the last anonymous mapping
+    assert f(0x1000) == -1                         # below every mapping
+    # round-5 ADVICE: an address in the GAP behind a mapping is nobody's (the closest start below it used to answer), and a mapping the kernel
+    # lists without per-node counts (device-file backed pinned memory) has no answer either
+    assert f(0x7f000000a000 + 64) == -1 and f(0x7f0000400000) == -1
+    assert f(0x7f0000600000 + 128) == -1
+    assert shard.numa_node_of_address(0x1000, "/nonexistent", str(maps)) == -1 and shard.numa_node_of_address(0x7f0000000010, str(numa), "/nonexistent") == -1
     assert shard.gpu_numa_node(0, sysfs="/nonexistent") == -1

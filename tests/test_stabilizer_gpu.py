@@ -382,9 +382,51 @@ def test_stabilizer_yuv420_in_out_bit_exact(ctx, oracle, clip, nv12, overlap):
     ost.close(); gst.close()
 
 
-@pytest.mark.parametrize("size,nv12", [((1080, 1920), False), ((2160, 3840), False), ((1080, 1920), True), ((4320, 7680), False)])
+@pytest.mark.parametrize("strict", [False, True])
+def test_4k_generator_clip_overlap_yuv420_bit_exact(ctx, oracle, strict):
+    """Full size on NON-degenerate texture (round-5 VERDICT: the other full-size clips are 4 x pixel-replicated small clips, every 4 x 4 block flat):
+    24 frames of SURVEY 8d's generator (tests/clipgen.py: gratings + rectangles + noise, smooth pan + AR(1) jitter) rendered at 3840 x 2160 on the
+    GPU, copied down once, through the I420 overlap path free-running -- the persistent remap grid next to the tracker -- with the shipped strict
+    QA preset and the relaxed one; every emitted plane bit-identical to the oracle chain, and the warp must be live (not crop only)."""
+    import torch
+    import livevisionkit_amd as lvk
+    from tests import clipgen
+    rows, cols, n = 2160, 3840, 24
+    clip = clipgen.Clip(rows, cols, n, seed=0x4C564B31 + 17, device="cuda", cut_at=None)
+    planes_d = [clip.render_i420(i) for i in range(n)]
+    torch.cuda.synchronize()
+    planes_h = [tuple(p.cpu().numpy() for p in pl) for pl in planes_d]
+    del clip
+    qa = {} if strict else dict(min_scene_quality=0.3, min_tracking_quality=0.2)
+    s = oracle_lib.preset("homography", predictive_samples=4, **qa)
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(s)
+    gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_to_settings(s))
+    gst.set_overlap(True)
+    wants, gots = [], []
+    for i in range(n):                                                              # the GPU stream first, back to back: a free-running caller
+        got, gts = gst.apply_yuv420(planes_d[i], timestamp=i)                      # (no synchronisation between pushes, every output its own planes)
+        if got is not None:
+            gots.append((gts, got))
+    ctx.sync()
+    for i in range(n):
+        want, wts = ost.push(oracle.ingest_yuv420(*planes_h[i]), ts=i, nthreads=32)
+        if want is not None:
+            wants.append((wts, oracle.egress_yuv420(want)))
+    assert len(wants) == n - 4 and [t for t, _ in wants] == [t for t, _ in gots]
+    wants, gots = [w for _, w in wants], [g for _, g in gots]
+    oracle_lib.require_live_warp(ost, f"4K generator clip, strict={strict}")
+    so, sg = ost.stats(), gst.stats()
+    assert (so.trust, so.n_matched, so.n_tracked, list(so.homography)) == (sg.trust, sg.n_matched, sg.n_tracked, list(sg.homography))
+    assert gst.schedule_counters()["remap_persistent"] >= n - 8                     # free-running: the co-scheduled grid is what ran
+    for i, (w, g) in enumerate(zip(wants, gots)):
+        for a, b in zip(g, w):
+            assert np.array_equal(a.cpu().numpy(), b), (strict, i)
+    ost.close(); gst.close()
+
+
+@pytest.mark.parametrize("size,nv12", [((1080, 1920), False), ((1080, 1920), True), ((4320, 7680), False)])
 def test_overlap_yuv420_full_size_persistent_grid_bit_exact(ctx, oracle, size, nv12):
-    """Overlap mode at 1080p / 4K / 8K (the largest OBS canvas): the fused remap + 4:2:0 egress runs on the persistent grid (several strips per block, double-buffered
+    """Overlap mode at 1080p / 8K (the largest OBS canvas; 4K: test_4k_generator_clip_overlap_yuv420_bit_exact): the fused remap + 4:2:0 egress runs on the persistent grid (several strips per block, double-buffered
     chroma exchange), free-running next to the tracker; every emitted plane bit-identical to the oracle chain."""
     import torch
     import livevisionkit_amd as lvk
