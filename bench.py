@@ -830,20 +830,15 @@ def main():
     # detector's start-up burst -- a new stream runs FAST on most of its first 2 N pushes while the suppression grid fills up (pushes of 0.13-0.15 ms
     # instead of 0.10); and the chip's clock / power ramp -- 35 pushes are 4 ms of GPU work after seconds of rendering the clip at a low duty cycle
     # (measured: pushes of 0.11-0.135 ms there against 0.100-0.105 ms a few hundred pushes later, same kernels).  None of the three is the steady state
-    # SURVEY 8d's metric is defined on ("after the N-frame delay has filled, >= 600 frames"): at least 2 N + 10 pushes AND at least 0.1 s of them,
-    # whatever --warmup is, so that the driver's `--steps 20 --warmup 5` region samples the same stream the default run's 2000 steps do.
-    n_fill = max(delay + 2, 2 * delay + 10)
-    for r in rigs:
+    # SURVEY 8d's metric is defined on ("after the N-frame delay has filled, >= 600 frames"): 1000 pushes (>= 2 N + 10; ~0.1 s at 4K -- a fixed
+    # count, so that two runs of the same command push the same frames), whatever --warmup is, so that the driver's `--steps 20 --warmup 5` region
+    # samples the same stream the default run's 2000 steps do.
+    n_fill = max(delay + 2, 2 * delay + 10, 1000)
+    if K == 1:
         for _ in range(n_fill):
-            r.step()
-    t_fill = time.perf_counter()
-    while time.perf_counter() - t_fill < 0.1:
-        if K == 1:
-            for _ in range(50):
-                step()
-        else:
-            run_region(rigs, 50, lambda: None, local_rank)
-        n_fill += 50
+            step()
+    else:
+        run_region(rigs, n_fill, lambda: None, local_rank)
     if K == 1:
         for _ in range(args.warmup):
             step()
@@ -1087,7 +1082,7 @@ def main():
                                 f"cycled; rendered on the GPU in {t_gen:.1f} s") if args.input is None else f"{args.input}: {pool} frames, cycled",
                        "parallelism": f"{n_ranks} rank(s), one per GPU, {K} independent stream(s) each, no collective (gloo barrier only)",
                        "streams_per_gpu": K, "frames_in_hbm": pool * K, "host_cpus_bound": len(numa_cpus),
-                       "pipeline_fill": f"{n_fill} untimed pushes (frame delay, the detector's start-up burst, 0.1 s for the chip's clock ramp) before the {args.warmup} warmup steps",
+                       "pipeline_fill": f"{n_fill} untimed pushes (frame delay, the detector's start-up burst, ~0.1 s for the chip's clock ramp) before the {args.warmup} warmup steps",
                        # copies of the line's steady-state figures (>= 600 frames, p50 / p99 of a synchronised push) where a parser that keeps
                        # only the contract's keys still finds them
                        "steady_state": {"frames_per_s": sustained_frames / sustained_max, "frames": int(sustained_frames),
