@@ -385,13 +385,14 @@ def test_stabilizer_yuv420_in_out_bit_exact(ctx, oracle, clip, nv12, overlap):
 @pytest.mark.parametrize("strict", [False, True])
 def test_4k_generator_clip_overlap_yuv420_bit_exact(ctx, oracle, strict):
     """Full size on NON-degenerate texture (round-5 VERDICT: the other full-size clips are 4 x pixel-replicated small clips, every 4 x 4 block flat):
-    24 frames of SURVEY 8d's generator (tests/clipgen.py: gratings + rectangles + noise, smooth pan + AR(1) jitter) rendered at 3840 x 2160 on the
+    24 (relaxed QA) / 38 (strict QA) frames of SURVEY 8d's generator (tests/clipgen.py: gratings + rectangles + noise, smooth pan + AR(1) jitter) rendered at 3840 x 2160 on the
     GPU, copied down once, through the I420 overlap path free-running -- the persistent remap grid next to the tracker -- with the shipped strict
     QA preset and the relaxed one; every emitted plane bit-identical to the oracle chain, and the warp must be live (not crop only)."""
     import torch
     import livevisionkit_amd as lvk
     from tests import clipgen
-    rows, cols, n = 2160, 3840, 24
+    # (strict QA: the scene quality -- a moving average that starts at zero -- passes 0.95 at the 29th frame, the trust factor leaves zero after that)
+    rows, cols, n = 2160, 3840, (38 if strict else 24)
     clip = clipgen.Clip(rows, cols, n, seed=0x4C564B31 + 17, device="cuda", cut_at=None)
     planes_d = [clip.render_i420(i) for i in range(n)]
     torch.cuda.synchronize()
