@@ -155,6 +155,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (1080p, lens-fused, field preset)")
     ap.add_argument("--no-reference-kernel", action="store_true", help="skip timing the reference's compiled remap kernel (oracle/_ref) on the same frame")
     ap.add_argument("--no-multi-stream", action="store_true", help="skip the extra leg with 4 concurrent streams on this GPU")
+    ap.add_argument("--no-sensors", action="store_true", help="do not sample the GPU's clock / power sensors (sysfs) during the timed regions")
     return ap.parse_args()
 
 
@@ -414,19 +415,28 @@ class Rig:
 def run_region(rigs, n, device_sync, local_rank):
     """n free-running pushes on every rig (one host thread per rig beyond the first), bracketed by device-wide synchronisations.
     Returns (seconds, frames emitted by all rigs, host time stamps of rig 0's pushes)."""
+    import gc
     import threading
     import torch
     if len(rigs) == 1:
         rig = rigs[0]
-        t0 = time.perf_counter()
-        emitted = 0
-        stamps = [t0]
-        for _ in range(n):
-            out, _ = rig.step()
-            emitted += 1 if out is not None else 0
-            stamps.append(time.perf_counter())
-        device_sync()
-        return time.perf_counter() - t0, emitted, stamps
+        # (as timeit does, and as the latency pass below does: the interpreter's collector is the host process, not the library under test -- a
+        #  generation-0 pass showed as one 0.21 ms push in every ~15 of the 0.10 ms ones, 4 % of a --steps 20 region)
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            emitted = 0
+            stamps = [t0]
+            for _ in range(n):
+                out, _ = rig.step()
+                emitted += 1 if out is not None else 0
+                stamps.append(time.perf_counter())
+            device_sync()
+            return time.perf_counter() - t0, emitted, stamps
+        finally:
+            if gc_was_on:
+                gc.enable()
     gate = threading.Barrier(len(rigs) + 1)
     res = [None] * len(rigs)
 
@@ -818,7 +828,7 @@ def main():
     # the sensor sampler (a separate process) is started BEFORE the warmup, so that nothing but the barrier sits between the warmup steps
     # and the timed region (its start-up wait used to idle the GPU for 0.3 s right in front of the timed pushes)
     sampler = None
-    if rank == 0:
+    if rank == 0 and not args.no_sensors:
         try:
             props = torch.cuda.get_device_properties(local_rank)
             bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id) if hasattr(props, "pci_bus_id") else None
@@ -892,6 +902,19 @@ def main():
     lats = latency_pass(rigs, 500 if K == 1 else 200, local_rank)
     lat = lats[0]
     schedule["latency_pass"] = filt.schedule_counters(reset=True)
+    # ... and the same push the way a LIVE source makes it (the plugin's pattern: one frame every 16.7 ms, the GPU idle in between): 90 frames paced at
+    # 60 fps, push + sync each -- whether clock / power management between frames costs a 4K60 stream latency (scripts/idle_probe.py sweeps the gap)
+    paced = None
+    if rank == 0 and K == 1:
+        paced_ms = []
+        for _ in range(90):
+            rig.sync()
+            t_next = time.perf_counter() + 1.0 / 60.0
+            while time.perf_counter() < t_next:
+                pass
+            t_ = time.perf_counter(); rig.step(); rig.sync(); paced_ms.append((time.perf_counter() - t_) * 1e3)
+        paced = dict(percentiles(paced_ms), samples=len(paced_ms), note="one synchronised push every 1 / 60 s (GPU idle for 16.5 ms before each)")
+        filt.schedule_counters(reset=True)
 
     # every stage's event timing in a separate free-running pass (outside the timed region: 16 event records per frame)
     filt.set_profiling(True)
@@ -1102,6 +1125,7 @@ def main():
             # whole job: the slowest rank's (= slowest stream's) p50 / p99 of the synchronised pushes; every rank's own pair is in `ranks`
             "latency_ms": {"p50": max(r["latency_ms"]["p50"] for r in rank_reports), "p99": max(r["latency_ms"]["p99"] for r in rank_reports),
                            "max": max(r["latency_ms"]["max"] for r in rank_reports), "samples": len(lat), "over": f"max over {n_ranks} rank(s) x {K} stream(s); per rank / per stream: ranks[].latency_ms, ranks[].stream_latency_ms"},
+            "latency_paced_60fps_ms": paced,
             "extras": ("single-rank only: pcie_inclusive, lookahead, reference_kernel, configs, multi_stream, cpu_baseline, quality and roofline.standalone_* run on "
                        "rank 0 of a --gpus 1 --streams-per-gpu 1 run and are null otherwise (N > 1: the host-fed leg and configs 4 / 5 run on EVERY rank at once, "
                        "multi_gpu_legs); free_running_ms / timed_region_ms / stage_us / tracking / roofline / schedule are rank 0's stream 0"),
