@@ -593,12 +593,15 @@ public:
         hip::ContextLock lock(m_Ctx->mutex());
         sync_gpu(profile);
         m_LastRows = input.rows; m_LastCols = input.cols;
+        // the output has the size of the DELAYED frame (a resized source still gets its queued frames at their own size, as in the reference)
         VideoFrame420 result;
-        result.create({input.cols, input.rows}, input.nv12, m_OutCtx);
+        lvk_frame_info due{input.rows, input.cols, LVK_FORMAT_YUV};
+        if (lvk_hip_stab_next_output(m_Stab, input.rows, input.cols, LVK_FORMAT_YUV, &due) != 1) due = lvk_frame_info{input.rows, input.cols, LVK_FORMAT_YUV};
+        result.create({due.cols, due.rows}, input.nv12, m_OutCtx);
         int produced = 0; uint64_t ts = 0;
         m_Ctx->check(lvk_hip_stab_push_yuv420(m_Stab, input.y(), input.y_step(), input.u(), input.uv_step(), input.v(), input.uv_step(), input.nv12 ? 1 : 0,
                                               input.rows, input.cols, input.timestamp,
-                                              result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), &produced, &ts),
+                                              result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), result.rows, &produced, &ts, nullptr),
                      "StabilizationFilter::apply(4:2:0)");
         if (produced) { result.timestamp = ts; output = std::move(result); }
         else output.release();
@@ -622,15 +625,18 @@ public:
         sync_gpu(profile);
         m_LastRows = input.rows; m_LastCols = input.cols;
         // pinned planes are expensive to allocate: outputs come from a pool and return to it when the caller drops them
+        // (sized like the DELAYED frame: a resized source still gets its queued frames at their own size)
+        lvk_frame_info due{input.rows, input.cols, LVK_FORMAT_YUV};
+        if (lvk_hip_stab_next_output(m_Stab, input.rows, input.cols, LVK_FORMAT_YUV, &due) != 1) due = lvk_frame_info{input.rows, input.cols, LVK_FORMAT_YUV};
         HostFrame420* slot = nullptr;
-        for (auto& f : m_HostPool) if (f.unique() && f.cols == input.cols && f.rows == input.rows) { slot = &f; break; }
+        for (auto& f : m_HostPool) if (f.unique() && f.cols == due.cols && f.rows == due.rows) { slot = &f; break; }
         if (!slot) { if (m_HostPool.size() >= 8) m_HostPool.erase(m_HostPool.begin()); m_HostPool.emplace_back(); slot = &m_HostPool.back(); }
-        slot->create({input.cols, input.rows}, input.nv12, m_Ctx);
+        slot->create({due.cols, due.rows}, input.nv12, m_Ctx);
         HostFrame420 result = *slot;
         int produced = 0; uint64_t ts = 0;
         m_Ctx->check(lvk_hip_stab_push_yuv420_host(m_Stab, input.y(), input.y_step(), input.u(), input.uv_step(), input.v(), input.uv_step(), input.nv12 ? 1 : 0,
                                                    input.rows, input.cols, input.timestamp,
-                                                   result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), &produced, &ts),
+                                                   result.y(), result.y_step(), result.u(), result.uv_step(), result.v(), result.uv_step(), result.rows, &produced, &ts, nullptr),
                      "StabilizationFilter::apply(host 4:2:0)");
         if (produced) { result.timestamp = ts; output = std::move(result); }
         else output.release();

@@ -263,12 +263,16 @@ int  lvk_hip_stab_push(lvk_hip_stab* stab, const void* d_frame, int step, int ro
  * frames the filter queues live in an internal pool; a warped frame leaves through one kernel that remaps and writes the planes.
  * Input planes are consumed when the call returns; output planes are complete after lvk_hip_sync().  A filter is fed EITHER
  * through this call OR through lvk_hip_stab_push -- switching needs lvk_hip_stab_restart() (the two own their queued frames
- * differently).  When rows / cols CHANGE in the middle of a stream, tracker and path smoother carry on (as in the reference) and the frames still
- * queued at the old size are dropped: *produced stays 0 until the delay has built up again. */
+ * differently).
+ * SIZE OF THE OUTPUT: as for lvk_hip_stab_push -- the emitted frame is the DELAYED one at its own size (the reference's queue holds whole
+ * frames, StabilizationFilter.cpp:118-131), so after rows / cols CHANGE in the middle of a stream the next `frame_delay` pushes emit frames of
+ * the OLD size (round 6; rounds 2-5 dropped them).  lvk_hip_stab_next_output(stab, rows, cols, LVK_FORMAT_YUV, &info) says what the push will
+ * emit; the output planes hold o_rows luma rows (o_rows / 2 chroma rows) at the given pitches, and a push whose output would not fit is refused
+ * with LVK_HIP_ERR_ARG before the filter changes.  *emitted (optional) = the geometry of the frame written. */
 int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
                               int rows, int cols, uint64_t timestamp,
-                              void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,
-                              int* produced, uint64_t* out_timestamp);
+                              void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int o_rows,
+                              int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted);
 
 /* The same path for frames that live in HOST memory -- FrameIngest::upload_planes -> to_ocl -> filter -> to_obs -> download_planes
  * (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602): h_* / oh_* are planes in PINNED host memory (lvk_hip_host_malloc,
@@ -277,13 +281,14 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
  * remap kernel ITSELF, straight into the pinned host planes (zero copy; the download route -- remap to device planes, then a D2H copy --
  * is kept behind LVK_HIP_HOST_SINK=copy for comparison: the runtime performs that copy with a blit kernel that is slower for every
  * caller measured) -- same pixels.  Input planes are consumed when the call returns; output planes are complete after
- * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed).  Pageable plane
+ * lvk_hip_sync().  rows and cols even.  Shares the frame queue with lvk_hip_stab_push_yuv420 (the two may be mixed), and its output sizing: the
+ * output planes have the DELAYED frame's size (lvk_hip_stab_next_output), o_rows luma rows of capacity.  Pageable plane
  * pointers are refused with LVK_HIP_ERR_ARG: both ends of every plane are looked up on every call (an address that was pinned once may
  * have been freed and handed out again as pageable memory). */
 int  lvk_hip_stab_push_yuv420_host(lvk_hip_stab* stab, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
                                    int rows, int cols, uint64_t timestamp,
-                                   void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
-                                   int* produced, uint64_t* out_timestamp);
+                                   void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step, int o_rows,
+                                   int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted);
 /* Look-ahead for streaming callers (the reader thread of VideoFilter::stream, Filters/VideoFilter.cpp:62-209, uploads ahead of the
  * filter thread): starts the upload of the planes that the NEXT lvk_hip_stab_push_yuv420_host call will push (same pointers), so that
  * the link carries frame n + 1 while frame n is tracked: announce frame n + 1, then push frame n.  Announced frames are pushed in the

@@ -86,9 +86,9 @@ _SIG = {
     "lvk_hip_stab_push": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64, _c.c_int, _P, _c.c_int, _c.c_int,
                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_P), _P]),
     "lvk_hip_stab_push_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,
-                                            _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64)]),
+                                            _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _P]),
     "lvk_hip_stab_push_yuv420_host": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,
-                                            _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64)]),
+                                            _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _P]),
     "lvk_hip_stab_prefetch_yuv420_host": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "lvk_hip_stab_prefetch_cancel": (_c.c_int, [_P]),
     "lvk_hip_stab_prefetch": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),

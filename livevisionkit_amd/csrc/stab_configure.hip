@@ -536,6 +536,7 @@ int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::rest
     st->queue.clear(); st->queue_kind = 0;
     st->pending_release = nullptr; st->pending_slot = -1;
     st->orphaned.clear();                          // restart(): every borrowed frame is the caller's again
+    { const int src = st->sweep_retired(); if (src != LVK_HIP_OK) return src; }      // pool slots of an earlier frame size whose frames were still queued
     st->reset_context();
     return LVK_HIP_OK;
 }

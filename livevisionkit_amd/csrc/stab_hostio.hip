@@ -205,8 +205,8 @@ int lvk_hip_stab_prefetch_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_s
 // Input planes are consumed when the call returns; output planes are complete after lvk_hip_sync().
 int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step, const void* h_u, int u_step, const void* h_v, int v_step, int nv12,
                                   int rows, int cols, uint64_t timestamp,
-                                  void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step,
-                                  int* produced, uint64_t* out_timestamp)
+                                  void* oh_y, int oy_step, void* oh_u, int ou_step, void* oh_v, int ov_step, int o_rows,
+                                  int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_device_guard device_guard(st->ctx);
@@ -216,10 +216,17 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     LVK_HIP_REQUIRE(ctx, y_step >= cols && u_step >= (nv12 ? cols : cols / 2) && (nv12 || v_step >= cols / 2));
     int rc;
     if ((rc = st->require_pinned_planes(h_y, y_step, h_u, u_step, h_v, v_step, nv12, rows, cols, "lvk_hip_stab_push_yuv420_host")) != LVK_HIP_OK) return rc;
-    if (oh_y && oh_u && (nv12 || oh_v))
+    // the frame this push emits is the DELAYED one, at its own size (frames queued before a resize leave at the old size): the output planes are
+    // checked -- pitch, rows, pinned over their whole extent -- against THAT geometry
+    QueuedFrame due{};
+    const bool will_emit = st->next_output(QueuedFrame{nullptr, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV}, &due);
+    const int erows = will_emit ? due.rows : rows, ecols = will_emit ? due.cols : cols;
+    if (oh_y && oh_u && (nv12 || oh_v) && will_emit)
     {
-        LVK_HIP_REQUIRE(ctx, oy_step >= cols && ou_step >= (nv12 ? cols : cols / 2) && (nv12 || ov_step >= cols / 2));
-        if ((rc = st->require_pinned_planes(oh_y, oy_step, oh_u, ou_step, oh_v, ov_step, nv12, rows, cols, "lvk_hip_stab_push_yuv420_host (output)")) != LVK_HIP_OK) return rc;
+        if (!(oy_step >= ecols && ou_step >= (nv12 ? ecols : ecols / 2) && (nv12 || ov_step >= ecols / 2) && o_rows >= erows))
+            return st->fail(LVK_HIP_ERR_ARG, "the output planes do not hold the frame this push emits: " + std::to_string(ecols) + " x " + std::to_string(erows) +
+                                             " (the DELAYED frame's own size -- lvk_hip_stab_next_output); nothing was queued");
+        if ((rc = st->require_pinned_planes(oh_y, oy_step, oh_u, ou_step, oh_v, ov_step, nv12, erows, ecols, "lvk_hip_stab_push_yuv420_host (output)")) != LVK_HIP_OK) return rc;
     }
     if ((rc = st->ensure_hostio(rows, cols)) != LVK_HIP_OK) return rc;
     lvk_hip_stab::HostIO& io = st->hostio;
@@ -263,7 +270,8 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     const bool have_out = oh_y && oh_u && (nv12 || oh_v);
     st->host_free_running_hint = st->caller_free_running_now() ||
                                  (io.last_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - io.last_end < std::chrono::microseconds(15));
-    const bool direct = have_out && st->host_sink_mode != 2;
+    // (a frame of an EARLIER size -- the staging planes of the download route have the new one -- always leaves through the kernel's own stores)
+    const bool direct = have_out && (st->host_sink_mode != 2 || erows != rows || ecols != cols);
     const int j = io.out_next;
     uint8_t* o_y = nullptr; uint8_t* o_u = nullptr; uint8_t* o_v = nullptr;
     int oys = oy_step, ous = ou_step, ovs = ov_step;
@@ -284,7 +292,7 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     int prod = 0;
     tr_mark(1);
     st->host_direct_now = direct;
-    rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, &prod, out_timestamp);
+    rc = lvk_hip_stab_push_yuv420(st, d_y, cols, d_u, ccols, d_v, ccols, nv12, rows, cols, timestamp, o_y, oys, o_u, ous, o_v, ovs, direct ? o_rows : rows, &prod, out_timestamp, emitted);
     tr_mark(2);
     // "consumed on return": the conversion (which waited for both uploads) has finished in every mode by now; the event costs nothing then
     LVK_HIP_CHECK(ctx, hipEventSynchronize(io.c_done[k]));

@@ -74,7 +74,7 @@ struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; int f
 
 
 // planes of a 4:2:0 output: when given, a warped frame leaves through the fused remap + egress kernel instead of d_out
-struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; };
+struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; int rows_cap = 0; };
 
 } // namespace lvkstab
 
@@ -342,8 +342,14 @@ struct lvk_hip_stab
 
     // ---- YUV420 front/back end: pool of packed frames the planes are converted into
     std::vector<void*> pool_all; std::deque<void*> pool_free;      // free slots are reused oldest first: the remap that read a slot is long done
-    void* pool_out = nullptr;
+    void* pool_out = nullptr; size_t pool_out_bytes = 0;
     int pool_rows = 0, pool_cols = 0;
+    // Slots of an EARLIER frame size whose frames are still queued (the frame size changed in the middle of the stream: the reference's queue holds whole
+    // frames and still emits them, StabilizationFilter.cpp:118-131).  Freed when their frame has been emitted (or dropped by restart / configure).
+    std::vector<void*> pool_retired;
+    bool is_retired(const void* p) const { for (void* q : pool_retired) if (q == p) return true; return false; }
+    int release_retired(const void* p);        // frees a retired slot once nothing in flight reads it
+    int sweep_retired();                       // retired slots whose frame left the queue outside a push (restart, a shrinking queue)
     int ensure_pool(int rows, int cols);
     void free_pool();
 };

@@ -394,7 +394,11 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         if (st->next_output(in, &due))
         {
             const bool to_planes = o420 && o420->y && (st->s.stabilize_output || st->s.crop_to_stable_region || st->lens);      // (the fused remap + egress kernel)
-            if (!to_planes && !(d_out != nullptr && out_step >= 3 * due.cols && out_rows >= due.rows))
+            // (4:2:0 entries: the planes take the frame whichever route it leaves by -- the fused kernel, or the packed buffer + the egress kernel)
+            const bool planes_fit = !o420 || (o420->y && o420->y_step >= due.cols && o420->u_step >= (o420->nv12 ? due.cols : due.cols / 2) &&
+                                              (o420->nv12 || o420->v_step >= due.cols / 2) && o420->rows_cap >= due.rows);
+            const bool fits = planes_fit && (to_planes || (d_out != nullptr && out_step >= 3 * due.cols && out_rows >= due.rows));
+            if (!fits)
                 return ctx->fail(LVK_HIP_ERR_ARG, "the output buffer does not hold the frame this push emits: " + std::to_string(due.cols) + " x " + std::to_string(due.rows) +
                                                       " (the DELAYED frame's own size -- lvk_hip_stab_next_output); nothing was queued");
         }
@@ -548,17 +552,32 @@ int lvk_hip_stab::ensure_pool(int rows, int cols)
     if (rows == pool_rows && cols == pool_cols && pool_all.size() >= want) return LVK_HIP_OK;
     if (rows != pool_rows || cols != pool_cols)
     {
-        // new geometry: queued pool frames of the old size stay valid until they are emitted, so only grow lazily
         LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
-        // A resolution change in the middle of a 4:2:0 stream: the frames still queued live in pool slots of the old geometry, and the
-        // caller's output planes have the new one -- they are DROPPED (the delay builds up again, `produced` stays 0 for predictive_samples
-        // pushes); tracker and path smoother carry on, as in the reference, which would also still emit those frames at their old size
-        // (StabilizationFilter.cpp:118-131 keeps whole VideoFrames in its queue).
-        if (!queue.empty() && !pool_all.empty()) { queue.clear(); pending_release = nullptr; pending_slot = -1; }
-        free_pool();
+        // A resolution change in the middle of a 4:2:0 stream.  The frames still queued live in pool slots of the old geometry; like the reference,
+        // whose queue holds whole VideoFrames (StabilizationFilter.cpp:118-131), they STAY queued and leave at their own size over the next
+        // `frame_delay` pushes (rounds 2-5 dropped them): their slots are retired -- kept until their frame has been emitted -- and the rest of the
+        // old pool is freed.  Tracker and path smoother carry on.
+        std::vector<void*> keep;
+        if (queue_kind == 2) for (const QueuedFrame& q : queue) keep.push_back(const_cast<void*>(q.d_ptr));
+        for (void* p : pool_all)
+        {
+            if (std::find(keep.begin(), keep.end(), p) != keep.end()) pool_retired.push_back(p);
+            else (void)hipFree(p);
+        }
+        for (hipEvent_t e : slot_read_done) if (e) (void)hipEventDestroy(e);
+        pool_all.clear(); pool_free.clear(); slot_read_done.clear(); slot_read_armed.clear();
+        pending_release = nullptr; pending_slot = -1;
         pool_rows = rows; pool_cols = cols;
-        LVK_HIP_CHECK(ctx, hipMalloc(&pool_out, (size_t)rows * cols * 3));
+        // the packed output of the un-fused egress route holds the largest frame that can still be emitted
+        size_t out_bytes = (size_t)rows * cols * 3;
+        if (queue_kind == 2) for (const QueuedFrame& q : queue) out_bytes = std::max(out_bytes, (size_t)q.rows * q.cols * 3);
+        if (out_bytes > pool_out_bytes)
+        {
+            if (pool_out) { (void)hipFree(pool_out); pool_out = nullptr; pool_out_bytes = 0; }
+            LVK_HIP_CHECK(ctx, hipMalloc(&pool_out, out_bytes));
+            pool_out_bytes = out_bytes;
+        }
     }
     while (pool_all.size() < want)
     {
@@ -569,12 +588,39 @@ int lvk_hip_stab::ensure_pool(int rows, int cols)
     return LVK_HIP_OK;
 }
 
+int lvk_hip_stab::release_retired(const void* p)
+{
+    auto it = std::find(pool_retired.begin(), pool_retired.end(), p);
+    if (it == pool_retired.end()) return LVK_HIP_OK;
+    // its remap was enqueued a moment ago (bulk or tracking stream): wait for it -- a handful of times per resize, never in steady state
+    LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (remap_stream) LVK_HIP_CHECK(ctx, hipStreamSynchronize(remap_stream));
+    (void)hipFree(*it);
+    pool_retired.erase(it);
+    return LVK_HIP_OK;
+}
+
+int lvk_hip_stab::sweep_retired()
+{
+    for (size_t i = 0; i < pool_retired.size();)
+    {
+        bool queued = false;
+        for (const QueuedFrame& q : queue) queued = queued || q.d_ptr == pool_retired[i];
+        if (queued) { i++; continue; }
+        const int rc = release_retired(pool_retired[i]);
+        if (rc != LVK_HIP_OK) return rc;
+    }
+    return LVK_HIP_OK;
+}
+
 void lvk_hip_stab::free_pool()
 {
     for (void* p : pool_all) (void)hipFree(p);
+    for (void* p : pool_retired) (void)hipFree(p);
     for (hipEvent_t e : slot_read_done) if (e) (void)hipEventDestroy(e);
-    pool_all.clear(); pool_free.clear(); slot_read_done.clear(); slot_read_armed.clear();
+    pool_all.clear(); pool_free.clear(); pool_retired.clear(); slot_read_done.clear(); slot_read_armed.clear();
     if (pool_out) { (void)hipFree(pool_out); pool_out = nullptr; }
+    pool_out_bytes = 0;
     pool_rows = pool_cols = 0;
 }
 
@@ -617,8 +663,8 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
 // are consumed before the call returns; the output planes are complete after lvk_hip_sync().
 int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
                              int rows, int cols, uint64_t timestamp,
-                             void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step,
-                             int* produced, uint64_t* out_timestamp)
+                             void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int o_rows,
+                             int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_device_guard device_guard(st->ctx);
@@ -633,6 +679,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     st->queue_kind = 2;
     int rc = st->ensure_pool(rows, cols);
     if (rc != LVK_HIP_OK) return rc;
+    if (!st->pool_retired.empty() && (rc = st->sweep_retired()) != LVK_HIP_OK) return rc;
     if ((rc = st->mark_caller_work()) != LVK_HIP_OK) return rc;
     if (st->pool_free.empty())
     {
@@ -683,11 +730,30 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     else { rc = do_ingest(); if (rc != LVK_HIP_OK) { st->pool_free.push_back(slot); return rc; } }
     int prod = 0; const void* released = nullptr;
     st->pool_frames = side_ingest;
-    OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false};
+    OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false, o_rows};
     if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
-    rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * cols, rows, &prod, out_timestamp, &released, &o420);
+    // (the packed route's buffer: pool_out, tight rows, as many as its allocation holds at the widest queued frame)
+    lvk_frame_info info{0, 0, 0};
+    {
+        QueuedFrame due{};
+        const bool will = st->next_output(QueuedFrame{slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV}, &due);
+        const int out_cols = will ? due.cols : cols;
+        rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * out_cols,
+                                (int)(st->pool_out_bytes / ((size_t)3 * out_cols)), &prod, out_timestamp, &released, &o420, &info);
+    }
+    {
+        // a push that was refused (or failed before the frame was queued) has not taken the slot: its conversion is not launched, the slot is free again
+        bool taken = released == slot;
+        for (const QueuedFrame& q : st->queue) taken = taken || q.d_ptr == slot;
+        if (!taken) { st->deferred_ingest = nullptr; st->pool_free.push_front(slot); }
+    }
     if (st->deferred_ingest) { const int r2 = st->run_deferred_ingest(); if (rc == LVK_HIP_OK) rc = r2; }      // (track() returned before its launches)
-    if (released) st->pool_free.push_back(const_cast<void*>(released));
+    if (released)
+    {
+        if (st->is_retired(released)) { const int r3 = st->release_retired(released); if (rc == LVK_HIP_OK) rc = r3; }      // a frame of an earlier size has left
+        else st->pool_free.push_back(const_cast<void*>(released));
+    }
+    if (emitted && prod) *emitted = info;
     if (side_ingest)
     {
         // (the next frame's pyramid is on its way behind this chain: nothing will shadow the list bookkeeping at the start of the next push --
@@ -705,12 +771,13 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     if (prod && o420.used) { if (produced) *produced = 1; }                // the fused remap + egress kernel has written the planes
     else if (prod)
     {
-        // the emitted frame has the geometry of the pool (all pooled frames share it)
+        // the emitted frame has ITS OWN geometry (a frame queued before the size changed leaves at the old size)
         LVK_HIP_REQUIRE(ctx, o_y && o_u && (nv12 || o_v));
+        LVK_HIP_REQUIRE(ctx, oy_step >= info.cols && ou_step >= (nv12 ? info.cols : info.cols / 2) && (nv12 || ov_step >= info.cols / 2) && o_rows >= info.rows);
         hipStream_t es = (st->overlap && st->s.stabilize_output) ? st->remap_stream : ctx->stream;
         if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(es, e, 0)); }
         pe = st->prof_begin(LVK_STAGE_EGRESS, es);
-        rc = lvk_launch_egress_yuv420(ctx, es, st->pool_out, 3 * cols, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12);
+        rc = lvk_launch_egress_yuv420(ctx, es, st->pool_out, 3 * info.cols, info.rows, info.cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12);
         st->prof_end(pe, es);
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;

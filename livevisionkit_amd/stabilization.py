@@ -170,24 +170,34 @@ class StabilizationFilter:
 
     def apply_yuv420(self, planes, timestamp=0, out=None):
         """The OBS async path in one call: planes = (y, u, v) I420 or (y, uv) NV12 torch uint8 tensors on the GPU.
-        Returns (output planes, timestamp) or (None, None) while the delay builds."""
+        Returns (output planes, timestamp) or (None, None) while the delay builds.  The output planes have the DELAYED frame's size (a stream
+        whose frame size changes still emits its queued frames at their own size): `out`, when given, must hold it (next_output())."""
         import torch
         t0 = time.perf_counter()
         nv12 = len(planes) == 2
         y, u = planes[0], planes[1]
         v = u if nv12 else planes[2]
         if out is None:
-            out = tuple(torch.empty_like(p) for p in planes)
+            due = self.next_output(y.shape[0], y.shape[1], FORMAT_YUV)
+            r, c = (due[0], due[1]) if due else (y.shape[0], y.shape[1])
+            if nv12:
+                out = (torch.empty((r, c), dtype=torch.uint8, device=y.device), torch.empty((r // 2, c // 2, 2), dtype=torch.uint8, device=y.device))
+            else:
+                out = (torch.empty((r, c), dtype=torch.uint8, device=y.device),) + tuple(torch.empty((r // 2, c // 2), dtype=torch.uint8, device=y.device) for _ in range(2))
         oy, ou = out[0], out[1]
         ov = ou if nv12 else out[2]
-        produced = _c.c_int(0); ots = _c.c_uint64(0)
+        produced = _c.c_int(0); ots = _c.c_uint64(0); info = FrameInfo()
         rc = self.lib.lvk_hip_stab_push_yuv420(self.handle, y.data_ptr(), y.stride(0), u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0),
                                                1 if nv12 else 0, y.shape[0], y.shape[1], int(timestamp),
-                                               oy.data_ptr(), oy.stride(0), ou.data_ptr(), ou.stride(0), ov.data_ptr(), ov.stride(0),
-                                               _c.byref(produced), _c.byref(ots))
+                                               oy.data_ptr(), oy.stride(0), ou.data_ptr(), ou.stride(0), ov.data_ptr(), ov.stride(0), oy.shape[0],
+                                               _c.byref(produced), _c.byref(ots), _c.byref(info))
         self.ctx._check(rc)
         self._timer._add(time.perf_counter() - t0)
-        return (out, ots.value) if produced.value else (None, None)
+        if not produced.value:
+            return None, None
+        if (info.rows, info.cols) != tuple(oy.shape[:2]):                # a larger buffer was given: the emitted frame is its top-left part
+            out = (oy[:info.rows, :info.cols],) + tuple(p[:info.rows // 2, :info.cols // 2] for p in out[1:])
+        return out, ots.value
 
     # ---- pre-marshalled arguments: a streaming caller that cycles through a fixed set of buffers converts the tensor addresses
     #      and pitches to ctypes objects once instead of on every frame (about half of the per-call Python cost)
@@ -204,7 +214,7 @@ class StabilizationFilter:
         """apply_yuv420 with argument blocks from prepare_yuv420 (src: input planes, dst: output planes)."""
         produced = self._produced; ots = self._ots
         rc = self.lib.lvk_hip_stab_push_yuv420(self.handle, *src["args"], src["nv12"], src["rows"], src["cols"], timestamp,
-                                               *dst["args"], self._produced_ref, self._ots_ref)
+                                               *dst["args"], dst["rows"], self._produced_ref, self._ots_ref, None)
         if rc != 0:
             self.ctx._check(rc)
         return (dst["planes"], ots.value) if produced.value else (None, None)
@@ -261,7 +271,7 @@ class StabilizationFilter:
         """lvk_hip_stab_push_yuv420_host: pinned host planes in, pinned host planes out (complete after Context.sync())."""
         produced = self._produced; ots = self._ots
         rc = self.lib.lvk_hip_stab_push_yuv420_host(self.handle, *src["args"], src["nv12"], src["rows"], src["cols"], timestamp,
-                                                    *dst["args"], self._produced_ref, self._ots_ref)
+                                                    *dst["args"], dst["rows"], self._produced_ref, self._ots_ref, None)
         if rc != 0:
             self.ctx._check(rc)
         return (dst["planes"], ots.value) if produced.value else (None, None)

@@ -509,43 +509,61 @@ def test_mixing_push_flavours_needs_a_restart(ctx):
     ctx.sync(); f.close()
 
 
-@pytest.mark.parametrize("entry", ["device", "host"])
-def test_yuv420_resolution_change_mid_stream(ctx, oracle, entry):
+@pytest.mark.parametrize("entry", ["device", "host", "host-copy"])
+def test_yuv420_resolution_change_mid_stream(ctx, oracle, entry, monkeypatch):
     """A 4:2:0 stream whose frame size changes (an OBS source that is resized; VSFilter.cpp does not restart its filter): tracker and path
-    smoother carry on, the frames still queued at the old size are dropped (the reference would still emit them at their old size -- its queue
-    holds whole VideoFrames), and every frame emitted afterwards equals the oracle's frame of the same timestamp."""
+    smoother carry on, and -- like the reference, whose queue holds whole VideoFrames (StabilizationFilter.cpp:118-131) -- the frames still queued
+    at the old size LEAVE AT THEIR OWN SIZE over the next frame_delay pushes (round 6; rounds 2-5 dropped them).  lvk_hip_stab_next_output sizes the
+    output planes; planes sized from the incoming frame are refused when the delayed one is larger, before anything changes; every emitted frame
+    equals the oracle's frame of the same timestamp.  Device planes, pinned host planes (direct sink) and the download route (copy sink)."""
     import torch
     import livevisionkit_amd as lvk
+    if entry == "host-copy":
+        monkeypatch.setenv("LVK_HIP_HOST_SINK", "copy")
     a, _ = synth.make_clip(360, 640, 10, seed=31, jitter=1.0)
-    b, _ = synth.make_clip(270, 480, 12, seed=31, jitter=1.0)
-    frames = list(a) + list(b)
+    b, _ = synth.make_clip(270, 480, 8, seed=31, jitter=1.0)
+    c, _ = synth.make_clip(360, 640, 8, seed=31, jitter=1.0)
+    frames = list(a) + list(b) + list(c[:8])
     s = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
     ost = oracle_lib.OracleStabilizer(oracle, s)
     gst = lvk.StabilizationFilter(_to_settings(s), context=ctx); gst.set_overlap(True)
-    want, got = {}, {}
+    want, got, refused = {}, {}, 0
     for i, f in enumerate(frames):
         planes = oracle.egress_yuv420(f)
-        big = np.zeros((360, 640, 3), np.uint8)                                  # the oracle may emit a frame of the OLD size
+        big = np.zeros((360, 640, 3), np.uint8)                                  # the oracle may emit a frame of another size than it is given
         w, wts = ost.push(oracle.ingest_yuv420(*planes), ts=i, out=big)
         if w is not None:
-            r, c = (360, 640) if wts < 10 else (270, 480)
-            want[wts] = oracle.egress_yuv420(np.ascontiguousarray(big[:r, :c]))
+            r, c_ = frames[wts].shape[:2]
+            want[wts] = oracle.egress_yuv420(np.ascontiguousarray(big[:r, :c_]))
+        due = gst.next_output(f.shape[0], f.shape[1])
+        assert (due is None) == (w is None), i
         if entry == "device":
-            g, gts = gst.apply_yuv420(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes), timestamp=i)
+            dp = tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes)
+            if due is not None and due[0] > f.shape[0]:
+                with pytest.raises(lvk.LvkHipError, match="DELAYED"):             # output planes sized from the INCOMING frame: refused, nothing changes
+                    gst.apply_yuv420(dp, timestamp=i, out=tuple(torch.empty_like(p) for p in dp))
+                refused += 1
+            g, gts = gst.apply_yuv420(dp, timestamp=i)
             ctx.sync()
             if g is not None:
                 got[gts] = [p.cpu().numpy() for p in g]
         else:
-            hin, hout = gst.host_planes(*f.shape[:2]), gst.host_planes(*f.shape[:2])
+            hin = gst.host_planes(*f.shape[:2])
             for d, p in zip(hin, planes):
                 d[...] = p
-            g, gts = gst.apply_yuv420_host_prepared(gst.prepare_yuv420_host(hin), i, gst.prepare_yuv420_host(hout))
+            if due is not None and due[0] > f.shape[0]:
+                with pytest.raises(lvk.LvkHipError, match="DELAYED"):
+                    gst.apply_yuv420_host_prepared(gst.prepare_yuv420_host(hin), i, gst.prepare_yuv420_host(gst.host_planes(*f.shape[:2])))
+                refused += 1
+            hout = gst.host_planes(*(due[:2] if due else f.shape[:2]))
+            g, _ = gst.apply_yuv420_host_prepared(gst.prepare_yuv420_host(hin), i, gst.prepare_yuv420_host(hout))
             ctx.sync()
             if g is not None:
                 got[gst._ots.value] = [np.array(p) for p in hout]
         assert np.array_equal(gst.features(), ost.features()), i
-    assert sorted(want) == list(range(0, 19))                                   # the oracle emits every frame, old sizes included
-    assert sorted(got) == list(range(0, 7)) + list(range(10, 19))               # 7, 8, 9 were queued at the old size when it changed
+    assert sorted(want) == list(range(0, len(frames) - 3))                      # the oracle emits every frame, old sizes included ...
+    assert sorted(got) == sorted(want)                                          # ... and so does the library
+    assert refused == 3                                                         # the three 640x360 frames that left while 480x270 frames came in
     for ts, planes in got.items():
         for p, q in zip(planes, want[ts]):
             assert p.shape == q.shape and np.array_equal(p, q), ts
