@@ -221,7 +221,8 @@ int lvk_hip_stab_push_yuv420_host(lvk_hip_stab* st, const void* h_y, int y_step,
     QueuedFrame due{};
     const bool will_emit = st->next_output(QueuedFrame{nullptr, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV}, &due);
     const int erows = will_emit ? due.rows : rows, ecols = will_emit ? due.cols : cols;
-    if (oh_y && oh_u && (nv12 || oh_v) && will_emit)
+    // (planes given to a push that emits nothing are held to the incoming frame's geometry: pageable memory is refused whenever it is seen)
+    if (oh_y && oh_u && (nv12 || oh_v))
     {
         if (!(oy_step >= ecols && ou_step >= (nv12 ? ecols : ecols / 2) && (nv12 || ov_step >= ecols / 2) && o_rows >= erows))
             return st->fail(LVK_HIP_ERR_ARG, "the output planes do not hold the frame this push emits: " + std::to_string(ecols) + " x " + std::to_string(erows) +
