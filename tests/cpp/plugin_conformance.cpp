@@ -239,6 +239,70 @@ int run_resize(const char* in_path, const char* out_path)
     return 0;
 }
 
+// --resize420 <in.bin> <out.bin>: the same for the plugin's 4:2:0 wire format -- apply(const VideoFrame420&, VideoFrame420&) on device planes (overlap on)
+// and apply(const HostFrame420&, HostFrame420&) on pinned host planes -- over an I420 stream whose size changes twice.  Records in / out: int32 rows,
+// cols; uint64 timestamp; rows * cols * 3 / 2 bytes (Y, U, V).  Every frame must leave, at its own size.
+int run_resize420(const char* in_path, const char* out_path)
+{
+    struct Rec { int32_t rows, cols; uint64_t ts; std::vector<uint8_t> px; };
+    std::vector<Rec> recs;
+    FILE* f = std::fopen(in_path, "rb");
+    if (!f) { std::printf("resize420: cannot read the clip\n"); return 1; }
+    for (;;)
+    {
+        Rec r; int32_t head[2];
+        if (std::fread(head, sizeof(int32_t), 2, f) != 2) break;
+        r.rows = head[0]; r.cols = head[1];
+        if (std::fread(&r.ts, sizeof(uint64_t), 1, f) != 1) return 1;
+        r.px.resize((size_t)r.rows * r.cols * 3 / 2);
+        if (std::fread(r.px.data(), 1, r.px.size(), f) != r.px.size()) return 1;
+        recs.push_back(std::move(r));
+    }
+    std::fclose(f);
+    FILE* out = std::fopen(out_path, "wb");
+    if (!out) return 1;
+    std::vector<uint8_t> host;
+    auto emit = [&](int rows, int cols, uint64_t ts, const uint8_t* px) {
+        const int32_t head[2] = {rows, cols};
+        std::fwrite(head, sizeof(int32_t), 2, out); std::fwrite(&ts, sizeof(uint64_t), 1, out);
+        std::fwrite(px, 1, (size_t)rows * cols * 3 / 2, out);
+    };
+    for (int pass = 0; pass < 2; pass++)
+    {
+        lvk::StabilizationFilter filter;
+        filter.configure(golden_settings("homography"));
+        filter.set_overlap(true);
+        int emitted = 0;
+        for (const Rec& r : recs)
+        {
+            if (pass == 0)
+            {
+                lvk::VideoFrame420 in, res;
+                in.upload(r.px.data(), r.rows, r.cols, false, r.ts);
+                filter.apply(in, res);
+                if (res.empty()) continue;
+                host.resize((size_t)res.rows * res.cols * 3 / 2);
+                res.download(host.data());
+                emit(res.rows, res.cols, res.timestamp, host.data());
+            }
+            else
+            {
+                lvk::HostFrame420 in, res;
+                in.create({r.cols, r.rows}, false);
+                std::memcpy(in.y(), r.px.data(), r.px.size()); in.timestamp = r.ts;
+                filter.apply(in, res, true);
+                if (res.empty()) continue;
+                res.wait();
+                emit(res.rows, res.cols, res.timestamp, res.y());
+            }
+            emitted++;
+        }
+        std::printf("resize420 pass %d: %d of %zu frames emitted\n", pass, emitted, recs.size());
+    }
+    std::fclose(out);
+    return 0;
+}
+
 // A chain whose stages run on DIFFERENT streams with nothing but the facade's fences between them: asynchronous upload on the
 // thread's context -> ScalingFilter (same context) -> StabilizationFilter (its own context; overlap: a third stream) -> ScalingFilter
 // on the output frame's context -> download.  Compared with the same chain run with a full synchronisation after every stage.
@@ -599,6 +663,7 @@ int main(int argc, char** argv)
 #ifdef RUN_ON_GPU
     if (argc >= 7 && std::string(argv[1]) == "--golden") return run_golden(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), argv[6]);
     if (argc >= 4 && std::string(argv[1]) == "--resize") return run_resize(argv[2], argv[3]);
+    if (argc >= 4 && std::string(argv[1]) == "--resize420") return run_resize420(argv[2], argv[3]);
     if (argc >= 7 && std::string(argv[1]) == "--bench") return run_bench(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5], std::atoi(argv[6]));
     if (argc >= 3 && std::string(argv[1]) == "--threads-and-files") return (run_two_threads_check() != 0 || run_cross_context_420_check() != 0 || run_file_input_check(argv[2]) != 0) ? 1 : 0;
     if (run_chain_race_check() != 0) return 1;

@@ -112,6 +112,49 @@ def test_facade_emits_old_size_frames_after_a_resize(tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_420_emits_old_size_frames_after_a_resize(tmp_path):
+    """The plugin's 4:2:0 wire format through the facade -- apply(const VideoFrame420&, ..) on device planes and apply(const HostFrame420&, ..) on pinned
+    host planes -- over an I420 stream that goes 1080p -> 1920x800 -> 1080p: every frame leaves at its own size (round 6; the 4:2:0 entries used to
+    drop the frames queued at the old size), equal to the oracle chain ingest -> filter -> egress by timestamp."""
+    import struct
+    import numpy as np
+    from tests import oracle_lib
+    from tests.test_golden import STAB_OVER
+    from tests.test_resize_packed_gpu import _segments, SEG
+    oracle = oracle_lib.load()
+    segs = [f for f, fmt in _segments() if fmt == 4][:3 * SEG]                      # 1080p x 6, 1920x800 x 6, 1080p x 6
+    planes = [oracle.egress_yuv420(f) for f in segs]
+    with open(tmp_path / "in.bin", "wb") as f:
+        for i, pl in enumerate(planes):
+            f.write(struct.pack("<iiQ", segs[i].shape[0], segs[i].shape[1], 700 + i))
+            for q in pl:
+                f.write(np.ascontiguousarray(q).tobytes())
+    exe = _build(tmp_path, ["-DRUN_ON_GPU"])
+    out = subprocess.check_output([exe, "--resize420", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], timeout=600).decode()
+    n = len(segs)
+    assert f"resize420 pass 0: {n - 3} of {n} frames emitted" in out and f"resize420 pass 1: {n - 3} of {n} frames emitted" in out
+    ost = oracle_lib.OracleStabilizer(oracle, oracle_lib.preset("default")); ost.configure(oracle_lib.preset("homography", **STAB_OVER))
+    want = {}
+    for i, pl in enumerate(planes):
+        big = np.zeros((1080, 1920, 3), np.uint8)
+        w, wts = ost.push(oracle.ingest_yuv420(*pl), ts=700 + i, out=big, nthreads=32)
+        if w is not None:
+            r, c = segs[wts - 700].shape[:2]
+            want[wts] = np.concatenate([q.reshape(-1) for q in oracle.egress_yuv420(np.ascontiguousarray(big[:r, :c]))])
+    ost.close()
+    raw = (tmp_path / "out.bin").read_bytes()
+    pos, seen = 0, []
+    while pos < len(raw):
+        rows, cols, ts = struct.unpack_from("<iiQ", raw, pos); pos += 16
+        nb = rows * cols * 3 // 2
+        px = np.frombuffer(raw, np.uint8, nb, pos); pos += nb
+        assert (rows, cols) == segs[ts - 700].shape[:2], (ts, rows, cols)
+        assert np.array_equal(px, want[ts]), f"frame {ts} ({cols}x{rows}) differs from the oracle's"
+        seen.append(ts)
+    assert seen == sorted(want) * 2
+
+
+@pytest.mark.gpu
 def test_facade_throughput_at_4k(tmp_path):
     """Frames/s through lvk::StabilizationFilter::apply at 3840x2160 with resident frames against the same loop over the C-ABI
     (lvk_hip_stab_push_yuv420, what bench.py times) on the same clip, in the same test on the same box: no per-frame hipMalloc / hipFree
