@@ -362,5 +362,6 @@ class MeshSolver:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.ctx.lib.lvk_hip_mesh_solver_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):          # (never hand the library a solver whose context is gone)
+                self.ctx.lib.lvk_hip_mesh_solver_destroy(self.handle)
             self.handle = None

@@ -376,11 +376,16 @@ class StabilizationFilter:
         return {k: (ms[i], int(n[i])) for i, k in enumerate(self.STAGES)}
 
     def close(self):
+        # (a filter that outlives its context -- a failed test whose traceback keeps it alive past the session's Context -- must not hand a dangling
+        #  context to the library: the handle is dropped, the process is ending anyway)
+        alive = getattr(self.ctx, "handle", None)
         if getattr(self, "handle", None):
-            self.lib.lvk_hip_stab_destroy(self.handle)
+            if alive:
+                self.lib.lvk_hip_stab_destroy(self.handle)
             self.handle = None
         for p in getattr(self, "_host_blocks", []):
-            self.lib.lvk_hip_host_free(self.ctx.handle, p)
+            if alive:
+                self.lib.lvk_hip_host_free(self.ctx.handle, p)
         self._host_blocks = []
 
     def __del__(self):

@@ -220,6 +220,12 @@ def test_schedule_fuzz_packed_stream_with_resizes(ctx, oracle, seed):
         if fmt != 4:
             f = f[..., [1, 0, 2]]                                     # the textured channel where the grey value weighs most
         events.append(ev); frames.append(np.ascontiguousarray(f)); fmts.append(fmt)
+    if sum(frames[i].shape != frames[i - 1].shape for i in range(1, n)) < 2:
+        # a draw with fewer than two size changes: two are put in (pushes 12-23 at the second size, 30.. at the third), whatever else the schedule does
+        for i in range(12, n):
+            k = 1 if i < 24 else (2 if i >= 30 else 0)
+            f = clips[k][i]
+            frames[i] = np.ascontiguousarray(f if fmts[i] == 4 else f[..., [1, 0, 2]])
     dev = [torch.from_numpy(f).cuda() for f in frames]
     torch.cuda.synchronize()
     want, got, log = {}, {}, []
