@@ -338,7 +338,9 @@ long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* stab);
 /* Which schedule the pushes of this filter took so far.  The library picks per push, from what it sees the caller doing (is the bulk stream still
  * busy with the previous remap? did this push begin within 15 us of the last one's return?), between the schedule of a FREE-RUNNING caller
  * (persistent remap grid of 4 blocks per CU next to the tracker, completion through an event) and that of a caller that WAITS for every frame
- * (full remap grid, completion through a word in host memory): same pixels, different throughput / latency.  A host -- and bench.py, per leg --
+ * (full remap grid, completion through a word in host memory): same pixels, different throughput / latency.  (After eight or more free-running pushes
+ * the first push that looks synchronous still takes the free-running schedule -- one synchronisation does not make a synchronous caller --, the second
+ * in a row switches.)  A host -- and bench.py, per leg --
  * reads here which one its pushes got.  reset != 0 zeroes the counters after reading. */
 #define LVK_SCHED_PUSH_FREE_RUNNING   0   /* pushes taken as a free-running caller's ... */
 #define LVK_SCHED_PUSH_SYNCHRONISED   1   /* ... and as those of a caller that waits for every frame */

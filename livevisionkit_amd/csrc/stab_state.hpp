@@ -186,6 +186,7 @@ struct lvk_hip_stab
     // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
     // for its frames synchronises and reads back in between: at least a remap's duration)
     bool caller_runs_free = false;
+    int free_streak = 0, sync_streak = 0;      // consecutive pushes seen as free-running / as synchronous (one push of grace after a free-running streak)
     std::chrono::steady_clock::time_point last_push_end{};
     // Which schedule the pushes took (lvk_hip_stab_schedule_counters): the mode is chosen per push from what the caller is seen doing, and a host
     // cannot tune what it cannot see (round-5 VERDICT).  Indices: LVK_SCHED_*.
