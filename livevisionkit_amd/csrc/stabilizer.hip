@@ -378,19 +378,6 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
     if (released) *released = nullptr;
     LVK_HIP_REQUIRE(ctx, d_frame && rows > 0 && cols > 0 && step >= 3 * cols);           // !input.empty()
     if (!st->buffers_ok) return ctx->fail(LVK_HIP_ERR_RUNTIME, "the last configure() failed while allocating the tracker's buffers: configure again");
-    st->caller_runs_free = st->caller_free_running_now() || st->host_free_running_hint;
-    // One push of grace: a caller that has been running free for a while and synchronises ONCE (the end of a batch, a barrier in front of a timed
-    // region) is most likely still a free-running caller -- its first push after the synchronisation keeps the free-running schedule (persistent
-    // remap grid, so that the chain of the push behind it finds room; round 6: the two pushes after a device-wide synchronisation 0.16-0.29 + 0.13-0.15 ms
-    // -> 0.10-0.21 + 0.10-0.12).  A second push in a row that looks synchronous switches the mode; a caller that waits for every frame never sees this.
-    if (st->caller_runs_free) { st->free_streak++; st->sync_streak = 0; }
-    else
-    {
-        const bool grace = st->free_streak >= 8 && st->sync_streak == 0;
-        st->sync_streak++;
-        if (grace) st->caller_runs_free = true; else st->free_streak = 0;
-    }
-    st->sched[st->caller_runs_free ? LVK_SCHED_PUSH_FREE_RUNNING : LVK_SCHED_PUSH_SYNCHRONISED]++;
     // 3-channel VideoFrame formats (VideoFrame.cpp:170-306): YUV tracks channel 0, BGR / RGB track cvtColor(..2GRAY); the remap
     // runs the YUV or the RGB EASU program by the frame's format (Image.cpp:36-41).  GRAY / 4-channel frames are not on this path.
     LVK_HIP_REQUIRE(ctx, format == LVK_FORMAT_YUV || format == LVK_FORMAT_BGR || format == LVK_FORMAT_RGB);
@@ -414,6 +401,20 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
                                                       " (the DELAYED frame's own size -- lvk_hip_stab_next_output); nothing was queued");
         }
     }
+    // (from here on the push happens: which schedule it takes is decided -- and counted -- now, not for a push that was refused above)
+    st->caller_runs_free = st->caller_free_running_now() || st->host_free_running_hint;
+    // One push of grace: a caller that has been running free for a while and synchronises ONCE (the end of a batch, a barrier in front of a timed
+    // region) is most likely still a free-running caller -- its first push after the synchronisation keeps the free-running schedule (persistent
+    // remap grid, so that the chain of the push behind it finds room; round 6: the two pushes after a device-wide synchronisation 0.16-0.29 + 0.13-0.15 ms
+    // -> 0.10-0.21 + 0.10-0.12).  A second push in a row that looks synchronous switches the mode; a caller that waits for every frame never sees this.
+    if (st->caller_runs_free) { st->free_streak++; st->sync_streak = 0; }
+    else
+    {
+        const bool grace = st->free_streak >= 8 && st->sync_streak == 0;
+        st->sync_streak++;
+        if (grace) st->caller_runs_free = true; else st->free_streak = 0;
+    }
+    st->sched[st->caller_runs_free ? LVK_SCHED_PUSH_FREE_RUNNING : LVK_SCHED_PUSH_SYNCHRONISED]++;
     { const int lrc = st->ensure_lens(rows, cols); if (lrc != LVK_HIP_OK) return lrc; }
     static const WarpMeshF identity_mesh(2, 2);
     const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
