@@ -36,14 +36,20 @@ def test_abi_version_of_header_and_library_agree():
     assert lib.lvk_hip_abi_version() == want
     assert ("ABI %d" % want).encode() in lib.lvk_hip_version()
     assert "PART 1 -- STABLE ABI" in text and "PART 2 -- EXPERIMENTAL / DIAGNOSTICS" in text
+    # ABI 6 (round 6): every push flavour takes the capacity of its output and reports the geometry it wrote (the delayed frame's own size)
+    assert want >= 6
+    for decl in (r"lvk_hip_stab_push\(.*?int out_step, int out_rows,.*?lvk_frame_info\* emitted\)", r"lvk_hip_stab_push_yuv420\(.*?int ov_step, int o_rows,.*?lvk_frame_info\* emitted\)",
+                 r"lvk_hip_stab_push_yuv420_host\(.*?int ov_step, int o_rows,.*?lvk_frame_info\* emitted\)"):
+        assert re.search(decl, text, re.S), decl
     stable, experimental = text.split("PART 2 -- EXPERIMENTAL / DIAGNOSTICS  (no ABI promise")
     # what a host of the reference binds sits in PART 1 ...
     for name in ("lvk_hip_stab_push(", "lvk_hip_stab_push_yuv420(", "lvk_hip_stab_push_yuv420_host(", "lvk_hip_stab_configure(", "lvk_hip_ctx_create(", "lvk_hip_malloc(",
-                 "lvk_hip_remap_homography(", "lvk_hip_upscale(", "lvk_hip_stab_set_overlap(", "lvk_hip_device_count("):
+                 "lvk_hip_remap_homography(", "lvk_hip_upscale(", "lvk_hip_stab_set_overlap(", "lvk_hip_device_count(", "lvk_hip_device_usable(",
+                 "lvk_hip_stab_next_output("):
         assert name in stable and name not in experimental, name
     # ... the per-stage test entry points, taps and profiling in PART 2
     for name in ("lvk_hip_fast_detect(", "lvk_hip_pyrlk(", "lvk_hip_estimate_global_motion(", "lvk_hip_mesh_solver_solve(", "lvk_hip_stab_get_stats(",
-                 "lvk_hip_stab_set_profiling(", "lvk_hip_stab_prefetch_yuv420(", "lvk_hip_native_rcp("):
+                 "lvk_hip_stab_set_profiling(", "lvk_hip_stab_prefetch_yuv420(", "lvk_hip_native_rcp(", "lvk_hip_stab_schedule_counters("):
         assert name in experimental and name not in stable, name
 
 
