@@ -1079,7 +1079,7 @@ def main():
                                   # short kernels: an event pair brackets the kernel AND the two markers' own latency (~2.5-3.5 us); the rocprofv3
                                   # means of the same command are the kernels' own durations
                                   "timing": "HIP events on the launch stream, all-stages pass (a lower bound on `frac`: rocprofv3 means in "
-                                            "profiles/r05_kernel_stats.csv are 5.8 us for the downscale = 18 %, 9.7 us for the conversion = 48 %)"})
+                                            "profiles/r06_kernel_stats.csv are 5.9 us for the downscale = 18 %, 9.5 us for the conversion = 49 %)"})
         n_ranks = len(rank_reports)
         legs_agg = aggregate_legs(leg_reports) if leg_reports else None
         result = {
