@@ -45,3 +45,23 @@ def test_bench_has_no_constant_standing_in_for_a_counter():
     assert "VALU_PEAK_MEASURED" not in text and "valu_frac_measured" not in text
     for k in ("clock_mhz_under_kernel", "valu_busy_frac", "valu_frac_at_kernel_clock"):
         assert k in text
+
+
+def test_aggregate_of_the_multi_gpu_legs():
+    """bench.py --gpus N > 1: whole-job figures of the legs every rank runs at once = the frames of all ranks / the SLOWEST rank's time; per-rank
+    figures kept; a leg that failed on one rank is reported as an error, a leg that did not run as null (pure function: no GPU needed)."""
+    b = _bench()
+
+    def host(v, s, p50, p99, node):
+        return {"value": v, "frames": 600, "elapsed_s": s, "GBps_each_way": v * 12.44 / 1e3, "latency_ms": {"p50": p50, "p99": p99}, "pinned_planes_numa_node": node}
+
+    def cfg(v, s, p50, p99):
+        return {"value": v, "steps": 400, "frames": 400, "elapsed_s": s, "p50_ms": p50, "p99_ms": p99}
+    reports = [{"rank": 0, "numa_node": 0, "pcie": {"current_link_width": "16"}, "host_fed": host(3000.0, 0.20, 0.52, 0.55, 0), "config4_1080p": cfg(11000.0, 0.036, 0.11, 0.14)},
+               {"rank": 1, "numa_node": 1, "pcie": {"current_link_width": "16"}, "host_fed": host(2400.0, 0.25, 0.60, 0.71, 1), "config4_1080p": {"workload": "x", "error": "boom"}}]
+    a = b.aggregate_legs(reports)
+    h = a["host_fed"]
+    assert h["frames"] == 1200 and h["slowest_rank_s"] == 0.25 and abs(h["value"] - 1200 / 0.25) < 1e-9
+    assert h["per_rank_frames_per_s"] == [3000.0, 2400.0] and h["p99_ms"] == 0.71 and h["p50_ms"] == 0.60 and h["per_rank_planes_numa_node"] == [0, 1]
+    assert len(h["per_rank_GBps_each_way"]) == 2
+    assert "error" in a["config4_1080p"] and a["config5_4k_lens"] is None and a["ranks"] is reports
