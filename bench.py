@@ -637,31 +637,15 @@ def shared_resource_legs(lvk, rig, rank, local_rank, world, device, seed, barrie
     headline's 4K plain stream does not cover.  Returns this rank's report; rank 0 aggregates (sum of the frames / max over ranks of the time)."""
     rep = {"rank": rank, "device": local_rank}
     rep.update(gpu_link_info(local_rank))
-    calls = [0]
-    outer = barrier
-
-    def barrier():
-        calls[0] += 1
-        outer()
-
-    def settle(target):                                               # a leg that failed half-way still meets the other ranks at its barriers
-        while calls[0] < target:
-            barrier()
-    legs_done = 0
+    legs = []
     if host_fed and rig.yuv420:
-        try:
-            rep["host_fed"] = host_fed_leg(rig, 600, 200, barrier=barrier)
-        except Exception as e:
-            rep["host_fed"] = {"error": repr(e)}
-        legs_done += 1; settle(2 * legs_done)
+        legs.append(("host_fed", lambda b: host_fed_leg(rig, 600, 200, barrier=b)))
     if configs:
         for key, (r_, c_, lens_, label_) in (("config4_1080p", (1080, 1920, "off", "1920x1080 I420, OBS 'homography' preset (BASELINE config 4: one such stream per GPU)")),
                                              ("config5_4k_lens", (2160, 3840, "fused", "3840x2160 I420, lens pre-warp fused into the remap (BASELINE config 5: one such stream per GPU)"))):
-            try:
-                rep[key] = config_leg(lvk, local_rank, device, r_, c_, "homography", lens_, label_, seed + 101, steps=400, barrier=barrier)
-            except Exception as e:
-                rep[key] = {"workload": label_, "error": repr(e)}
-            legs_done += 1; settle(2 * legs_done)
+            legs.append((key, lambda b, r_=r_, c_=c_, lens_=lens_, label_=label_: config_leg(lvk, local_rank, device, r_, c_, "homography", lens_, label_, seed + 101, steps=400, barrier=b)))
+    # (a leg that fails half-way on this rank still meets the other ranks at its two barriers: lvk.shard.run_legs)
+    rep.update(lvk.shard.run_legs(legs, barrier, per_leg=2))
     return rep
 
 

@@ -36,6 +36,37 @@ def gather_rank_reports(report):
     return out
 
 
+class LegBarriers:
+    """Barrier bookkeeping for legs that every rank runs at the same time (bench.py --gpus N > 1: the host-fed leg, configs 4 / 5): each leg meets the
+    other ranks at a fixed number of barriers; a leg that FAILS half-way on one rank must still meet them, or the ranks that did not fail wait for
+    it for ever.  barrier() counts, settle(n) makes up the calls a failed leg skipped."""
+
+    def __init__(self, barrier):
+        self._barrier, self.calls = barrier, 0
+
+    def __call__(self):
+        self.calls += 1
+        self._barrier()
+
+    def settle(self, target):
+        while self.calls < target:
+            self()
+
+
+def run_legs(legs, barrier, per_leg=2):
+    """legs: [(key, callable(barrier))], each callable calling `barrier` exactly `per_leg` times when it succeeds.  Returns {key: result or
+    {"error": repr}}; whatever a leg did, this rank has passed per_leg * len(legs) barriers when it returns."""
+    b = LegBarriers(barrier)
+    out = {}
+    for k, (key, fn) in enumerate(legs):
+        try:
+            out[key] = fn(b)
+        except Exception as e:          # an extra leg must never break the contract line -- nor hang the other ranks
+            out[key] = {"error": repr(e)}
+        b.settle(per_leg * (k + 1))
+    return out
+
+
 def _parse_cpulist(text):
     cpus = []
     for part in text.strip().split(","):

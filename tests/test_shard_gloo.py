@@ -77,3 +77,44 @@ def test_numa_node_of_address_reads_numa_maps(tmp_path):
     assert f(0x7f0000600000 + 128) == -1
     assert shard.numa_node_of_address(0x1000, "/nonexistent", str(maps)) == -1 and shard.numa_node_of_address(0x7f0000000010, str(numa), "/nonexistent") == -1
     assert shard.gpu_numa_node(0, sysfs="/nonexistent") == -1
+
+
+def test_a_leg_that_fails_on_one_rank_does_not_hang_the_others(tmp_path):
+    """bench.py --gpus N > 1 runs its shared-resource legs on every rank at once, two barriers per leg (shard.run_legs): rank 1's second leg raises
+    between its barriers, its third before the first -- both ranks must come out, with the error recorded on rank 1 and the results on rank 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import torch.distributed as dist
+        from livevisionkit_amd import shard
+        rank, local, world = shard.rank_info()
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+        def good(b):
+            b(); b(); return {{"value": 1.0 + rank}}
+
+        def fails_between(b):
+            b()
+            if rank == 1: raise RuntimeError("half-way")
+            b(); return {{"value": 2.0}}
+
+        def fails_before(b):
+            if rank == 1: raise RuntimeError("at once")
+            b(); b(); return {{"value": 3.0}}
+        out = shard.run_legs([("a", good), ("b", fails_between), ("c", fails_before), ("d", good)], dist.barrier)
+        reps = shard.gather_rank_reports(out)
+        assert reps[0] == {{"a": {{"value": 1.0}}, "b": {{"value": 2.0}}, "c": {{"value": 3.0}}, "d": {{"value": 1.0}}}}, reps[0]
+        assert reps[1]["a"] == {{"value": 2.0}} and "half-way" in reps[1]["b"]["error"] and "at once" in reps[1]["c"]["error"] and reps[1]["d"] == {{"value": 2.0}}, reps[1]
+        dist.destroy_process_group()
+        print("ok", rank)
+    """))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
