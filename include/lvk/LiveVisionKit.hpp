@@ -962,3 +962,6 @@ using PathStabilizerSettings = PathSmootherSettings;
 using GridDetectorSettings = FeatureDetectorSettings;
 
 } // namespace lvk
+
+// Math/Homography.hpp, Math/WarpMesh.hpp, the lvk::remap launchers of Functions/Image.hpp
+#include "WarpMesh.hpp"

@@ -34,6 +34,7 @@ template <typename T> struct Point_
 };
 using Point = Point_<int>;
 using Point2f = Point_<float>;
+using Point2d = Point_<double>;
 
 template <typename T> struct Rect_
 {
