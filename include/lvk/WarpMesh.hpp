@@ -2,6 +2,7 @@
 //   Math/Homography.hpp:25-110 / Homography.cpp      3 x 3 binary64 matrix, transform = cv::perspectiveTransform
 //   Math/WarpMesh.hpp:31-140 / WarpMesh.cpp:34-551   mesh of NORMALISED BACKWARD offsets; the arithmetic SURVEY.md section 8 row a11 names, apply() (row a14)
 //   Functions/Image.hpp:26-34 / Image.cpp:28-151      lvk::remap(src, dst, offset_map, background), lvk::remap(src, dst, homography, background, inverted) (row a15)
+//   Functions/Drawing.hpp:23-71 / Drawing.tpp:53-196  colour constants, lvk::draw_grid, lvk::draw_crosses (section 8f row 4)
 // These are what the plugin touches outside the stabilizer (LCFilter holds a WarpMesh: set_to(map) -> crop_in -> apply,
 // Modules/OBS-Plugin/Sources/Enhancement/LCFilter.cpp:133-192).  The mesh arithmetic is lvk::detail::WarpMeshF -- the same code the library's host
 // logic runs and the parity tests hold to the oracle (include/lvk/WarpMeshCore.hpp); apply() and remap() forward to the C-ABI.
@@ -326,5 +327,48 @@ inline WarpMesh operator+(WarpMesh a, const WarpMesh& b) { a += b; return a; }
 inline WarpMesh operator-(WarpMesh a, const WarpMesh& b) { a -= b; return a; }
 inline WarpMesh operator*(WarpMesh a, const float s) { a *= s; return a; }
 inline WarpMesh operator/(WarpMesh a, const float s) { a /= s; return a; }
+
+// ---------------------------------------------------------------------------------------------- Functions/Drawing.hpp
+// Colour constants (Drawing.hpp:23-71; lvk::col::X[frame.format]) and the two overlay launchers the stabilizer's test mode and LCFilter's test grid use:
+// lvk::draw_grid (Drawing.tpp:53-93, kernel `grid`) and lvk::draw_crosses (Drawing.tpp:146-196, kernel `crosses`; the points are scaled by
+// coord_scaling and rounded to pixels like cv::multiply(.., CV_32S)).  In place on a packed 8UC3 device frame, asynchronous on the frame's context.
+namespace rgb { const cv::Scalar BLACK(0, 0, 0), WHITE(255, 255, 255), MAGENTA(255, 0, 255), GREEN(0, 255, 0), BLUE(0, 0, 255), RED(255, 0, 0); }
+namespace bgr { const cv::Scalar BLACK(0, 0, 0), WHITE(255, 255, 255), MAGENTA(255, 0, 255), GREEN(0, 255, 0), BLUE(255, 0, 0), RED(0, 0, 255); }
+namespace yuv { const cv::Scalar BLACK(0, 128, 128), WHITE(255, 0, 0), MAGENTA(105, 212, 234), GREEN(149, 43, 21), BLUE(29, 255, 107), RED(76, 84, 255); }
+namespace gray { const cv::Scalar BLACK(0), WHITE(255), MAGENTA(105), GREEN(149), BLUE(29), RED(76); }
+namespace col
+{
+    // Formats: BGR, BGRA, RGB, RGBA, YUV, GRAY
+    const cv::Scalar BLACK[] = {bgr::BLACK, bgr::BLACK, rgb::BLACK, rgb::BLACK, yuv::BLACK, gray::BLACK};
+    const cv::Scalar WHITE[] = {bgr::WHITE, bgr::WHITE, rgb::WHITE, rgb::WHITE, yuv::WHITE, gray::WHITE};
+    const cv::Scalar MAGENTA[] = {bgr::MAGENTA, bgr::MAGENTA, rgb::MAGENTA, rgb::MAGENTA, yuv::MAGENTA, gray::MAGENTA};
+    const cv::Scalar GREEN[] = {bgr::GREEN, bgr::GREEN, rgb::GREEN, rgb::GREEN, yuv::GREEN, gray::GREEN};
+    const cv::Scalar BLUE[] = {bgr::BLUE, bgr::BLUE, rgb::BLUE, rgb::BLUE, yuv::BLUE, gray::BLUE};
+    const cv::Scalar RED[] = {bgr::RED, bgr::RED, rgb::RED, rgb::RED, yuv::RED, gray::RED};
+}
+
+inline void draw_grid(VideoFrame& dst, const cv::Size& grid, const cv::Scalar& color, const int thickness)
+{
+    LVK_HIP_ASSERT(thickness >= 1 && !dst.empty() && grid.width >= 1 && grid.height >= 1);
+    const uint8_t c[3] = {(uint8_t)color[0], (uint8_t)color[1], (uint8_t)color[2]};
+    const auto& ctx = dst.context();
+    hip::ContextLock lock(ctx->mutex());
+    ctx->check(lvk_hip_draw_grid(ctx->get(), dst.device_ptr(), (int)dst.step, dst.rows, dst.cols, grid.width, grid.height, c, thickness), "draw_grid");
+}
+
+template <typename T>
+inline void draw_crosses(VideoFrame& dst, const std::vector<cv::Point_<T>>& points, const cv::Scalar& color, const int32_t cross_size,
+                         const int32_t cross_thickness, const cv::Size2f& coord_scaling = {1.0f, 1.0f})
+{
+    LVK_HIP_ASSERT(coord_scaling.width >= 0 && coord_scaling.height >= 0 && cross_thickness >= 1 && cross_size >= 1 && !dst.empty());
+    if (points.empty()) return;
+    std::vector<float> xy(points.size() * 2);
+    for (size_t i = 0; i < points.size(); i++) { xy[2 * i] = (float)points[i].x; xy[2 * i + 1] = (float)points[i].y; }
+    const uint8_t c[3] = {(uint8_t)color[0], (uint8_t)color[1], (uint8_t)color[2]};
+    const auto& ctx = dst.context();
+    hip::ContextLock lock(ctx->mutex());
+    ctx->check(lvk_hip_draw_crosses(ctx->get(), dst.device_ptr(), (int)dst.step, dst.rows, dst.cols, xy.data(), (int)points.size(),
+                                    coord_scaling.width, coord_scaling.height, c, cross_size, cross_thickness), "draw_crosses");
+}
 
 } // namespace lvk

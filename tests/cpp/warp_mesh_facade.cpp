@@ -151,8 +151,15 @@ int gpu_part(const char* in_path, const char* out_path)
     lvk::VideoFrame r3; r3.timestamp = 9; r3.format = lvk::VideoFrame::YUV;
     lvk::remap(src, r3, dmap, bg);
     if (!emit(r3, 9)) { std::printf("remap(map): bad frame\n"); return 1; }
+    // (f) the overlay launchers on a copy of the frame: LCFilter's test grid (LCFilter.cpp:177, col::MAGENTA[format]) + crosses at scaled points
+    lvk::VideoFrame drawn = src.clone();
+    drawn.timestamp = 11;
+    lvk::draw_grid(drawn, cv::Size(8, 5), lvk::col::MAGENTA[drawn.format], 1);
+    const std::vector<cv::Point2f> pts = {{10.5f, 7.25f}, {100.0f, 60.0f}, {239.6f, 134.4f}, {0.0f, 0.0f}, {130.2f, 20.9f}};
+    lvk::draw_crosses(drawn, pts, lvk::yuv::GREEN, 7, 4, cv::Size2f(2.0f, 2.0f));
+    if (!emit(drawn, 11)) { std::printf("draw: bad frame\n"); return 1; }
     std::fclose(out);
-    std::printf("gpu part done: 6 frames\n");
+    std::printf("gpu part done: 7 frames\n");
     return 0;
 }
 

@@ -152,8 +152,8 @@ def test_apply_and_remap_match_the_oracle(tmp_path, oracle):
     (tmp_path / "in.bin").write_bytes(struct.pack("<ii", rows, cols) + src.tobytes())
     exe = _build(tmp_path)
     out = subprocess.check_output([exe, "--gpu", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], timeout=300).decode()
-    assert "gpu part done: 6 frames" in out, out
-    got = np.frombuffer((tmp_path / "out.bin").read_bytes(), np.uint8).reshape(6, rows, cols, 3)
+    assert "gpu part done: 7 frames" in out, out
+    got = np.frombuffer((tmp_path / "out.bin").read_bytes(), np.uint8).reshape(7, rows, cols, 3)
     bg = (105, 212, 235)
     # (a) 2 x 2 mesh of the homography -> getPerspectiveTransform + easu_remap_homography; (b) 16 x 16 -> interpolated offsets + easu_remap
     assert np.array_equal(got[0], oracle.warpmesh_apply(src, from_homography(KH, cols, rows, 2, 2), bg=bg, yuv=True))
@@ -172,3 +172,7 @@ def test_apply_and_remap_match_the_oracle(tmp_path, oracle):
     cc, rr = np.meshgrid(np.arange(cols, dtype=f32), np.arange(rows, dtype=f32))
     offs = pixel_map(rows, cols); offs[..., 0] -= cc; offs[..., 1] -= rr
     assert np.array_equal(got[5], oracle.remap_map(src, offs, bg=bg, yuv=True))
+    # (f) lvk::draw_grid + lvk::draw_crosses (Drawing.tpp:53-93,146-196) with the reference's colour constants
+    want = oracle.draw_grid(src, (8, 5), (105, 212, 234), 1)
+    want = oracle.draw_crosses(want, [(10.5, 7.25), (100.0, 60.0), (239.6, 134.4), (0.0, 0.0), (130.2, 20.9)], (149, 43, 21), 7, 4, scaling=(2.0, 2.0))
+    assert np.array_equal(got[6], want) and not np.array_equal(got[6], src)
