@@ -129,8 +129,12 @@ class GpuSampler:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)     # 2000 x ~0.12 ms: a 0.25 s timed region (a 40 ms one is at the mercy of clock ramps)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=250)      # 250 steps x 16 frames x ~0.11 ms: a 0.45 s timed region
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--frames-per-step", type=int, default=16,
+                    help="one step = one batch of this many consecutive frames of the stream (that many pushes).  Round 6: a step of ONE frame made the driver's "
+                         "`--steps 20` region 2.5 ms between two device-wide synchronisations, 8-12 %% of which are the empty pipeline behind the first and the "
+                         "lone remap in front of the second (6 800-8 800 frames/s from run to run on one box); 20 batches of 16 frames are 35 ms")
     ap.add_argument("--rows", type=int, default=2160)
     ap.add_argument("--cols", type=int, default=3840)
     ap.add_argument("--preset", default="homography", choices=["homography", "field"])
@@ -833,11 +837,13 @@ def main():
             step()
     else:
         run_region(rigs, n_fill, lambda: None, local_rank)
+    fps_ = max(1, args.frames_per_step)
+    n_timed, n_warm = args.steps * fps_, args.warmup * fps_
     if K == 1:
-        for _ in range(args.warmup):
+        for _ in range(n_warm):
             step()
     else:
-        run_region(rigs, args.warmup, lambda: None, local_rank)
+        run_region(rigs, n_warm, lambda: None, local_rank)
     # live HIP-event timing of the dominant kernel inside the timed region: that stage only, and one launch in eight (an event pair per
     # frame is two host API calls in the per-frame turnaround -- the measurement would slow what it measures by ~4 %)
     filt.set_profiling(True, stages=("remap",), every=8)
@@ -857,7 +863,7 @@ def main():
     schedule = {}
     filt.schedule_counters(reset=True)
     wall0 = time.time()
-    elapsed, emitted, stamps = run_region(rigs, args.steps, device_sync, local_rank)
+    elapsed, emitted, stamps = run_region(rigs, n_timed, device_sync, local_rank)
     wall1 = time.time()
     schedule["timed_region"] = filt.schedule_counters(reset=True)
     free_running = np.diff(np.array(stamps)) * 1e3          # host time per push of stream 0 in the free-running timed region
@@ -866,7 +872,7 @@ def main():
     # pushes right behind the timed region -- a --steps 20 timed region is 2.6 ms, of which the pipeline fill after the barrier and the
     # un-overlapped last remap are 6-8 %.  Outside `value` (the contract times exactly --steps), reported beside it; it also gives the
     # roofline its >= 64 event samples of the remap whatever --steps was.
-    n_sustained = max(600, 64 * 8 - args.steps)
+    n_sustained = max(600, 64 * 8 - n_timed)
     wall2 = time.time()
     sustained_s, sustained_emitted, _ = run_region(rigs, n_sustained, device_sync, local_rank)
     wall3 = time.time()
@@ -1074,7 +1080,8 @@ def main():
             "n_gpus": n_ranks,                               # the ranks that timed
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "ms_per_step": elapsed_max / args.steps * 1e3,          # one step = frames_per_step consecutive frames (config.frames_per_step)
+            "ms_per_frame": elapsed_max / n_timed * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1089,6 +1096,9 @@ def main():
                                 f"cycled; rendered on the GPU in {t_gen:.1f} s") if args.input is None else f"{args.input}: {pool} frames, cycled",
                        "parallelism": f"{n_ranks} rank(s), one per GPU, {K} independent stream(s) each, no collective (gloo barrier only)",
                        "streams_per_gpu": K, "frames_in_hbm": pool * K, "host_cpus_bound": len(numa_cpus),
+                       "frames_per_step": fps_,
+                       "step": f"one step = one batch of {fps_} consecutive frames of the stream = {fps_} pushes (lvk_hip_stab_push_yuv420), each emitting one stabilized frame; "
+                               f"the timed region is exactly {args.steps} steps = {n_timed} pushes per stream",
                        "pipeline_fill": f"{n_fill} untimed pushes (frame delay, the detector's start-up burst, ~0.1 s for the chip's clock ramp) before the {args.warmup} warmup steps",
                        # copies of the line's steady-state figures (>= 600 frames, p50 / p99 of a synchronised push) where a parser that keeps
                        # only the contract's keys still finds them

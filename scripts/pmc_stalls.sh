@@ -18,7 +18,7 @@ done
 P2="$P2 GRBM_GUI_ACTIVE"
 echo "pass 2 counters: $P2" > $OUT/passes.txt
 ALONE="python $R/scripts/bench_remap.py"
-LIVE="python $R/bench.py --steps 120 --warmup 10 --pool 64 --no-cpu-baseline --no-pcie --no-configs --no-multi-stream --no-lookahead ${BENCH_ARGS:-}"
+LIVE="python $R/bench.py --frames-per-step 1 --steps 120 --warmup 10 --pool 64 --no-cpu-baseline --no-pcie --no-configs --no-multi-stream --no-lookahead ${BENCH_ARGS:-}"
 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $OUT/alone_p1 -- $ALONE > $OUT/alone_p1.log 2>&1
 rocprofv3 --pmc $P2 --kernel-trace --output-format csv -d $OUT/alone_p2 -- $ALONE > $OUT/alone_p2.log 2>&1
 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $OUT/live_p1 -- $LIVE > $OUT/live_p1.log 2>&1

@@ -2,7 +2,7 @@
 # K streams on ONE GPU (bench.py --streams-per-gpu K): aggregate frames/s and per-stream latency, K = 1 .. 8.  Run on the GPU box.
 mkdir -p gpurun_out/sweep
 for K in 1 2 3 4 6 8; do
-python bench.py --streams-per-gpu $K --steps 1000 --warmup 50 --pool 64 --no-cpu-baseline --no-pcie --no-configs --no-multi-stream --no-reference-kernel --no-lookahead > gpurun_out/sweep/k$K.json 2> gpurun_out/sweep/k$K.err
+python bench.py --streams-per-gpu $K --frames-per-step 1 --steps 1000 --warmup 50 --pool 64 --no-cpu-baseline --no-pcie --no-configs --no-multi-stream --no-reference-kernel --no-lookahead > gpurun_out/sweep/k$K.json 2> gpurun_out/sweep/k$K.err
 python - <<P
 import json
 d = json.loads(open('gpurun_out/sweep/k$K.json').read().strip().splitlines()[-1])

@@ -35,7 +35,7 @@ if stats:
                 lines.append((k or "__amd_rocclr_copyBuffer", int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                               float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 120 --warmup 10 --no-cpu-baseline --no-pcie %s (MI355X, %dx%d)\n" % (os.environ.get("BENCH_ARGS", ""), cols, rows))
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --frames-per-step 1 --steps 120 --warmup 10 --no-cpu-baseline --no-pcie %s (MI355X, %dx%d)\n" % (os.environ.get("BENCH_ARGS", ""), cols, rows))
         f.write("kernel,calls,avg_us,min_us,max_us,total_ms\n")
         for l in sorted(lines, key=lambda x: -x[5]):
             f.write("%s,%d,%.2f,%.2f,%.2f,%.3f\n" % l)

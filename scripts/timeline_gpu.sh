@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-pcie ${BENCH_ARGS:-}"
+CMD="python $R/bench.py --frames-per-step 1 --steps 40 --warmup 10 --no-cpu-baseline --no-pcie ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/t -- $CMD > $OUT/log.txt 2>&1
 find $OUT -name "*.csv" -size +0 | head
 python - <<PY

@@ -29,10 +29,10 @@ def test_bench_two_ranks_on_a_shared_gpu():
     ranks = r["ranks"]
     assert [x["rank"] for x in ranks] == [0, 1]
     assert ranks[0]["clip_seed"] != ranks[1]["clip_seed"]                       # two DIFFERENT streams, not one stream twice
-    assert all(x["frames"] == 20 for x in ranks)
+    assert r["config"]["frames_per_step"] == 16 and all(x["frames"] == 20 * 16 for x in ranks)      # one step = a batch of 16 consecutive frames
     slowest = max(x["elapsed_s"] for x in ranks)
-    assert abs(r["value"] - 40 / slowest) <= 0.02 * r["value"]                  # aggregate = sum of the frames / max over ranks of the time
-    assert abs(r["ms_per_step"] - slowest / 20 * 1e3) <= 0.02 * r["ms_per_step"]
+    assert abs(r["value"] - 2 * 320 / slowest) <= 0.02 * r["value"]             # aggregate = sum of the frames / max over ranks of the time
+    assert abs(r["ms_per_step"] - slowest / 20 * 1e3) <= 0.02 * r["ms_per_step"] and abs(r["ms_per_frame"] * 16 - r["ms_per_step"]) <= 1e-9 * r["ms_per_step"]
     assert r["sustained"]["frames"] >= 1200
     # per-rank latency (north star: throughput AND p99 at 1 / 2 / 4 / 8 GPUs): every rank reports its own pair, the line's is the slowest rank's
     assert all(x["latency_ms"]["p99"] >= x["latency_ms"]["p50"] > 0 for x in ranks) and all(len(x["stream_latency_ms"]) == 1 for x in ranks)
@@ -52,7 +52,7 @@ def test_bench_two_ranks_on_a_shared_gpu():
     assert r["config"]["shared_resource_legs"]["host_fed"]["value"] == legs["host_fed"]["value"]
     # the steady-state figures beside the contract's value, and the schedule the library chose per region
     assert r["value_sustained"] == r["sustained"]["frames_per_s"] == r["config"]["steady_state"]["frames_per_s"] and r["p99_ms"] == r["latency_ms"]["p99"]
-    assert r["schedule"]["timed_region"]["push_free_running"] + r["schedule"]["timed_region"]["push_synchronised"] == 20
+    assert r["schedule"]["timed_region"]["push_free_running"] + r["schedule"]["timed_region"]["push_synchronised"] == 320
     assert r["schedule"]["latency_pass"]["push_synchronised"] >= 450, r["schedule"]
     print("\n[bench --gpus 2 on a shared GPU] value %.0f frames/s; per rank: %s" % (r["value"], [(x["device"], x["numa_cpus"], round(x["frames_per_s"])) for x in ranks]))
 
@@ -70,11 +70,11 @@ def test_bench_eight_ranks_on_a_shared_gpu():
     ranks = r["ranks"]
     assert r["n_gpus"] == 8 and [x["rank"] for x in ranks] == list(range(8))
     assert len({x["clip_seed"] for x in ranks}) == 8                             # eight different streams
-    assert all(x["frames"] == 20 for x in ranks)
+    assert all(x["frames"] == 320 for x in ranks)
     assert all(x["latency_ms"]["p99"] >= x["latency_ms"]["p50"] > 0 for x in ranks)
     assert r["latency_ms"]["p99"] == max(x["latency_ms"]["p99"] for x in ranks)
     slowest = max(x["elapsed_s"] for x in ranks)
-    assert abs(r["value"] - 160 / slowest) <= 0.02 * r["value"]
+    assert abs(r["value"] - 8 * 320 / slowest) <= 0.02 * r["value"]
     assert "8 rank(s)" in r["config"]["parallelism"] and r["scaling"] == "weak"
     legs = r["multi_gpu_legs"]
     assert legs["host_fed"]["value"] > 0 and len(legs["host_fed"]["per_rank_p99_ms"]) == 8 and len(legs["ranks"]) == 8
@@ -99,7 +99,7 @@ def test_bench_spawns_its_own_ranks_when_launched_plainly():
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and len(r["ranks"]) == 2 and r["ranks"][0]["clip_seed"] != r["ranks"][1]["clip_seed"]
-    assert all(x["frames"] == 20 for x in r["ranks"])
+    assert all(x["frames"] == 320 for x in r["ranks"])
 
 
 @pytest.mark.gpu
@@ -121,8 +121,8 @@ def test_bench_streams_per_gpu():
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert r["n_gpus"] == 1 and r["config"]["streams_per_gpu"] == 3
     rk = r["ranks"][0]
-    assert rk["frames"] == 60 and rk["streams"] == 3 and len(rk["stream_latency_ms"]) == 3
-    assert abs(r["value"] - 60 / rk["elapsed_s"]) <= 0.02 * r["value"]
+    assert rk["frames"] == 3 * 320 and rk["streams"] == 3 and len(rk["stream_latency_ms"]) == 3
+    assert abs(r["value"] - 3 * 320 / rk["elapsed_s"]) <= 0.02 * r["value"]
     assert r["sustained"]["frames"] >= 1800
     print("\n[bench --streams-per-gpu 3, 1080p] value %.0f frames/s, per-stream p99 ms: %s" % (r["value"], [round(x["p99"], 3) for x in rk["stream_latency_ms"]]))
 
