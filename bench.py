@@ -2,8 +2,10 @@
 """bench.py -- stabilized frames/sec of the LiveVisionKit stabilization hot path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 the driver launches it through torch.distributed.run, one rank per
-GPU).  A "step" is one pass of the hot path over one frame in steady state (one lvk_hip_stab_push_yuv420: ingest the 4:2:0 planes, track
-the new frame, smooth the path, remap + egress the delayed frame).  Independent streams shard one per GPU with no data-path collective
+GPU).  A "step" is one pass of the hot path over one BATCH of synthetic input: 16 consecutive frames of the stream in steady state (16 x
+lvk_hip_stab_push_yuv420: ingest the 4:2:0 planes, track the new frame, smooth the path, remap + egress the delayed frame; --frames-per-step).
+Rounds 1-5 stepped one frame at a time; the driver's `--steps 20` region was then 2.5 ms between two device-wide synchronisations and read 6 800-8 800
+frames/s from run to run on one box while the same line's 600-frame continuation read 8 570-9 200 -- 20 batches are 35 ms and agree with it to ~1 %.  Independent streams shard one per GPU with no data-path collective
 (SURVEY.md section 8e): the process group is gloo (CPU) and carries only the barrier and the max-over-ranks of the elapsed time -- no RCCL.
 Rank 0 prints ONE JSON line.
 
