@@ -832,7 +832,7 @@ def main():
     # (measured: pushes of 0.11-0.135 ms there against 0.100-0.105 ms a few hundred pushes later, same kernels).  None of the three is the steady state
     # SURVEY 8d's metric is defined on ("after the N-frame delay has filled, >= 600 frames"): 1000 pushes (>= 2 N + 10; ~0.1 s at 4K -- a fixed
     # count, so that two runs of the same command push the same frames), whatever --warmup is, so that the driver's `--steps 20 --warmup 5` region
-    # samples the same stream the default run's 2000 steps do.
+    # samples the same stream the default run does.
     n_fill = max(delay + 2, 2 * delay + 10, 1000)
     if K == 1:
         for _ in range(n_fill):
