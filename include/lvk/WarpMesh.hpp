@@ -200,7 +200,7 @@ public:
     cv::Size size() const { return {m.cols, m.rows}; }
     int cols() const { return m.cols; }
     int rows() const { return m.rows; }
-    float* offsets() { return m.off.data(); }                                   // rows x cols x (dx, dy), normalised backward offsets
+    float* offsets() { m_MapStale = true; return m.off.data(); }                // rows x cols x (dx, dy), normalised backward offsets
     const float* offsets() const { return m.off.data(); }
 
     // to_map (WarpMesh.cpp:159-168): offsets + identity grid of the mesh's own resolution
@@ -216,15 +216,17 @@ public:
     }
     void normalize(const cv::Size2f& motion_scale)                              // :172-180 (cv::multiply by the reciprocal)
     {
+        m_MapStale = true;
         const float nx = 1.0f / motion_scale.width, ny = 1.0f / motion_scale.height;
         for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] * nx; m.off[i + 1] = m.off[i + 1] * ny; }
     }
 
-    void set_identity() { m.set_identity(); }
-    void set_to(const cv::Point2f& motion) { for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = -motion.x; m.off[i + 1] = -motion.y; } }      // "the warp is specified backwards"
-    void set_to(const Homography& motion, const cv::Size2f& motion_scale) { m.from_homography(motion.data(), motion_scale.width, motion_scale.height); }
+    void set_identity() { m_MapStale = true; m.set_identity(); }
+    void set_to(const cv::Point2f& motion) { m_MapStale = true; for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = -motion.x; m.off[i + 1] = -motion.y; } }      // "the warp is specified backwards"
+    void set_to(const Homography& motion, const cv::Size2f& motion_scale) { m_MapStale = true; m.from_homography(motion.data(), motion_scale.width, motion_scale.height); }
     void set_to(const float* warp_map, const cv::Size& size, const bool as_offsets, const bool normalized)      // :345-365
     {
+        m_MapStale = true;
         LVK_HIP_ASSERT(warp_map != nullptr && size.width >= 2 && size.height >= 2);
         m = detail::WarpMeshF(size.height, size.width);
         std::copy(warp_map, warp_map + m.off.size(), m.off.begin());
@@ -237,25 +239,28 @@ public:
     void scale(const cv::Size2f& scaling_factor)                                // :369-375
     {
         LVK_FP_CONTRACT_OFF
+        m_MapStale = true;
         const float kx = ((1.0f / scaling_factor.width) - 1.0f) / (float)(m.cols - 1), ky = ((1.0f / scaling_factor.height) - 1.0f) / (float)(m.rows - 1);
         for (int r = 0; r < m.rows; r++)
             for (int c = 0; c < m.cols; c++) { const size_t i = ((size_t)r * m.cols + c) * 2; m.off[i] += (float)c * kx; m.off[i + 1] += (float)r * ky; }
     }
     void crop_in(const cv::Rect2f& region)                                      // :379-390
     {
+        m_MapStale = true;
         LVK_HIP_ASSERT(region.width >= 0 && region.width <= (float)cols() && region.height >= 0 && region.height <= (float)rows() && region.x >= 0 && region.y >= 0);
         m.crop_in(region.x, region.y, region.width, region.height);
     }
-    void clamp(const cv::Size2f& magnitude) { m.clamp(magnitude.width, magnitude.height); }                     // :411-417
+    void clamp(const cv::Size2f& magnitude) { m_MapStale = true; m.clamp(magnitude.width, magnitude.height); }                     // :411-417
     void clamp(const cv::Size2f& min, const cv::Size2f& max)                    // :421-427
     {
+        m_MapStale = true;
         for (size_t i = 0; i + 1 < m.off.size(); i += 2)
         {
             m.off[i] = std::min(std::max(m.off[i], min.width), max.width);
             m.off[i + 1] = std::min(std::max(m.off[i + 1], min.height), max.height);
         }
     }
-    void combine(const WarpMesh& mesh, const float scaling = 1.0f) { LVK_HIP_ASSERT(size() == mesh.size()); m.scale_add(mesh.m, scaling); }      // cv::scaleAdd, :445-448
+    void combine(const WarpMesh& mesh, const float scaling = 1.0f) { LVK_HIP_ASSERT(size() == mesh.size()); m_MapStale = true; m.scale_add(mesh.m, scaling); }      // cv::scaleAdd, :445-448
 
     void read(const std::function<void(const cv::Point2f& offset, const cv::Point& coord)>& operation, const bool /*parallel*/ = true) const      // :264-287
     {
@@ -264,6 +269,7 @@ public:
     }
     void write(const std::function<void(cv::Point2f& offset, const cv::Point& coord)>& operation, const bool /*parallel*/ = true)                 // :291-314
     {
+        m_MapStale = true;
         for (int r = 0; r < m.rows; r++)
             for (int c = 0; c < m.cols; c++)
             {
@@ -274,19 +280,20 @@ public:
             }
     }
 
-    void operator+=(const WarpMesh& other) { LVK_HIP_ASSERT(size() == other.size()); m += other.m; }
-    void operator-=(const WarpMesh& other) { LVK_HIP_ASSERT(size() == other.size()); m -= other.m; }
-    void operator*=(const WarpMesh& other) { LVK_HIP_ASSERT(size() == other.size()); for (size_t i = 0; i < m.off.size(); i++) m.off[i] = m.off[i] * other.m.off[i]; }
-    void operator+=(const cv::Point2f& offset) { for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] + offset.x; m.off[i + 1] = m.off[i + 1] + offset.y; } }
-    void operator-=(const cv::Point2f& offset) { for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] - offset.x; m.off[i + 1] = m.off[i + 1] - offset.y; } }
-    void operator*=(const cv::Size2f& scaling) { for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] * scaling.width; m.off[i + 1] = m.off[i + 1] * scaling.height; } }
+    void operator+=(const WarpMesh& other) { LVK_HIP_ASSERT(size() == other.size()); m_MapStale = true; m += other.m; }
+    void operator-=(const WarpMesh& other) { LVK_HIP_ASSERT(size() == other.size()); m_MapStale = true; m -= other.m; }
+    void operator*=(const WarpMesh& other) { LVK_HIP_ASSERT(size() == other.size()); m_MapStale = true; for (size_t i = 0; i < m.off.size(); i++) m.off[i] = m.off[i] * other.m.off[i]; }
+    void operator+=(const cv::Point2f& offset) { m_MapStale = true; for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] + offset.x; m.off[i + 1] = m.off[i + 1] + offset.y; } }
+    void operator-=(const cv::Point2f& offset) { m_MapStale = true; for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] - offset.x; m.off[i + 1] = m.off[i + 1] - offset.y; } }
+    void operator*=(const cv::Size2f& scaling) { m_MapStale = true; for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] * scaling.width; m.off[i + 1] = m.off[i + 1] * scaling.height; } }
     void operator/=(const cv::Size2f& scaling)
     {
+        m_MapStale = true;
         LVK_HIP_ASSERT(scaling.width != 0.0f && scaling.height != 0.0f);
         for (size_t i = 0; i + 1 < m.off.size(); i += 2) { m.off[i] = m.off[i] / scaling.width; m.off[i + 1] = m.off[i + 1] / scaling.height; }
     }
-    void operator*=(const float scaling) { m.scale(scaling); }
-    void operator/=(const float scaling) { LVK_HIP_ASSERT(scaling != 0.0f); for (float& v : m.off) v = v / scaling; }
+    void operator*=(const float scaling) { m_MapStale = true; m.scale(scaling); }
+    void operator/=(const float scaling) { LVK_HIP_ASSERT(scaling != 0.0f); m_MapStale = true; for (float& v : m.off) v = v / scaling; }
 
     // WarpMesh::apply (WarpMesh.cpp:183-223).  2 x 2: cv::getPerspectiveTransform of the displaced corners + the homography kernel; larger meshes: the
     // reference resizes the offsets to the frame (INTER_LINEAR_EXACT), multiplies by (W, H) and remaps through the map -- here the same interpolation runs
@@ -301,10 +308,16 @@ public:
         VideoFrame out;                                        // dst may be the object src refers to (LCFilter swaps, VSFilter aliases)
         if (m.cols == src.cols && m.rows == src.rows && (size_t)m.cols * m.rows * 8 > 65536)
         {
-            const float w = (float)src.cols, h = (float)src.rows;
-            std::vector<float> map(m.off.size());
-            for (size_t i = 0; i + 1 < map.size(); i += 2) { map[i] = m.off[i] * w; map[i + 1] = m.off[i + 1] * h; }
-            m_Map.upload(map.data(), src.size(), ctx);
+            // (the map is rebuilt and uploaded when the mesh has changed -- LCFilter applies ONE mesh to every frame: 16.6 MB at 1080p that the
+            //  reference's cv::resize + cv::multiply into m_WarpMap redo per frame)
+            if (m_MapStale || m_Map.empty() || m_Map.size() != src.size() || m_Map.context() != ctx)
+            {
+                const float w = (float)src.cols, h = (float)src.rows;
+                std::vector<float> map(m.off.size());
+                for (size_t i = 0; i + 1 < map.size(); i += 2) { map[i] = m.off[i] * w; map[i + 1] = m.off[i + 1] * h; }
+                m_Map.upload(map.data(), src.size(), ctx);
+                m_MapStale = false;
+            }
             out.timestamp = src.timestamp; out.format = src.format;
             remap(src, out, m_Map, background);
         }
@@ -322,6 +335,7 @@ public:
 private:
     detail::WarpMeshF m;
     mutable OffsetMap m_Map;                                                   // (the reference's m_WarpMap)
+    mutable bool m_MapStale = true;                                            // the mesh changed since m_Map was made
 };
 inline WarpMesh operator+(WarpMesh a, const WarpMesh& b) { a += b; return a; }
 inline WarpMesh operator-(WarpMesh a, const WarpMesh& b) { a -= b; return a; }

@@ -136,6 +136,17 @@ int gpu_part(const char* in_path, const char* out_path)
     lvk::VideoFrame corrected;
     full.apply(src, corrected, bg);
     if (!emit(corrected, 4242)) { std::printf("apply full-size: bad frame\n"); return 1; }
+    {
+        // the device map is cached while the mesh does not change: a second apply gives the same bytes, a changed mesh different ones
+        lvk::VideoFrame again, moved;
+        full.apply(src, again, bg);
+        std::vector<uint8_t> a(px.size()), b(px.size()), c(px.size());
+        corrected.download(a.data()); again.download(b.data());
+        full += cv::Point2f(0.01f, 0.0f);
+        full.apply(src, moved, bg);
+        moved.download(c.data());
+        if (a != b || a == c) { std::printf("apply full-size: the cached map is stale or not reused\n"); return 1; }
+    }
     // (d) lvk::remap(homography): dst -> src given (inverted), and src -> dst given (inverted = false: the launcher inverts)
     lvk::VideoFrame r1, r2;
     r1.timestamp = 5; r1.format = lvk::VideoFrame::YUV; r2.timestamp = 6; r2.format = lvk::VideoFrame::YUV;
