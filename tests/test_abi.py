@@ -53,6 +53,23 @@ def test_abi_version_of_header_and_library_agree():
         assert name in experimental and name not in stable, name
 
 
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/lvk_hip.h compiles as C99 with -pedantic (no C++ in the signatures, no torch / OpenCV types), and a C
+    translation unit that uses its types links against the library."""
+    import subprocess
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "lvk_hip.h"\n'
+                   'int main(void) { lvk_frame_info i = {0, 0, 0}; lvk_stab_settings s; lvk_stab_default_settings(&s); (void)i;\n'
+                   '  return (lvk_hip_abi_version() == LVK_HIP_ABI_VERSION && s.predictive_samples == 10) ? 0 : 1; }\n')
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    exe = str(tmp_path / "c_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L" + os.path.join(ROOT, "livevisionkit_amd"), "-llvk_hip", "-L" + tlib, "-l:libamdhip64.so",
+                           "-Wl,-rpath," + os.path.join(ROOT, "livevisionkit_amd"), "-Wl,-rpath," + tlib])
+    assert subprocess.run([exe]).returncode == 0
+
+
 def test_environment_knobs_are_documented_with_their_tests():
     """Every getenv of the product is listed in INTEGRATION.md section 4 together with the test that exercises it (round-4 VERDICT: every rejected
     experiment that keeps a code path is a path no test pins)."""
