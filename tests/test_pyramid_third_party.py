@@ -30,3 +30,28 @@ def test_scharr_derivatives_equal_scipy_separable_filter(oracle, shape):
     iy = ndimage.correlate1d(ndimage.correlate1d(img, smooth, axis=1, mode="mirror"), diff, axis=0, mode="mirror")
     d = oracle.scharr_deriv(img.astype(np.uint8))
     assert np.array_equal(d[..., 0], ix.astype(np.int16)) and np.array_equal(d[..., 1], iy.astype(np.int16))
+
+
+@pytest.mark.parametrize("shape,nv12", [((36, 48), False), ((270, 480), False), ((38, 50), True), ((1080, 1920), False)])
+def test_chroma_upsampling_of_the_ingest_equals_scipy_zoom_up_to_ties(oracle, shape, nv12):
+    """I4XXIngest / NV12Ingest::to_ocl (FrameIngest.cpp:494-522,567-585): cv::resize(chroma, frame size, INTER_LINEAR).  The sampling geometry
+    (pixel centres at half-integers, replicated edges) and the bilinear weights (1/4, 3/4 per axis: exact values are multiples of 1/16) are
+    pinned to scipy.ndimage.zoom(order=1, grid_mode=True, mode="nearest"): the oracle's plane equals its result rounded to nearest wherever
+    the exact fraction lies outside [8/16, 10/16].  Inside that band OpenCV's two-stage fixed point decides -- the vertical pass drops the low
+    four bits of each row sum and sixteen of each product before it adds its rounding constant, up to 2/16 in total -- which only the
+    restatement knows: there the value must be one of the two neighbours, and both must occur."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows + cols)
+    y = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    u = rng.integers(0, 256, (rows // 2, cols // 2), dtype=np.uint8); v = rng.integers(0, 256, (rows // 2, cols // 2), dtype=np.uint8)
+    packed = oracle.ingest_yuv420(y, np.ascontiguousarray(np.stack([u, v], -1))) if nv12 else oracle.ingest_yuv420(y, u, v)
+    assert np.array_equal(packed[..., 0], y)
+    for ch, plane in ((1, u), (2, v)):
+        z = ndimage.zoom(plane.astype(np.float64), 2, order=1, mode="nearest", grid_mode=True)
+        assert z.shape == (rows, cols) and np.array_equal(z * 16, np.round(z * 16))
+        got = packed[..., ch].astype(np.float64)
+        frac = z - np.floor(z)
+        band = (frac >= 0.5) & (frac <= 0.625)
+        assert np.array_equal(got[~band], np.floor(z[~band] + 0.5))
+        up = got[band] - np.floor(z[band])
+        assert np.isin(up, (0.0, 1.0)).all() and 0.2 < up.mean() < 0.8 and 0.1 < band.mean() < 0.3
