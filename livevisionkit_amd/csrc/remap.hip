@@ -50,6 +50,11 @@ struct F3 { float x, y, z; };
 //  byte-select shift instead of v_cvt_f32_ubyteN + v_mul_f32 -- 36 VALU instructions per pixel fewer (1 949 instead of 2 066 static per
 //  4-pixel thread, same bits), and 94.5 instead of 82.5 us alone / 117.5 instead of 109.3 us next to the tracker: 36 data-dependent LDS reads
 //  per pixel cost more in the LDS pipe than the 36 instructions they save in the VALU.  profiles/r05_ab_remap_lds_table.txt.)
+// (Round 6, measured and rejected: the conversion without v_cvt_f32_ubyteN -- the byte OR-ed into the mantissa of 2^23 by an SDWA byte select, then
+//  ONE fused multiply-add (2^23 + b) * n - 2^23 * n, which is float(b) * n bit for bit because 2^23 * n is exact: 144 instructions of the
+//  4-cycle class per thread fewer, same bits (68 parity tests), and 109 instead of 88 us: an SDWA operand costs a full issue round and, unlike
+//  a conversion, does not share it with a neighbouring fma (scripts/valu_peak.hip: fma : or_sdwa 1:1 = 3.65 cycles per instruction, fma :
+//  cvt_ubyte 1:1 = 2.3).  profiles/r06_ab_remap_variants.txt.)
 __device__ __forceinline__ F3 unpack3(uint32_t lo_bytes)   // bytes 0,1,2 of the dword
 {
     const float norm_factor = 0.00392156862f;               // FSR.cl:205
@@ -373,6 +378,13 @@ constexpr int PXT = 4, STRIP_W = 64 * PXT, STRIP_H = 4;
 #define LVK_CO_WAVES 4
 #endif
 #define LVK_CO_SCHEDULED
+// occupancy experiments (scripts/variant_build.sh waves8 -DLVK_REMAP_WAVES=8; round 6: 6 waves per SIMD = the default's time, 8 spill and
+// are 8 % slower, profiles/r06_ab_remap_variants.txt): empty in the product build
+#ifdef LVK_REMAP_WAVES
+#define LVK_REMAP_ATTR __attribute__((amdgpu_waves_per_eu(LVK_REMAP_WAVES, LVK_REMAP_WAVES)))
+#else
+#define LVK_REMAP_ATTR
+#endif
 constexpr int NUM_XCD = 8;
 
 // Output pixels are written once and not read again by this GPU for N frames: streaming (non-temporal) stores keep them from sitting
@@ -523,7 +535,7 @@ __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR
 void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                         uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
                         int off_x, int off_y, HomographyArgs H, uint32_t bg)
@@ -533,7 +545,7 @@ void k_remap_homography(const uint8_t* __restrict__ src, int src_step, int src_r
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_homography_co(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                         uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
                         int off_x, int off_y, HomographyArgs H, uint32_t bg)
@@ -543,7 +555,7 @@ void k_remap_homography_co(const uint8_t* __restrict__ src, int src_step, int sr
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR
 void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                   uint8_t* __restrict__ dst, int dst_step,
                   const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
@@ -556,7 +568,7 @@ void k_remap_mesh(const uint8_t* __restrict__ src, int src_step, int src_rows, i
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_mesh_co(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                   uint8_t* __restrict__ dst, int dst_step,
                   const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
@@ -569,7 +581,7 @@ void k_remap_mesh_co(const uint8_t* __restrict__ src, int src_step, int src_rows
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR
 void k_remap_homography_lens(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                              uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
                              int off_x, int off_y, HomographyArgs H, LensArgs L, uint32_t bg)
@@ -579,7 +591,7 @@ void k_remap_homography_lens(const uint8_t* __restrict__ src, int src_step, int 
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_homography_lens_co(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                              uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols,
                              int off_x, int off_y, HomographyArgs H, LensArgs L, uint32_t bg)
@@ -589,7 +601,7 @@ void k_remap_homography_lens_co(const uint8_t* __restrict__ src, int src_step, i
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR
 void k_remap_mesh_lens(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                        uint8_t* __restrict__ dst, int dst_step,
                        const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
@@ -604,7 +616,7 @@ void k_remap_mesh_lens(const uint8_t* __restrict__ src, int src_step, int src_ro
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_mesh_lens_co(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                        uint8_t* __restrict__ dst, int dst_step,
                        const float* __restrict__ mesh, int mesh_cols, int mesh_floats,
@@ -619,7 +631,7 @@ void k_remap_mesh_lens_co(const uint8_t* __restrict__ src, int src_step, int src
 }
 
 template <bool YUV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR
 void k_remap_map(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                  uint8_t* __restrict__ dst, int dst_step, const uint8_t* __restrict__ map, int map_step, uint32_t bg)
 {
@@ -630,7 +642,7 @@ void k_remap_map(const uint8_t* __restrict__ src, int src_step, int src_rows, in
 // lvk::upscale (Image.cpp:155-202): the same strip body; the source coordinate never leaves the image, so the border band is the
 // nearest copy of FSR.cl:342-351 and the background is unreachable.
 template <bool YUV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR
 void k_easu_scale(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                   uint8_t* __restrict__ dst, int dst_step, int dst_rows, int dst_cols, float rsx, float rsy)
 {
@@ -643,7 +655,7 @@ void k_easu_scale(const uint8_t* __restrict__ src, int src_step, int src_rows, i
 struct Planes420 { uint8_t* y; int y_step; uint8_t* u; int u_step; uint8_t* v; int v_step; };
 
 template <bool NV12>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_homography_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, uint32_t bg)
 {
     LVK_TL(0);
@@ -652,7 +664,7 @@ void k_remap_homography_420(const uint8_t* __restrict__ src, int src_step, int r
 }
 
 template <bool NV12>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_homography_lens_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, LensArgs L, uint32_t bg)
 {
     const LensCoord<HomographyCoord> coord{HomographyCoord{H, 0, 0}, L, rows, cols};
@@ -660,7 +672,7 @@ void k_remap_homography_lens_420(const uint8_t* __restrict__ src, int src_step, 
 }
 
 template <bool NV12>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_mesh_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
                       const float* __restrict__ mesh, int mesh_cols, int mesh_floats, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg)
 {
@@ -670,7 +682,7 @@ void k_remap_mesh_420(const uint8_t* __restrict__ src, int src_step, int rows, i
 }
 
 template <bool NV12>
-__global__ __launch_bounds__(256) LVK_CO_SCHEDULED
+__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
 void k_remap_mesh_lens_420(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
                            const float* __restrict__ mesh, int mesh_cols, int mesh_floats, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab,
                            LensArgs L, uint32_t bg)

@@ -82,6 +82,13 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed)
             if (MODE == 53) LVK_ASM8("v_add_f32 %0, -%0, %1");
             if (MODE == 54) LVK_ASM8("v_mul_f32 %0, %0, %1 clamp");
             if (MODE == 55) LVK_ASM8("v_add_f32_e64 %0, |%0|, %1");
+            // round 6: SDWA byte selects on a fast opcode (the byte -> 2^23 + byte trick of the remap's unpack) and their mixes
+            if (MODE == 56) LVK_ASM8("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD");
+            if (MODE == 57) LVK_MIX("v_fma_f32 %0, %0, %1, %2", "v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD");
+            if (MODE == 58) LVK_MIX("v_mul_f32 %0, %0, %1", "v_cvt_f32_ubyte1 %0, %0");
+            if (MODE == 59) LVK_MIX31("v_fma_f32 %0, %0, %1, %2", "v_cvt_f32_ubyte1 %0, %0");
+            if (MODE == 60) LVK_MIX31("v_fma_f32 %0, %0, %1, %2", "v_min_f32 %0, %0, %1");
+            if (MODE == 61) LVK_ASM8("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD");
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
@@ -156,5 +163,11 @@ int main()
     run<53>("v_add_f32 neg mod", 16 * 8, 1);
     run<54>("v_mul_f32 clamp", 16 * 8, 1);
     run<55>("v_add_f32_e64 abs", 16 * 8, 1);
+    run<56>("v_or_b32_sdwa BYTE_1", 16 * 8, 1);
+    run<57>("fma:or_sdwa 1:1", 16 * 8, 1);
+    run<58>("mul:cvt_ubyte 1:1", 16 * 8, 1);
+    run<59>("fma:cvt_ubyte 3:1", 16 * 8, 1);
+    run<60>("fma:min 3:1", 16 * 8, 1);
+    run<61>("v_add_u32_sdwa BYTE_2", 16 * 8, 1);
     return 0;
 }
