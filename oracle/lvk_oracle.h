@@ -197,6 +197,9 @@ int lvko_ingest_yuv420(const uint8_t* y, int y_step, const uint8_t* u, int u_ste
                        int rows, int cols, uint8_t* dst, int dst_step);
 int lvko_egress_yuv420(const uint8_t* src, int src_step, int rows, int cols,
                        uint8_t* y, int y_step, uint8_t* u, int u_step, uint8_t* v, int v_step, int nv12);
+/* every format of FrameIngest::Select (FrameIngest.cpp:36-75,476-753); fmt = libobs' enum video_format; Y800 frames have one channel, all others three */
+int lvko_ingest_obs(int fmt, const uint8_t* const planes[3], const int steps[3], int rows, int cols, uint8_t* dst, int dst_step);
+int lvko_egress_obs(int fmt, const uint8_t* src, int src_step, int rows, int cols, uint8_t* const planes[3], const int steps[3]);
 
 
 /* ------------------------------------------------------------------------------------------------

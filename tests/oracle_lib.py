@@ -201,6 +201,55 @@ class Oracle:
         assert rc == 0
         return (y, u) if nv12 else (y, u, v)
 
+    # ---- every OBS video format of FrameIngest::Select (oracle/ingest.cpp::lvko_ingest_obs / lvko_egress_obs) ----
+    VIDEO_FORMATS = {"I420": 1, "NV12": 2, "YVYU": 3, "YUY2": 4, "UYVY": 5, "RGBA": 6, "BGRA": 7, "BGRX": 8, "Y800": 9, "I444": 10, "BGR3": 11,
+                     "I422": 12, "I40A": 13, "I42A": 14, "YUVA": 15, "AYUV": 16}
+
+    @staticmethod
+    def obs_plane_shapes(fmt, rows, cols):
+        """shapes of the planes OBS holds for one frame of `fmt` (the alpha planes of I40A / I42A / YUVA are not touched by FrameIngest)"""
+        if fmt in ("I420", "I40A"): return [(rows, cols), (rows // 2, cols // 2), (rows // 2, cols // 2)]
+        if fmt == "NV12": return [(rows, cols), (rows // 2, cols // 2, 2)]
+        if fmt in ("I422", "I42A"): return [(rows, cols), (rows, cols // 2), (rows, cols // 2)]
+        if fmt in ("I444", "YUVA"): return [(rows, cols)] * 3
+        if fmt in ("YUY2", "YVYU", "UYVY"): return [(rows, cols, 2)]
+        if fmt in ("AYUV", "RGBA", "BGRA", "BGRX"): return [(rows, cols, 4)]
+        if fmt == "BGR3": return [(rows, cols, 3)]
+        if fmt == "Y800": return [(rows, cols)]
+        raise ValueError(fmt)
+
+    def _obs_args(self, planes):
+        planes = [np.ascontiguousarray(p, np.uint8) for p in planes]
+        ptrs = (_u8p * 3)(*[_p(p, _u8p) for p in planes] + [None] * (3 - len(planes)))
+        steps = (_c.c_int * 3)(*[p.strides[0] for p in planes] + [0] * (3 - len(planes)))
+        return planes, ptrs, steps
+
+    def ingest_obs(self, fmt, planes):
+        """OBS planes (numpy uint8, shapes of obs_plane_shapes) -> the VideoFrame FrameIngest::to_ocl makes: [rows, cols, 3] ([rows, cols] for Y800)."""
+        planes, ptrs, steps = self._obs_args(planes)
+        rows, cols = planes[0].shape[:2]
+        dst = np.zeros((rows, cols) if fmt == "Y800" else (rows, cols, 3), np.uint8)
+        fn = self.lib.lvko_ingest_obs
+        fn.restype = _c.c_int
+        fn.argtypes = [_c.c_int, _u8p * 3, _c.c_int * 3, _c.c_int, _c.c_int, _u8p, _c.c_int]
+        rc = fn(self.VIDEO_FORMATS[fmt], ptrs, steps, rows, cols, _p(dst, _u8p), dst.strides[0])
+        assert rc == 0, f"lvko_ingest_obs({fmt}) = {rc}"
+        return dst
+
+    def egress_obs(self, fmt, frame, planes=None):
+        """FrameIngest::to_obs: the frame into OBS planes (`planes`: existing planes to write into -- bytes the reference leaves alone stay)."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        rows, cols = frame.shape[:2]
+        if planes is None:
+            planes = [np.zeros(sh, np.uint8) for sh in self.obs_plane_shapes(fmt, rows, cols)]
+        planes, ptrs, steps = self._obs_args(planes)
+        fn = self.lib.lvko_egress_obs
+        fn.restype = _c.c_int
+        fn.argtypes = [_c.c_int, _u8p, _c.c_int, _c.c_int, _c.c_int, _u8p * 3, _c.c_int * 3]
+        rc = fn(self.VIDEO_FORMATS[fmt], _p(frame, _u8p), frame.strides[0], rows, cols, ptrs, steps)
+        assert rc == 0, f"lvko_egress_obs({fmt}) = {rc}"
+        return planes
+
     def lens_offset_map(self, params, rows, cols):
         """params = (fx, fy, cx, cy, k1, k2, p1, p2, k3). Returns (offsets [rows, cols, 2] float32 in pixels, view (x, y, w, h))."""
         pr = np.ascontiguousarray(params, np.float64).reshape(9)
