@@ -167,6 +167,40 @@ int lvk_hip_ingest_yuv420(lvk_hip_ctx* ctx, const void* d_y, int y_step, const v
 int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
                           void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
 
+/* Every video format FrameIngest::Select accepts (Modules/OBS-Plugin/Interop/FrameIngest.cpp:36-75): video_format is libobs' enum video_format
+ * (media-io/video-io.h of libobs 27.2.4), i.e. obs_source_frame::format passed through.  d_planes / steps = the frame's data[] / linesize[] on the
+ * device (3 entries; unused ones NULL / 0; the alpha planes of I40A / I42A / YUVA are not touched, as in the reference).
+ *   I420 / I40A / NV12            -> lvk_hip_ingest_yuv420 / lvk_hip_egress_yuv420 above (I4XXIngest, NV12Ingest)
+ *   I422 / I42A                   I4XXIngest with chroma (cols / 2) x rows: INTER_LINEAR upsampling of the width in, INTER_AREA (0.5, 1.0) out (:494-557)
+ *   I444 / YUVA                   merge / split (:521,531)
+ *   YUY2 / YVYU / UYVY            P422Ingest::to_ocl / to_obs (:615-666): 2 bytes per pixel, chroma shared by a pixel pair
+ *   AYUV                          P444Ingest (:679-703): the last three of A Y U V in; A = 255 out
+ *   Y800 / BGR3                   DirectIngest (:728-753): the bytes as they are (Y800: a one-channel frame, which lvk_hip_stab_push refuses like the
+ *                                 reference's lvk::remap does, Functions/Image.cpp:32)
+ *   RGBA / BGRA / BGRX            DirectIngest as written: rows * cols * 3 BYTES from data[0] viewed as 3-byte pixels (:743-747) -- the colour planes are
+ *                                 not separated; steps[0] must be 4 * cols.  Reproduced, not endorsed.
+ * cols even for the 4:2:2 formats, rows and cols even for 4:2:0.  The frame is 8UC3 (Y800: 8UC1) of rows x cols; lvk_hip_obs_frame_format gives the
+ * LVK_FORMAT_* its pixels carry (the VideoFrame::Format each ingest declares), negative for a format FrameIngest::Select rejects. */
+#define LVK_VIDEO_FORMAT_I420 1
+#define LVK_VIDEO_FORMAT_NV12 2
+#define LVK_VIDEO_FORMAT_YVYU 3
+#define LVK_VIDEO_FORMAT_YUY2 4
+#define LVK_VIDEO_FORMAT_UYVY 5
+#define LVK_VIDEO_FORMAT_RGBA 6
+#define LVK_VIDEO_FORMAT_BGRA 7
+#define LVK_VIDEO_FORMAT_BGRX 8
+#define LVK_VIDEO_FORMAT_Y800 9
+#define LVK_VIDEO_FORMAT_I444 10
+#define LVK_VIDEO_FORMAT_BGR3 11
+#define LVK_VIDEO_FORMAT_I422 12
+#define LVK_VIDEO_FORMAT_I40A 13
+#define LVK_VIDEO_FORMAT_I42A 14
+#define LVK_VIDEO_FORMAT_YUVA 15
+#define LVK_VIDEO_FORMAT_AYUV 16
+int lvk_hip_ingest_obs(lvk_hip_ctx* ctx, int video_format, const void* const d_planes[3], const int steps[3], int rows, int cols, void* d_dst, int dst_step);
+int lvk_hip_egress_obs(lvk_hip_ctx* ctx, int video_format, const void* d_src, int src_step, int rows, int cols, void* const d_planes[3], const int steps[3]);
+int lvk_hip_obs_frame_format(int video_format);
+
 /* ---- a1/a2: the stabilization filter ----------------------------------------------------------------------
  * lvk_stab_settings flattens lvk::StabilizationFilterSettings (Filters/StabilizationFilter.hpp:28-39) and its bases
  * FrameTrackerSettings (Vision/FrameTracker.hpp:31-44) : FeatureDetectorSettings (Vision/FeatureDetector.hpp:28-37) and

@@ -71,6 +71,9 @@ _SIG = {
                                  _c.c_double, _c.c_double]),
     "lvk_hip_ingest_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int]),
     "lvk_hip_egress_yuv420": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int]),
+    "lvk_hip_ingest_obs": (_c.c_int, [_P, _c.c_int, _P * 3, _c.c_int * 3, _c.c_int, _c.c_int, _P, _c.c_int]),
+    "lvk_hip_egress_obs": (_c.c_int, [_P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P * 3, _c.c_int * 3]),
+    "lvk_hip_obs_frame_format": (_c.c_int, [_c.c_int]),
     "lvk_hip_estimate_global_motion": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int, _c.c_double,
                                                   _c.c_double, _c.c_double, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint8)]),
     "lvk_stab_default_settings": (None, [_P]),

@@ -209,6 +209,36 @@ class Context:
                                                    u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), 1 if nv12 else 0))
         return (y, u) if nv12 else (y, u, v)
 
+    # ---- every OBS video format of FrameIngest::Select (Modules/OBS-Plugin/Interop/FrameIngest.cpp:36-75) ----------------------
+    VIDEO_FORMATS = {"I420": 1, "NV12": 2, "YVYU": 3, "YUY2": 4, "UYVY": 5, "RGBA": 6, "BGRA": 7, "BGRX": 8, "Y800": 9, "I444": 10, "BGR3": 11,
+                     "I422": 12, "I40A": 13, "I42A": 14, "YUVA": 15, "AYUV": 16}
+
+    def _obs_args(self, planes):
+        import ctypes as c
+        ptrs = (c.c_void_p * 3)(*[p.data_ptr() for p in planes] + [None] * (3 - len(planes)))
+        steps = (c.c_int * 3)(*[p.stride(0) for p in planes] + [0] * (3 - len(planes)))
+        return ptrs, steps
+
+    def ingest_obs(self, fmt, planes, out=None):
+        """FrameIngest::to_ocl: the planes OBS holds for one frame of `fmt` (torch uint8, on the GPU) -> the packed frame [rows, cols, 3] ([rows, cols] for Y800)."""
+        import torch
+        rows, cols = planes[0].shape[:2]
+        if out is None:
+            out = torch.empty((rows, cols) if fmt == "Y800" else (rows, cols, 3), dtype=torch.uint8, device=planes[0].device)
+        ptrs, steps = self._obs_args(planes)
+        self._check(self.lib.lvk_hip_ingest_obs(self.handle, self.VIDEO_FORMATS[fmt], ptrs, steps, rows, cols, out.data_ptr(), out.stride(0)))
+        return out
+
+    def egress_obs(self, fmt, frame, planes):
+        """FrameIngest::to_obs: the frame into the given OBS planes (bytes the reference leaves alone stay what they are)."""
+        rows, cols = frame.shape[:2]
+        ptrs, steps = self._obs_args(planes)
+        self._check(self.lib.lvk_hip_egress_obs(self.handle, self.VIDEO_FORMATS[fmt], frame.data_ptr(), frame.stride(0), rows, cols, ptrs, steps))
+        return planes
+
+    def obs_frame_format(self, fmt):
+        return self.lib.lvk_hip_obs_frame_format(self.VIDEO_FORMATS[fmt] if isinstance(fmt, str) else int(fmt))
+
     # ---- lens correction (SURVEY section 8f row 1) --------------------------------------------------------------------
     def remap_map(self, src, offsets, bg=(255, 0, 255), yuv=True, out=None):
         """lvk::remap(src, dst, offset_map): offsets = torch float32 [rows, cols, 2] on the GPU (pixels)."""

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <algorithm>
+#include <string>
 
 // streaming stores: the converted frame is read N pushes later, see remap.hip
 #define LVK_STREAM_STORE(ptr, v) __builtin_nontemporal_store((uint32_t)(v), (ptr))
@@ -165,6 +166,125 @@ void k_egress_yuv420(const uint8_t* __restrict__ src, int src_step, int rows, in
     else { up[(long)cy * u_step + cx] = u; vp[(long)cy * v_step + cx] = v; }
 }
 
+
+// ---- the other OBS video formats of FrameIngest::Select (round 6; reference Modules/OBS-Plugin/Interop/FrameIngest.cpp:476-753) ----------------
+// 4:2:2 (planar I422 / I42A, packed YUY2 / YVYU / UYVY) -> packed 444: cv::resize(chroma, frame size, INTER_LINEAR) where only the width doubles.
+// The two-pass fixed point collapses for the exact 2x: horizontal (c_a 512 + c_b 1536) >> 4 = 32 (c_a + 3 c_b), vertical pass with (2048, 0):
+// (2048 * 32 t) >> 16 = t, result (t + 2) >> 2; at the frame edge the single sample (4 c + 2) >> 2 = c, which is the same formula with the edge
+// column replicated.  LAYOUT: 0 planar, 1 YUY2 (Y U Y V), 2 YVYU (Y V Y U), 3 UYVY (U Y V Y).  A thread = 4 output pixels.
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_ingest_422(const uint8_t* __restrict__ p0, int s0, const uint8_t* __restrict__ p1, int s1, const uint8_t* __restrict__ p2, int s2,
+                  int rows, int cols, uint8_t* __restrict__ dst, int dst_step, int fast)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    const int cc = cols >> 1;
+    constexpr int YOFF = LAYOUT == 3 ? 1 : 0, COFF = 1 - YOFF;                 // P422Ingest::m_YFirst
+    constexpr bool UFIRST = LAYOUT != 2;                                        // P422Ingest::m_UFirst
+    const uint8_t* r0 = p0 + (long)y * s0;
+    const uint8_t* r1 = LAYOUT == 0 ? p1 + (long)y * s1 : r0;
+    const uint8_t* r2 = LAYOUT == 0 ? p2 + (long)y * s2 : r0;
+    auto U = [&](int k) -> uint32_t { k = min(max(k, 0), cc - 1); return LAYOUT == 0 ? r1[k] : r0[4 * k + COFF + (UFIRST ? 0 : 2)]; };
+    auto V = [&](int k) -> uint32_t { k = min(max(k, 0), cc - 1); return LAYOUT == 0 ? r2[k] : r0[4 * k + COFF + (UFIRST ? 2 : 0)]; };
+    const int npx = min(4, cols - x0);
+    uint32_t px[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+    {
+        px[p] = 0;
+        if (p < npx)
+        {
+            const int x = x0 + p, k = x >> 1, o = (x & 1) ? k + 1 : k - 1;      // the nearer chroma column k (weight 3/4) and the other one (1/4)
+            const uint32_t yy = LAYOUT == 0 ? r0[x] : r0[2 * x + YOFF];
+            const uint32_t u = (U(o) + 3u * U(k) + 2u) >> 2, v = (V(o) + 3u * V(k) + 2u) >> 2;
+            px[p] = yy | (u << 8) | (v << 16);
+        }
+    }
+    uint8_t* drow = dst + (long)y * dst_step;
+    if (fast && npx == 4)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);
+        LVK_STREAM_STORE(d + 0, px[0] | (px[1] << 24)); LVK_STREAM_STORE(d + 1, (px[1] >> 8) | (px[2] << 16)); LVK_STREAM_STORE(d + 2, (px[2] >> 16) | (px[3] << 8));
+    }
+    else
+        for (int p = 0; p < npx; p++) { uint8_t* d = drow + 3 * (x0 + p); d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16); }
+}
+
+// 4:4:4 -> packed 444: cv::merge of the three planes (I444 / YUVA, FrameIngest.cpp:521) or the last three bytes of A Y U V (AYUV, :686).  LAYOUT 0 / 1.
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_ingest_444(const uint8_t* __restrict__ p0, int s0, const uint8_t* __restrict__ p1, int s1, const uint8_t* __restrict__ p2, int s2,
+                  int rows, int cols, uint8_t* __restrict__ dst, int dst_step, int fast)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    const int npx = min(4, cols - x0);
+    uint32_t px[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+    {
+        px[p] = 0;
+        if (p < npx)
+        {
+            const int x = x0 + p;
+            if (LAYOUT == 0) px[p] = (uint32_t)p0[(long)y * s0 + x] | ((uint32_t)p1[(long)y * s1 + x] << 8) | ((uint32_t)p2[(long)y * s2 + x] << 16);
+            else { const uint8_t* s = p0 + (long)y * s0 + 4 * x; px[p] = (uint32_t)s[1] | ((uint32_t)s[2] << 8) | ((uint32_t)s[3] << 16); }
+        }
+    }
+    uint8_t* drow = dst + (long)y * dst_step;
+    if (fast && npx == 4)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(drow + 3 * x0);
+        LVK_STREAM_STORE(d + 0, px[0] | (px[1] << 24)); LVK_STREAM_STORE(d + 1, (px[1] >> 8) | (px[2] << 16)); LVK_STREAM_STORE(d + 2, (px[2] >> 16) | (px[3] << 8));
+    }
+    else
+        for (int p = 0; p < npx; p++) { uint8_t* d = drow + 3 * (x0 + p); d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16); }
+}
+
+// packed 444 -> 4:2:2: cv::resize(Size(), 0.5, 1.0, INTER_AREA) on the chroma = saturate_cast<uchar>((a + b) * 0.5f), round half to EVEN
+// (resizeAreaFast_'s generic loop; only the 2 x 2 case has the (s + 2) >> 2 vector kernel).  A thread = one pixel pair.
+__device__ __forceinline__ uint32_t half_even(uint32_t s) { return (s + ((s >> 1) & 1u)) >> 1; }
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_egress_422(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
+                  uint8_t* __restrict__ p0, int s0, uint8_t* __restrict__ p1, int s1, uint8_t* __restrict__ p2, int s2)
+{
+    const int cx = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (cx >= cols / 2 || y >= rows) return;
+    const uint8_t* s = src + (long)y * src_step + 6 * (long)cx;
+    const uint32_t y0 = s[0], y1 = s[3], u = half_even((uint32_t)s[1] + s[4]), v = half_even((uint32_t)s[2] + s[5]);
+    if (LAYOUT == 0)
+    {
+        uint8_t* d = p0 + (long)y * s0 + 2 * cx; d[0] = (uint8_t)y0; d[1] = (uint8_t)y1;
+        p1[(long)y * s1 + cx] = (uint8_t)u; p2[(long)y * s2 + cx] = (uint8_t)v;
+    }
+    else
+    {
+        constexpr int YOFF = LAYOUT == 3 ? 1 : 0, COFF = 1 - YOFF;
+        const uint32_t first = LAYOUT != 2 ? u : v, second = LAYOUT != 2 ? v : u;
+        uint8_t* d = p0 + (long)y * s0 + 4 * (long)cx;
+        d[YOFF] = (uint8_t)y0; d[2 + YOFF] = (uint8_t)y1; d[COFF] = (uint8_t)first; d[2 + COFF] = (uint8_t)second;
+    }
+}
+
+// packed 444 -> three planes (cv::split, FrameIngest.cpp:531) or A Y U V with A = 255 (:694-701).  A thread = one pixel.
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_egress_444(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
+                  uint8_t* __restrict__ p0, int s0, uint8_t* __restrict__ p1, int s1, uint8_t* __restrict__ p2, int s2)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const uint8_t* s = src + (long)y * src_step + 3 * (long)x;
+    if (LAYOUT == 0) { p0[(long)y * s0 + x] = s[0]; p1[(long)y * s1 + x] = s[1]; p2[(long)y * s2 + x] = s[2]; }
+    else *reinterpret_cast<uint32_t*>(p0 + (long)y * s0 + 4 * (long)x) = 255u | ((uint32_t)s[0] << 8) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 24);
+}
+
 } // namespace
 
 // cv::resize(8U, INTER_LINEAR) table (OpenCV 4.8 resize.cpp), coefficients as 11-bit shorts.
@@ -254,6 +374,113 @@ int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
     return LVK_HIP_OK;
 }
 
+// FrameIngest::Select's switch (FrameIngest.cpp:36-75) as one pair of launchers.  video_format = libobs' enum video_format (LVK_VIDEO_FORMAT_*).
+int lvk_launch_ingest_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* const d_planes[3], const int steps[3],
+                          int rows, int cols, void* d_dst, int dst_step)
+{
+    LVK_HIP_REQUIRE(ctx, d_planes && steps && d_planes[0] && d_dst && rows > 0 && cols > 0);
+    const uint8_t* p0 = (const uint8_t*)d_planes[0]; const uint8_t* p1 = (const uint8_t*)d_planes[1]; const uint8_t* p2 = (const uint8_t*)d_planes[2];
+    const int fast = ((reinterpret_cast<uintptr_t>(d_dst) | (uintptr_t)dst_step) & 3u) == 0 ? 1 : 0;
+    const dim3 block(64, 4), grid((cols + 255) / 256, (rows + 3) / 4);
+    switch (video_format)
+    {
+    case LVK_VIDEO_FORMAT_I420: case LVK_VIDEO_FORMAT_I40A:
+        return lvk_launch_ingest_yuv420(ctx, stream, p0, steps[0], p1, steps[1], p2, steps[2], 0, rows, cols, d_dst, dst_step);
+    case LVK_VIDEO_FORMAT_NV12:
+        return lvk_launch_ingest_yuv420(ctx, stream, p0, steps[0], p1, steps[1], nullptr, 0, 1, rows, cols, d_dst, dst_step);
+    case LVK_VIDEO_FORMAT_I422: case LVK_VIDEO_FORMAT_I42A:
+        LVK_HIP_REQUIRE(ctx, p1 && p2 && (cols & 1) == 0 && steps[0] >= cols && steps[1] >= cols / 2 && steps[2] >= cols / 2 && dst_step >= 3 * cols);
+        hipLaunchKernelGGL(k_ingest_422<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        break;
+    case LVK_VIDEO_FORMAT_YUY2: case LVK_VIDEO_FORMAT_YVYU: case LVK_VIDEO_FORMAT_UYVY:
+        LVK_HIP_REQUIRE(ctx, (cols & 1) == 0 && steps[0] >= 2 * cols && dst_step >= 3 * cols);
+        if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_ingest_422<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        else if (video_format == LVK_VIDEO_FORMAT_YVYU) hipLaunchKernelGGL(k_ingest_422<2>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        else hipLaunchKernelGGL(k_ingest_422<3>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        break;
+    case LVK_VIDEO_FORMAT_I444: case LVK_VIDEO_FORMAT_YUVA:
+        LVK_HIP_REQUIRE(ctx, p1 && p2 && steps[0] >= cols && steps[1] >= cols && steps[2] >= cols && dst_step >= 3 * cols);
+        hipLaunchKernelGGL(k_ingest_444<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        break;
+    case LVK_VIDEO_FORMAT_AYUV:
+        LVK_HIP_REQUIRE(ctx, steps[0] >= 4 * cols && dst_step >= 3 * cols);
+        hipLaunchKernelGGL(k_ingest_444<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        break;
+    case LVK_VIDEO_FORMAT_Y800:                                   // DirectIngest: upload_planes(src, 1).copyTo(dst)
+        LVK_HIP_REQUIRE(ctx, steps[0] >= cols && dst_step >= cols);
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_step, p0, (size_t)steps[0], (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    case LVK_VIDEO_FORMAT_BGR3:
+        LVK_HIP_REQUIRE(ctx, steps[0] >= 3 * cols && dst_step >= 3 * cols);
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_step, p0, (size_t)steps[0], 3 * (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    case LVK_VIDEO_FORMAT_RGBA: case LVK_VIDEO_FORMAT_BGRA: case LVK_VIDEO_FORMAT_BGRX:
+        // DirectIngest::to_ocl as written (FrameIngest.cpp:743-747): rows * cols * 3 BYTES of the tightly packed 4-byte pixels, viewed as 3-byte pixels
+        LVK_HIP_REQUIRE(ctx, steps[0] == 4 * cols && dst_step >= 3 * cols);
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_step, p0, 3 * (size_t)cols, 3 * (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    default:
+        return ctx->fail(LVK_HIP_ERR_ARG, "lvk_hip_ingest_obs: video format " + std::to_string(video_format) + " is not one FrameIngest::Select knows");
+    }
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+int lvk_launch_egress_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* d_src, int src_step, int rows, int cols,
+                          void* const d_planes[3], const int steps[3])
+{
+    LVK_HIP_REQUIRE(ctx, d_planes && steps && d_planes[0] && d_src && rows > 0 && cols > 0);
+    uint8_t* p0 = (uint8_t*)d_planes[0]; uint8_t* p1 = (uint8_t*)d_planes[1]; uint8_t* p2 = (uint8_t*)d_planes[2];
+    const uint8_t* src = (const uint8_t*)d_src;
+    const dim3 block(64, 4);
+    switch (video_format)
+    {
+    case LVK_VIDEO_FORMAT_I420: case LVK_VIDEO_FORMAT_I40A:
+        return lvk_launch_egress_yuv420(ctx, stream, d_src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2], 0);
+    case LVK_VIDEO_FORMAT_NV12:
+        return lvk_launch_egress_yuv420(ctx, stream, d_src, src_step, rows, cols, p0, steps[0], p1, steps[1], nullptr, 0, 1);
+    case LVK_VIDEO_FORMAT_I422: case LVK_VIDEO_FORMAT_I42A:
+        LVK_HIP_REQUIRE(ctx, p1 && p2 && (cols & 1) == 0 && steps[0] >= cols && steps[1] >= cols / 2 && steps[2] >= cols / 2 && src_step >= 3 * cols);
+        hipLaunchKernelGGL(k_egress_422<0>, dim3((cols / 2 + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
+        break;
+    case LVK_VIDEO_FORMAT_YUY2: case LVK_VIDEO_FORMAT_YVYU: case LVK_VIDEO_FORMAT_UYVY:
+    {
+        LVK_HIP_REQUIRE(ctx, (cols & 1) == 0 && steps[0] >= 2 * cols && src_step >= 3 * cols);
+        const dim3 grid((cols / 2 + 63) / 64, (rows + 3) / 4);
+        if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_egress_422<1>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        else if (video_format == LVK_VIDEO_FORMAT_YVYU) hipLaunchKernelGGL(k_egress_422<2>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        else hipLaunchKernelGGL(k_egress_422<3>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        break;
+    }
+    case LVK_VIDEO_FORMAT_I444: case LVK_VIDEO_FORMAT_YUVA:
+        LVK_HIP_REQUIRE(ctx, p1 && p2 && steps[0] >= cols && steps[1] >= cols && steps[2] >= cols && src_step >= 3 * cols);
+        hipLaunchKernelGGL(k_egress_444<0>, dim3((cols + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
+        break;
+    case LVK_VIDEO_FORMAT_AYUV:
+        LVK_HIP_REQUIRE(ctx, steps[0] >= 4 * cols && (steps[0] & 3) == 0 && (reinterpret_cast<uintptr_t>(p0) & 3u) == 0 && src_step >= 3 * cols);
+        hipLaunchKernelGGL(k_egress_444<1>, dim3((cols + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        break;
+    case LVK_VIDEO_FORMAT_Y800:
+        LVK_HIP_REQUIRE(ctx, steps[0] >= cols && src_step >= cols);
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(p0, (size_t)steps[0], src, (size_t)src_step, (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    case LVK_VIDEO_FORMAT_BGR3:
+        LVK_HIP_REQUIRE(ctx, steps[0] >= 3 * cols && src_step >= 3 * cols);
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(p0, (size_t)steps[0], src, (size_t)src_step, 3 * (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    case LVK_VIDEO_FORMAT_RGBA: case LVK_VIDEO_FORMAT_BGRA: case LVK_VIDEO_FORMAT_BGRX:
+        // DirectIngest::to_obs: download_planes(src, dst) writes rows * cols * 3 bytes at data[0] (FrameIngest.cpp:751-753); the last quarter stays
+        LVK_HIP_REQUIRE(ctx, steps[0] == 4 * cols && src_step >= 3 * cols);
+        LVK_HIP_CHECK(ctx, hipMemcpy2DAsync(p0, 3 * (size_t)cols, src, (size_t)src_step, 3 * (size_t)cols, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+        return LVK_HIP_OK;
+    default:
+        return ctx->fail(LVK_HIP_ERR_ARG, "lvk_hip_egress_obs: video format " + std::to_string(video_format) + " is not one FrameIngest::Select knows");
+    }
+    LVK_HIP_CHECK(ctx, hipGetLastError());
+    return LVK_HIP_OK;
+}
+
+
 extern "C" {
 
 int lvk_hip_ingest_yuv420(lvk_hip_ctx* ctx, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
@@ -268,6 +495,32 @@ int lvk_hip_egress_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_step, int
 {
     LVK_HIP_ENTRY(ctx);
     return lvk_launch_egress_yuv420(ctx, ctx->stream, d_src, src_step, rows, cols, d_y, y_step, d_u, u_step, d_v, v_step, nv12);
+}
+
+int lvk_hip_ingest_obs(lvk_hip_ctx* ctx, int video_format, const void* const d_planes[3], const int steps[3], int rows, int cols, void* d_dst, int dst_step)
+{
+    LVK_HIP_ENTRY(ctx);
+    return lvk_launch_ingest_obs(ctx, ctx->stream, video_format, d_planes, steps, rows, cols, d_dst, dst_step);
+}
+
+int lvk_hip_egress_obs(lvk_hip_ctx* ctx, int video_format, const void* d_src, int src_step, int rows, int cols, void* const d_planes[3], const int steps[3])
+{
+    LVK_HIP_ENTRY(ctx);
+    return lvk_launch_egress_obs(ctx, ctx->stream, video_format, d_src, src_step, rows, cols, d_planes, steps);
+}
+
+int lvk_hip_obs_frame_format(int video_format)
+{
+    switch (video_format)                                         // FrameIngest.cpp:476-490,562,604-611,672,715-726: the VideoFrame::Format each ingest declares
+    {
+    case LVK_VIDEO_FORMAT_I420: case LVK_VIDEO_FORMAT_NV12: case LVK_VIDEO_FORMAT_I422: case LVK_VIDEO_FORMAT_I444: case LVK_VIDEO_FORMAT_I40A:
+    case LVK_VIDEO_FORMAT_I42A: case LVK_VIDEO_FORMAT_YUVA: case LVK_VIDEO_FORMAT_YUY2: case LVK_VIDEO_FORMAT_YVYU: case LVK_VIDEO_FORMAT_UYVY:
+    case LVK_VIDEO_FORMAT_AYUV: return LVK_FORMAT_YUV;
+    case LVK_VIDEO_FORMAT_Y800: return LVK_FORMAT_GRAY;
+    case LVK_VIDEO_FORMAT_RGBA: return LVK_FORMAT_RGB;
+    case LVK_VIDEO_FORMAT_BGRX: case LVK_VIDEO_FORMAT_BGRA: case LVK_VIDEO_FORMAT_BGR3: return LVK_FORMAT_BGR;
+    default: return LVK_HIP_ERR_ARG;
+    }
 }
 
 } // extern "C"
