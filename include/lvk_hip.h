@@ -307,6 +307,13 @@ int  lvk_hip_stab_push_yuv420(lvk_hip_stab* stab, const void* d_y, int y_step, c
                               int rows, int cols, uint64_t timestamp,
                               void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int o_rows,
                               int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted);
+/* The same call for ANY video format FrameIngest::Select accepts except Y800 (LVK_VIDEO_FORMAT_*; d_planes / steps as for lvk_hip_ingest_obs, o_planes /
+ * o_steps / o_rows the planes of the emitted frame and their row capacity): I420 / I40A / NV12 take lvk_hip_stab_push_yuv420's route; the other formats
+ * are converted into the filter's frame pool (FrameIngest::to_ocl), pushed, and the emitted frame -- the DELAYED one, at its own size -- converted back
+ * (::to_obs).  Input planes consumed when the call returns; output planes complete after lvk_hip_sync(); planes that cannot hold the emitted frame are
+ * refused before anything changes.  Shares the frame queue with lvk_hip_stab_push_yuv420. */
+int  lvk_hip_stab_push_obs(lvk_hip_stab* stab, int video_format, const void* const d_planes[3], const int steps[3], int rows, int cols, uint64_t timestamp,
+                           void* const o_planes[3], const int o_steps[3], int o_rows, int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted);
 
 /* The same path for frames that live in HOST memory -- FrameIngest::upload_planes -> to_ocl -> filter -> to_obs -> download_planes
  * (Modules/OBS-Plugin/Interop/FrameIngest.cpp:415-474,494-602): h_* / oh_* are planes in PINNED host memory (lvk_hip_host_malloc,

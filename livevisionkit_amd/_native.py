@@ -90,6 +90,8 @@ _SIG = {
                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_P), _P]),
     "lvk_hip_stab_push_yuv420": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,
                                             _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _P]),
+    "lvk_hip_stab_push_obs": (_c.c_int, [_P, _c.c_int, _P * 3, _c.c_int * 3, _c.c_int, _c.c_int, _c.c_uint64, _P * 3, _c.c_int * 3, _c.c_int,
+                                         _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _P]),
     "lvk_hip_stab_push_yuv420_host": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_uint64,
                                             _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _P]),
     "lvk_hip_stab_prefetch_yuv420_host": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),

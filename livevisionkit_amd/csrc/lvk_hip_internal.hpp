@@ -274,6 +274,10 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
                              const void* d_v, int v_step, int nv12, int rows, int cols, void* d_dst, int dst_step);
 int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                              void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
+int lvk_launch_ingest_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* const d_planes[3], const int steps[3],
+                          int rows, int cols, void* d_dst, int dst_step);
+int lvk_launch_egress_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* d_src, int src_step, int rows, int cols,
+                          void* const d_planes[3], const int steps[3]);
 
 
 int lvk_launch_remap_map(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,

@@ -57,9 +57,10 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     // either of them, bounds the frame rate.
     finish_post();
     if (post_error) { post_error = false; return fail(LVK_HIP_ERR_RUNTIME, "GPU-side fast_filter disagrees with the host's"); }
-    // A push that ends before the chain's synchronisation below still has the downscale reading the caller's Y plane (4:2:0 entry, luma_pix
-    // == 1: "the input planes are consumed before the call returns"): wait for it.  Packed frames stay borrowed until they are released.
-    auto leave_early = [&]() -> int { if (luma_pix == 1) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LVK_HIP_OK; };
+    // A push that ends before the chain's synchronisation below still has the downscale reading the caller's luma (the plane entries: luma_pix 1 for
+    // planar formats, 2 / 4 for packed 4:2:2 / AYUV -- "the input planes are consumed before the call returns"): wait for it.  Packed frames (luma_pix
+    // 3) stay borrowed until they are released.
+    auto leave_early = [&]() -> int { if (luma_pix != 3) LVK_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LVK_HIP_OK; };
     if (!initialized || cur_w != prev_w || cur_h != prev_h) { initialized = true; return leave_early(); }
 
     // ---- FeatureDetector::detect
@@ -673,14 +674,35 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
 // (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-212, FrameIngest.cpp:494-602).  Planar (or NV12) 4:2:0 in, 4:2:0 out;
 // the packed 8UC3 frames the filter works on live in an internal pool (predictive_samples + 4 frames).  The input planes
 // are consumed before the call returns; the output planes are complete after lvk_hip_sync().
-int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
-                             int rows, int cols, uint64_t timestamp,
-                             void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int o_rows,
-                             int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted)
+// (shared by lvk_hip_stab_push_yuv420 and lvk_hip_stab_push_obs: `vf` = the OBS video format of the planes; the 4:2:0 formats leave through the fused
+//  remap + egress kernel, every other format through the packed buffer and its egress kernel)
+static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_planes[3], const int in_steps[3], int rows, int cols, uint64_t timestamp,
+                                void* const out_planes[3], const int out_steps[3], int o_rows,
+                                int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted)
 {
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_device_guard device_guard(st->ctx);
     lvk_hip_ctx* ctx = st->ctx;
+    const bool is420 = vf == LVK_VIDEO_FORMAT_I420 || vf == LVK_VIDEO_FORMAT_I40A || vf == LVK_VIDEO_FORMAT_NV12;
+    const int nv12 = vf == LVK_VIDEO_FORMAT_NV12 ? 1 : 0;
+    const int frame_format = lvk_hip_obs_frame_format(vf);
+    if (frame_format < 0 || frame_format == LVK_FORMAT_GRAY || !in_planes || !in_steps || !in_planes[0])
+        return st->fail(LVK_HIP_ERR_ARG, "lvk_hip_stab_push_obs: video format " + std::to_string(vf) + " has no three-channel frame the filter could take (FrameIngest::Select, lvk::remap: CV_8UC3)");
+    const std::array<const void*, 3> ip{in_planes[0], in_planes[1], in_planes[2]};
+    const std::array<int, 3> is_{in_steps[0], in_steps[1], in_steps[2]};
+    std::array<void*, 3> op{nullptr, nullptr, nullptr}; std::array<int, 3> os{0, 0, 0};
+    if (out_planes && out_steps) { op = {out_planes[0], out_planes[1], out_planes[2]}; os = {out_steps[0], out_steps[1], out_steps[2]}; }
+    // (the names of the 4:2:0 route)
+    const void* d_y = ip[0]; const int y_step = is_[0];
+    void* o_y = op[0]; void* o_u = op[1]; void* o_v = nv12 ? op[1] : op[2];
+    const int oy_step = os[0], ou_step = os[1], ov_step = nv12 ? os[1] : os[2];
+    // where the tracker reads its luma (VideoFrame::viewAsFormat(GRAY), VideoFrame.cpp:260): the caller's Y plane / the Y bytes of the packed formats; the
+    // BGR / RGB frames of DirectIngest are tracked from the converted copy (cvtColor needs all three channels)
+    const bool direct = frame_format != LVK_FORMAT_YUV;
+    const uint8_t* luma = static_cast<const uint8_t*>(ip[0]); int luma_step = is_[0], luma_pix = 1;
+    if (vf == LVK_VIDEO_FORMAT_YUY2 || vf == LVK_VIDEO_FORMAT_YVYU) luma_pix = 2;
+    else if (vf == LVK_VIDEO_FORMAT_UYVY) { luma += 1; luma_pix = 2; }
+    else if (vf == LVK_VIDEO_FORMAT_AYUV) { luma += 1; luma_pix = 4; }
     st->trace.begin();
     st->prof_tick++;
     st->push_seq++;
@@ -688,6 +710,23 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     if (produced) *produced = 0;
     if (st->queue.empty()) st->queue_kind = 0;
     if (st->queue_kind == 1) return st->fail(LVK_HIP_ERR_ARG, "borrowed frames of lvk_hip_stab_push are still queued: restart() before switching to lvk_hip_stab_push_yuv420");
+    if (!is420)
+    {
+        // the planes of the frame this push emits (the DELAYED one, at its own size) must hold it: refused before anything changes, like the 4:2:0 planes
+        QueuedFrame due{};
+        if (st->next_output(QueuedFrame{nullptr, 3 * cols, rows, cols, timestamp, frame_format}, &due))
+        {
+            const int packed = (vf == LVK_VIDEO_FORMAT_YUY2 || vf == LVK_VIDEO_FORMAT_YVYU || vf == LVK_VIDEO_FORMAT_UYVY) ? 2 :
+                               (vf == LVK_VIDEO_FORMAT_AYUV || vf == LVK_VIDEO_FORMAT_RGBA || vf == LVK_VIDEO_FORMAT_BGRA || vf == LVK_VIDEO_FORMAT_BGRX) ? 4 :
+                               vf == LVK_VIDEO_FORMAT_BGR3 ? 3 : 0;
+            const int cw = (vf == LVK_VIDEO_FORMAT_I422 || vf == LVK_VIDEO_FORMAT_I42A) ? due.cols / 2 : due.cols;
+            const bool fits = op[0] && o_rows >= due.rows &&
+                              (packed ? os[0] >= packed * due.cols : (op[1] && op[2] && os[0] >= due.cols && os[1] >= cw && os[2] >= cw));
+            if (!fits)
+                return st->fail(LVK_HIP_ERR_ARG, "the output planes do not hold the frame this push emits: " + std::to_string(due.cols) + " x " + std::to_string(due.rows) +
+                                                     " (the DELAYED frame's own size -- lvk_hip_stab_next_output); nothing was queued");
+        }
+    }
     st->queue_kind = 2;
     int rc = st->ensure_pool(rows, cols);
     if (rc != LVK_HIP_OK) return rc;
@@ -707,7 +746,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     void* slot = st->pool_free.front(); st->pool_free.pop_front();
     // The packed frame is only read by the remap `predictive_samples` pushes later (the tracker reads the luma plane itself), so in
     // overlap mode the conversion runs on the remap stream, off the tracker's critical path; same-stream order protects the slot.
-    const bool side_ingest = st->overlap && st->s.stabilize_output;
+    const bool side_ingest = st->overlap && st->s.stabilize_output && !direct;
     // a delayed frame (its remap is launched after later synchronisations of the tracking stream) may be converted on either stream: track() decides
     st->tracker_ingest_capable = side_ingest && st->queue_capacity > 1;
     st->ingest_on_tracker = false;
@@ -725,7 +764,7 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         // host-resident frames: the planes are still arriving on the upload stream
         for (hipEvent_t& e : st->ingest_wait) if (e) { LVK_HIP_CHECK(ctx, hipStreamWaitEvent(is, e, 0)); e = nullptr; }
         const int pi = st->prof_begin(LVK_STAGE_INGEST, is);
-        const int r = lvk_launch_ingest_yuv420(ctx, is, d_y, y_step, d_u, u_step, d_v, v_step, nv12, rows, cols, slot, 3 * cols);
+        const int r = lvk_launch_ingest_obs(ctx, is, vf, ip.data(), is_.data(), rows, cols, slot, 3 * cols);
         st->prof_end(pi, is);
         if (r != LVK_HIP_OK) return r;
         if (side_ingest)
@@ -744,14 +783,16 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     st->pool_frames = side_ingest;
     OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false, o_rows};
     if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
+    (void)d_y; (void)y_step;
     // (the packed route's buffer: pool_out, tight rows, as many as its allocation holds at the widest queued frame)
     lvk_frame_info info{0, 0, 0};
     {
         QueuedFrame due{};
-        const bool will = st->next_output(QueuedFrame{slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV}, &due);
+        const bool will = st->next_output(QueuedFrame{slot, 3 * cols, rows, cols, timestamp, frame_format}, &due);
         const int out_cols = will ? due.cols : cols;
-        rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, LVK_FORMAT_YUV, d_y, y_step, 1, st->pool_out, 3 * out_cols,
-                                (int)(st->pool_out_bytes / ((size_t)3 * out_cols)), &prod, out_timestamp, &released, &o420, &info);
+        rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, frame_format, direct ? slot : (const void*)luma, direct ? 3 * cols : luma_step, direct ? 3 : luma_pix,
+                                st->pool_out, 3 * out_cols, (int)(st->pool_out_bytes / ((size_t)3 * out_cols)), &prod, out_timestamp, &released,
+                                is420 ? &o420 : nullptr, &info);
     }
     {
         // a push that was refused (or failed before the frame was queued) has not taken the slot: its conversion is not launched, the slot is free again
@@ -778,18 +819,23 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
         st->trace.mark(HostTrace::EXIT_WAIT);
     }
     // same contract without a tracker pass (delay-only mode, stabilize_output off): nothing has synchronised behind the conversion yet
-    else if (!st->s.stabilize_output) LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // (and for DirectIngest's formats, whose copy runs on the tracking stream and whose tracker reads the copy: an early return of track() has not waited)
+    else if (!st->s.stabilize_output || direct) LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (rc != LVK_HIP_OK) return rc;
     if (prod && o420.used) { if (produced) *produced = 1; }                // the fused remap + egress kernel has written the planes
     else if (prod)
     {
         // the emitted frame has ITS OWN geometry (a frame queued before the size changed leaves at the old size)
-        LVK_HIP_REQUIRE(ctx, o_y && o_u && (nv12 || o_v));
-        LVK_HIP_REQUIRE(ctx, oy_step >= info.cols && ou_step >= (nv12 ? info.cols : info.cols / 2) && (nv12 || ov_step >= info.cols / 2) && o_rows >= info.rows);
+        if (is420)
+        {
+            LVK_HIP_REQUIRE(ctx, o_y && o_u && (nv12 || o_v));
+            LVK_HIP_REQUIRE(ctx, oy_step >= info.cols && ou_step >= (nv12 ? info.cols : info.cols / 2) && (nv12 || ov_step >= info.cols / 2) && o_rows >= info.rows);
+        }
+        else LVK_HIP_REQUIRE(ctx, op[0] && o_rows >= info.rows);
         hipStream_t es = (st->overlap && st->s.stabilize_output) ? st->remap_stream : ctx->stream;
         if (st->remap_wait) { const hipEvent_t e = st->remap_wait; st->remap_wait = nullptr; LVK_HIP_CHECK(ctx, hipStreamWaitEvent(es, e, 0)); }
         pe = st->prof_begin(LVK_STAGE_EGRESS, es);
-        rc = lvk_launch_egress_yuv420(ctx, es, st->pool_out, 3 * info.cols, info.rows, info.cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12);
+        rc = lvk_launch_egress_obs(ctx, es, vf, st->pool_out, 3 * info.cols, info.rows, info.cols, op.data(), os.data());
         st->prof_end(pe, es);
         if (rc != LVK_HIP_OK) return rc;
         if (produced) *produced = 1;
@@ -797,6 +843,25 @@ int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, cons
     st->trace.mark(HostTrace::EXIT);
     st->last_push_end = std::chrono::steady_clock::now();
     return LVK_HIP_OK;
+}
+
+int lvk_hip_stab_push_yuv420(lvk_hip_stab* st, const void* d_y, int y_step, const void* d_u, int u_step, const void* d_v, int v_step, int nv12,
+                             int rows, int cols, uint64_t timestamp,
+                             void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int o_rows,
+                             int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted)
+{
+    const void* in_planes[3] = {d_y, d_u, nv12 ? nullptr : d_v}; const int in_steps[3] = {y_step, u_step, nv12 ? 0 : v_step};
+    void* out_planes[3] = {o_y, o_u, nv12 ? nullptr : o_v}; const int out_steps[3] = {oy_step, ou_step, nv12 ? 0 : ov_step};
+    return lvk_stab_push_planes(st, nv12 ? LVK_VIDEO_FORMAT_NV12 : LVK_VIDEO_FORMAT_I420, in_planes, in_steps, rows, cols, timestamp,
+                                out_planes, out_steps, o_rows, produced, out_timestamp, emitted);
+}
+
+// The plugin's asynchronous path for ANY format FrameIngest::Select accepts (except Y800), one call per frame: to_ocl -> StabilizationFilter::filter
+// -> to_obs (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-212, FrameIngest.cpp:36-75).
+int lvk_hip_stab_push_obs(lvk_hip_stab* st, int video_format, const void* const d_planes[3], const int steps[3], int rows, int cols, uint64_t timestamp,
+                          void* const o_planes[3], const int o_steps[3], int o_rows, int* produced, uint64_t* out_timestamp, lvk_frame_info* emitted)
+{
+    return lvk_stab_push_planes(st, video_format, d_planes, steps, rows, cols, timestamp, o_planes, o_steps, o_rows, produced, out_timestamp, emitted);
 }
 
 } // extern "C"

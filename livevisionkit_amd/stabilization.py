@@ -168,6 +168,31 @@ class StabilizationFilter:
         self.last_format = info.format
         return out[:info.rows, :info.cols], ots.value
 
+    def apply_obs(self, fmt, planes, timestamp=0, out=None):
+        """The plugin's asynchronous path for any OBS video format (lvk_hip_stab_push_obs): `planes` as Context.ingest_obs takes them, `out` = planes for
+        the emitted frame (same format; they must hold the DELAYED frame's size, next_output()).  Returns (out planes, timestamp) or (None, None)."""
+        import torch
+        t0 = time.perf_counter()
+        vf = self.ctx.VIDEO_FORMATS[fmt]
+        rows, cols = planes[0].shape[:2]
+        if out is None:
+            due = self.next_output(rows, cols, self.ctx.obs_frame_format(fmt))
+            r, c = (due[0], due[1]) if due else (rows, cols)
+            out = [torch.empty((p.shape[0] * r // rows, p.shape[1] * c // cols) + tuple(p.shape[2:]), dtype=torch.uint8, device=p.device) for p in planes]
+        iptr, istep = self.ctx._obs_args(planes)
+        optr, ostep = self.ctx._obs_args(out)
+        produced = _c.c_int(0); ots = _c.c_uint64(0); info = FrameInfo()
+        rc = self.lib.lvk_hip_stab_push_obs(self.handle, vf, iptr, istep, rows, cols, int(timestamp), optr, ostep, out[0].shape[0],
+                                            _c.byref(produced), _c.byref(ots), _c.byref(info))
+        self.ctx._check(rc)
+        self._timer._add(time.perf_counter() - t0)
+        if not produced.value:
+            return None, None
+        self.last_format = info.format
+        if (info.rows, info.cols) != (out[0].shape[0], out[0].shape[1]):     # a larger buffer was given: the emitted frame is its top-left part
+            out = [p[:p.shape[0] * info.rows // out[0].shape[0], :p.shape[1] * info.cols // out[0].shape[1]] for p in out]
+        return out, ots.value
+
     def apply_yuv420(self, planes, timestamp=0, out=None):
         """The OBS async path in one call: planes = (y, u, v) I420 or (y, uv) NV12 torch uint8 tensors on the GPU.
         Returns (output planes, timestamp) or (None, None) while the delay builds.  The output planes have the DELAYED frame's size (a stream

@@ -153,3 +153,109 @@ def test_stabilizer_fed_from_packed_422(ctx, oracle):
             ctx.sync()
             assert np.array_equal(back[0].cpu().numpy(), oracle.egress_obs("UYVY", w)[0])
     assert emitted >= n - 4
+
+
+# ---- lvk_hip_stab_push_obs: the plugin's asynchronous path in one call, for every format ---------------------------------------------------------
+def _obs_stream(oracle, fmt, clip):
+    """the clip as an OBS source of `fmt` would deliver it: (planes, the packed frame FrameIngest::to_ocl makes of them) per frame"""
+    out = []
+    for f in clip:
+        planes = oracle.egress_obs(fmt, f)
+        out.append((planes, oracle.ingest_obs(fmt, planes)))
+    return out
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("fmt", ["I422", "I444", "YUY2", "YVYU", "UYVY", "AYUV", "BGR3", "I42A", "NV12", "I420"])
+def test_push_obs_equals_oracle_ingest_filter_egress(ctx, oracle, fmt, overlap):
+    import livevisionkit_amd as lvk
+    from tests import oracle_lib, synth
+    from tests.test_stabilizer_gpu import _to_settings
+    rows, cols, n = 270, 480, 12
+    clip, _ = synth.make_clip(rows, cols, n, seed=41, jitter=1.0)
+    s = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    gst.set_overlap(overlap)
+    ffmt = ctx.obs_frame_format(fmt)
+    emitted = 0
+    for i, (planes, packed) in enumerate(_obs_stream(oracle, fmt, clip)):
+        w, wts = ost.push(packed, ts=i, fmt=ffmt)
+        dev = [_gpu(p) for p in planes]
+        out, ots = gst.apply_obs(fmt, dev, timestamp=i)
+        for d in dev:
+            d.fill_(0x33)                                                   # the planes are consumed when the call returns
+        ctx.sync()
+        assert (out is None) == (w is None), (fmt, i)
+        if out is not None:
+            emitted += 1
+            assert ots == wts
+            for g, want in zip(out, oracle.egress_obs(fmt, w)):
+                assert np.array_equal(g.cpu().numpy(), want), (fmt, i)
+    assert emitted == n - 3
+    gst.close()
+
+
+def test_push_obs_420_is_push_yuv420(ctx, oracle):
+    """the 4:2:0 formats through lvk_hip_stab_push_obs take lvk_hip_stab_push_yuv420's route: same bytes, fused remap + egress (no ingest / egress stage of their own)"""
+    import livevisionkit_amd as lvk
+    from tests import synth
+    rows, cols, n = 270, 480, 10
+    clip, _ = synth.make_clip(rows, cols, n, seed=43, jitter=1.0)
+    a = lvk.StabilizationFilter(lvk.StabilizationFilterSettings.obs_preset("homography", strict=False, predictive_samples=2), context=ctx)
+    b = lvk.StabilizationFilter(lvk.StabilizationFilterSettings.obs_preset("homography", strict=False, predictive_samples=2), context=ctx)
+    a.set_overlap(True); b.set_overlap(True)
+    for i, f in enumerate(clip):
+        y, u, v = oracle.egress_yuv420(f)
+        pa = [_gpu(p) for p in (y, u, v)]; pb = [_gpu(p) for p in (y, u, v)]
+        oa, _ = a.apply_obs("I420", pa, timestamp=i)
+        ob, _ = b.apply_yuv420(tuple(pb), timestamp=i)
+        ctx.sync()
+        assert (oa is None) == (ob is None)
+        if oa is not None:
+            for g, h in zip(oa, ob):
+                assert np.array_equal(g.cpu().numpy(), h.cpu().numpy())
+    a.close(); b.close()
+
+
+def test_push_obs_frame_size_change_and_refusal(ctx, oracle):
+    """a UYVY source that is resized mid-stream: the queued frames leave at their OWN size; planes sized from the incoming frame are refused before
+    anything changes (lvk_hip_stab_next_output), and the same push with planes that hold the delayed frame carries on bit-exactly; Y800 is refused."""
+    import torch
+    import livevisionkit_amd as lvk
+    from tests import oracle_lib, synth
+    from tests.test_stabilizer_gpu import _to_settings
+    base, _ = synth.make_clip(360, 640, 12, seed=47, jitter=1.0)
+    frames = [np.ascontiguousarray(f) for f in base[:6]] + [np.ascontiguousarray(f[60:300, 100:500]) for f in base[6:]]      # 640 x 360, then 400 x 240
+    s = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    size_of = {i: f.shape[:2] for i, f in enumerate(frames)}
+    refused = 0
+    for i, f in enumerate(frames):
+        planes = oracle.egress_obs("UYVY", f)
+        packed = oracle.ingest_obs("UYVY", planes)
+        big = np.zeros((360, 640, 3), np.uint8)
+        w, wts = ost.push(packed, ts=i, fmt=4, out=big)
+        dev = [_gpu(p) for p in planes]
+        due = gst.next_output(f.shape[0], f.shape[1], 4)
+        assert (due is None) == (w is None)
+        if due is not None and (due[0], due[1]) != f.shape[:2]:
+            small = [torch.empty((f.shape[0], f.shape[1], 2), dtype=torch.uint8, device="cuda")]
+            before = gst.features()
+            with pytest.raises(lvk.LvkHipError, match="DELAYED"):
+                gst.apply_obs("UYVY", dev, timestamp=i, out=small)
+            assert np.array_equal(gst.features(), before) and gst.next_output(f.shape[0], f.shape[1], 4) == due
+            refused += 1
+        out, ots = gst.apply_obs("UYVY", dev, timestamp=i)
+        ctx.sync()
+        assert (out is None) == (w is None)
+        if out is not None:
+            r, c = size_of[wts]
+            assert ots == wts and tuple(out[0].shape[:2]) == (r, c)
+            assert np.array_equal(out[0].cpu().numpy(), oracle.egress_obs("UYVY", w[:r, :c])[0])
+    assert refused == 3
+    y = torch.zeros((240, 400), dtype=torch.uint8, device="cuda")
+    with pytest.raises(lvk.LvkHipError):
+        gst.apply_obs("Y800", [y], timestamp=99, out=[y.clone()])
+    gst.close()
