@@ -359,3 +359,70 @@ def test_soak_3000_pushes_give_every_byte_back():
     for a, b in zip(last, again):
         assert np.array_equal(a, b), "two runs of the same free-running schedule emitted different last frames"
     assert abs(delta) < 16.0, f"device memory not returned: {delta:+.1f} MB"
+
+
+OBS_YUV_FORMATS = ["I420", "NV12", "I422", "I42A", "I444", "YUVA", "YUY2", "YVYU", "UYVY", "AYUV", "I40A"]
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_schedule_fuzz_obs_formats_against_the_oracle(ctx, oracle, seed):
+    """lvk_hip_stab_push_obs, fuzzed: one source whose video format changes from frame to frame (every YUV format FrameIngest::Select accepts -- they
+    all become the same packed frame), whose size changes twice, that is restarted, that turns stabilize_output off and on, in either schedule.  Every
+    emitted frame -- the DELAYED one, at its own size, converted to the format of the push that emits it -- against the oracle's
+    ingest -> filter -> egress; planes that cannot hold it are refused before anything changes."""
+    import torch
+    import livevisionkit_amd as lvk
+    rng = np.random.default_rng(7000 + seed)
+    n = 44
+    base, _ = synth.make_clip(SIZE_B[0], SIZE_B[1], n, seed=300 + seed, jitter=1.0)
+    cuts = sorted(rng.choice(np.arange(8, n - 8), 2, replace=False))
+    sizes = [SIZE_B, (288, 512), (240, 400)]
+    frames = []
+    for i in range(n):
+        r, c = sizes[int(i >= cuts[0]) + int(i >= cuts[1])]
+        y0, x0 = (SIZE_B[0] - r) // 2, (SIZE_B[1] - c) // 2
+        frames.append(np.ascontiguousarray(base[i][y0:y0 + r, x0:x0 + c]))
+    delay = int(rng.integers(1, 5))
+    s = _settings("homography", delay)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    gst = lvk.StabilizationFilter(_conv(s), context=ctx)
+    gst.set_overlap(bool(seed & 1))
+    size_of = {}
+    log, emitted, refused = [], 0, 0
+    keep = []
+    for i, f in enumerate(frames):
+        a = int(rng.integers(0, 16))
+        if a == 0 and i > 4:
+            ost.restart(); gst.restart(); log.append((i, "restart"))
+        elif a == 1:
+            s.stabilize_output = 1 - s.stabilize_output
+            ost.configure(s); gst.configure(_conv(s)); log.append((i, "stabilize_output=%d" % s.stabilize_output))
+        fmt = OBS_YUV_FORMATS[int(rng.integers(0, len(OBS_YUV_FORMATS)))]
+        size_of[i] = f.shape[:2]
+        planes = oracle.egress_obs(fmt, f)
+        packed = oracle.ingest_obs(fmt, planes)
+        big = np.zeros((SIZE_B[0], SIZE_B[1], 3), np.uint8)
+        w, wts = ost.push(packed, ts=i, fmt=4, out=big)
+        dev = [torch.from_numpy(p).cuda() for p in planes]; keep.append(dev)
+        due = gst.next_output(f.shape[0], f.shape[1], 4)
+        assert (due is None) == (w is None), (seed, i, log)
+        if due is not None and (due[0] > f.shape[0] or due[1] > f.shape[1]) and int(rng.integers(0, 2)):
+            small = [torch.empty_like(p) for p in dev]                        # planes sized from the INCOMING frame: too small for the delayed one
+            with pytest.raises(lvk.LvkHipError, match="DELAYED"):
+                gst.apply_obs(fmt, dev, timestamp=i, out=small)
+            assert gst.next_output(f.shape[0], f.shape[1], 4) == due
+            refused += 1
+        out, ots = gst.apply_obs(fmt, dev, timestamp=i)
+        if int(rng.integers(0, 3)) == 0:
+            ctx.sync()                                                        # a caller that sometimes waits for its frame
+        assert (out is None) == (w is None), (seed, i, log)
+        if out is not None:
+            ctx.sync()
+            emitted += 1
+            r, c = size_of[wts]
+            assert ots == wts and tuple(out[0].shape[:2]) == (r, c), (seed, i, fmt, log)
+            for g, want in zip(out, oracle.egress_obs(fmt, np.ascontiguousarray(w[:r, :c]))):
+                assert np.array_equal(g.cpu().numpy(), want), (seed, i, fmt, log)
+    ctx.sync(); gst.close()
+    assert emitted >= n - 6 * (delay + 1), (emitted, log)
+    print(f"[obs fuzz {seed}] {emitted} frames, delay {delay}, cuts {cuts}, {refused} refusals, events {log}")
