@@ -341,7 +341,8 @@ class Rig:
             if fmt != "packed":
                 raise SystemExit("--lens two-pass needs --format packed")
             self.lens_map, _ = self.ctx.lens_map(self.lens_params, rows, cols)
-        self.yuv420 = fmt != "packed"
+        self.obs_fmt = fmt.upper() if fmt in ("uyvy", "yuy2", "i422", "i444", "ayuv") else None      # any other OBS format: lvk_hip_stab_push_obs
+        self.yuv420 = fmt != "packed" and self.obs_fmt is None
         self.nv12 = fmt == "nv12"
         self.pingpong = pingpong
         self.file = None
@@ -370,6 +371,21 @@ class Rig:
             self.outs = [tuple(torch.empty_like(q) for q in planes[0]) for _ in range(4)]
             self.planes_args = [self.filt.prepare_yuv420(q) for q in planes]          # addresses / pitches marshalled once, outside the timed region
             self.outs_args = [self.filt.prepare_yuv420(o) for o in self.outs]
+        elif self.obs_fmt is not None:
+            # the source as an OBS source of that format delivers it: the generator's 4:4:4 frames through FrameIngest::to_obs, on the GPU
+            def shapes():
+                return {"UYVY": [(rows, cols, 2)], "YUY2": [(rows, cols, 2)], "AYUV": [(rows, cols, 4)], "I444": [(rows, cols)] * 3,
+                        "I422": [(rows, cols), (rows, cols // 2), (rows, cols // 2)]}[self.obs_fmt]
+            self.frames = None
+            self.obs_planes = []
+            for i in range(pool):
+                pl = [torch.empty(sh, dtype=torch.uint8, device=device) for sh in shapes()]
+                self.ctx.egress_obs(self.obs_fmt, self.clip.render444(i), pl)
+                self.obs_planes.append(pl)
+            self.ctx.sync()
+            self.outs = [[torch.empty(sh, dtype=torch.uint8, device=device) for sh in shapes()] for _ in range(4)]
+            self.planes_args = [self.filt.prepare_obs(self.obs_fmt, q) for q in self.obs_planes]
+            self.outs_args = [self.filt.prepare_obs(self.obs_fmt, o) for o in self.outs]
         else:
             self.frames = [self.clip.render444(i) for i in range(pool)]
             self.outs = [torch.empty_like(self.frames[0]) for _ in range(4)]
@@ -406,6 +422,8 @@ class Rig:
             if announce:                # the next frame is resident already: lvk_hip_stab_prefetch_yuv420, then the push of this one
                 self.filt.prefetch_yuv420_prepared(self.planes_args[self.index(i + 1)])
             return self.filt.apply_yuv420_prepared(self.planes_args[k], i, self.outs_args[i & 3])
+        if self.obs_fmt is not None:
+            return self.filt.apply_obs_prepared(self.planes_args[k], i, self.outs_args[i & 3])
         if self.lens_map is not None:
             corrected = self.ctx.remap_map(self.frames[k], self.lens_map, bg=(0, 0, 0), out=self.lens_bufs[i % len(self.lens_bufs)])     # LCFilter::filter
             return self.filt.apply(corrected, timestamp=i, out=self.outs[i & 3])
@@ -515,11 +533,11 @@ def _latency_pass(rigs, one, lats, local_rank):
     return lats
 
 
-def config_leg(lvk, local_rank, device, rows, cols, preset, lens, label, seed, steps=400, barrier=None):
+def config_leg(lvk, local_rank, device, rows, cols, preset, lens, label, seed, steps=400, barrier=None, fmt="i420"):
     """A short leg of another BASELINE configuration (outside `value`): same generator, 48 poses played forward and backward, I420 planes
     resident in HBM, overlap on; free-running rate over `steps` pushes, p50 / p99 of 150 synchronised pushes, live remap time."""
     import torch
-    rig = Rig(lvk, local_rank, device, seed, rows, cols, preset, "i420", lens, True, 48, cut=False, pingpong=True)
+    rig = Rig(lvk, local_rank, device, seed, rows, cols, preset, fmt, lens, True, 48, cut=False, pingpong=True)
     try:
         for _ in range(rig.delay + 2 + 60):
             rig.step()
@@ -1000,6 +1018,13 @@ def main():
                 configs.append(config_leg(lvk, local_rank, device, r_, c_, preset_, lens_, label_, seed0 + 101))
             except Exception as e:
                 configs.append({"workload": label_, "error": repr(e)})
+        # a source that is not 4:2:0 (what a capture card delivers): the plugin's whole path through lvk_hip_stab_push_obs -- P422Ingest::to_ocl, the
+        # filter, ::to_obs (FrameIngest.cpp:604-666); its remap leaves through the packed buffer and the format's egress kernel
+        label_ = "1920x1080 UYVY (packed 4:2:2) through lvk_hip_stab_push_obs, OBS 'homography' preset"
+        try:
+            configs.append(config_leg(lvk, local_rank, device, 1080, 1920, "homography", "off", label_, seed0 + 102, fmt="uyvy"))
+        except Exception as e:
+            configs.append({"workload": label_, "error": repr(e)})
     multi_stream = multi_stream_field = None
     if extras and not args.no_multi_stream and args.input is None and yuv420:
         multi_stream = multi_stream_leg(lvk, local_rank, device, seed0 + 200, rows, cols, args.preset, args.format, args.lens, not args.no_overlap, 4)

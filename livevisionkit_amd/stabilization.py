@@ -244,6 +244,21 @@ class StabilizationFilter:
             self.ctx._check(rc)
         return (dst["planes"], ots.value) if produced.value else (None, None)
 
+    def prepare_obs(self, fmt, planes):
+        """ctypes argument block of one OBS frame's planes for apply_obs_prepared (keeps the tensors alive)."""
+        ptrs, steps = self.ctx._obs_args(planes)
+        return {"vf": _c.c_int(self.ctx.VIDEO_FORMATS[fmt]), "ptrs": ptrs, "steps": steps, "rows": _c.c_int(planes[0].shape[0]), "cols": _c.c_int(planes[0].shape[1]),
+                "planes": planes}
+
+    def apply_obs_prepared(self, src, timestamp, dst):
+        """apply_obs with argument blocks from prepare_obs (src: the incoming frame's planes, dst: planes for the emitted frame)."""
+        produced = self._produced; ots = self._ots
+        rc = self.lib.lvk_hip_stab_push_obs(self.handle, src["vf"], src["ptrs"], src["steps"], src["rows"], src["cols"], timestamp,
+                                            dst["ptrs"], dst["steps"], dst["rows"], self._produced_ref, self._ots_ref, None)
+        if rc != 0:
+            self.ctx._check(rc)
+        return (dst["planes"], ots.value) if produced.value else (None, None)
+
     # ---- host-resident frames (FrameIngest::upload_planes ... download_planes, FrameIngest.cpp:415-474,567-602)
     def host_planes(self, rows, cols, nv12=False):
         """One pinned, CONTIGUOUS 4:2:0 frame (the OBS layout): returns numpy views (y, u, v) / (y, uv) of one lvk_hip_host_malloc block."""
