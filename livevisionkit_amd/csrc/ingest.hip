@@ -244,6 +244,100 @@ void k_ingest_444(const uint8_t* __restrict__ p0, int s0, const uint8_t* __restr
         for (int p = 0; p < npx; p++) { uint8_t* d = drow + 3 * (x0 + p); d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16); }
 }
 
+// ---- dword paths of the four kernels above (cols % 4 == 0, >= 8 columns, planes and pitches 4-byte aligned: what OBS delivers): the same arithmetic on
+// whole dwords -- a thread reads its 4 pixels' luma as one dword, its four chroma columns c0 - 1 .. c0 + 2 as one (unaligned) dword per plane or as
+// four pixel-pair dwords of the packed layouts, and writes three packed dwords; no byte-sized memory instruction is left.
+__device__ __forceinline__ void pack4(uint8_t* __restrict__ dst, uint32_t yw, const uint32_t (&u)[4], const uint32_t (&v)[4])
+{
+    uint32_t px[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) px[p] = ((yw >> (8 * p)) & 0xffu) | (u[p] << 8) | (v[p] << 16);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    LVK_STREAM_STORE(d + 0, px[0] | (px[1] << 24)); LVK_STREAM_STORE(d + 1, (px[1] >> 8) | (px[2] << 16)); LVK_STREAM_STORE(d + 2, (px[2] >> 16) | (px[3] << 8));
+}
+
+// chroma of the 4 output columns x0 .. x0 + 3 from the samples s0 .. s3 = columns c0 - 1 .. c0 + 2 (one per byte of w): (other + 3 nearer + 2) >> 2
+__device__ __forceinline__ void up2x(uint32_t w, uint32_t (&o)[4])
+{
+    const uint32_t s0 = w & 0xffu, s1 = (w >> 8) & 0xffu, s2 = (w >> 16) & 0xffu, s3 = w >> 24;
+    const uint32_t m1 = s1 + s1 + s1 + 2u, m2 = s2 + s2 + s2 + 2u;
+    o[0] = (s0 + m1) >> 2; o[1] = (s2 + m1) >> 2; o[2] = (s1 + m2) >> 2; o[3] = (s3 + m2) >> 2;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_ingest_422_dw(const uint8_t* __restrict__ p0, int s0, const uint8_t* __restrict__ p1, int s1, const uint8_t* __restrict__ p2, int s2,
+                     int rows, int cols, uint8_t* __restrict__ dst, int dst_step)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    const int cc = cols >> 1, c0 = x0 >> 1;
+    struct __attribute__((packed, aligned(1))) P4 { uint32_t w; };
+    uint32_t yw, uw, vw;
+    if (LAYOUT == 0)
+    {
+        const bool left = x0 == 0, right = x0 == cols - 4;
+        const int lc = left ? 0 : (right ? cc - 4 : c0 - 1);
+        yw = *reinterpret_cast<const uint32_t*>(p0 + (long)y * s0 + x0);
+        uw = reinterpret_cast<const P4*>(p1 + (long)y * s1 + lc)->w;
+        vw = reinterpret_cast<const P4*>(p2 + (long)y * s2 + lc)->w;
+        if (left)  { uw = (uw << 8) | (uw & 0xffu); vw = (vw << 8) | (vw & 0xffu); }
+        if (right) { uw = (uw >> 8) | (uw & 0xff000000u); vw = (vw >> 8) | (vw & 0xff000000u); }
+    }
+    else
+    {
+        // the pixel pairs c0 - 1 .. c0 + 2, one dword each (Y C Y C or C Y C Y); clamping the pair index replicates the edge samples
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(p0 + (long)y * s0);
+        const uint32_t a = r[max(c0 - 1, 0)], b = r[c0], c = r[c0 + 1], d = r[min(c0 + 2, cc - 1)];
+        constexpr int YS = LAYOUT == 3 ? 8 : 0, CS = LAYOUT == 3 ? 0 : 8;          // bit offset of the first luma / chroma byte of a pair
+        yw = ((b >> YS) & 0xffu) | (((b >> (YS + 16)) & 0xffu) << 8) | (((c >> YS) & 0xffu) << 16) | (((c >> (YS + 16)) & 0xffu) << 24);
+        const uint32_t first = ((a >> CS) & 0xffu) | (((b >> CS) & 0xffu) << 8) | (((c >> CS) & 0xffu) << 16) | (((d >> CS) & 0xffu) << 24);
+        const uint32_t second = ((a >> (CS + 16)) & 0xffu) | (((b >> (CS + 16)) & 0xffu) << 8) | (((c >> (CS + 16)) & 0xffu) << 16) | (((d >> (CS + 16)) & 0xffu) << 24);
+        uw = LAYOUT != 2 ? first : second; vw = LAYOUT != 2 ? second : first;
+    }
+    uint32_t u[4], v[4];
+    up2x(uw, u); up2x(vw, v);
+    pack4(dst + (long)y * dst_step + 3 * x0, yw, u, v);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_ingest_444_dw(const uint8_t* __restrict__ p0, int s0, const uint8_t* __restrict__ p1, int s1, const uint8_t* __restrict__ p2, int s2,
+                     int rows, int cols, uint8_t* __restrict__ dst, int dst_step)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    uint32_t yw, u[4], v[4];
+    if (LAYOUT == 0)
+    {
+        yw = *reinterpret_cast<const uint32_t*>(p0 + (long)y * s0 + x0);
+        const uint32_t uw = *reinterpret_cast<const uint32_t*>(p1 + (long)y * s1 + x0), vw = *reinterpret_cast<const uint32_t*>(p2 + (long)y * s2 + x0);
+#pragma unroll
+        for (int p = 0; p < 4; p++) { u[p] = (uw >> (8 * p)) & 0xffu; v[p] = (vw >> (8 * p)) & 0xffu; }
+    }
+    else
+    {
+        const uint4 q = *reinterpret_cast<const uint4*>(p0 + (long)y * s0 + 4 * (long)x0);      // A Y U V x 4
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        yw = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) { yw |= ((w[p] >> 8) & 0xffu) << (8 * p); u[p] = (w[p] >> 16) & 0xffu; v[p] = w[p] >> 24; }
+    }
+    pack4(dst + (long)y * dst_step + 3 * x0, yw, u, v);
+}
+
+// 4 packed pixels (12 bytes = 3 dwords) -> their channels, one per byte
+__device__ __forceinline__ void unpack4(const uint8_t* __restrict__ src, uint32_t& yw, uint32_t& uw, uint32_t& vw)
+{
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    const uint32_t a = s[0], b = s[1], c = s[2];            // y0 u0 v0 y1 | u1 v1 y2 u2 | v2 y3 u3 v3
+    yw = (a & 0xffu) | ((a >> 24) << 8) | (((b >> 16) & 0xffu) << 16) | (((c >> 8) & 0xffu) << 24);
+    uw = ((a >> 8) & 0xffu) | ((b & 0xffu) << 8) | ((b >> 24) << 16) | (((c >> 16) & 0xffu) << 24);
+    vw = ((a >> 16) & 0xffu) | (((b >> 8) & 0xffu) << 8) | ((c & 0xffu) << 16) | ((c >> 24) << 24);
+}
+
 // packed 444 -> 4:2:2: cv::resize(Size(), 0.5, 1.0, INTER_AREA) on the chroma = saturate_cast<uchar>((a + b) * 0.5f), round half to EVEN
 // (resizeAreaFast_'s generic loop; only the 2 x 2 case has the (s + 2) >> 2 vector kernel).  A thread = one pixel pair.
 __device__ __forceinline__ uint32_t half_even(uint32_t s) { return (s + ((s >> 1) & 1u)) >> 1; }
@@ -283,6 +377,62 @@ void k_egress_444(const uint8_t* __restrict__ src, int src_step, int rows, int c
     const uint8_t* s = src + (long)y * src_step + 3 * (long)x;
     if (LAYOUT == 0) { p0[(long)y * s0 + x] = s[0]; p1[(long)y * s1 + x] = s[1]; p2[(long)y * s2 + x] = s[2]; }
     else *reinterpret_cast<uint32_t*>(p0 + (long)y * s0 + 4 * (long)x) = 255u | ((uint32_t)s[0] << 8) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 24);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_egress_422_dw(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
+                     uint8_t* __restrict__ p0, int s0, uint8_t* __restrict__ p1, int s1, uint8_t* __restrict__ p2, int s2)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    uint32_t yw, uw, vw;
+    unpack4(src + (long)y * src_step + 3 * (long)x0, yw, uw, vw);
+    const uint32_t u0 = half_even((uw & 0xffu) + ((uw >> 8) & 0xffu)), u1 = half_even(((uw >> 16) & 0xffu) + (uw >> 24));
+    const uint32_t v0 = half_even((vw & 0xffu) + ((vw >> 8) & 0xffu)), v1 = half_even(((vw >> 16) & 0xffu) + (vw >> 24));
+    if (LAYOUT == 0)
+    {
+        *reinterpret_cast<uint32_t*>(p0 + (long)y * s0 + x0) = yw;
+        *reinterpret_cast<uint16_t*>(p1 + (long)y * s1 + (x0 >> 1)) = (uint16_t)(u0 | (u1 << 8));
+        *reinterpret_cast<uint16_t*>(p2 + (long)y * s2 + (x0 >> 1)) = (uint16_t)(v0 | (v1 << 8));
+    }
+    else
+    {
+        const uint32_t f0 = LAYOUT != 2 ? u0 : v0, g0 = LAYOUT != 2 ? v0 : u0, f1 = LAYOUT != 2 ? u1 : v1, g1 = LAYOUT != 2 ? v1 : u1;
+        const uint32_t y0 = yw & 0xffu, y1 = (yw >> 8) & 0xffu, y2 = (yw >> 16) & 0xffu, y3 = yw >> 24;
+        uint2 o;
+        if (LAYOUT == 3) { o.x = f0 | (y0 << 8) | (g0 << 16) | (y1 << 24); o.y = f1 | (y2 << 8) | (g1 << 16) | (y3 << 24); }
+        else             { o.x = y0 | (f0 << 8) | (y1 << 16) | (g0 << 24); o.y = y2 | (f1 << 8) | (y3 << 16) | (g1 << 24); }
+        *reinterpret_cast<uint2*>(p0 + (long)y * s0 + 2 * (long)x0) = o;
+    }
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256)
+void k_egress_444_dw(const uint8_t* __restrict__ src, int src_step, int rows, int cols,
+                     uint8_t* __restrict__ p0, int s0, uint8_t* __restrict__ p1, int s1, uint8_t* __restrict__ p2, int s2)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cols || y >= rows) return;
+    uint32_t yw, uw, vw;
+    unpack4(src + (long)y * src_step + 3 * (long)x0, yw, uw, vw);
+    if (LAYOUT == 0)
+    {
+        *reinterpret_cast<uint32_t*>(p0 + (long)y * s0 + x0) = yw;
+        *reinterpret_cast<uint32_t*>(p1 + (long)y * s1 + x0) = uw;
+        *reinterpret_cast<uint32_t*>(p2 + (long)y * s2 + x0) = vw;
+    }
+    else
+    {
+        uint4 o;
+        o.x = 255u | ((yw & 0xffu) << 8) | ((uw & 0xffu) << 16) | ((vw & 0xffu) << 24);
+        o.y = 255u | (((yw >> 8) & 0xffu) << 8) | (((uw >> 8) & 0xffu) << 16) | (((vw >> 8) & 0xffu) << 24);
+        o.z = 255u | (((yw >> 16) & 0xffu) << 8) | (((uw >> 16) & 0xffu) << 16) | (((vw >> 16) & 0xffu) << 24);
+        o.w = 255u | ((yw >> 24) << 8) | ((uw >> 24) << 16) | ((vw >> 24) << 24);
+        *reinterpret_cast<uint4*>(p0 + (long)y * s0 + 4 * (long)x0) = o;
+    }
 }
 
 } // namespace
@@ -374,6 +524,8 @@ int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
     return LVK_HIP_OK;
 }
 
+static inline bool aligned_to(const void* p, int step, unsigned a) { return ((reinterpret_cast<uintptr_t>(p) | (uintptr_t)step) & (a - 1)) == 0; }
+
 // FrameIngest::Select's switch (FrameIngest.cpp:36-75) as one pair of launchers.  video_format = libobs' enum video_format (LVK_VIDEO_FORMAT_*).
 int lvk_launch_ingest_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* const d_planes[3], const int steps[3],
                           int rows, int cols, void* d_dst, int dst_step)
@@ -390,21 +542,36 @@ int lvk_launch_ingest_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format
         return lvk_launch_ingest_yuv420(ctx, stream, p0, steps[0], p1, steps[1], nullptr, 0, 1, rows, cols, d_dst, dst_step);
     case LVK_VIDEO_FORMAT_I422: case LVK_VIDEO_FORMAT_I42A:
         LVK_HIP_REQUIRE(ctx, p1 && p2 && (cols & 1) == 0 && steps[0] >= cols && steps[1] >= cols / 2 && steps[2] >= cols / 2 && dst_step >= 3 * cols);
-        hipLaunchKernelGGL(k_ingest_422<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        if (fast && cols % 4 == 0 && cols >= 8 && aligned_to(p0, steps[0], 4))
+            hipLaunchKernelGGL(k_ingest_422_dw<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step);
+        else
+            hipLaunchKernelGGL(k_ingest_422<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step, fast);
         break;
     case LVK_VIDEO_FORMAT_YUY2: case LVK_VIDEO_FORMAT_YVYU: case LVK_VIDEO_FORMAT_UYVY:
         LVK_HIP_REQUIRE(ctx, (cols & 1) == 0 && steps[0] >= 2 * cols && dst_step >= 3 * cols);
-        if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_ingest_422<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        if (fast && cols % 4 == 0 && aligned_to(p0, steps[0], 4))
+        {
+            if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_ingest_422_dw<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step);
+            else if (video_format == LVK_VIDEO_FORMAT_YVYU) hipLaunchKernelGGL(k_ingest_422_dw<2>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step);
+            else hipLaunchKernelGGL(k_ingest_422_dw<3>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step);
+        }
+        else if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_ingest_422<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
         else if (video_format == LVK_VIDEO_FORMAT_YVYU) hipLaunchKernelGGL(k_ingest_422<2>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
         else hipLaunchKernelGGL(k_ingest_422<3>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
         break;
     case LVK_VIDEO_FORMAT_I444: case LVK_VIDEO_FORMAT_YUVA:
         LVK_HIP_REQUIRE(ctx, p1 && p2 && steps[0] >= cols && steps[1] >= cols && steps[2] >= cols && dst_step >= 3 * cols);
-        hipLaunchKernelGGL(k_ingest_444<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        if (fast && cols % 4 == 0 && aligned_to(p0, steps[0], 4) && aligned_to(p1, steps[1], 4) && aligned_to(p2, steps[2], 4))
+            hipLaunchKernelGGL(k_ingest_444_dw<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step);
+        else
+            hipLaunchKernelGGL(k_ingest_444<0>, grid, block, 0, stream, p0, steps[0], p1, steps[1], p2, steps[2], rows, cols, (uint8_t*)d_dst, dst_step, fast);
         break;
     case LVK_VIDEO_FORMAT_AYUV:
         LVK_HIP_REQUIRE(ctx, steps[0] >= 4 * cols && dst_step >= 3 * cols);
-        hipLaunchKernelGGL(k_ingest_444<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
+        if (fast && cols % 4 == 0 && aligned_to(p0, steps[0], 16))
+            hipLaunchKernelGGL(k_ingest_444_dw<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step);
+        else
+            hipLaunchKernelGGL(k_ingest_444<1>, grid, block, 0, stream, p0, steps[0], p0, 0, p0, 0, rows, cols, (uint8_t*)d_dst, dst_step, fast);
         break;
     case LVK_VIDEO_FORMAT_Y800:                                   // DirectIngest: upload_planes(src, 1).copyTo(dst)
         LVK_HIP_REQUIRE(ctx, steps[0] >= cols && dst_step >= cols);
@@ -441,24 +608,39 @@ int lvk_launch_egress_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format
         return lvk_launch_egress_yuv420(ctx, stream, d_src, src_step, rows, cols, p0, steps[0], p1, steps[1], nullptr, 0, 1);
     case LVK_VIDEO_FORMAT_I422: case LVK_VIDEO_FORMAT_I42A:
         LVK_HIP_REQUIRE(ctx, p1 && p2 && (cols & 1) == 0 && steps[0] >= cols && steps[1] >= cols / 2 && steps[2] >= cols / 2 && src_step >= 3 * cols);
-        hipLaunchKernelGGL(k_egress_422<0>, dim3((cols / 2 + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
+        if (cols % 4 == 0 && aligned_to(src, src_step, 4) && aligned_to(p0, steps[0], 4) && aligned_to(p1, steps[1], 2) && aligned_to(p2, steps[2], 2))
+            hipLaunchKernelGGL(k_egress_422_dw<0>, dim3((cols + 255) / 256, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
+        else
+            hipLaunchKernelGGL(k_egress_422<0>, dim3((cols / 2 + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
         break;
     case LVK_VIDEO_FORMAT_YUY2: case LVK_VIDEO_FORMAT_YVYU: case LVK_VIDEO_FORMAT_UYVY:
     {
         LVK_HIP_REQUIRE(ctx, (cols & 1) == 0 && steps[0] >= 2 * cols && src_step >= 3 * cols);
-        const dim3 grid((cols / 2 + 63) / 64, (rows + 3) / 4);
-        if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_egress_422<1>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        const dim3 grid((cols / 2 + 63) / 64, (rows + 3) / 4), grid4((cols + 255) / 256, (rows + 3) / 4);
+        if (cols % 4 == 0 && aligned_to(src, src_step, 4) && aligned_to(p0, steps[0], 8))
+        {
+            if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_egress_422_dw<1>, grid4, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+            else if (video_format == LVK_VIDEO_FORMAT_YVYU) hipLaunchKernelGGL(k_egress_422_dw<2>, grid4, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+            else hipLaunchKernelGGL(k_egress_422_dw<3>, grid4, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        }
+        else if (video_format == LVK_VIDEO_FORMAT_YUY2) hipLaunchKernelGGL(k_egress_422<1>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
         else if (video_format == LVK_VIDEO_FORMAT_YVYU) hipLaunchKernelGGL(k_egress_422<2>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
         else hipLaunchKernelGGL(k_egress_422<3>, grid, block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
         break;
     }
     case LVK_VIDEO_FORMAT_I444: case LVK_VIDEO_FORMAT_YUVA:
         LVK_HIP_REQUIRE(ctx, p1 && p2 && steps[0] >= cols && steps[1] >= cols && steps[2] >= cols && src_step >= 3 * cols);
-        hipLaunchKernelGGL(k_egress_444<0>, dim3((cols + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
+        if (cols % 4 == 0 && aligned_to(src, src_step, 4) && aligned_to(p0, steps[0], 4) && aligned_to(p1, steps[1], 4) && aligned_to(p2, steps[2], 4))
+            hipLaunchKernelGGL(k_egress_444_dw<0>, dim3((cols + 255) / 256, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
+        else
+            hipLaunchKernelGGL(k_egress_444<0>, dim3((cols + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p1, steps[1], p2, steps[2]);
         break;
     case LVK_VIDEO_FORMAT_AYUV:
         LVK_HIP_REQUIRE(ctx, steps[0] >= 4 * cols && (steps[0] & 3) == 0 && (reinterpret_cast<uintptr_t>(p0) & 3u) == 0 && src_step >= 3 * cols);
-        hipLaunchKernelGGL(k_egress_444<1>, dim3((cols + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        if (cols % 4 == 0 && aligned_to(src, src_step, 4) && aligned_to(p0, steps[0], 16))
+            hipLaunchKernelGGL(k_egress_444_dw<1>, dim3((cols + 255) / 256, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
+        else
+            hipLaunchKernelGGL(k_egress_444<1>, dim3((cols + 63) / 64, (rows + 3) / 4), block, 0, stream, src, src_step, rows, cols, p0, steps[0], p0, 0, p0, 0);
         break;
     case LVK_VIDEO_FORMAT_Y800:
         LVK_HIP_REQUIRE(ctx, steps[0] >= cols && src_step >= cols);
