@@ -1019,7 +1019,7 @@ def main():
             except Exception as e:
                 configs.append({"workload": label_, "error": repr(e)})
         # a source that is not 4:2:0 (what a capture card delivers): the plugin's whole path through lvk_hip_stab_push_obs -- P422Ingest::to_ocl, the
-        # filter, ::to_obs (FrameIngest.cpp:604-666); its remap leaves through the packed buffer and the format's egress kernel
+        # filter, ::to_obs (FrameIngest.cpp:604-666); its remap writes the UYVY pairs itself (csrc/remap_obs.hip)
         label_ = "1920x1080 UYVY (packed 4:2:2) through lvk_hip_stab_push_obs, OBS 'homography' preset"
         try:
             configs.append(config_leg(lvk, local_rank, device, 1080, 1920, "homography", "off", label_, seed0 + 102, fmt="uyvy"))

@@ -353,4 +353,8 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
                                   const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens,
-                                  bool co_scheduled);          // co_scheduled: the persistent grid of the overlap mode
+                                  bool co_scheduled);
+bool lvk_remap_obs_fusable(int video_format);
+int lvk_launch_warpmesh_apply_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* d_src, int src_step, int rows, int cols,
+                                  void* const planes[3], const int steps[3], const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
+                                  const LensArgs* lens, bool co);          // co_scheduled: the persistent grid of the overlap mode

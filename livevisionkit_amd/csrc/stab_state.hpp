@@ -74,7 +74,9 @@ struct QueuedFrame { const void* d_ptr; int step, rows, cols; uint64_t ts; int f
 
 
 // planes of a 4:2:0 output: when given, a warped frame leaves through the fused remap + egress kernel instead of d_out
-struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; int rows_cap = 0; };
+// the caller's output planes of the plane entries.  vf == 0: I420 / NV12 (y, u, v, nv12); vf != 0: another OBS video format whose egress is fused into the
+// remap (lvk_launch_warpmesh_apply_obs): planes / steps as FrameIngest::to_obs writes them, their geometry checked by lvk_stab_push_planes
+struct OutPlanes420 { void* y; int y_step; void* u; int u_step; void* v; int v_step; int nv12; bool used; int rows_cap = 0; int vf = 0; void* p[3] = {nullptr, nullptr, nullptr}; int s[3] = {0, 0, 0}; };
 
 } // namespace lvkstab
 

@@ -394,8 +394,9 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         {
             const bool to_planes = o420 && o420->y && (st->s.stabilize_output || st->s.crop_to_stable_region || st->lens);      // (the fused remap + egress kernel)
             // (4:2:0 entries: the planes take the frame whichever route it leaves by -- the fused kernel, or the packed buffer + the egress kernel)
-            const bool planes_fit = !o420 || (o420->y && o420->y_step >= due.cols && o420->u_step >= (o420->nv12 ? due.cols : due.cols / 2) &&
-                                              (o420->nv12 || o420->v_step >= due.cols / 2) && o420->rows_cap >= due.rows);
+            const bool planes_fit = !o420 || o420->vf != 0 ||
+                                    (o420->y && o420->y_step >= due.cols && o420->u_step >= (o420->nv12 ? due.cols : due.cols / 2) &&
+                                     (o420->nv12 || o420->v_step >= due.cols / 2) && o420->rows_cap >= due.rows);
             const bool fits = planes_fit && (to_planes || (d_out != nullptr && out_step >= 3 * due.cols && out_rows >= due.rows));
             if (!fits)
                 return ctx->fail(LVK_HIP_ERR_ARG, "the output buffer does not hold the frame this push emits: " + std::to_string(due.cols) + " x " + std::to_string(due.rows) +
@@ -457,7 +458,12 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
                 std::memcpy(lens_other.f, m.f, sizeof(lens_other.f)); lens_args = &lens_other;
             }
         }
-        if (mesh && o420 && o420->y)
+        if (mesh && o420 && o420->y && o420->vf != 0)
+        {
+            rc = lvk_launch_warpmesh_apply_obs(ctx, rs, o420->vf, f.d_ptr, f.step, f.rows, f.cols, o420->p, o420->s, mesh->off.data(), mesh->rows, mesh->cols, bg, lens_args, persistent);
+            o420->used = true;
+        }
+        else if (mesh && o420 && o420->y)
         {
             rc = lvk_launch_warpmesh_apply_420(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, o420->y, o420->y_step, o420->u, o420->u_step, o420->v, o420->v_step,
                                                o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, lens_args, persistent);
@@ -783,6 +789,8 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
     st->pool_frames = side_ingest;
     OutPlanes420 o420{o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12, false, o_rows};
     if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
+    const bool fused_obs = !is420 && lvk_remap_obs_fusable(vf) && op[0];
+    if (fused_obs) { o420.vf = vf; o420.y = op[0]; for (int i = 0; i < 3; i++) { o420.p[i] = op[i]; o420.s[i] = os[i]; } }
     (void)d_y; (void)y_step;
     // (the packed route's buffer: pool_out, tight rows, as many as its allocation holds at the widest queued frame)
     lvk_frame_info info{0, 0, 0};
@@ -792,7 +800,7 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
         const int out_cols = will ? due.cols : cols;
         rc = lvk_stab_push_impl(st, slot, 3 * cols, rows, cols, timestamp, frame_format, direct ? slot : (const void*)luma, direct ? 3 * cols : luma_step, direct ? 3 : luma_pix,
                                 st->pool_out, 3 * out_cols, (int)(st->pool_out_bytes / ((size_t)3 * out_cols)), &prod, out_timestamp, &released,
-                                is420 ? &o420 : nullptr, &info);
+                                (is420 || fused_obs) ? &o420 : nullptr, &info);
     }
     {
         // a push that was refused (or failed before the frame was queued) has not taken the slot: its conversion is not launched, the slot is free again

@@ -166,14 +166,18 @@ def _obs_stream(oracle, fmt, clip):
 
 
 @pytest.mark.parametrize("overlap", [False, True])
-@pytest.mark.parametrize("fmt", ["I422", "I444", "YUY2", "YVYU", "UYVY", "AYUV", "BGR3", "I42A", "NV12", "I420"])
-def test_push_obs_equals_oracle_ingest_filter_egress(ctx, oracle, fmt, overlap):
+@pytest.mark.parametrize("fmt,size,preset", [(f, (270, 480), "homography") for f in ("I422", "I444", "YUY2", "YVYU", "UYVY", "AYUV", "BGR3", "I42A", "NV12", "I420")] +
+                         [(f, (146, 258), "homography") for f in ("I422", "I444", "UYVY", "YUY2", "AYUV")] +                 # ragged: tails of 2 pixels, rows at odd alignments
+                         [(f, (270, 480), "field") for f in ("UYVY", "I444", "I422")])                                       # the mesh kernels' fused sinks
+def test_push_obs_equals_oracle_ingest_filter_egress(ctx, oracle, fmt, size, preset, overlap):
+    """(the formats with a fused remap + egress kernel -- 4:2:2, 4:4:4, AYUV -- leave through it whenever the remap runs, and through the packed buffer +
+    egress kernel on the frames the filter passes through: both routes are in every one of these streams)"""
     import livevisionkit_amd as lvk
     from tests import oracle_lib, synth
     from tests.test_stabilizer_gpu import _to_settings
-    rows, cols, n = 270, 480, 12
+    (rows, cols), n = size, 12
     clip, _ = synth.make_clip(rows, cols, n, seed=41, jitter=1.0)
-    s = oracle_lib.preset("homography", predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
+    s = oracle_lib.preset(preset, predictive_samples=3, min_scene_quality=0.3, min_tracking_quality=0.2)
     ost = oracle_lib.OracleStabilizer(oracle, s)
     gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
     gst.set_overlap(overlap)
