@@ -699,7 +699,6 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
     std::array<void*, 3> op{nullptr, nullptr, nullptr}; std::array<int, 3> os{0, 0, 0};
     if (out_planes && out_steps) { op = {out_planes[0], out_planes[1], out_planes[2]}; os = {out_steps[0], out_steps[1], out_steps[2]}; }
     // (the names of the 4:2:0 route)
-    const void* d_y = ip[0]; const int y_step = is_[0];
     void* o_y = op[0]; void* o_u = op[1]; void* o_v = nv12 ? op[1] : op[2];
     const int oy_step = os[0], ou_step = os[1], ov_step = nv12 ? os[1] : os[2];
     // where the tracker reads its luma (VideoFrame::viewAsFormat(GRAY), VideoFrame.cpp:260): the caller's Y plane / the Y bytes of the packed formats; the
@@ -791,7 +790,6 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
     if (!(o_y && o_u && (nv12 || o_v))) o420.y = nullptr;
     const bool fused_obs = !is420 && lvk_remap_obs_fusable(vf) && op[0];
     if (fused_obs) { o420.vf = vf; o420.y = op[0]; for (int i = 0; i < 3; i++) { o420.p[i] = op[i]; o420.s[i] = os[i]; } }
-    (void)d_y; (void)y_step;
     // (the packed route's buffer: pool_out, tight rows, as many as its allocation holds at the widest queued frame)
     lvk_frame_info info{0, 0, 0};
     {
