@@ -35,8 +35,64 @@ static int plane_table(int fmt, int rows, int cols, int prow[3], int pbytes[3], 
     return 0;
 }
 
+// The plugin's asynchronous path with the facade's classes (Modules/OBS-Plugin/Interop/VisionFilter.cpp:151-253 around VSFilter.cpp:352-364):
+//   ingest->upload_obs_frame(obs frame, frame); filter.apply(std::move(frame), frame); if (!frame.empty()) ingest->download_ocl_frame(frame, obs frame)
+// usage: frame_ingest_facade --stream <obs format> <rows> <cols> <n frames> <delay> <planes.bin> <out.bin>     (planes.bin: n frames' tight planes; out.bin: the emitted ones)
+static int run_stream(int argc, char** argv)
+{
+    if (argc < 9) return 2;
+    const int fmt = std::atoi(argv[2]), rows = std::atoi(argv[3]), cols = std::atoi(argv[4]), n = std::atoi(argv[5]), delay = std::atoi(argv[6]);
+    int prow[3], pbytes[3], pwritten[3];
+    const int np = plane_table(fmt, rows, cols, prow, pbytes, pwritten);
+    size_t frame_bytes = 0;
+    for (int i = 0; i < np; i++) frame_bytes += (size_t)prow[i] * pbytes[i];
+    std::vector<uint8_t> clip(frame_bytes * n), back(frame_bytes);
+    FILE* f = std::fopen(argv[7], "rb");
+    if (!f || std::fread(clip.data(), 1, clip.size(), f) != clip.size()) return 2;
+    std::fclose(f);
+    FILE* out = std::fopen(argv[8], "wb");
+    if (!out) return 2;
+    auto ingest = lvk::FrameIngest::Select(fmt);
+    if (!ingest) return 1;
+    lvk::StabilizationFilter filter;                         // the plugin's order: a default-constructed filter, then the preset (VSFilter.cpp:235-294)
+    filter.reconfigure([&](lvk::StabilizationFilterSettings& s) {
+        s.detection_resolution = {480, 270}; s.detection_regions = {2, 1}; s.motion_resolution = {2, 2};
+        s.acceptance_threshold = 3.0f; s.track_local_motions = false;
+        s.max_feature_density = 0.12f; s.min_feature_density = 0.04f; s.accumulation_rate = 3.0f;
+        s.corrective_limits = {0.05f, 0.05f}; s.crop_to_stable_region = true; s.background_colour = {105, 212, 235};
+        s.predictive_samples = (size_t)delay; s.min_scene_quality = 0.3f; s.min_tracking_quality = 0.2f;
+    });
+    lvk::Frame frame;
+    int emitted = 0;
+    for (int k = 0; k < n; k++)
+    {
+        fake_obs_source_frame obs;
+        obs.width = cols; obs.height = rows; obs.format = fmt; obs.timestamp = 500 + k;
+        uint8_t* p = clip.data() + frame_bytes * k;
+        for (int i = 0; i < np; i++) { obs.data[i] = p; obs.linesize[i] = pbytes[i]; p += (size_t)prow[i] * pbytes[i]; }
+        ingest->upload_obs_frame(&obs, frame);
+        filter.apply(std::move(frame), frame);
+        if (frame.empty()) continue;
+        if (frame.timestamp != (uint64_t)(500 + k - delay)) { std::fprintf(stderr, "timestamp\n"); return 1; }
+        // the plugin downloads into the OBS frame it re-associates by timestamp (VisionFilter.cpp:232-253): here a scratch frame of the same layout
+        fake_obs_source_frame dst;
+        dst.width = cols; dst.height = rows; dst.format = fmt;
+        std::fill(back.begin(), back.end(), 0x5A);
+        p = back.data();
+        for (int i = 0; i < np; i++) { dst.data[i] = p; dst.linesize[i] = pbytes[i]; p += (size_t)prow[i] * pbytes[i]; }
+        ingest->download_ocl_frame(frame, &dst);
+        if (dst.timestamp != frame.timestamp) return 1;
+        std::fwrite(back.data(), 1, back.size(), out);
+        emitted++;
+    }
+    std::fclose(out);
+    std::printf("stream ok: %d frames\n", emitted);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "--stream") return run_stream(argc, argv);
     if (argc < 7) { std::fprintf(stderr, "usage\n"); return 2; }
     const int fmt = std::atoi(argv[1]), rows = std::atoi(argv[2]), cols = std::atoi(argv[3]);
     int pad = std::atoi(argv[4]);

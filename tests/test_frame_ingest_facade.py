@@ -50,3 +50,36 @@ def test_facade_frame_ingest_every_format(tmp_path, oracle):
             for b in back:
                 assert np.array_equal(raw[off:off + b.size].reshape(b.shape), b), (name, rows, cols)
                 off += b.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["UYVY", "I444", "I420", "BGR3"])
+def test_facade_ingest_filter_download_chain(tmp_path, oracle, name):
+    """upload_obs_frame -> StabilizationFilter::apply(std::move(frame), frame) -> download_ocl_frame, the plugin's asynchronous path with the facade's
+    classes (Interop/VisionFilter.cpp:151-253 around VSFilter.cpp:352-364), against the oracle's ingest -> filter -> egress."""
+    from tests import oracle_lib, synth
+    exe = _build(tmp_path)
+    rows, cols, n, delay = 270, 480, 12, 3
+    clip, _ = synth.make_clip(rows, cols, n, seed=53, jitter=1.0)
+    fmt = FORMATS[name]
+    ffmt = {"BGR3": 0}.get(name, 4)
+    s = oracle_lib.preset("homography", predictive_samples=delay, min_scene_quality=0.3, min_tracking_quality=0.2)
+    ost = oracle_lib.OracleStabilizer(oracle, s)
+    want = []
+    with open(tmp_path / "clip.bin", "wb") as f:
+        for i, fr in enumerate(clip):
+            planes = oracle.egress_obs(name, fr)
+            for p in planes:
+                f.write(p.tobytes())
+            w, wts = ost.push(oracle.ingest_obs(name, planes), ts=i, fmt=ffmt)
+            if w is not None:
+                want.append(np.concatenate([p.reshape(-1) for p in oracle.egress_obs(name, w, planes=[np.full_like(p, 0x5A) for p in planes])]))
+    r = subprocess.run([exe, "--stream", str(fmt), str(rows), str(cols), str(n), str(delay), str(tmp_path / "clip.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and f"stream ok: {len(want)} frames" in r.stdout, (r.stdout, r.stderr)
+    got = np.fromfile(tmp_path / "out.bin", np.uint8)
+    assert got.size == sum(w.size for w in want)
+    off = 0
+    for k, w in enumerate(want):
+        assert np.array_equal(got[off:off + w.size], w), (name, k)
+        off += w.size
