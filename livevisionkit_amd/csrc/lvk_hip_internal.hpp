@@ -114,7 +114,8 @@ struct lvk_device_guard
 
 // Instrumented kernels (in-kernel clocks, printf) never go into the product library: the defines below are only accepted together with
 // -DLVK_PROBE_BUILD, which scripts/variant_build.sh passes for the variants under livevisionkit_amd/variants/ (round-4 ADVICE).
-#if (defined(LVK_TIMELINE) || defined(LVK_RANSAC_TIMING) || defined(LVK_MESH_TIMING)) && !defined(LVK_PROBE_BUILD)
+// (the same for kernels that are NOT bit-exact: LVK_EASU_TOLERANT, the tolerance-mode A / B partner of the remap -- remap_core.hpp)
+#if (defined(LVK_TIMELINE) || defined(LVK_RANSAC_TIMING) || defined(LVK_MESH_TIMING) || defined(LVK_EASU_TOLERANT)) && !defined(LVK_PROBE_BUILD)
 #error "instrumented build: pass -DLVK_PROBE_BUILD (scripts/variant_build.sh); never the library the tests and the bench load by default"
 #endif
 

@@ -63,9 +63,17 @@ __device__ __forceinline__ F3 unpack3(uint32_t lo_bytes)   // bytes 0,1,2 of the
 {
     const float norm_factor = 0.00392156862f;               // FSR.cl:205
     F3 r;
+#if defined(LVK_EASU_TOLERANT) && LVK_EASU_TOLERANT >= 2
+    // (tolerance-mode A / B partner, level 2, never the product build: the colours stay in 0 .. 255, only the luma is normalised -- easu_core below)
+    (void)norm_factor;
+    r.x = (float)(lo_bytes & 0xffu);
+    r.y = (float)((lo_bytes >> 8) & 0xffu);
+    r.z = (float)((lo_bytes >> 16) & 0xffu);
+#else
     r.x = (float)(lo_bytes & 0xffu) * norm_factor;
     r.y = (float)((lo_bytes >> 8) & 0xffu) * norm_factor;
     r.z = (float)((lo_bytes >> 16) & 0xffu) * norm_factor;
+#endif
     return r;
 }
 
@@ -73,7 +81,13 @@ template <bool YUV>
 __device__ __forceinline__ float luma(const F3& p)
 {
     // FSR.cl:229-241 (the YUV program is the one that uses the 3-channel pseudo luma)
+#if defined(LVK_EASU_TOLERANT) && LVK_EASU_TOLERANT >= 2
+    // the direction analysis keeps the reference's scale: its bit-trick reciprocals (rcp_lo / rsq_lo) have a mantissa-dependent error of several
+    // percent, so an analysis on 255 x the luma would shape other kernels (> 1 LSB on edges); 0.5 x + y + 0.5 z is exact on bytes, one rounding follows
+    return (YUV ? fma_(p.z, 0.5f, fma_(p.x, 0.5f, p.y)) : p.x) * 0.00392156862f;
+#else
     return YUV ? fma_(p.z, 0.5f, fma_(p.x, 0.5f, p.y)) : p.x;
+#endif
 }
 
 __device__ __forceinline__ void accumulate(float& dirx, float& diry, float& len, float w,
@@ -170,6 +184,58 @@ __device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, flo
     const F3 mi4{ min_(f.x, min_(g.x, min_(j.x, k.x))), min_(f.y, min_(g.y, min_(j.y, k.y))), min_(f.z, min_(g.z, min_(j.z, k.z))) };
     const F3 ma4{ max_(f.x, max_(g.x, max_(j.x, k.x))), max_(f.y, max_(g.y, max_(j.y, k.y))), max_(f.z, max_(g.z, max_(j.z, k.z))) };
 
+#ifdef LVK_EASU_TOLERANT
+    // Tolerance-mode A / B partner (SURVEY 8c allows <= 1 LSB / PSNR >= 50 dB for the remap), measured in round 6 and NOT shipped: level 1 (the two regroupings
+    // below) is within 1 LSB everywhere and 6-7 % faster, level 2 (raw colours as well) 10 % faster and up to 22 LSB off where the reference's analysis
+    // amplifies the rounding noise of its own normalisation (profiles/r06_ab_remap_tolerant.txt).  Same 12 taps, same window,
+    // algebraically regrouped -- not the reference's operation sequence:
+    //   * a tap's distance d2 = |diag(len2) R(dir) off|^2 is a quadratic form in off = (i - ppx, j - ppy): d2 = (q11 ox + 2 q12 oy) ox + q22 oy^2, two
+    //     fused multiply-adds per tap over per-row / per-pixel terms instead of rotate (2) + scale (2) + square (2);
+    //   * the window (25/16 (2/5 u - 1)^2 - 9/16) (lob u - 1)^2 = ((u / 4 - 5 / 4) u + 1) (lob u - 1)^2: five operations instead of six;
+    //   * the colours stay in 0 .. 255 (36 normalising multiplies fewer, 12 for the luma more); the closing x 255 becomes x (norm_factor x 255), which
+    //     maps every integer exactly as the reference's round trip does (k -> k - 1 for k >= 1: 0.00392156862f is below 1 / 255).
+    F3 aC{0.0f, 0.0f, 0.0f};
+    float aW = 0.0f;
+    {
+        const float a = len2x * dirx, b = len2x * diry, c = len2y * diry, d = len2y * dirx;      // rows of diag(len2) R: (a, b), (-c, d)
+        const float q11 = fma_(a, a, c * c), q22 = fma_(b, b, d * d);
+        const float q12 = fma_(a, b, -(c * d));
+        const float q12x2 = q12 + q12;
+        const float ox[4] = {-1.0f - ppx, 0.0f - ppx, 1.0f - ppx, 2.0f - ppx};
+        const float oy[4] = {-1.0f - ppy, 0.0f - ppy, 1.0f - ppy, 2.0f - ppy};
+        float E[4], B[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { E[j] = q12x2 * oy[j]; B[j] = (q22 * oy[j]) * oy[j]; }
+#define LVK_TAP(I, J, T)                                                                   \
+        {                                                                                  \
+            const float u = min_(fma_(fma_(q11, ox[I], E[J]), ox[I], B[J]), clp);          \
+            const float sA = fma_(lob, u, -1.0f);                                          \
+            const float qB = fma_(fma_(u, 0.25f, -1.25f), u, 1.0f);                        \
+            const float w = qB * (sA * sA);                                                \
+            aC.x = fma_(t[T].x, w, aC.x);                                                  \
+            aC.y = fma_(t[T].y, w, aC.y);                                                  \
+            aC.z = fma_(t[T].z, w, aC.z);                                                  \
+            aW += w;                                                                       \
+        }
+        LVK_TAP(1, 0, TB) LVK_TAP(2, 0, TC)
+        LVK_TAP(0, 1, TE) LVK_TAP(1, 1, TF) LVK_TAP(2, 1, TG) LVK_TAP(3, 1, TH_)
+        LVK_TAP(0, 2, TI) LVK_TAP(1, 2, TJ) LVK_TAP(2, 2, TK) LVK_TAP(3, 2, TL)
+        LVK_TAP(1, 3, TN) LVK_TAP(2, 3, TO)
+#undef LVK_TAP
+    }
+    const float rW = rcp_native(aW);
+#if LVK_EASU_TOLERANT >= 2
+    const float out_scale = 0.99999994f;            // float(0.00392156862f * 255): trunc(k * out_scale) == trunc((k * norm_factor) * 255) for every byte k
+#else
+    const float out_scale = 255.0f;                 // level 1: the taps are normalised as in the reference
+#endif
+    const float px = clamp3_(aC.x * rW, mi4.x, ma4.x);
+    const float py = clamp3_(aC.y * rW, mi4.y, ma4.y);
+    const float pz = clamp3_(aC.z * rW, mi4.z, ma4.z);
+    const uint32_t ux = (uint32_t)(int)(px * out_scale) & 0xffu;
+    const uint32_t uy = (uint32_t)(int)(py * out_scale) & 0xffu;
+    const uint32_t uz = (uint32_t)(int)(pz * out_scale) & 0xffu;
+#else
     // FSR.cl:299-313
     F3 aC{0.0f, 0.0f, 0.0f};
     float aW = 0.0f;
@@ -198,6 +264,7 @@ __device__ __forceinline__ uint32_t easu_core(const float4 t[12], float ppx, flo
     const uint32_t ux = (uint32_t)(int)(px * 255.0f) & 0xffu;
     const uint32_t uy = (uint32_t)(int)(py * 255.0f) & 0xffu;
     const uint32_t uz = (uint32_t)(int)(pz * 255.0f) & 0xffu;
+#endif
     return ux | (uy << 8) | (uz << 16);
 }
 
