@@ -350,14 +350,6 @@ int  lvk_hip_stab_prefetch_cancel(lvk_hip_stab* stab);
  * next push is safe (same stream).  Frames dropped outside a push (queue shrunk by configure, mode toggled) come back through
  * *released of the following pushes. */
 int  lvk_hip_stab_set_overlap(lvk_hip_stab* stab, int enable);
-/* Optional, overlap mode only: the caller LENDS the device planes of lvk_hip_stab_push_yuv420 (I420 / NV12) to the filter until the NEXT push of this
- * filter has returned (or lvk_hip_sync / lvk_hip_stab_restart / destroy) instead of getting them back when the call returns -- the reference's ownership:
- * VideoFilter::apply(std::move(frame), ..) moves the input into the filter's queue (StabilizationFilter.cpp:118).  What it buys: for a free-running caller
- * the 4:2:0 -> 4:4:4 conversion of the new frame no longer is a kernel of its own in the cycle of either stream -- it runs as side work INSIDE the output
- * remap of the delayed frame (that kernel is VALU-bound and leaves the memory pipes idle; lvk_hip_warpmesh_apply_yuv420_ingest), one launch per frame
- * on the bulk stream.  Same pixels.  A caller that overwrites or frees the planes earlier than that gets undefined frames; a caller that waits for every
- * frame is scheduled as before.  Default off; the C++ facade keeps a reference to the input frame and switches it on. */
-int  lvk_hip_stab_set_input_borrow(lvk_hip_stab* stab, int enable);
 /* The same mode on a stream the caller owns: the bulk kernels run on the stream of `bulk` (a second context on the same device; NULL
  * switches overlap off).  For hosts whose output frames outlive the stabilizer or feed stream-ordered consumers: outputs belong to `bulk`. */
 int  lvk_hip_stab_set_bulk_context(lvk_hip_stab* stab, lvk_hip_ctx* bulk);
@@ -401,20 +393,8 @@ long long lvk_hip_stab_lookahead_frames(lvk_hip_stab* stab);
 #define LVK_SCHED_WAIT_SIGNAL_WORD    7   /* chain completions taken from the host signal word ... */
 #define LVK_SCHED_WAIT_EVENT          8   /* ... from hipEventSynchronize / hipStreamSynchronize */
 #define LVK_SCHED_WAIT_WORD_TIMEOUT   9   /* signal-word waits that fell through to the event / stream wait (bounded spin) */
-#define LVK_SCHED_INGEST_FUSED       10   /* ... as side work of the output remap (input-borrow mode, lvk_hip_stab_set_input_borrow) */
-#define LVK_SCHED_COUNT              11
+#define LVK_SCHED_COUNT              10
 int  lvk_hip_stab_schedule_counters(lvk_hip_stab* stab, long long out[LVK_SCHED_COUNT], int reset);
-
-/* lvk_hip_warpmesh_apply_yuv420 with the 4:2:0 -> packed 4:4:4 conversion (lvk_hip_ingest_yuv420) of ANOTHER frame as side work of the SAME launch: the
- * remap is VALU-bound, the conversion memory-bound, and the blocks of the one kernel run conversion units between their strips (what
- * lvk_hip_stab_push_yuv420 launches in input-borrow mode, lvk_hip_stab_set_input_borrow).  in_*: planes of the same layout (nv12) as the output's, dword
- * aligned luma and d_new, in_cols % 4 == 0, in_cols >= 16; d_new != d_src.  Both results bit-identical to the two separate calls.  co != 0: the
- * persistent grid of the overlap mode.  For the parity tests and scripts/bench_remap.py. */
-int  lvk_hip_warpmesh_apply_yuv420_ingest(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
-                                          void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
-                                          const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
-                                          const void* in_y, int in_y_step, const void* in_u, int in_u_step, const void* in_v, int in_v_step, int in_rows, int in_cols,
-                                          void* d_new, int new_step, int co);
 
 int  lvk_hip_stab_get_stats(const lvk_hip_stab* stab, lvk_stab_stats* out);
 /* Frames on which FeatureDetector::detect ran FAST so far (Vision/FeatureDetector.cpp:125-157), by where the corners went through the

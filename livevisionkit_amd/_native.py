@@ -57,9 +57,6 @@ _SIG = {
                                         _c.POINTER(_c.c_uint8), _c.c_int, _c.c_int]),
     "lvk_hip_warpmesh_apply_yuv420": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int,
                                                  _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8)]),
-    "lvk_hip_warpmesh_apply_yuv420_ingest": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int,
-                                                        _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8),
-                                                        _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int]),
     "lvk_hip_warpmesh_apply": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                           _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.POINTER(_c.c_uint8), _c.c_int]),
     "lvk_hip_luma_area_resize": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _c.c_int]),
@@ -110,7 +107,6 @@ _SIG = {
     "lvk_hip_stab_get_meshes": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _c.c_int]),
     "lvk_hip_stab_get_features": (_c.c_int, [_P, _c.POINTER(_c.c_float), _c.c_int]),
     "lvk_hip_stab_set_overlap": (_c.c_int, [_P, _c.c_int]),
-    "lvk_hip_stab_set_input_borrow": (_c.c_int, [_P, _c.c_int]),
     "lvk_hip_stab_set_bulk_context": (_c.c_int, [_P, _P]),
     "lvk_hip_stab_set_profiling": (_c.c_int, [_P, _c.c_int]),
     "lvk_hip_stab_get_profile": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_longlong)]),

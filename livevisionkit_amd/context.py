@@ -365,30 +365,6 @@ class Context:
                                                            mp, m.shape[0], m.shape[1], bgp))
         return (y, u) if nv12 else (y, u, v)
 
-    def warpmesh_apply_yuv420_ingest(self, src, mesh, planes, new_frame=None, bg=(255, 0, 255), nv12=False, co=False):
-        """warpmesh_apply_yuv420(src, mesh) with ingest_yuv420(planes) as side work of the same launch: returns (output planes, packed new frame)."""
-        import torch
-        rows, cols = src.shape[0], src.shape[1]
-        y = torch.empty((rows, cols), dtype=torch.uint8, device=src.device)
-        if nv12:
-            u = torch.empty((rows // 2, cols // 2, 2), dtype=torch.uint8, device=src.device); v = u
-        else:
-            u = torch.empty((rows // 2, cols // 2), dtype=torch.uint8, device=src.device); v = torch.empty_like(u)
-        iy, iu = planes[0], planes[1]
-        iv = iu if nv12 else planes[2]
-        irows, icols = iy.shape[0], iy.shape[1]
-        if new_frame is None:
-            new_frame = torch.empty((irows, icols, 3), dtype=torch.uint8, device=src.device)
-        m = np.ascontiguousarray(mesh, dtype=np.float32)
-        ma, mp = _f32(m)
-        bga, bgp = _u8x3(bg)
-        self._check(self.lib.lvk_hip_warpmesh_apply_yuv420_ingest(
-            self.handle, src.data_ptr(), src.stride(0), rows, cols, y.data_ptr(), y.stride(0), u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0),
-            1 if nv12 else 0, mp, m.shape[0], m.shape[1], bgp,
-            iy.data_ptr(), iy.stride(0), iu.data_ptr(), iu.stride(0), iv.data_ptr(), iv.stride(0), irows, icols,
-            new_frame.data_ptr(), new_frame.stride(0), 1 if co else 0))
-        return ((y, u) if nv12 else (y, u, v)), new_frame
-
 
 class MeshSolver:
     """lvk_hip_mesh_solver_*: FrameTracker::estimate_local_motions on the device; keeps the previous solution between calls."""

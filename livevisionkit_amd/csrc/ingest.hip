@@ -7,11 +7,13 @@
 // (fixed-point bilinear with 11-bit coefficients and the ((b * (S >> 4)) >> 16) vertical pass; 2x2 area = (s + 2) >> 2).
 // Integer only -> bit-exact.  Both kernels are pure streaming kernels: every byte is read and written once.
 #include "lvk_hip_internal.hpp"
-#include "ingest_core.hpp"
 
 #include <cmath>
 #include <algorithm>
 #include <string>
+
+// streaming stores: the converted frame is read N pushes later, see remap.hip
+#define LVK_STREAM_STORE(ptr, v) __builtin_nontemporal_store((uint32_t)(v), (ptr))
 
 namespace {
 
@@ -62,14 +64,84 @@ void k_ingest_yuv420(const uint8_t* __restrict__ yp, int y_step, const uint8_t* 
         for (int p = 0; p < npx; p++) { uint8_t* d = drow + 3 * (x0 + p); d[0] = (uint8_t)px[p]; d[1] = (uint8_t)(px[p] >> 8); d[2] = (uint8_t)(px[p] >> 16); }
 }
 
-// (the 2x chroma upsampling itself: ingest_core.hpp, shared with the remap's fused variant)
+// Exact 2x chroma upsampling (always the case for 4:2:0) without tables, byte loads, multiplications or left shifts.  For the 2x
+// case the fixed-point INTER_LINEAR of the general kernel collapses: the horizontal pass (c_a a0 + c_b a1) >> 4 with (a0, a1) =
+// (512, 1536) / (1536, 512) / (2048, 0 at the frame edge) is exactly 32 t with t = c_a + 3 c_b / 3 c_a + c_b / 4 c_a, the edge case
+// being the general one with the edge sample replicated; and the vertical pass ((1536 h0 >> 16) + (512 h1 >> 16) + 2) >> 2 is
+// ((3 t0 >> 2) + (t1 >> 2) + 2) >> 2.  Only additions, right shifts and ANDs remain -- the opcodes gfx950 issues at full rate
+// (scripts/valu_peak.hip); the multiply / 64-bit-shift form this replaces was VALU-bound at 11.4 us for a 4K frame.
+// A thread produces the 4 x 2 output pixels of the luma rows 2k - 1 and 2k: both interpolate between the SAME two chroma rows
+// (k - 1, k) with mirrored weights.  Its chroma columns c0 - 1 .. c0 + 2 (c0 = x0 / 2) are one unaligned dword per plane and row
+// (NV12: one 8-byte load, de-interleaved with v_perm_b32); the first / last thread of a row replicates the edge sample.
+// Preconditions (checked by the launcher): Y and dst dword aligned incl. pitch, cols % 4 == 0, cols >= 16.
 template <bool NV12>
 __global__ __launch_bounds__(256)
 void k_ingest_yuv420_x2(const uint8_t* __restrict__ yp, int y_step, const uint8_t* __restrict__ up, int u_step,
                         const uint8_t* __restrict__ vp, int v_step, int rows, int cols, uint8_t* __restrict__ dst, int dst_step)
 {
     LVK_TL(0);
-    ingest420_x2_thread<NV12>(yp, y_step, up, u_step, vp, v_step, rows, cols, dst, dst_step, (blockIdx.x * 64 + threadIdx.x) * 4, blockIdx.y * 4 + threadIdx.y);
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int k = blockIdx.y * 4 + threadIdx.y;                   // luma rows 2k - 1 (odd) and 2k (even); k = 0 .. rows / 2
+    const int cc = cols >> 1, cr = rows >> 1;
+    if (x0 >= cols || k > cr) return;
+    // vertical taps (rows clipped individually, coefficients unclamped -- resize.cpp resizeGeneric_Invoker)
+    const int r0 = max(k - 1, 0), r1 = min(k, cr - 1);
+    const int c0 = x0 >> 1;
+    const bool left = x0 == 0, right = x0 == cols - 4;
+    const int lc = left ? 0 : (right ? cc - 4 : c0 - 1);          // first chroma column of the dword that is loaded
+    struct __attribute__((packed, aligned(1))) P4 { uint32_t w; };
+    struct __attribute__((packed, aligned(1))) P8 { uint32_t w[2]; };
+    uint32_t su0, su1, sv0, sv1;                                   // samples c0 - 1 .. c0 + 2 of (U, V) x (row r0, row r1), one per byte
+    if (NV12)
+    {
+        const P8 a = *reinterpret_cast<const P8*>(up + (long)r0 * u_step + 2 * lc);
+        const P8 b = *reinterpret_cast<const P8*>(up + (long)r1 * u_step + 2 * lc);
+        su0 = __builtin_amdgcn_perm(a.w[1], a.w[0], 0x06040200u); sv0 = __builtin_amdgcn_perm(a.w[1], a.w[0], 0x07050301u);
+        su1 = __builtin_amdgcn_perm(b.w[1], b.w[0], 0x06040200u); sv1 = __builtin_amdgcn_perm(b.w[1], b.w[0], 0x07050301u);
+    }
+    else
+    {
+        su0 = reinterpret_cast<const P4*>(up + (long)r0 * u_step + lc)->w;
+        su1 = reinterpret_cast<const P4*>(up + (long)r1 * u_step + lc)->w;
+        sv0 = reinterpret_cast<const P4*>(vp + (long)r0 * v_step + lc)->w;
+        sv1 = reinterpret_cast<const P4*>(vp + (long)r1 * v_step + lc)->w;
+    }
+    if (left)  { su0 = (su0 << 8) | (su0 & 0xffu); su1 = (su1 << 8) | (su1 & 0xffu); sv0 = (sv0 << 8) | (sv0 & 0xffu); sv1 = (sv1 << 8) | (sv1 & 0xffu); }
+    if (right) { su0 = (su0 >> 8) | (su0 & 0xff000000u); su1 = (su1 >> 8) | (su1 & 0xff000000u);
+                 sv0 = (sv0 >> 8) | (sv0 & 0xff000000u); sv1 = (sv1 >> 8) | (sv1 & 0xff000000u); }
+    // horizontal pass: t[p] for the 4 output columns of one window
+    auto horizontal = [](uint32_t w, uint32_t (&t)[4]) {
+        const uint32_t s0 = w & 0xffu, s1 = (w >> 8) & 0xffu, s2 = (w >> 16) & 0xffu, s3 = w >> 24;
+        const uint32_t m1 = s1 + s1 + s1, m2 = s2 + s2 + s2;
+        t[0] = s0 + m1; t[1] = m1 + s2; t[2] = s1 + m2; t[3] = m2 + s3;
+    };
+    uint32_t tu0[4], tu1[4], tv0[4], tv1[4];
+    horizontal(su0, tu0); horizontal(su1, tu1); horizontal(sv0, tv0); horizontal(sv1, tv1);
+    const int ya = 2 * k - 1, yb = 2 * k;
+    const bool has_a = ya >= 0, has_b = yb < rows;
+    const uint32_t ywa = has_a ? *reinterpret_cast<const uint32_t*>(yp + (long)ya * y_step + x0) : 0u;
+    const uint32_t ywb = has_b ? *reinterpret_cast<const uint32_t*>(yp + (long)yb * y_step + x0) : 0u;
+    uint32_t pa[4], pb[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+    {
+        // odd row 2k - 1: weights (3/4, 1/4) on chroma rows (k - 1, k); even row 2k: (1/4, 3/4)
+        const uint32_t u0 = tu0[p], u1 = tu1[p], v0 = tv0[p], v1 = tv1[p];
+        const uint32_t ua = ((((u0 + u0 + u0) >> 2) + (u1 >> 2) + 2u) >> 2), ub = (((u0 >> 2) + ((u1 + u1 + u1) >> 2) + 2u) >> 2);
+        const uint32_t va = ((((v0 + v0 + v0) >> 2) + (v1 >> 2) + 2u) >> 2), vb = (((v0 >> 2) + ((v1 + v1 + v1) >> 2) + 2u) >> 2);
+        pa[p] = ((ywa >> (8 * p)) & 0xffu) | (ua << 8) | (va << 16);
+        pb[p] = ((ywb >> (8 * p)) & 0xffu) | (ub << 8) | (vb << 16);
+    }
+    if (has_a)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)ya * dst_step + 3 * x0);
+        LVK_STREAM_STORE(d + 0, pa[0] | (pa[1] << 24)); LVK_STREAM_STORE(d + 1, (pa[1] >> 8) | (pa[2] << 16)); LVK_STREAM_STORE(d + 2, (pa[2] >> 16) | (pa[3] << 8));
+    }
+    if (has_b)
+    {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (long)yb * dst_step + 3 * x0);
+        LVK_STREAM_STORE(d + 0, pb[0] | (pb[1] << 24)); LVK_STREAM_STORE(d + 1, (pb[1] >> 8) | (pb[2] << 16)); LVK_STREAM_STORE(d + 2, (pb[2] >> 16) | (pb[3] << 8));
+    }
 }
 
 // thread = one 2x2 block of packed pixels -> 4 luma bytes + one (U, V) sample
@@ -402,12 +474,6 @@ int lvk_get_lin8tab(lvk_hip_ctx* ctx, int ssize, int dsize, bool vertical, const
     return LVK_HIP_OK;
 }
 
-bool lvk_ingest420_x2_ok(const void* d_y, int y_step, int rows, int cols, const void* d_dst, int dst_step)
-{
-    return ((reinterpret_cast<uintptr_t>(d_dst) | (uintptr_t)dst_step) & 3u) == 0 && ((reinterpret_cast<uintptr_t>(d_y) | (uintptr_t)y_step) & 3u) == 0 &&
-           (rows & 1) == 0 && cols % 4 == 0 && cols >= 16 && rows >= 4;
-}
-
 int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_y, int y_step, const void* d_u, int u_step,
                              const void* d_v, int v_step, int nv12, int rows, int cols, void* d_dst, int dst_step)
 {
@@ -420,7 +486,8 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
     if ((rc = lvk_get_lin8tab(ctx, rows / 2, rows, true, &yt)) != LVK_HIP_OK) return rc;
     const int fast = ((reinterpret_cast<uintptr_t>(d_dst) | (uintptr_t)dst_step) & 3u) == 0 ? 1 : 0;
     const dim3 block(64, 4), grid1((cols / 4 + 63 + (cols % 4 ? 1 : 0)) / 64, (rows + 3) / 4);
-    const bool x2 = lvk_ingest420_x2_ok(d_y, y_step, rows, cols, d_dst, dst_step);
+    const bool x2 = fast && cols % 4 == 0 && cols >= 16 && rows >= 4 &&
+                    ((reinterpret_cast<uintptr_t>(d_y) | (uintptr_t)y_step) & 3u) == 0;
     if (x2)
     {
         const dim3 grid(grid1.x, (rows / 2 + 1 + 3) / 4);                       // one thread row per chroma row pair: k = 0 .. rows / 2

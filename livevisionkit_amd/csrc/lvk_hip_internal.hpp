@@ -275,10 +275,6 @@ int lvk_launch_ingest_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d
                              const void* d_v, int v_step, int nv12, int rows, int cols, void* d_dst, int dst_step);
 int lvk_launch_egress_yuv420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                              void* d_y, int y_step, void* d_u, int u_step, void* d_v, int v_step, int nv12);
-// does lvk_launch_ingest_yuv420 run the table-free 2x kernel on these buffers?  (what the remap's fused variant can take as side work)
-bool lvk_ingest420_x2_ok(const void* d_y, int y_step, int rows, int cols, const void* d_dst, int dst_step);
-// a 4:2:0 -> packed 4:4:4 conversion handed to a remap launch as side work (remap_core.hpp, remap_strip): planes of the layout of that launch's output
-struct LvkIngest420 { const void* y; int y_step; const void* u; int u_step; const void* v; int v_step; int rows, cols; void* dst; int dst_step; };
 int lvk_launch_ingest_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* const d_planes[3], const int steps[3],
                           int rows, int cols, void* d_dst, int dst_step);
 int lvk_launch_egress_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* d_src, int src_step, int rows, int cols,
@@ -358,7 +354,7 @@ int lvk_launch_mesh_solve(lvk_mesh_solver_dev* s, hipStream_t stream, void* d_sc
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
                                   const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens,
-                                  bool co_scheduled, const LvkIngest420* side = nullptr);
+                                  bool co_scheduled);
 bool lvk_remap_obs_fusable(int video_format);
 int lvk_launch_warpmesh_apply_obs(lvk_hip_ctx* ctx, hipStream_t stream, int video_format, const void* d_src, int src_step, int rows, int cols,
                                   void* const planes[3], const int steps[3], const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],

@@ -2,7 +2,6 @@
 // (Math/WarpMesh.cpp:183-223), lvk::upscale (Image.cpp:155-202) and the fused remap + 4:2:0 egress of the plugin's path.  The EASU arithmetic, the
 // coordinate generators, the sinks and the strip walk are in remap_core.hpp.
 #include "remap_core.hpp"
-#include "ingest_core.hpp"
 
 namespace {
 
@@ -167,58 +166,6 @@ void k_remap_mesh_lens_420(const uint8_t* __restrict__ src, int src_step, int ro
         remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, LensCoord<MeshCoordT<false>>{MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols}, bg);
 }
 
-// ---- the same four kernels with the 4:2:0 -> 4:4:4 conversion of the stream's NEW frame as side work (remap_core.hpp, remap_strip): what
-//      lvk_hip_stab_push_yuv420 launches for a free-running caller that lends its input planes until the next push (lvk_hip_stab_set_input_borrow).
-//      One launch instead of two on the bulk stream, the conversion's 37 MB of traffic hidden behind the EASU arithmetic.
-template <bool NV12>
-struct IngestSide
-{
-    Ingest420Args a;
-    __device__ __forceinline__ void operator()(int unit) const { ingest420_x2_unit<NV12>(a, unit); }
-};
-
-template <bool NV12>
-__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
-void k_remap_homography_420_ingest(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, uint32_t bg, Ingest420Args in)
-{
-    LVK_TL(0);
-    const HomographyCoord coord{H, 0, 0};
-    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg, IngestSide<NV12>{in}, in.units);
-}
-
-template <bool NV12>
-__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
-void k_remap_homography_lens_420_ingest(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o, HomographyArgs H, LensArgs L, uint32_t bg, Ingest420Args in)
-{
-    const LensCoord<HomographyCoord> coord{HomographyCoord{H, 0, 0}, L, rows, cols};
-    remap_strip<true>(src, src_step, rows, cols, Sink420<NV12>{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step}, rows, cols, coord, bg, IngestSide<NV12>{in}, in.units);
-}
-
-template <bool NV12>
-__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
-void k_remap_mesh_420_ingest(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
-                             const float* __restrict__ mesh, int mesh_cols, int mesh_floats, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab, uint32_t bg,
-                             Ingest420Args in)
-{
-    const Sink420<NV12> sink{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step};
-    const IngestSide<NV12> side{in};
-    if (mesh_to_lds(mesh, mesh_floats)) remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, bg, side, in.units);
-    else remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, bg, side, in.units);
-}
-
-template <bool NV12>
-__global__ __launch_bounds__(256) LVK_REMAP_ATTR LVK_CO_SCHEDULED
-void k_remap_mesh_lens_420_ingest(const uint8_t* __restrict__ src, int src_step, int rows, int cols, Planes420 o,
-                                  const float* __restrict__ mesh, int mesh_cols, int mesh_floats, const LinTabEntry* __restrict__ xtab, const LinTabEntry* __restrict__ ytab,
-                                  LensArgs L, uint32_t bg, Ingest420Args in)
-{
-    const Sink420<NV12> sink{o.y, o.y_step, o.u, o.u_step, o.v, o.v_step};
-    const IngestSide<NV12> side{in};
-    if (mesh_to_lds(mesh, mesh_floats))
-        remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, LensCoord<MeshCoordT<true>>{MeshCoordT<true>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols}, bg, side, in.units);
-    else
-        remap_strip<true>(src, src_step, rows, cols, sink, rows, cols, LensCoord<MeshCoordT<false>>{MeshCoordT<false>{mesh, mesh_cols, xtab, ytab, (float)cols, (float)rows}, L, rows, cols}, bg, side, in.units);
-}
 
 } // namespace
 
@@ -369,7 +316,7 @@ int lvk_launch_warpmesh_apply_lens(lvk_hip_ctx* ctx, hipStream_t stream,
 // WarpMesh::apply + I4XXIngest / NV12Ingest::to_obs in one launch: d_src packed YUV 8UC3, output planar 4:2:0 (I420: y, u, v; NV12: y, uv).
 int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const void* d_src, int src_step, int rows, int cols,
                                   void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
-                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens, bool co, const LvkIngest420* side)
+                                  const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3], const LensArgs* lens, bool co)
 {
     LVK_HIP_REQUIRE(ctx, d_src && o_y && o_u && (nv12 || o_v) && mesh && bg && mesh_rows >= 2 && mesh_cols >= 2);
     LVK_HIP_REQUIRE(ctx, rows > 0 && cols > 0 && (rows & 1) == 0 && (cols & 1) == 0 && src_step >= 3 * cols);
@@ -377,14 +324,6 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
     LVK_HIP_REQUIRE(ctx, fits_u32(src_step, rows) && fits_u32(oy_step, rows) && fits_u32(ou_step, rows / 2) && (nv12 || fits_u32(ov_step, rows / 2)));
     const Planes420 o{(uint8_t*)o_y, oy_step, (uint8_t*)o_u, ou_step, (uint8_t*)(nv12 ? o_u : o_v), nv12 ? ou_step : ov_step};
     const dim3 block(256), grid = co ? lvk_co_grid(ctx, rows, cols) : remap_grid(rows, cols);
-    // side work: the conversion of the stream's new frame (planes of the SAME 4:2:0 layout as the output's) into its pool slot, the x2 kernel's preconditions
-    Ingest420Args in{};
-    if (side)
-    {
-        LVK_HIP_REQUIRE(ctx, side->y && side->u && (nv12 || side->v) && side->dst && side->dst != d_src && lvk_ingest420_x2_ok(side->y, side->y_step, side->rows, side->cols, side->dst, side->dst_step));
-        LVK_HIP_REQUIRE(ctx, side->y_step >= side->cols && side->dst_step >= 3 * side->cols && side->u_step >= (nv12 ? side->cols : side->cols / 2) && (nv12 || side->v_step >= side->cols / 2));
-        in = ingest420_args(side->y, side->y_step, side->u, side->u_step, nv12 ? side->u : side->v, nv12 ? side->u_step : side->v_step, side->rows, side->cols, side->dst, side->dst_step);
-    }
     int stage_slot = -1;
     if (mesh_rows == 2 && mesh_cols == 2)
     {
@@ -401,17 +340,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
             for (int q = 0; q < 9; q++) M[q] = (q % 4 == 0) ? 1.0 : 0.0;
         HomographyArgs args;
         for (int q = 0; q < 9; q++) args.h[q] = (float)M[q];
-        if (side && lens)
-        {
-            if (nv12) hipLaunchKernelGGL(k_remap_homography_lens_420_ingest<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg), in);
-            else hipLaunchKernelGGL(k_remap_homography_lens_420_ingest<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg), in);
-        }
-        else if (side)
-        {
-            if (nv12) hipLaunchKernelGGL(k_remap_homography_420_ingest<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg), in);
-            else hipLaunchKernelGGL(k_remap_homography_420_ingest<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg), in);
-        }
-        else if (lens)
+        if (lens)
         {
             if (nv12) hipLaunchKernelGGL(k_remap_homography_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
             else hipLaunchKernelGGL(k_remap_homography_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
@@ -432,18 +361,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
         if ((rc = lvk_get_lintab(ctx, mesh_rows, rows, true, &ytab)) != LVK_HIP_OK) return rc;
         void* d_mesh = nullptr;
         if ((rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot)) != LVK_HIP_OK) return rc;
-        const int mf = mesh_rows * mesh_cols * 2;
-        if (side && lens)
-        {
-            if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420_ingest<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mf, xtab, ytab, *lens, pack_bg(bg), in);
-            else hipLaunchKernelGGL(k_remap_mesh_lens_420_ingest<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mf, xtab, ytab, *lens, pack_bg(bg), in);
-        }
-        else if (side)
-        {
-            if (nv12) hipLaunchKernelGGL(k_remap_mesh_420_ingest<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mf, xtab, ytab, pack_bg(bg), in);
-            else hipLaunchKernelGGL(k_remap_mesh_420_ingest<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mf, xtab, ytab, pack_bg(bg), in);
-        }
-        else if (lens)
+        if (lens)
         {
             if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
             else hipLaunchKernelGGL(k_remap_mesh_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
@@ -506,20 +424,6 @@ int lvk_hip_warpmesh_apply_yuv420(lvk_hip_ctx* ctx, const void* d_src, int src_s
     LVK_HIP_ENTRY(ctx);
     return lvk_launch_warpmesh_apply_420(ctx, ctx->stream, d_src, src_step, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12,
                                          mesh, mesh_rows, mesh_cols, bg, nullptr, false);
-}
-
-// lvk_hip_warpmesh_apply_yuv420 with the 4:2:0 -> 4:4:4 conversion of ANOTHER frame (planes of the same layout as the output's) as side work of the same
-// launch -- what lvk_hip_stab_push_yuv420 runs in input-borrow mode; here for the parity tests and the micro-benchmark.  co != 0: the persistent grid.
-int lvk_hip_warpmesh_apply_yuv420_ingest(lvk_hip_ctx* ctx, const void* d_src, int src_step, int rows, int cols,
-                                         void* o_y, int oy_step, void* o_u, int ou_step, void* o_v, int ov_step, int nv12,
-                                         const float* mesh, int mesh_rows, int mesh_cols, const uint8_t bg[3],
-                                         const void* in_y, int in_y_step, const void* in_u, int in_u_step, const void* in_v, int in_v_step, int in_rows, int in_cols,
-                                         void* d_new, int new_step, int co)
-{
-    LVK_HIP_ENTRY(ctx);
-    const LvkIngest420 side{in_y, in_y_step, in_u, in_u_step, in_v, in_v_step, in_rows, in_cols, d_new, new_step};
-    return lvk_launch_warpmesh_apply_420(ctx, ctx->stream, d_src, src_step, rows, cols, o_y, oy_step, o_u, ou_step, o_v, ov_step, nv12,
-                                         mesh, mesh_rows, mesh_cols, bg, nullptr, co != 0, &side);
 }
 
 int lvk_hip_upscale(lvk_hip_ctx* ctx, const void* d_src, int src_step, int src_rows, int src_cols,

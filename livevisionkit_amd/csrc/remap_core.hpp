@@ -19,7 +19,6 @@
 #include "lvk_hip_internal.hpp"
 
 #include <climits>
-#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
@@ -583,17 +582,10 @@ __device__ __forceinline__ void remap_one_strip(const uint8_t* __restrict__ src,
     sink.store(x0, y, npx, px, active, parity);
 }
 
-// Side work of a remap kernel: memory-bound work units (256 threads each, no barriers, independent of the remap) that the blocks execute BETWEEN their
-// strips.  The remap is VALU-issue bound and leaves the memory pipes idle; a streaming conversion that runs as a kernel of its own next to it gets few
-// wave slots and three times its time, but as side work its loads and stores are in flight while the block's other waves issue
-// EASU arithmetic -- the 4:2:0 -> 4:4:4 conversion of the NEW frame rides along with the remap of the DELAYED one (k_remap_*_420_ingest, remap.hip).
-// Units are dealt round-robin over the launch's blocks: one after every second strip, the rest behind the last strip.
-struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
-
-template <bool YUV, class Coord, class Sink, class Side = NoSide>
+template <bool YUV, class Coord, class Sink>
 __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int src_step, int src_rows, int src_cols,
                                             const Sink& sink, int dst_rows, int dst_cols,
-                                            const Coord& coord, uint32_t bg, const Side& side = Side(), int side_units = 0)
+                                            const Coord& coord, uint32_t bg)
 {
     const int strips_x = (dst_cols + STRIP_W - 1) / STRIP_W, strips_y = (dst_rows + STRIP_H - 1) / STRIP_H;
     const int nstrips = strips_x * strips_y;
@@ -605,17 +597,12 @@ __device__ __forceinline__ void remap_strip(const uint8_t* __restrict__ src, int
     const int xcd = (int)(blockIdx.x % NUM_XCD);
     const int kstride = (int)(gridDim.x / NUM_XCD);
     int parity = 0;
-    int unit = (int)blockIdx.x, it = 0;
-    for (int k = (int)(blockIdx.x / NUM_XCD); k < band; k += kstride, parity ^= 1, it++)
+    for (int k = (int)(blockIdx.x / NUM_XCD); k < band; k += kstride, parity ^= 1)
     {
         const int strip = xcd * band + k;
         if (strip >= nstrips) break;                                    // block-uniform (only the last band is short)
         remap_one_strip<YUV>(src, src_step, src_rows, src_cols, sink, dst_rows, dst_cols, coord, bg, strip, nstrips, strips_x, parity);
-        if constexpr (!std::is_same<Side, NoSide>::value)
-            if ((it & 1) == 0 && unit < side_units) { side(unit); unit += (int)gridDim.x; }
     }
-    if constexpr (!std::is_same<Side, NoSide>::value)
-        for (; unit < side_units; unit += (int)gridDim.x) side(unit);
 }
 inline dim3 remap_grid(int dst_rows, int dst_cols)
 {

@@ -325,7 +325,6 @@ void lvk_hip_stab_destroy(lvk_hip_stab* st)
     }
     for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventDestroy(st->remap_done[i]);
     if (st->ingest_done) (void)hipEventDestroy(st->ingest_done);
-    for (hipEvent_t e : st->borrow_done) if (e) (void)hipEventDestroy(e);
     if (st->chain_done) (void)hipEventDestroy(st->chain_done);
     if (st->caller_ready) (void)hipEventDestroy(st->caller_ready);
     if (st->ahead_read_done) (void)hipEventDestroy(st->ahead_read_done);
@@ -368,7 +367,6 @@ static int stab_detach_bulk_stream(lvk_hip_stab* st)
     std::fill(st->slot_read_armed.begin(), st->slot_read_armed.end(), (char)0);
     for (int i = 0; i < 2; i++) if (st->remap_done[i]) (void)hipEventRecord(st->remap_done[i], ctx->stream);
     if (st->ingest_done) (void)hipEventRecord(st->ingest_done, ctx->stream);
-    st->borrow_pending = -1;                     // (the bulk stream was synchronised above: no fused kernel still reads borrowed planes)
     st->remap_wait = nullptr;
     auto& aux = ctx->aux_streams;
     { std::lock_guard<std::mutex> alock(ctx->aux_mutex); aux.erase(std::remove(aux.begin(), aux.end(), st->remap_stream), aux.end()); }
@@ -423,22 +421,6 @@ int lvk_hip_stab_set_overlap(lvk_hip_stab* st, int enable)
     if (!st) return LVK_HIP_ERR_ARG;
     lvk_device_guard device_guard(st->ctx);
     return stab_set_overlap(st, enable != 0, nullptr);
-}
-
-// Input-borrow mode (lvk_hip.h): planes lent until the next push has returned; the conversion may then ride inside the output remap.
-int lvk_hip_stab_set_input_borrow(lvk_hip_stab* st, int enable)
-{
-    if (!st) return LVK_HIP_ERR_ARG;
-    lvk_device_guard device_guard(st->ctx);
-    lvk_hip_ctx* ctx = st->ctx;
-    if (!enable && st->borrow_pending >= 0)
-    {
-        // switching off hands every plane back now
-        LVK_HIP_CHECK(ctx, hipEventSynchronize(st->borrow_done[st->borrow_pending]));
-        st->borrow_pending = -1;
-    }
-    st->input_borrow = enable != 0;
-    return LVK_HIP_OK;
 }
 
 // Overlap mode on a stream the CALLER owns: the bulk kernels run on `bulk`'s stream (NULL: overlap off).  For hosts whose output frames
@@ -545,7 +527,6 @@ int lvk_hip_stab_restart(lvk_hip_stab* st)          // StabilizationFilter::rest
     lvk_device_guard device_guard(st->ctx);
     // the queue's frames go back to their owners: nothing on the bulk stream may still be reading them
     if (st->remap_stream) LVK_HIP_CHECK(st->ctx, hipStreamSynchronize(st->remap_stream));
-    st->borrow_pending = -1;                       // (input-borrow mode: no fused kernel is left that reads lent planes)
     // host entry points: the emitted frame whose download has not been handed to the copy engine yet still goes out (*produced was
     // reported); frames that were announced and never pushed are forgotten -- a restart is where a caller seeks or switches sources, and a
     // stale announcement would otherwise refuse every later push ("another frame has been announced") or, matched by pointer identity,

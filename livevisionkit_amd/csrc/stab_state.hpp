@@ -173,14 +173,6 @@ struct lvk_hip_stab
     std::function<int()> deferred_ingest;      // the newest frame's 4:2:0 conversion, not yet launched (see lvk_hip_stab_push_yuv420)
     int run_deferred_ingest() { auto f = std::move(deferred_ingest); deferred_ingest = nullptr; return f ? f() : LVK_HIP_OK; }
     hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame
-    // Input-borrow mode (lvk_hip_stab_set_input_borrow): the caller's planes stay the filter's until the next push has returned, so the conversion of a
-    // free-running caller's new frame can ride inside the output remap of the delayed one (k_remap_*_420_ingest) instead of being a kernel of its own
-    // in the cycle of either stream.  fuse_candidate: this push's conversion qualifies (set by the plane entry); fuse_now: and the push runs free
-    // (decided in lvk_stab_push_impl); fuse_side: the conversion; borrow_done: "the fused kernel of the push before this one has read its planes".
-    bool input_borrow = false, fuse_candidate = false, fuse_now = false, fused_this_push = false;
-    LvkIngest420 fuse_side{};
-    hipEvent_t borrow_done[2] = {nullptr, nullptr};
-    int borrow_pending = -1, borrow_next = 0;  // event index the NEXT push has to wait for before it returns (-1: none)
     // Overlap mode with a frame delay: the conversion runs on the TRACKING stream, in the slot that stream has free between the last
     // kernel of a frame's chain and the first of the next frame's (the host's turn: ~25 us) -- behind an event the push waits on instead
     // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which
@@ -196,8 +188,6 @@ struct lvk_hip_stab
     // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
     // for its frames synchronises and reads back in between: at least a remap's duration)
     bool caller_runs_free = false;
-    // tests: LVK_HIP_ASSUME_CALLER=free|sync pins what the pushes are taken for (frames so small that the host's turn outlasts the remap never look free-running)
-    int assume_caller = [] { const char* e = std::getenv("LVK_HIP_ASSUME_CALLER"); return !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == 's' ? 2 : 0)); }();
     int free_streak = 0, sync_streak = 0;      // consecutive pushes seen as free-running / as synchronous (one push of grace after a free-running streak)
     std::chrono::steady_clock::time_point last_push_end{};
     // Which schedule the pushes took (lvk_hip_stab_schedule_counters): the mode is chosen per push from what the caller is seen doing, and a host

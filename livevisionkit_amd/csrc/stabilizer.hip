@@ -169,9 +169,7 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     }
     trace.mark(HostTrace::LK_LAUNCH);
     bool chain_event_armed = false;              // local: an error return below must not leave a stale event armed for the next push
-    // (input-borrow mode, free-running caller: the conversion is not launched here at all -- it rides inside the output remap, emit())
-    const bool ingest_here = (bool)deferred_ingest && !fuse_now;
-    if (ingest_here && tracker_ingest_capable)
+    if (deferred_ingest && tracker_ingest_capable)
     {
         // Where the conversion goes: a bulk stream that is idle (a caller that synchronises every frame) takes it now, next to the
         // chain -- the remap that follows then has the GPU to itself; a bulk stream that is still busy with the previous remap (a
@@ -188,12 +186,12 @@ int lvk_hip_stab::track(const QueuedFrame& f, const void* luma, int luma_step, i
     }
     // (an announced next frame: its downscale + pyramid go behind the chain too, so the push waits for the chain through the event as well)
     const bool build_ahead = chained && ahead_announced.luma != nullptr && pyr_w == cur_w && pyr_h == cur_h;
-    if (chained && ((ingest_here && tracker_ingest_capable && ingest_on_tracker) || build_ahead))
+    if (chained && ((deferred_ingest && tracker_ingest_capable && ingest_on_tracker) || build_ahead))
     {
         if (!chain_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&chain_done, hipEventDisableTiming));
         LVK_HIP_CHECK(ctx, hipEventRecord(chain_done, st)); chain_event_armed = true;
     }
-    if (ingest_here && (rc = run_deferred_ingest()) != LVK_HIP_OK) return rc;
+    if (deferred_ingest && (rc = run_deferred_ingest()) != LVK_HIP_OK) return rc;
     if (build_ahead && (rc = launch_build_ahead(P, cur_w, cur_h)) != LVK_HIP_OK) return rc;
     if (lens && !chained)
     {
@@ -419,10 +417,6 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         if (grace) st->caller_runs_free = true; else st->free_streak = 0;
     }
     st->sched[st->caller_runs_free ? LVK_SCHED_PUSH_FREE_RUNNING : LVK_SCHED_PUSH_SYNCHRONISED]++;
-    // input-borrow mode: a free-running caller's conversion rides inside this push's output remap (a caller that waits for every frame keeps the
-    // schedule that puts it next to the chain on the idle bulk stream: its remap then has the GPU to itself)
-    st->fuse_now = st->fuse_candidate && st->caller_runs_free && st->s.stabilize_output && st->overlap;
-    st->fused_this_push = false;
     { const int lrc = st->ensure_lens(rows, cols); if (lrc != LVK_HIP_OK) return lrc; }
     static const WarpMeshF identity_mesh(2, 2);
     const uint8_t bg[3] = {(uint8_t)st->s.background[0], (uint8_t)st->s.background[1], (uint8_t)st->s.background[2]};
@@ -471,22 +465,9 @@ int lvk_stab_push_impl(lvk_hip_stab* st, const void* d_frame, int step, int rows
         }
         else if (mesh && o420 && o420->y)
         {
-            // input-borrow mode: the new frame's 4:2:0 -> 4:4:4 conversion as side work of this launch (same stream as every remap that read the slot it
-            // writes: stream order protects it); the caller's planes are lent until the next push has returned (borrow_done)
-            const bool fuse = st->fuse_now && persistent && st->deferred_ingest && st->fuse_side.dst != f.d_ptr;
             rc = lvk_launch_warpmesh_apply_420(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, o420->y, o420->y_step, o420->u, o420->u_step, o420->v, o420->v_step,
-                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, lens_args, persistent, fuse ? &st->fuse_side : nullptr);
+                                               o420->nv12, mesh->off.data(), mesh->rows, mesh->cols, bg, lens_args, persistent);
             o420->used = true;
-            if (fuse && rc == LVK_HIP_OK)
-            {
-                st->deferred_ingest = nullptr;
-                st->sched[LVK_SCHED_INGEST_FUSED]++;
-                const int bi = st->borrow_next;
-                if (!st->borrow_done[bi]) { hipError_t e = hipEventCreateWithFlags(&st->borrow_done[bi], hipEventDisableTiming); if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e)); }
-                hipError_t e = hipEventRecord(st->borrow_done[bi], rs);
-                if (e != hipSuccess) return ctx->fail(LVK_HIP_ERR_RUNTIME, hipGetErrorString(e));
-                st->fused_this_push = true;
-            }
         }
         else if (mesh) rc = lvk_launch_warpmesh_apply_lens(ctx, rs, f.d_ptr, f.step, f.rows, f.cols, d_out, out_step, mesh->off.data(), mesh->rows, mesh->cols, bg,
                                                       f.format == LVK_FORMAT_YUV ? 1 : 0, lens_args, persistent);
@@ -581,7 +562,6 @@ bool lvk_hip_stab::caller_free_running_now()
         if (q != hipSuccess) (void)hipGetLastError();
         bulk_busy_at_push = q == hipErrorNotReady;
     }
-    if (assume_caller) return assume_caller == 1;
     return bulk_busy_at_push || (last_push_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - last_push_end < std::chrono::microseconds(15));
 }
 
@@ -687,7 +667,6 @@ int lvk_hip_stab_push(lvk_hip_stab* st, const void* d_frame, int step, int rows,
     if (st->queue_kind == 2) return st->fail(LVK_HIP_ERR_ARG, "frames of lvk_hip_stab_push_yuv420 are still queued: restart() before switching to lvk_hip_stab_push");
     st->queue_kind = 1;
     st->pool_frames = false;
-    st->fuse_candidate = st->fuse_now = false;
     int rc = st->mark_caller_work();
     if (rc != LVK_HIP_OK) return rc;
     rc = lvk_stab_push_impl(st, d_frame, step, rows, cols, timestamp, format, d_frame, step, 3, d_out, out_step, out_rows, produced, out_timestamp, released, nullptr, emitted);
@@ -800,13 +779,6 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
         }
         return LVK_HIP_OK;
     };
-    // input-borrow mode: does this push's conversion qualify for riding inside the output remap?  (device planes of a 4:2:0 layout the 2x kernel takes,
-    // a frame delay, output planes for the fused remap + egress kernel; lvk_stab_push_impl adds "and the caller runs free")
-    st->fuse_candidate = st->input_borrow && side_ingest && is420 && st->queue_capacity > 1 && !st->host_direct_now && !st->ingest_wait[0] && !st->ingest_wait[1] &&
-                         o_y && o_u && (nv12 || o_v) && ip[1] && (nv12 || ip[2]) && lvk_ingest420_x2_ok(ip[0], is_[0], rows, cols, slot, 3 * cols) &&
-                         st->next_output(QueuedFrame{slot, 3 * cols, rows, cols, timestamp, frame_format}, nullptr);          // (this push emits a frame)
-    st->fuse_side = LvkIngest420{ip[0], is_[0], ip[1], is_[1], nv12 ? ip[1] : ip[2], nv12 ? is_[1] : is_[2], rows, cols, slot, 3 * cols};
-    struct FuseEnds { lvk_hip_stab* s; ~FuseEnds() { s->fuse_candidate = s->fuse_now = false; } } fuse_ends{st};
     // Overlap mode: the conversion is not on the tracker's critical path (it runs behind the previous remap on the bulk stream), so its
     // launch and its event record wait until the tracker's kernels are on their way -- track() calls it after its last launch.
     // (8.05k -> 8.17k frames/s, p50 latency -7 us.)
@@ -849,17 +821,12 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
         st->trace.mark(HostTrace::EXIT_PRE);
         // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago).  An event, not
         // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
-        // (input-borrow mode, conversion inside the remap: the planes are lent until the NEXT push has returned -- below)
-        if (!st->fused_this_push) LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
+        LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
         st->trace.mark(HostTrace::EXIT_WAIT);
     }
     // same contract without a tracker pass (delay-only mode, stabilize_output off): nothing has synchronised behind the conversion yet
     // (and for DirectIngest's formats, whose copy runs on the tracking stream and whose tracker reads the copy: an early return of track() has not waited)
     else if (!st->s.stabilize_output || direct) LVK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // input-borrow mode: the planes lent by the push BEFORE this one come back now -- the remap that converted them was launched a whole push ago, and
-    // this push's own remap is already queued behind it, so the bulk stream does not run dry while the host waits here
-    if (st->borrow_pending >= 0) { const int bp = st->borrow_pending; st->borrow_pending = -1; LVK_HIP_CHECK(ctx, hipEventSynchronize(st->borrow_done[bp])); }
-    if (st->fused_this_push) { st->borrow_pending = st->borrow_next; st->borrow_next ^= 1; st->fused_this_push = false; }
     if (rc != LVK_HIP_OK) return rc;
     if (prod && o420.used) { if (produced) *produced = 1; }                // the fused remap + egress kernel has written the planes
     else if (prod)

@@ -347,7 +347,7 @@ class StabilizationFilter:
         return a.value, b.value
 
     SCHEDULE = ("push_free_running", "push_synchronised", "ingest_on_tracker", "ingest_on_bulk", "ingest_inline", "remap_persistent", "remap_full",
-                "wait_signal_word", "wait_event", "wait_word_timeout", "ingest_fused")
+                "wait_signal_word", "wait_event", "wait_word_timeout")
 
     def schedule_counters(self, reset=False):
         """lvk_hip_stab_schedule_counters: which schedule the pushes so far took (the library picks per push from what it sees the caller doing:
@@ -390,11 +390,6 @@ class StabilizationFilter:
     def set_overlap(self, enable=True):
         """Run the output remap on a second stream, overlapping the next frame's tracking (output valid after ctx.sync())."""
         self.ctx._check(self.lib.lvk_hip_stab_set_overlap(self.handle, 1 if enable else 0))
-
-    def set_input_borrow(self, enable=True):
-        """lvk_hip_stab_set_input_borrow: the planes of apply_yuv420 stay the filter's until the NEXT push has returned (or ctx.sync()); a free-running
-        caller's 4:2:0 conversion then rides inside the output remap (one kernel per frame on the bulk stream).  Same frames."""
-        self.ctx._check(self.lib.lvk_hip_stab_set_input_borrow(self.handle, 1 if enable else 0))
 
     STAGES = ("downscale", "pyramid", "fast", "pyrlk", "motion", "remap", "ingest", "egress")
 

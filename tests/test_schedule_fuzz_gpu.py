@@ -8,7 +8,6 @@ The fuzz: one 4:2:0 stream whose pushes are drawn at random from everything a ho
   * overlap mode switched on / off, restart(), reconfigure (frame delay up and down, homography <-> vector-field preset, stabilize_output off
     and on again = the delay-only passthrough), the fused lens pre-warp switched on / off (restarts the filter);
   * one resolution change in the middle of the stream;
-  * input-borrow mode (lvk_hip_stab_set_input_borrow) switched on / off: the conversion of a free-running push inside the output remap;
 the pushes free-running (no synchronisation between them beyond what the calls do themselves), every output in a buffer of its own.
 After the last push every emitted plane is compared, BY TIMESTAMP, with the oracle chain ingest_yuv420 -> OracleStabilizer ->
 egress_yuv420 driven through the same restarts / reconfigurations; the set of emitted timestamps must be the oracle's -- the frames
@@ -55,13 +54,9 @@ def _seeds():
 
 
 @pytest.mark.parametrize("seed", _seeds())
-def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed, monkeypatch):
+def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
     import torch
     import livevisionkit_amd as lvk
-    if seed & 4:
-        # frames this small never look free-running to the library (the host's turn outlasts their remap): half of the seeds pin the free-running
-        # schedule -- persistent grids, conversions behind the chain or, in input-borrow mode, inside the remap -- (read when the filter is created)
-        monkeypatch.setenv("LVK_HIP_ASSUME_CALLER", "free")
     rng = np.random.default_rng(9000 + seed)
     n = 44
     change_at = int(rng.integers(18, 26))                        # first push of the second frame size
@@ -79,8 +74,6 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed, monkeypa
     gst = lvk.StabilizationFilter(lvk.StabilizationFilterSettings(), context=ctx); gst.configure(_conv(s))
     overlap, stabilize, lens_on, stab_back_at = True, True, False, 0
     gst.set_overlap(overlap)
-    borrow = bool(seed & 2)
-    gst.set_input_borrow(borrow)
     dev_args = [gst.prepare_yuv420(p) for p in planes_d]
 
     def host_copy(i):
@@ -122,10 +115,6 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed, monkeypa
             r, c = frames[i].shape[:2]
             prof = np.array([0.8 * c, 0.8 * c, c / 2.0, r / 2.0, -0.12, 0.03, 0.0, 0.0, 0.0]) if lens_on else None
             ost.set_lens(prof); gst.set_lens(prof); host_announced = None; log.append((i, "lens %d" % lens_on))
-        elif ev in (6, 7):
-            # input-borrow mode on / off (round 6): the device planes are lent until the next push has returned -- this test never touches them again --
-            # and a free-running push's conversion rides inside the output remap; the pixels must not know
-            borrow = not borrow; gst.set_input_borrow(borrow); log.append((i, "borrow %d" % borrow))
         # ---- the oracle's push
         buf = big.copy()
         w, wts = ost.push(oracle.ingest_yuv420(*planes_h[i]), ts=i, nthreads=32, out=buf)
@@ -176,8 +165,6 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed, monkeypa
     # frames of the old size still queued when the size changed leave at their own size, as in the oracle and the reference (rounds 2-5 dropped them)
     late = {ts for ts, at in want_push.items() if ts < change_at <= at}
     assert sorted(got) == sorted(want), (log, sorted(late))
-    if seed & 4:
-        assert gst.schedule_counters()["push_free_running"] > 0
     assert len(got) >= 10, (len(got), log)                           # (schedules that restart every few pushes emit little: the suite's seeds emit 25-35)
     assert live >= 4, f"only {live} emitted frames had a trust factor above zero: the schedule restarts too often to test the warp ({log})"
     for ts, (kind, planes) in sorted(got.items()):
@@ -188,8 +175,7 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed, monkeypa
                 d = np.abs(p.astype(np.int32) - q.astype(np.int32))
                 raise AssertionError(f"seed {seed}: frame ts {ts} ({kind} push) plane {k}: {int((d > 0).sum())} bytes differ, max |d| {d.max()}; schedule {log}")
     print(f"\n[schedule fuzz seed {seed}] {len(got)} frames compared ({live} of the oracle's with trust > 0), {len(late)} of the old size emitted after the size change (push {change_at}), "
-          f"{refused} wrong host announcements refused, {gst.lookahead_frames()} pushes found their pyramid built ahead, {gst.schedule_counters()['ingest_fused']} conversions "
-          f"inside a remap; events {log}")
+          f"{refused} wrong host announcements refused, {gst.lookahead_frames()} pushes found their pyramid built ahead; events {log}")
     ost.close(); gst.close()
 
 
