@@ -188,6 +188,8 @@ struct lvk_hip_stab
     // a free-running caller: the bulk stream still busy, or this push began within 15 us of the previous one's return (a caller that waits
     // for its frames synchronises and reads back in between: at least a remap's duration)
     bool caller_runs_free = false;
+    // tests: LVK_HIP_ASSUME_CALLER=free|sync pins what the pushes are taken for (frames so small that the host's turn outlasts the remap never look free-running)
+    int assume_caller = [] { const char* e = std::getenv("LVK_HIP_ASSUME_CALLER"); return !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == 's' ? 2 : 0)); }();
     int free_streak = 0, sync_streak = 0;      // consecutive pushes seen as free-running / as synchronous (one push of grace after a free-running streak)
     std::chrono::steady_clock::time_point last_push_end{};
     // Which schedule the pushes took (lvk_hip_stab_schedule_counters): the mode is chosen per push from what the caller is seen doing, and a host

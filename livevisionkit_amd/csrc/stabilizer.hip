@@ -562,6 +562,7 @@ bool lvk_hip_stab::caller_free_running_now()
         if (q != hipSuccess) (void)hipGetLastError();
         bulk_busy_at_push = q == hipErrorNotReady;
     }
+    if (assume_caller) return assume_caller == 1;
     return bulk_busy_at_push || (last_push_end.time_since_epoch().count() != 0 && std::chrono::steady_clock::now() - last_push_end < std::chrono::microseconds(15));
 }
 

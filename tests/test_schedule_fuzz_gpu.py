@@ -40,12 +40,12 @@ def _settings(preset, delay, stabilize=True):
     return oracle_lib.preset(preset, predictive_samples=delay, min_scene_quality=0.3, min_tracking_quality=0.2, stabilize_output=1 if stabilize else 0)
 
 
-# LVK_FUZZ_SEEDS="5-40" (or "7,9,11"): more seeds for a one-off sweep on a GPU box; the suite itself runs four
+# LVK_FUZZ_SEEDS="5-40" (or "7,9,11"): more seeds for a one-off sweep on a GPU box; the suite itself runs six
 def _seeds():
     import os
     spec = os.environ.get("LVK_FUZZ_SEEDS")
     if not spec:
-        return [1, 2, 3, 4]
+        return [1, 2, 3, 4, 5, 6]
     out = []
     for part in spec.split(","):
         lo, _, hi = part.partition("-")
@@ -54,9 +54,13 @@ def _seeds():
 
 
 @pytest.mark.parametrize("seed", _seeds())
-def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
+def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed, monkeypatch):
     import torch
     import livevisionkit_amd as lvk
+    if seed & 4:
+        # frames this small never look free-running to the library (the host's turn outlasts their remap): the seeds with bit 2 set pin the free-running
+        # schedule -- persistent remap grids, conversions behind the chain on the tracking stream -- (the variable is read when the filter is created)
+        monkeypatch.setenv("LVK_HIP_ASSUME_CALLER", "free")
     rng = np.random.default_rng(9000 + seed)
     n = 44
     change_at = int(rng.integers(18, 26))                        # first push of the second frame size
@@ -165,6 +169,9 @@ def test_schedule_fuzz_one_stream_against_the_oracle(ctx, oracle, seed):
     # frames of the old size still queued when the size changed leave at their own size, as in the oracle and the reference (rounds 2-5 dropped them)
     late = {ts for ts, at in want_push.items() if ts < change_at <= at}
     assert sorted(got) == sorted(want), (log, sorted(late))
+    if seed & 4:
+        c = gst.schedule_counters()
+        assert c["push_free_running"] > 0 and c["push_synchronised"] == 0, c
     assert len(got) >= 10, (len(got), log)                           # (schedules that restart every few pushes emit little: the suite's seeds emit 25-35)
     assert live >= 4, f"only {live} emitted frames had a trust factor above zero: the schedule restarts too often to test the warp ({log})"
     for ts, (kind, planes) in sorted(got.items()):
