@@ -2,6 +2,9 @@
 // (Math/WarpMesh.cpp:183-223), lvk::upscale (Image.cpp:155-202) and the fused remap + 4:2:0 egress of the plugin's path.  The EASU arithmetic, the
 // coordinate generators, the sinks and the strip walk are in remap_core.hpp.
 #include "remap_core.hpp"
+#ifndef LVK_CO_LDS_PAD
+#define LVK_CO_LDS_PAD 0
+#endif
 
 namespace {
 
@@ -324,6 +327,7 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
     LVK_HIP_REQUIRE(ctx, fits_u32(src_step, rows) && fits_u32(oy_step, rows) && fits_u32(ou_step, rows / 2) && (nv12 || fits_u32(ov_step, rows / 2)));
     const Planes420 o{(uint8_t*)o_y, oy_step, (uint8_t*)o_u, ou_step, (uint8_t*)(nv12 ? o_u : o_v), nv12 ? ou_step : ov_step};
     const dim3 block(256), grid = co ? lvk_co_grid(ctx, rows, cols) : remap_grid(rows, cols);
+    const size_t lds_pad = co ? (size_t)LVK_CO_LDS_PAD : 0;          // A / B switch (scripts/variant_build.sh): unused LDS that caps the persistent grid's blocks per CU
     int stage_slot = -1;
     if (mesh_rows == 2 && mesh_cols == 2)
     {
@@ -342,13 +346,13 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
         for (int q = 0; q < 9; q++) args.h[q] = (float)M[q];
         if (lens)
         {
-            if (nv12) hipLaunchKernelGGL(k_remap_homography_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
-            else hipLaunchKernelGGL(k_remap_homography_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
+            if (nv12) hipLaunchKernelGGL(k_remap_homography_lens_420<true>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_homography_lens_420<false>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, *lens, pack_bg(bg));
         }
         else
         {
-            if (nv12) hipLaunchKernelGGL(k_remap_homography_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg));
-            else hipLaunchKernelGGL(k_remap_homography_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg));
+            if (nv12) hipLaunchKernelGGL(k_remap_homography_420<true>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_homography_420<false>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, args, pack_bg(bg));
         }
     }
     else
@@ -363,13 +367,13 @@ int lvk_launch_warpmesh_apply_420(lvk_hip_ctx* ctx, hipStream_t stream, const vo
         if ((rc = lvk_stage_params(ctx, stream, mesh, mesh_bytes, &d_mesh, &stage_slot)) != LVK_HIP_OK) return rc;
         if (lens)
         {
-            if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
-            else hipLaunchKernelGGL(k_remap_mesh_lens_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
+            if (nv12) hipLaunchKernelGGL(k_remap_mesh_lens_420<true>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_mesh_lens_420<false>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, *lens, pack_bg(bg));
         }
         else
         {
-            if (nv12) hipLaunchKernelGGL(k_remap_mesh_420<true>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, pack_bg(bg));
-            else hipLaunchKernelGGL(k_remap_mesh_420<false>, grid, block, 0, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, pack_bg(bg));
+            if (nv12) hipLaunchKernelGGL(k_remap_mesh_420<true>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, pack_bg(bg));
+            else hipLaunchKernelGGL(k_remap_mesh_420<false>, grid, block, lds_pad, stream, (const uint8_t*)d_src, src_step, rows, cols, o, (const float*)d_mesh, mesh_cols, mesh_rows * mesh_cols * 2, xtab, ytab, pack_bg(bg));
         }
     }
     const hipError_t le = hipGetLastError();
