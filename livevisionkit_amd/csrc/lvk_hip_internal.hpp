@@ -102,7 +102,10 @@ struct lvk_device_guard
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
         if (_e != hipSuccess)                                                                         \
+        {                                                                                             \
+            (void)hipGetLastError();   /* reported HERE: not again by the hipGetLastError() behind a later, successful launch */ \
             return (ctx)->fail(LVK_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                             \
     } while (0)
 
 // First statement of the tracker's small, latency-bound kernels: their waves take instruction-issue priority over the waves of the

@@ -173,6 +173,7 @@ struct lvk_hip_stab
     std::function<int()> deferred_ingest;      // the newest frame's 4:2:0 conversion, not yet launched (see lvk_hip_stab_push_yuv420)
     int run_deferred_ingest() { auto f = std::move(deferred_ingest); deferred_ingest = nullptr; return f ? f() : LVK_HIP_OK; }
     hipEvent_t ingest_done = nullptr;          // 4:2:0 ingest of the newest frame
+    unsigned long long ingest_recorded_for = 0; // push_seq of the push whose conversion recorded ingest_done (a refused push launches none: nothing to wait for)
     // Overlap mode with a frame delay: the conversion runs on the TRACKING stream, in the slot that stream has free between the last
     // kernel of a frame's chain and the first of the next frame's (the host's turn: ~25 us) -- behind an event the push waits on instead
     // of the whole stream.  On the bulk stream it sat between two remaps: 13 us + a kernel boundary of every bulk-stream period, which

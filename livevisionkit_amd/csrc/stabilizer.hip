@@ -777,6 +777,7 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
         {
             if (!st->ingest_done) LVK_HIP_CHECK(ctx, hipEventCreateWithFlags(&st->ingest_done, hipEventDisableTiming));
             LVK_HIP_CHECK(ctx, hipEventRecord(st->ingest_done, is));
+            st->ingest_recorded_for = st->push_seq;
         }
         return LVK_HIP_OK;
     };
@@ -822,7 +823,10 @@ static int lvk_stab_push_planes(lvk_hip_stab* st, int vf, const void* const in_p
         st->trace.mark(HostTrace::EXIT_PRE);
         // contract: the caller's planes are consumed when the call returns (the conversion started ~a tracking pass ago).  An event, not
         // hipStreamSynchronize: synchronising the bulk stream itself costs ~10 us of host time even when it is idle (measured).
-        LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
+        // (only a conversion that THIS push launched: a push that was refused -- or failed -- before its frame was queued has launched none, and when it is
+        //  the first overlap-mode push of the filter's life the event does not exist yet: the wait failed with "invalid resource handle", hid the refusal's own
+        //  message and left a sticky runtime error for the next launch to report -- found by fuzz seeds 389 / 390 of the round-6 sweep)
+        if (st->ingest_recorded_for == st->push_seq) LVK_HIP_CHECK(ctx, hipEventSynchronize(st->ingest_done));
         st->trace.mark(HostTrace::EXIT_WAIT);
     }
     // same contract without a tracker pass (delay-only mode, stabilize_output off): nothing has synchronised behind the conversion yet

@@ -753,3 +753,40 @@ def test_device_lookahead_packed_frames(ctx, oracle, clip):
     assert len(runs[0]) == len(runs[1]) == n - 2
     for i, (a, b) in enumerate(zip(*runs)):
         assert np.array_equal(a, b), i
+
+
+def test_refused_first_overlap_push_reports_the_refusal_and_leaves_no_error_behind(ctx):
+    """A push that is refused (output planes too small for the DELAYED frame) launches no conversion.  When it is the first push of the filter's life that
+    would have put one on the bulk stream -- the frames before it went through the passthrough (stabilize_output off: conversion inline) --, the event the
+    push waits for at its end does not exist yet: until round 6 that wait failed with "invalid resource handle", replaced the refusal's message and left a
+    sticky runtime error for the next (valid) launch to trip over (found by seeds 389 / 390 of the OBS-format fuzz sweep).  Reference behaviour this
+    protects: a resize in the middle of a stream emits the queued frames at their own size (StabilizationFilter.cpp:118-131, WarpMesh.cpp:183-223)."""
+    import torch
+    import livevisionkit_amd as lvk
+    big, small = (432, 768), (360, 640)
+    s = oracle_lib.preset("homography", predictive_samples=2, stabilize_output=0)
+    gst = lvk.StabilizationFilter(_to_settings(s), context=ctx)
+    gst.set_overlap(True)
+
+    def planes(size, v):
+        r, c = size
+        return (torch.full((r, c), v, dtype=torch.uint8, device="cuda"), torch.full((r // 2, c // 2), 128, dtype=torch.uint8, device="cuda"),
+                torch.full((r // 2, c // 2), 128, dtype=torch.uint8, device="cuda"))
+
+    for i in range(2):
+        out, _ = gst.apply_yuv420(planes(big, 40 + i), timestamp=i)
+        assert out is None
+    s.stabilize_output = 1
+    gst.configure(_to_settings(s))                                            # from here on the conversion is a bulk-stream kernel with an event behind it
+    assert gst.next_output(*small)[:2] == big                                 # the third push emits the first frame, at ITS size
+    too_small = planes(small, 0)
+    with pytest.raises(lvk.LvkHipError, match="DELAYED"):
+        gst.apply_yuv420(planes(small, 50), timestamp=2, out=too_small)
+    assert gst.next_output(*small)[:2] == big                                 # nothing was queued
+    out, ts = gst.apply_yuv420(planes(small, 50), timestamp=2)                # planes of the right size: the push goes through ...
+    ctx.sync()
+    assert ts == 0 and tuple(out[0].shape) == big
+    out, ts = gst.apply_yuv420(planes(small, 51), timestamp=3)                # ... and so does the next one: no stale runtime error
+    ctx.sync()
+    assert ts == 1 and tuple(out[0].shape) == big
+    gst.close()
