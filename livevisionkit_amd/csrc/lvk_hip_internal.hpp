@@ -74,7 +74,9 @@ struct lvk_hip_ctx
     // Cached tables of the INTER_AREA ENLARGEMENT (2 taps per destination index, 11-bit fixed point): key = (source extent, destination extent)
     std::map<std::pair<int, int>, int4*> enlargetabs;        // per destination index: (s0, s1, w0, w1)
 
-    int fail(int code, const std::string& msg) { last_error = msg; return code; }
+    // (a runtime error is reported HERE: the runtime's sticky "last error" is cleared with it, so that the hipGetLastError() check behind a later, perfectly
+    //  good launch does not report it a second time -- round 6, the failure of one call made the next valid push fail as well)
+    int fail(int code, const std::string& msg) { last_error = msg; if (code == LVK_HIP_ERR_RUNTIME) (void)hipGetLastError(); return code; }
 };
 
 // The current device is a per-thread setting of the HIP runtime, and events / streams / allocations are made on it: an entry point that may
